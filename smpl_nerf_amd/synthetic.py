@@ -1,0 +1,142 @@
+"""Deterministic synthetic inputs for the ray-march path (host side, numpy only).
+
+The reference's datasets need SMPL assets and rendered PNGs that are not shipped, so tests, the
+golden-vector generator and bench.py all draw their cameras, rays, coarse samples and network
+weights from here.  Formulas follow the reference:
+
+* camera pose      camera.py:86-110 (get_sphere_pose) / camera.py:33-37 (get_pose_matrix)
+* focal length     datasets/rays_from_images_dataset.py:44  (.5*w/tan(.5*camera_angle_x)),
+                   camera_angle_x = pi/3 (create_dataset.py:141)
+* rays             utils.py:50-54 (get_rays; integer pixel centres, un-normalised directions, fp64)
+* coarse samples   datasets/transforms.py:80-89 (bins linear in disparity, one jitter per ray, fp64
+                   math, cast to fp32 by ToTensor :13-21)
+* weights          torch.nn.Linear default init bounds (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for
+                   weight and bias) drawn from numpy's PCG64 so that fixtures need not store them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def pose_matrix(x=0.0, y=0.0, z=0.0, phi=0.0, theta=0.0, psi=0.0) -> np.ndarray:
+    """Extrinsic 'xyz' Euler rotation in degrees + translation (camera.py:33-37)."""
+    a, b, c = np.radians([phi, theta, psi])
+    rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    pose = np.eye(4)
+    pose[:3, :3] = rz @ ry @ rx          # scipy 'xyz' (lower case) = extrinsic x, then y, then z
+    pose[:3, 3] = [x, y, z]
+    return pose
+
+
+def sphere_pose(phi: float, theta: float, r: float) -> np.ndarray:
+    """camera.py:106-110."""
+    z = r * np.cos(np.radians(phi)) * np.cos(np.radians(theta))
+    x = r * np.cos(np.radians(phi)) * np.sin(np.radians(theta))
+    y = r * np.sin(np.radians(phi))
+    return pose_matrix(x=x, y=y, z=z, theta=theta, phi=-phi)
+
+
+def focal_length(w: int, camera_angle_x: float = np.pi / 3) -> float:
+    return .5 * w / np.tan(.5 * camera_angle_x)
+
+
+def camera_rays(h: int, w: int, pose: np.ndarray, camera_angle_x: float = np.pi / 3):
+    """utils.py:50-54 -> (translation[h*w,3], direction[h*w,3]) float64, row-major pixels."""
+    focal = focal_length(w, camera_angle_x)
+    i, j = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="xy")
+    dirs = np.stack([(i - w * .5) / focal, -(j - h * .5) / focal, -np.ones_like(i)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * pose[:3, :3], -1)
+    rays_o = np.broadcast_to(pose[:3, -1], rays_d.shape)
+    return rays_o.reshape(-1, 3).astype(np.float64), rays_d.reshape(-1, 3).astype(np.float64)
+
+
+def coarse_samples(rays_o, rays_d, near: float, far: float, n: int, jitter):
+    """datasets/transforms.py:80-89 batched; `jitter` is the per-ray np.random.rand() scalar."""
+    t = np.linspace(0., 1., n)
+    z = 1. / (1. / near * (1. - t) + 1. / far * t)
+    mids = .5 * (z[1:] + z[:-1])
+    upper = np.concatenate([mids, z[-1:]], -1)
+    lower = np.concatenate([z[:1], mids], -1)
+    jitter = np.broadcast_to(np.asarray(jitter, np.float64).reshape(-1, 1), (rays_o.shape[0], 1))
+    zs = lower[None, :] + (upper - lower)[None, :] * jitter
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * zs[:, :, None]
+    return pts.astype(F32), rays_o.astype(F32), rays_d.astype(F32), zs.astype(F32)
+
+
+def frame_batch(h=128, w=128, phi=0.0, theta=0.0, radius=2.4, near=1.0, far=4.0, n_coarse=64,
+                jitter=0.5, seed=None):
+    """One frame worth of pipeline inputs [ray_samples, ray_translation, ray_direction, z_vals,
+    rgb_truth] as fp32 numpy arrays (the list layout of solver/nerf_solver.py:77-81)."""
+    o, d = camera_rays(h, w, sphere_pose(phi, theta, radius))
+    if seed is not None:
+        jitter = np.random.default_rng(seed).random(o.shape[0])
+    pts, o32, d32, z = coarse_samples(o, d, near, far, n_coarse, jitter)
+    rgb = procedural_image(h, w, phi, theta).reshape(-1, 3)
+    return [pts, o32, d32, z, rgb]
+
+
+def procedural_image(h: int, w: int, phi: float = 0.0, theta: float = 0.0) -> np.ndarray:
+    """A fixed analytic BGR image in [0,1] (values only feed the loss)."""
+    yy, xx = np.meshgrid(np.linspace(-1, 1, h), np.linspace(-1, 1, w), indexing="ij")
+    r2 = (xx - 0.2 * np.sin(np.radians(theta))) ** 2 + (yy + 0.1 * np.sin(np.radians(phi))) ** 2
+    img = np.stack([np.exp(-4 * r2), 0.5 + 0.5 * np.cos(6 * xx) * np.exp(-2 * r2), np.clip(1 - r2, 0, 1)], -1)
+    return img.astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------------
+def render_ray_net_shapes(n_layers=8, width=256, positions_dim=60, directions_dim=24,
+                          additional_input_dim=0, skips=(4,), use_directional_input=1):
+    """state_dict (name, shape) pairs in registration order (models/render_ray_net.py:19-40)."""
+    pin = positions_dim + additional_input_dim
+    layers = [("positions_pose_input", width, pin)]
+    for i in range(n_layers - 1):
+        layers.append((f"positional_net.{i}", width, width + pin if i in skips else width))
+    layers.append(("additional_linear_layer", width, width))
+    layers.append(("sigma_out_layer", 1, width))
+    dw = width // 2
+    layers.append(("directional_input", dw, width + directions_dim if use_directional_input else width))
+    layers.append(("directional_net.0", dw, dw))
+    layers.append(("rgb_out_layer", 3, dw))
+    return layers
+
+
+def init_linear_stack(layers, seed: int) -> dict:
+    rng = np.random.default_rng(seed)
+    params = {}
+    for name, fan_out, fan_in in layers:
+        bound = 1.0 / np.sqrt(fan_in)
+        params[name + ".weight"] = rng.uniform(-bound, bound, (fan_out, fan_in)).astype(F32)
+        params[name + ".bias"] = rng.uniform(-bound, bound, (fan_out,)).astype(F32)
+    return params
+
+
+def make_render_ray_net_params(seed: int, sigma_scale: float = 1.0, rgb_scale: float = 1.0, **net_kw) -> dict:
+    """Seeded RenderRayNet parameters.  `sigma_scale`/`rgb_scale` multiply the two head weight
+    matrices so that a random-init net produces non-trivial densities and colours."""
+    params = init_linear_stack(render_ray_net_shapes(**net_kw), seed)
+    params["sigma_out_layer.weight"] = (params["sigma_out_layer.weight"] * F32(sigma_scale)).astype(F32)
+    params["rgb_out_layer.weight"] = (params["rgb_out_layer.weight"] * F32(rgb_scale)).astype(F32)
+    return params
+
+
+def make_warp_field_params(seed: int, positions_dim=60, pose_dim=40, width=256, out_scale=1.0) -> dict:
+    """WarpFieldNet: linear1 (width, positions_dim+pose_dim), linear2 (3, width) (models/warp_field_net.py:14-15)."""
+    params = init_linear_stack([("linear1", width, positions_dim + pose_dim), ("linear2", 3, width)], seed)
+    params["linear2.weight"] = (params["linear2.weight"] * F32(out_scale)).astype(F32)
+    return params
+
+
+def human_poses(joints=(41, 38), start=0.0, end=60.0, steps=10) -> np.ndarray:
+    """render.py:190-220 (get_human_poses) -> [steps, 69] fp32, radians at the listed joints."""
+    angles = np.linspace(start, end, steps)
+    poses = np.zeros((steps, 69), F32)
+    for i, a in enumerate(angles):
+        for j in joints:
+            poses[i, j] = np.deg2rad(a)
+    return poses
