@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py - ray-samples/s of the NeRF ray-march path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path - NerfPipeline.forward (models/nerf_pipeline.py:14-67) - over one
+batch of synthetic input: a whole 128x128 frame (16 384 rays) with 64 coarse + 128 fine samples per ray
+through two 8-layer / 256-wide RenderRayNets (BASELINE configs[1]).  One ray-sample = one MLP
+evaluation of one sample point: 64 (coarse) + 192 (fine) = 256 per ray, 4 194 304 per step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Inputs are resident in HBM before the timed region.  Rays of independent frames shard across ranks
+(each rank renders its own camera pose); rendering has no exchange step, so there is no data-path
+collective - RCCL is used only for the barrier and the max-over-ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FLOP_PER_EVAL = 2 * 607872           # RenderRayNet 8x256, pos 60, dir 24, skips=[4]
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+
+
+def build_pipeline(dev):
+    from smpl_nerf_amd import synthetic as syn
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline
+    from oracle.nerf_oracle import Args  # plain namespace only (no compute)
+
+    params = [syn.make_render_ray_net_params(s, 30.0, 10.0, skips=(4,)) for s in (101, 102)]
+    nets = []
+    for p in params:
+        m = RenderRayNet(8, 256, 60, 24, skips=[4])
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+        nets.append(m.to(dev).eval())
+    args = Args(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0)
+    pipe = NerfPipeline(nets[0], nets[1], args, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    return pipe, params
+
+
+def cpu_baseline(params, data_np, n_rays, u):
+    """The numpy oracle (a port of the reference's CPU path) timed on the host cores on a bounded
+    sample of the same workload: the first n_rays rays of the same frame, same weights."""
+    from oracle import nerf_oracle as O
+    args = O.Args(u=u)
+    pe, de = O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0)
+    sub = [a[:n_rays] for a in data_np]
+    O.nerf_pipeline_forward(params[0], params[1], args, pe, de, [a[:64] for a in data_np])   # warm-up
+    t0 = time.perf_counter()
+    out = O.nerf_pipeline_forward(params[0], params[1], args, pe, de, sub)
+    dt = time.perf_counter() - t0
+    return n_rays * 256 / dt, dt, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the frame the CPU baseline renders (0 = skip)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from smpl_nerf_amd import _lib, synthetic as syn
+    from smpl_nerf_amd.dist import barrier, max_over_ranks, shard_frames
+
+    pipe, params = build_pipeline(dev)
+    # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
+    frame_id = shard_frames(world, rank)
+    data_np = syn.frame_batch(128, 128, phi=7.0 * frame_id, theta=25.0 * frame_id, seed=7 + frame_id)
+    data = [torch.from_numpy(x).to(dev) for x in data_np]
+    rays = data[0].shape[0]
+    evals_per_step = rays * 256
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out = pipe(data)
+        barrier(dev)
+        torch.cuda.synchronize()
+        with _lib.profile() as prof:
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                out = pipe(data)
+            torch.cuda.synchronize()
+            barrier(dev)
+            elapsed = time.perf_counter() - t0
+        kern = prof.summary()
+    elapsed = max_over_ranks(elapsed, dev)
+
+    if rank == 0:
+        value = world * a.steps * evals_per_step / elapsed
+        # dominant kernel = the fine-pass fused encode+MLP launch (16384*192 samples)
+        n_fine = rays * 192
+        calls, ms = kern[f"mlp_fwd[n={n_fine}]"]
+        avg_ms = ms / calls
+        achieved = FLOP_PER_EVAL * n_fine / (avg_ms * 1e-3) / 1e12
+        line = {
+            "metric": "ray-samples/sec (coarse+fine) at 128^2 / 64+128 samples",
+            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "nerf 128x128 frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, "
+                                   "width 256, skips [4], forward render (BASELINE configs[1])",
+                       "rays_per_step_per_gpu": rays, "ray_samples_per_ray": 256, "parallelism": f"dp{world} (rays of "
+                       "independent frames per rank, no data-path collective)"},
+            "rays_per_s": world * a.steps * rays / elapsed,
+            "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel<256,4,false> (fine pass, n=%d)" % n_fine,
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "flop_per_unit": FLOP_PER_EVAL, "units_per_launch": n_fine,
+                         "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32"},
+            "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(kern.items())},
+        }
+        if world == 1 and a.cpu_rays > 0:
+            from smpl_nerf_amd.ops import uniform_u
+            u = uniform_u(128, dev).cpu().numpy()
+            cpu_val, cpu_dt, ref = cpu_baseline(params, data_np, min(a.cpu_rays, rays), u)
+            n = min(a.cpu_rays, rays)
+            err = float(np.max(np.abs(out[1][:n].cpu().numpy() - ref[1])))
+            line["cpu_baseline"] = {"value": cpu_val, "unit": "ray-samples/s", "cores": os.cpu_count(),
+                                    "kind": "port", "sample": f"first {n} rays of the same frame, same weights "
+                                    f"({n * 256} ray-samples, {cpu_dt:.1f} s): numpy oracle, BLAS threads = host cores"}
+            line["rgb_fine_max_abs_diff_vs_oracle"] = err
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/* smplnerf.h - C-ABI of libsmplnerf_hip.so: the MI355X (gfx950) NeRF ray-march path.
+ *
+ * Drop-in boundary for the hot path of HannesStark/SMPL-NeRF (citations are reference file:line):
+ *
+ *   snerf_searchsorted_f32   replaces  torchsearchsorted.searchsorted
+ *                            (torchsearchsorted/src/torchsearchsorted/searchsorted.py:20-53; native
+ *                            searchsorted_cpu_wrapper.cpp:82-122, searchsorted_cuda_kernel.cu:84-141)
+ *   snerf_posenc_f32         replaces  PositionalEncoder.encode            (utils.py:114-131)
+ *   snerf_composite_fwd_f32  replaces  raw2outputs                         (utils.py:134-191)
+ *   snerf_sample_pdf_f32     replaces  sample_pdf + fine_sampling          (utils.py:194-264)
+ *   snerf_mlp_*              replaces  RenderRayNet.forward                (models/render_ray_net.py:42-61)
+ *                            fused with the positional encoding of its inputs as used by
+ *                            NerfPipeline.forward                          (models/nerf_pipeline.py:29-41, :49-60)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; buffers are borrowed
+ *     for the duration of the call only; outputs are caller-allocated; nothing is retained.
+ *   - `stream` is a hipStream_t (pass PyTorch's current stream); all work is enqueued
+ *     asynchronously on it, no call synchronises the device.
+ *   - return value: 0 on success, <0 = SNERF_E_*; nothing throws across the ABI.
+ *     snerf_last_error_string() describes the last failure on the calling thread.
+ *   - row-major, densely packed fp32 tensors; indices are int64 (torch.long) like the reference.
+ *   - no global mutable state; re-entrant and thread-safe.
+ */
+#ifndef SMPLNERF_H
+#define SMPLNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNERF_VERSION 100 /* 0.1.0 */
+
+#define SNERF_OK 0
+#define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
+#define SNERF_E_ALIGN (-2)    /* pointer not aligned as documented */
+#define SNERF_E_LAUNCH (-3)   /* HIP launch / runtime error */
+#define SNERF_E_NODEVICE (-4) /* no gfx950 device visible */
+
+typedef void *snerf_stream_t; /* hipStream_t */
+
+int snerf_version(void);
+const char *snerf_last_error_string(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int snerf_device_count(void);
+
+/* ---- a6: batched searchsorted --------------------------------------------------------------
+ * out[r, c] = #{ k : a[ra, k] <  v[rv, c] }   (side_left != 0, numpy side='left')
+ *           = #{ k : a[ra, k] <= v[rv, c] }   (side_left == 0, side='right')
+ * rows of `a` must be sorted ascending.  ra = 0 if nrow_a == 1 else r (same for rv): the
+ * reference's row broadcast (searchsorted_cpu_wrapper.cpp:109-110).  nrow_a and nrow_v must be
+ * equal or one of them 1 (searchsorted.py:23-28).  out: int64 [max(nrow_a,nrow_v), ncol_v]. */
+int snerf_searchsorted_f32(const float *a, int64_t nrow_a, int64_t ncol_a,
+                           const float *v, int64_t nrow_v, int64_t ncol_v,
+                           int64_t *out, int side_left, snerf_stream_t stream);
+
+/* ---- a1: positional encoding ----------------------------------------------------------------
+ * x [n, c] -> out [n, c*(identity + 2*L)], frequency-major: [x] [sin(2^0 x) cos(2^0 x)] ...
+ * (utils.py:116-131; no pi factor). */
+int snerf_posenc_f32(const float *x, int64_t n, int c, int L, int identity, float *out,
+                     snerf_stream_t stream);
+
+/* ---- a4: alpha compositing --------------------------------------------------------------------
+ * raw [B, N, 4] (r, g, b, sigma), z [B, N], dirs: [B, 3] when dirs_per_sample == 0 (the ray
+ * direction broadcast over samples) or [B, N, 3]; dists are scaled by ||dirs|| (utils.py:165).
+ * noise: nullable [B, N], added to sigma before relu (utils.py:171-173; the caller draws it).
+ * rgb [B, 3], weights [B, N], alpha [B, N] (any of the three may be NULL to skip the store).
+ * N == 1 reproduces the reference's early return (utils.py:168-169): weights = alpha = 1. */
+int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+                            const float *noise, int64_t B, int N, int white_background,
+                            float *rgb, float *weights, float *alpha, snerf_stream_t stream);
+
+/* ---- a5: inverse-CDF hierarchical sampling + merge + point generation ------------------------------
+ * z [B, Nc] coarse depths (ascending), weights [B, Nc] from compositing, u [Nf] = linspace(0,1,Nf)
+ * (passed in so that the caller controls its bits, see oracle/nerf_oracle.py:linspace01),
+ * o, d [B, 3].  Outputs (each nullable): inds int64 [B, Nf] (searchsorted(cdf,u,'right')),
+ * z_samples [B, Nf], z_fine [B, Nc+Nf] ascending, pts [B, Nc+Nf, 3] = o + d * z_fine.
+ * 3 <= Nc <= 1024, 1 <= Nf <= 1024. */
+int snerf_sample_pdf_f32(const float *z, const float *weights, const float *u,
+                         const float *o, const float *d, int64_t B, int Nc, int Nf,
+                         int64_t *inds, float *z_samples, float *z_fine, float *pts,
+                         snerf_stream_t stream);
+
+/* The literal sample_pdf(bins, weights, args) convention (utils.py:194-228): bins [B, Nb] (coarse
+ * midpoints), weights [B, Nb-1] (interior coarse weights) -> inds int64 [B, Nf] (nullable),
+ * z_samples [B, Nf].  2 <= Nb <= 1023. */
+int snerf_sample_pdf_bins_f32(const float *bins, const float *weights, const float *u, int64_t B,
+                              int Nb, int Nf, int64_t *inds, float *z_samples, snerf_stream_t stream);
+
+/* ---- a2: RenderRayNet -----------------------------------------------------------------------------
+ * Mirrors RenderRayNet.__init__ (models/render_ray_net.py:8): n_layers, width, skips as a bit mask
+ * over positional_net indices, use_directional_input; positions_dim / directions_dim are expressed
+ * through the encoders that feed them (pos_freqs/pos_identity, dir_freqs/dir_identity; 3 input
+ * channels each), additional_input_dim = add_dim per-ray constants appended to the position
+ * encoding (train.py:154-159). */
+typedef struct snerf_mlp_desc {
+    int32_t n_layers;     /* 8 */
+    int32_t width;        /* 256 (or 128) */
+    int32_t pos_freqs;    /* 10 */
+    int32_t pos_identity; /* 0 */
+    int32_t dir_freqs;    /* 4 */
+    int32_t dir_identity; /* 0 */
+    int32_t add_dim;      /* 0 */
+    uint32_t skip_mask;   /* bit i set <=> i in skips */
+    int32_t use_dir;      /* 1 */
+} snerf_mlp_desc;
+
+/* Number of floats in the flat parameter vector: weights and biases in state_dict order
+ * (positions_pose_input.weight, .bias, positional_net.0.weight, ... rgb_out_layer.bias). */
+int64_t snerf_mlp_param_floats(const snerf_mlp_desc *desc);
+/* Number of floats of the MFMA-ordered weight stream produced by snerf_mlp_pack_f32. */
+int64_t snerf_mlp_packed_floats(const snerf_mlp_desc *desc);
+/* params_flat -> packed (both device).  Run once per weight update. */
+int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed,
+                       snerf_stream_t stream);
+
+/* Fused positional encoding + MLP.  x [n, 3] sample positions; directions dirs: [n/samples_per_ray, 3]
+ * when dirs_per_sample == 0 (one per ray, samples of a ray contiguous) or [n, 3]; directions are
+ * normalised inside (models/nerf_pipeline.py:33-34).  add: nullable [n/samples_per_ray, add_dim].
+ * raw [n, 4] = [rgb | sigma] (models/render_ray_net.py:61). */
+int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
+                      const float *dirs, int dirs_per_sample, const float *add,
+                      int64_t n, int samples_per_ray, float *raw, snerf_stream_t stream);
+
+/* Same network on already-encoded rows x_enc [n, row_floats] (the literal RenderRayNet.forward(x)
+ * signature): positions_pose = x[:, :positions_dim+add_dim], directions = x[:, -directions_dim:]
+ * (models/render_ray_net.py:42-43). */
+int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
+                              int64_t n, int64_t row_floats, float *raw, snerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMPLNERF_H */

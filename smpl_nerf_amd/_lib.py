@@ -1,0 +1,137 @@
+"""ctypes binding of libsmplnerf_hip.so (include/smplnerf.h).
+
+There is exactly one implementation of every op in this package: the HIP library.  If it is
+missing, or a call fails, a RuntimeError is raised - there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libsmplnerf_hip.so")
+
+SNERF_OK = 0
+
+
+class MlpDesc(ctypes.Structure):
+    """struct snerf_mlp_desc (include/smplnerf.h) - mirrors RenderRayNet.__init__ (models/render_ray_net.py:8)."""
+    _fields_ = [("n_layers", c_int32), ("width", c_int32), ("pos_freqs", c_int32), ("pos_identity", c_int32),
+                ("dir_freqs", c_int32), ("dir_identity", c_int32), ("add_dim", c_int32), ("skip_mask", c_uint32),
+                ("use_dir", c_int32)]
+
+
+_P = c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+# name -> (restype, argtypes); must list every symbol include/smplnerf.h declares
+SIGNATURES = {
+    "snerf_version": (c_int, []),
+    "snerf_last_error_string": (c_char_p, []),
+    "snerf_device_count": (c_int, []),
+    "snerf_searchsorted_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
+    "snerf_posenc_f32": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P]),
+    "snerf_composite_fwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "snerf_sample_pdf_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "snerf_sample_pdf_bins_f32": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    "snerf_mlp_param_floats": (c_int64, [POINTER(MlpDesc)]),
+    "snerf_mlp_packed_floats": (c_int64, [POINTER(MlpDesc)]),
+    "snerf_mlp_pack_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
+    "snerf_mlp_fwd_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P]),
+    "snerf_mlp_fwd_encoded_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int64, c_int64, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m smpl_nerf_amd.build` (hipcc, gfx950). "
+            "smpl_nerf_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
+    except Exception:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != SNERF_OK:
+        msg = load().snerf_last_error_string()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- optional per-launch timing (HIP events on the launch stream) ---------------------------------
+_PROFILE = None
+
+
+class profile:
+    """Context manager: records a pair of events (on the stream the kernels are launched on, i.e.
+    PyTorch's current stream) around every C-ABI launch made through `timed()`.
+
+        with _lib.profile() as prof: pipeline(data)
+        prof.summary() -> {name: (calls, total_ms)}
+    """
+
+    def __enter__(self):
+        global _PROFILE
+        self.records = []
+        self._prev = _PROFILE
+        _PROFILE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _PROFILE
+        _PROFILE = self._prev
+        return False
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.records:
+            calls, ms = out.get(name, (0, 0.0))
+            out[name] = (calls + 1, ms + e0.elapsed_time(e1))
+        return out
+
+
+class timed:
+    """with timed("mlp_fwd"): lib.snerf_...(...)  - no-op unless a profile() is active."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            import torch
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.e1.record()
+            _PROFILE.records.append((self.name, self.e0, self.e1))
+        return False

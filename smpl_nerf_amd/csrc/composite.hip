@@ -1,0 +1,119 @@
+// snerf_composite_fwd_f32 - alpha compositing of one ray per wavefront (a4, utils.py:134-191).
+//
+//   dist_i  = (z_{i+1} - z_i) * ||dir||,  dist_{N-1} = 1e10 * ||dir||          (utils.py:161-165)
+//   alpha_i = 1 - exp(-relu(sigma_i + noise_i) * dist_i)                        (utils.py:159,173)
+//   T_i     = prod_{j<i} (1 - alpha_j + 1e-10)      exclusive cumprod           (utils.py:174-179)
+//   w_i     = alpha_i * T_i ;  rgb = sum_i w_i * sigmoid(raw_i.rgb) (+ 1 - sum w if white bg)
+//
+// HBM-bound: 20 B read (raw 16 + z 4) and 8 B written (weights, alpha) per sample, +12 B per ray.
+// One 64-lane wavefront owns a ray; samples are walked in chunks of 64 so every load/store is a
+// fully coalesced 256 B / 1 KiB wave access; the transmittance is a wavefront prefix product with
+// a scalar carry between chunks.  The prefix product runs in fp64 and is rounded once per sample:
+// that is what torch's CPU cumprod does (accumulate in double, store float), so the result does
+// not depend on the scan order and matches the reference to the last bit of T in practice.
+#include "snerf_common.h"
+
+namespace snerf {
+
+constexpr int CP_THREADS = 256;  // 4 rays per workgroup
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
+    const float4 *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs, int dirs_per_sample,
+    const float *__restrict__ noise, int64_t B, int N, int white_bg, float *__restrict__ rgb_out,
+    float *__restrict__ w_out, float *__restrict__ alpha_out) {
+    const int lane = lane_id();
+    const int64_t ray = (int64_t)blockIdx.x * (CP_THREADS / WAVE) + (threadIdx.x >> 6);
+    if (ray >= B) return;  // wave-uniform
+    const int64_t base = ray * N;
+
+    if (N == 1) {  // utils.py:168-169: sigmoid(rgb), weights = alpha = ones
+        if (lane == 0) {
+            const float4 r = raw[base];
+            if (rgb_out) {
+                rgb_out[ray * 3 + 0] = sigmoidf_ref(r.x);
+                rgb_out[ray * 3 + 1] = sigmoidf_ref(r.y);
+                rgb_out[ray * 3 + 2] = sigmoidf_ref(r.z);
+            }
+            if (w_out) w_out[ray] = 1.0f;
+            if (alpha_out) alpha_out[ray] = 1.0f;
+        }
+        return;
+    }
+
+    float ray_norm = 0.f;
+    if (!dirs_per_sample) {
+        const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+        ray_norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    }
+
+    double carry = 1.0;  // product of (1 - alpha + 1e-10) over all previous chunks
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_w = 0.f;
+    for (int c0 = 0; c0 < N; c0 += WAVE) {
+        const int i = c0 + lane;
+        const bool ok = i < N;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        float zi = 0.f, zn = 0.f, nrm = ray_norm, nz = 0.f;
+        if (ok) {
+            r = raw[base + i];
+            zi = z[base + i];
+            zn = (i + 1 < N) ? z[base + i + 1] : 0.f;
+            if (noise) nz = noise[base + i];
+            if (dirs_per_sample) {
+                const float *dp = dirs + (base + i) * 3;
+                nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dp[0], dp[0]), __fmul_rn(dp[1], dp[1])), __fmul_rn(dp[2], dp[2])));
+            }
+        }
+        float dist = (i + 1 < N) ? __fsub_rn(zn, zi) : 1e10f;
+        dist = __fmul_rn(dist, nrm);
+        const float sig = noise ? __fadd_rn(r.w, nz) : r.w;
+        const float a = ok ? __fsub_rn(1.0f, expf(__fmul_rn(-fmaxf(sig, 0.f), dist))) : 0.f;
+        const float om = ok ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
+        // inclusive fp64 prefix product over the chunk, shifted to exclusive
+        const double incl = wave_scan_mul((double)om, lane);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(carry * excl);
+        carry *= __shfl(incl, 63, 64);
+        const float w = __fmul_rn(a, T);
+        if (ok) {
+            if (w_out) w_out[base + i] = w;
+            if (alpha_out) alpha_out[base + i] = a;
+            acc_r = __fadd_rn(acc_r, __fmul_rn(w, sigmoidf_ref(r.x)));
+            acc_g = __fadd_rn(acc_g, __fmul_rn(w, sigmoidf_ref(r.y)));
+            acc_b = __fadd_rn(acc_b, __fmul_rn(w, sigmoidf_ref(r.z)));
+            acc_w = __fadd_rn(acc_w, w);
+        }
+    }
+    acc_r = wave_sum(acc_r);
+    acc_g = wave_sum(acc_g);
+    acc_b = wave_sum(acc_b);
+    acc_w = wave_sum(acc_w);
+    if (lane == 0 && rgb_out) {
+        const float bg = white_bg ? __fsub_rn(1.0f, acc_w) : 0.f;
+        rgb_out[ray * 3 + 0] = white_bg ? __fadd_rn(acc_r, bg) : acc_r;
+        rgb_out[ray * 3 + 1] = white_bg ? __fadd_rn(acc_g, bg) : acc_g;
+        rgb_out[ray * 3 + 2] = white_bg ? __fadd_rn(acc_b, bg) : acc_b;
+    }
+}
+
+}  // namespace snerf
+
+extern "C" int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+                                       const float *noise, int64_t B, int N, int white_background, float *rgb,
+                                       float *weights, float *alpha, snerf_stream_t stream) {
+    using namespace snerf;
+    if (B < 0 || N < 1) return fail(SNERF_E_BADARG, "composite: bad B/N");
+    if (B == 0) return SNERF_OK;
+    if (!raw || !z) return fail(SNERF_E_BADARG, "composite: raw/z is null");
+    if (N > 1 && !dirs) return fail(SNERF_E_BADARG, "composite: dirs is null");
+    if (!aligned(raw, 16)) return fail(SNERF_E_ALIGN, "composite: raw must be 16-byte aligned");
+    const int rays_per_block = CP_THREADS / WAVE;
+    const int64_t grid = (B + rays_per_block - 1) / rays_per_block;
+    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "composite: B too large");
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)grid), dim3(CP_THREADS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(raw), z, dirs, dirs_per_sample ? 1 : 0, noise, B, N,
+                       white_background ? 1 : 0, rgb, weights, alpha);
+    return check_launch("composite_fwd");
+}

@@ -1,0 +1,156 @@
+// Host+device description of how a RenderRayNet (models/render_ray_net.py:8-61) is laid out as a
+// stream of 17 KiB "slabs" of MFMA A-operands that the fused kernel consumes in order.
+//
+// MFMA used: v_mfma_f32_16x16x4_f32 (exact fp32).  The kernel computes the TRANSPOSED layer
+//     out^T[feature, sample] = W[feature, k] * in^T[k, sample]
+// so W is the A operand (lane l supplies W[16*to + (l&15)][k-slot l>>4]) and the activations are
+// the B operand (lane l supplies feature k-slot l>>4 of sample l&15).  The accumulator of output
+// tile `to` leaves feature 16*to + 4*(l>>4) + r of sample l&15 in register r of lane l - which is
+// exactly the B-operand layout of k-step (kb=to, r) of the next layer if that k-step is defined to
+// contract features {16*kb + 4*g + r : g = 0..3}.  Activations therefore never leave registers
+// between layers; only the weights move, pre-permuted here into consumption order.
+//
+// k-block kb  = 4 k-steps r=0..3 = 16 input features; one ds_read_b128 per (kb, output tile) gives a
+//               lane its 4 A values: W[16*to + (l&15)][col(kb, g=l>>4, r)], r = 0..3.
+// slab        = 4096 floats of A tiles ([k-block in slab][to][lane][r]) + 256 floats of bias
+//               (valid in the first slab of a layer).  k-blocks per slab = 16 / t_out.
+// Input segments of a layer (columns of its weight matrix), each a whole number of k-blocks:
+//   HIDDEN  col = col_off + 16*kb + 4*g + r                     (previous layer's accumulator)
+//   PE      encoder output of a 3-vector (utils.py:114-131), two "units" per k-block per lane:
+//           unit p = 4*(2*kb + (r>>1)) + g;  identity units p < 3*id carry (x_p, -);
+//           p' = p - 3*id -> frequency k = p'/3, channel c = p'%3 carries (sin, cos)(2^k x_c):
+//           col = col_off + {3*id + 6*k + c, 3*id + 6*k + 3 + c}[r&1]
+//   ADD     per-ray additional inputs, col = col_off + 16*kb + 4*g + r
+#pragma once
+#include <stdint.h>
+
+namespace snerf {
+
+constexpr int SLAB_A_FLOATS = 4096;
+constexpr int SLAB_AUX_FLOATS = 256;
+constexpr int SLAB_FLOATS = SLAB_A_FLOATS + SLAB_AUX_FLOATS;  // 4352 floats = 17 KiB
+constexpr int SLAB_PAD = 3;                                    // zero slabs after the stream (prefetch overrun)
+constexpr int MAX_LAYERS = 21;  // n_layers <= 16, + 5 fixed layers
+
+enum SegType : int { SEG_HIDDEN = 0, SEG_PE = 1, SEG_ADD = 2 };
+
+struct Seg {
+    int type;
+    int col_off;   // first column of this segment in the layer's weight matrix
+    int ncols;     // real columns
+    int nkb;       // k-blocks (16 slots each)
+    int L, ident;  // PE only
+};
+
+struct Layer {
+    int64_t w_off, b_off;  // offsets into params_flat
+    int n_out, n_in;       // weight is [n_out, n_in] row-major
+    int t_out;             // output tiles of 16 rows (n_out padded)
+    int nseg;
+    Seg seg[3];
+    int nkb;         // total k-blocks
+    int first_slab;  // index of the layer's first slab in the stream
+    int nslab;
+};
+
+struct Plan {
+    int nlayers;
+    int total_slabs;
+    int width, n_hidden;  // n_hidden = n_layers - 1 positional_net layers
+    int pos_nkb, dir_nkb, add_nkb;
+    int pos_dim, dir_dim, add_dim;
+    int64_t param_floats;
+    Layer layer[MAX_LAYERS];
+};
+
+__host__ __device__ inline int pe_units(int L, int ident) { return 3 * (ident ? 1 : 0) + 3 * L; }
+__host__ __device__ inline int pe_nkb(int L, int ident) {
+    const int per_lane = (pe_units(L, ident) + 3) / 4;  // units per lane group g
+    return (2 * per_lane + 3) / 4;
+}
+// column (within the encoder output) feeding slot (kb, g, r) of a PE segment; -1 = zero padding
+__host__ __device__ inline int pe_slot_col(int L, int ident, int kb, int g, int r) {
+    const int p = 4 * (2 * kb + (r >> 1)) + g;
+    const int nid = ident ? 3 : 0;
+    if (p < nid) return (r & 1) ? -1 : p;
+    const int pp = p - nid;
+    if (pp >= 3 * L) return -1;
+    const int k = pp / 3, c = pp - 3 * k;
+    return nid + 6 * k + ((r & 1) ? 3 : 0) + c;
+}
+
+// Builds the plan; returns 0 or a negative SNERF_E_* with `why` set.
+inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why) {
+    why = "";
+    if (d.n_layers < 2 || d.n_layers > 16) { why = "n_layers must be in [2,16]"; return -1; }
+    if (d.width != 256 && d.width != 128) { why = "width must be 256 or 128"; return -1; }
+    if (d.pos_freqs < 0 || d.pos_freqs > 16 || d.dir_freqs < 0 || d.dir_freqs > 16) { why = "bad encoder frequencies"; return -1; }
+    if (d.add_dim < 0 || d.add_dim > 4096) { why = "bad add_dim"; return -1; }
+    const int W = d.width, WD = W / 2;
+    const int pid = d.pos_identity ? 1 : 0, did = d.dir_identity ? 1 : 0;
+    P.width = W;
+    P.n_hidden = d.n_layers - 1;
+    P.pos_dim = 3 * (pid + 2 * d.pos_freqs);
+    P.dir_dim = 3 * (did + 2 * d.dir_freqs);
+    P.add_dim = d.add_dim;
+    if (P.pos_dim + P.add_dim == 0) { why = "empty position input"; return -1; }
+    if (d.use_dir && P.dir_dim == 0) { why = "empty direction encoding"; return -1; }
+    P.pos_nkb = pe_nkb(d.pos_freqs, pid);
+    P.dir_nkb = d.use_dir ? pe_nkb(d.dir_freqs, did) : 0;
+    P.add_nkb = (d.add_dim + 15) / 16;
+    const int pin = P.pos_dim + P.add_dim;
+    int nl = 0, slab = 0;
+    int64_t off = 0;
+    auto add_layer = [&](int n_out, bool hidden, int hidden_cols, int extra /*0 none, 1 pos(+add), 2 dir*/) {
+        Layer &Ly = P.layer[nl++];
+        Ly.n_out = n_out;
+        Ly.t_out = (n_out + 15) / 16;
+        Ly.nseg = 0;
+        int col = 0;
+        if (hidden) {
+            Seg &s = Ly.seg[Ly.nseg++];
+            s = Seg{SEG_HIDDEN, col, hidden_cols, hidden_cols / 16, 0, 0};
+            col += hidden_cols;
+        }
+        if (extra == 1) {
+            Seg &s = Ly.seg[Ly.nseg++];
+            s = Seg{SEG_PE, col, P.pos_dim, P.pos_nkb, d.pos_freqs, pid};
+            col += P.pos_dim;
+            if (P.add_dim) {
+                Seg &a = Ly.seg[Ly.nseg++];
+                a = Seg{SEG_ADD, col, P.add_dim, P.add_nkb, 0, 0};
+                col += P.add_dim;
+            }
+        } else if (extra == 2) {
+            Seg &s = Ly.seg[Ly.nseg++];
+            s = Seg{SEG_PE, col, P.dir_dim, P.dir_nkb, d.dir_freqs, did};
+            col += P.dir_dim;
+        }
+        Ly.n_in = col;
+        Ly.nkb = 0;
+        for (int i = 0; i < Ly.nseg; ++i) Ly.nkb += Ly.seg[i].nkb;
+        const int kps = 16 / Ly.t_out;
+        Ly.first_slab = slab;
+        Ly.nslab = (Ly.nkb + kps - 1) / kps;
+        slab += Ly.nslab;
+        Ly.w_off = off;
+        off += (int64_t)Ly.n_out * Ly.n_in;
+        Ly.b_off = off;
+        off += Ly.n_out;
+    };
+    add_layer(W, false, 0, 1);                                   // positions_pose_input   (:19)
+    for (int i = 0; i < d.n_layers - 1; ++i)                     // positional_net[i]      (:21-25)
+        add_layer(W, true, W, ((d.skip_mask >> i) & 1u) ? 1 : 0);
+    add_layer(W, true, W, 0);                                    // additional_linear_layer (:27)
+    add_layer(1, true, W, 0);                                    // sigma_out_layer        (:28)
+    add_layer(WD, true, W, d.use_dir ? 2 : 0);                   // directional_input      (:31-34)
+    add_layer(WD, true, WD, 0);                                  // directional_net[0]     (:38-39)
+    add_layer(3, true, WD, 0);                                   // rgb_out_layer          (:40)
+    (void)pin;
+    P.nlayers = nl;
+    P.total_slabs = slab;
+    P.param_floats = off;
+    return 0;
+}
+
+}  // namespace snerf

@@ -1,0 +1,83 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPU node, "gloo" in the CPU tests).
+
+The ray-march path shards by rays: rays (and whole frames) are independent, so rendering needs no
+data-path collective at all.  The only exchange in the path is the gradient of the replicated MLP
+parameters in a training step (one flat fp32 all-reduce), provided here as
+`allreduce_mean_`; everything else is index arithmetic.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_rank():
+    return (dist.get_world_size(), dist.get_rank()) if is_dist() else (1, 0)
+
+
+def shard_frames(world: int, rank: int, frame0: int = 0) -> int:
+    """Frame (camera pose) index rendered by `rank` in one step: frames are dealt round-robin."""
+    return frame0 + rank
+
+
+def shard_range(n: int, world: int, rank: int):
+    """Contiguous [begin, end) slice of n rays for `rank`; sizes differ by at most one and the
+    concatenation over ranks is exactly range(n) (ragged n is fine)."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_rays(tensors, world: int = None, rank: int = None):
+    """Slice every per-ray tensor of a pipeline input list along dim 0 for this rank."""
+    if world is None:
+        world, rank = world_rank()
+    n = tensors[0].shape[0]
+    b, e = shard_range(n, world, rank)
+    return [t[b:e] for t in tensors]
+
+
+def barrier(device=None):
+    if is_dist():
+        if device is not None and device.type == "cuda":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not is_dist():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """All-gather ragged per-rank row blocks (the inverse of shard_rays) - used to assemble a frame
+    rendered cooperatively by several ranks (196 KiB of RGB per 128x128 frame)."""
+    if not is_dist():
+        return local
+    world, rank = world_rank()
+    sizes = [shard_range(n_total, world, r) for r in range(world)]
+    maxn = max(e - b for b, e in sizes)
+    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[: e - b] for o, (b, e) in zip(outs, sizes)], 0)
+
+
+def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
+    """In-place mean over ranks of the flat gradient buffer (1 220 872 fp32 = 4.88 MB for nerf): the
+    one collective of a data-parallel training step.  A single bucket: at this size a ring over xGMI
+    is latency-bound, so splitting it only adds launches."""
+    if is_dist():
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad.div_(dist.get_world_size())
+    return flat_grad

@@ -1,0 +1,178 @@
+"""RenderRayNet drop-in (models/render_ray_net.py:8-61): same constructor arguments, same
+sub-module names and therefore the same state_dict keys / checkpoint files (utils.py:267-289), but
+forward() runs the fused HIP kernel instead of 13 nn.Linear calls.
+
+The nn.Linear children only hold the parameters; they are never called.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import MlpDesc, check, current_stream, ptr
+
+
+def _encoder_shape(dim: int):
+    """(L, identity) of a 3-channel encoder producing `dim` features, or None."""
+    if dim % 6 == 0:
+        return dim // 6, 0
+    if dim >= 3 and (dim - 3) % 6 == 0:
+        return (dim - 3) // 6, 1
+    return None
+
+
+class RenderRayNet(nn.Module):
+
+    def __init__(self, n_layers=8, width=256, positions_dim=60, directions_dim=24, additional_input_dim=0,
+                 skips=[4], use_directional_input=1):
+        super(RenderRayNet, self).__init__()
+        self.n_layers = n_layers
+        self.width = width
+        self.positions_dim = positions_dim
+        self.direcions_dim = directions_dim  # (sic) attribute name of the reference, :14
+        self.skips = skips
+        self.additional_input_dim = additional_input_dim
+        self.use_directional_input = use_directional_input
+
+        self.positions_pose_input = torch.nn.Linear(positions_dim + additional_input_dim, width)
+        self.positional_net = nn.ModuleList()
+        for i in range(self.n_layers - 1):
+            if i in skips:
+                self.positional_net.append(torch.nn.Linear(width + positions_dim + additional_input_dim, width))
+            else:
+                self.positional_net.append(torch.nn.Linear(width, width))
+        self.additional_linear_layer = torch.nn.Linear(width, width)
+        self.sigma_out_layer = torch.nn.Linear(width, 1)
+        directional_width = width // 2
+        if use_directional_input:
+            self.directional_input = torch.nn.Linear(width + directions_dim, directional_width)
+        else:
+            self.directional_input = torch.nn.Linear(width, directional_width)
+        self.directional_net = nn.ModuleList()
+        for i in range(1):
+            self.directional_net.append(torch.nn.Linear(directional_width, directional_width))
+        self.rgb_out_layer = torch.nn.Linear(directional_width, 3)
+        self._pack_cache = {}
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _ordered_params(self):
+        """Weights and biases in registration (= state_dict) order, which is the order the C-ABI's
+        flat parameter vector uses (include/smplnerf.h: snerf_mlp_param_floats)."""
+        mods = [self.positions_pose_input] + list(self.positional_net) + [
+            self.additional_linear_layer, self.sigma_out_layer, self.directional_input] + list(
+            self.directional_net) + [self.rgb_out_layer]
+        out = []
+        for m in mods:
+            out += [m.weight, m.bias]
+        return out
+
+    def _skip_mask(self) -> int:
+        mask = 0
+        for i in self.skips:
+            if 0 <= i < self.n_layers - 1:
+                mask |= 1 << i
+        return mask
+
+    def make_desc(self, pos_L, pos_id, dir_L, dir_id, add_dim) -> MlpDesc:
+        return MlpDesc(self.n_layers, self.width, pos_L, pos_id, dir_L, dir_id, add_dim, self._skip_mask(),
+                       1 if self.use_directional_input else 0)
+
+    def desc_for_encoders(self, position_encoder, direction_encoder) -> MlpDesc:
+        """Descriptor of the fused (encode + MLP) path; checks that the encoders produce what this net
+        was built for (train.py:102-107: positions_dim = 3 * encoder.output_dim)."""
+        pos_L, pos_id = position_encoder.number_frequencies, 1 if position_encoder.include_identity else 0
+        dir_L, dir_id = direction_encoder.number_frequencies, 1 if direction_encoder.include_identity else 0
+        if 3 * (pos_id + 2 * pos_L) != self.positions_dim or 3 * (dir_id + 2 * dir_L) != self.direcions_dim:
+            raise RuntimeError("RenderRayNet: encoder output sizes do not match positions_dim/directions_dim")
+        return self.make_desc(pos_L, pos_id, dir_L, dir_id, self.additional_input_dim)
+
+    def desc_for_encoded(self) -> MlpDesc:
+        """Descriptor for forward(x) on already-encoded rows: any slot assignment of the position
+        columns is valid there, so an encoder-shaped one is used when positions_dim allows it and
+        plain columns otherwise."""
+        d = _encoder_shape(self.direcions_dim) if self.use_directional_input else (0, 0)
+        if d is None:
+            raise RuntimeError(f"RenderRayNet: directions_dim={self.direcions_dim} is not a 3-channel encoding")
+        p = _encoder_shape(self.positions_dim)
+        if p is None:
+            return self.make_desc(0, 0, d[0], d[1], self.positions_dim + self.additional_input_dim)
+        return self.make_desc(p[0], p[1], d[0], d[1], self.additional_input_dim)
+
+    def packed_weights(self, desc: MlpDesc) -> torch.Tensor:
+        """MFMA-ordered weight stream for `desc`, re-packed only when a parameter changed."""
+        params = self._ordered_params()
+        dev = params[0].device
+        if not params[0].is_cuda:
+            raise RuntimeError("RenderRayNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
+        key = tuple(getattr(desc, f[0]) for f in desc._fields_)
+        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = _lib.load()
+        n_param = lib.snerf_mlp_param_floats(desc)
+        n_pack = lib.snerf_mlp_packed_floats(desc)
+        if n_param < 0 or n_pack < 0:
+            check(int(min(n_param, n_pack)), "snerf_mlp_packed_floats")
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        if flat.numel() != n_param:
+            raise RuntimeError(f"RenderRayNet: {flat.numel()} parameters but the descriptor expects {n_param}")
+        packed = torch.empty(n_pack, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(lib.snerf_mlp_pack_f32(desc, ptr(flat), ptr(packed), current_stream()), "snerf_mlp_pack_f32")
+        self._pack_cache = {key: (stamp, packed)}
+        return packed
+
+    # ------------------------------------------------------------------ forward paths
+    def forward(self, x):
+        """x [..., positions_dim + additional_input_dim + directions_dim] -> [..., 4] = [rgb | sigma]
+        (models/render_ray_net.py:42-61)."""
+        if not x.is_cuda:
+            raise RuntimeError("RenderRayNet.forward: input must be on the GPU (no CPU path)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("RenderRayNet: backward is not implemented yet; run under torch.no_grad()")
+        desc = self.desc_for_encoded()
+        packed = self.packed_weights(desc)
+        xf = x.reshape(-1, x.shape[-1]).contiguous().float()
+        n = xf.shape[0]
+        raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            check(lib.snerf_mlp_fwd_encoded_f32(desc, ptr(packed), ptr(xf), n, xf.shape[1], ptr(raw),
+                                                current_stream()), "snerf_mlp_fwd_encoded_f32")
+        return raw.reshape(x.shape[:-1] + (4,))
+
+    def forward_fused(self, positions, directions, samples_per_ray, position_encoder, direction_encoder,
+                      additional=None):
+        """Encode + MLP in one launch.  positions [n,3] (samples of a ray contiguous), directions
+        [n/samples_per_ray, 3] (per ray) or [n, 3] (per sample), un-normalised; additional: optional
+        [n/samples_per_ray, additional_input_dim].  Returns raw [n, 4]."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("RenderRayNet: backward is not implemented yet; run under torch.no_grad()")
+        desc = self.desc_for_encoders(position_encoder, direction_encoder)
+        packed = self.packed_weights(desc)
+        x = positions.reshape(-1, 3).contiguous()
+        n = x.shape[0]
+        d = directions.reshape(-1, 3).contiguous()
+        if d.shape[0] == n and samples_per_ray != 1:
+            per_sample = 1
+        else:
+            per_sample = 0
+            if d.shape[0] * samples_per_ray != n:
+                raise RuntimeError("forward_fused: directions do not match positions / samples_per_ray")
+        add = None
+        if self.additional_input_dim:
+            if additional is None:
+                raise RuntimeError("forward_fused: this net needs `additional` inputs")
+            add = additional.reshape(-1, self.additional_input_dim).contiguous()
+        raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(x.device), _lib.timed(f"mlp_fwd[n={n}]"):
+            check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n,
+                                        int(samples_per_ray), ptr(raw), current_stream()), "snerf_mlp_fwd_f32")
+        return raw
+
+    @property
+    def is_cuda(self):
+        return next(self.parameters()).is_cuda

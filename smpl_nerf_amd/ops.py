@@ -1,0 +1,213 @@
+"""Drop-in operators with the reference's names, signatures and error behaviour, running on the
+HIP library (include/smplnerf.h).  Reference counterparts:
+
+    searchsorted        torchsearchsorted/src/torchsearchsorted/searchsorted.py:20-53
+    PositionalEncoder   utils.py:114-131
+    raw2outputs         utils.py:134-191
+    sample_pdf          utils.py:194-228
+    fine_sampling       utils.py:231-264
+
+Every function takes CUDA (ROCm) fp32 tensors and launches on PyTorch's current stream.  There is
+no CPU implementation here: a CPU tensor is an error, like a missing library.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+
+def _need_cuda(name: str, t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError(f"smpl_nerf_amd: `{name}` must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"smpl_nerf_amd: `{name}` must be float32 (got {t.dtype})")
+
+
+def _no_grad_inputs(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            "smpl_nerf_amd: this op has no backward yet; call it under torch.no_grad() or detach its inputs")
+
+
+# ------------------------------------------------------------------------------------------------
+# a6 searchsorted
+# ------------------------------------------------------------------------------------------------
+def searchsorted(a: torch.Tensor, v: torch.Tensor, out: Optional[torch.LongTensor] = None,
+                 side="left") -> torch.LongTensor:
+    """Same contract as torchsearchsorted.searchsorted (searchsorted.py:20-53): 2-D `a` (sorted rows)
+    and `v`, equal row counts or one of them a single row, int64 result of shape
+    (max(rows), v.shape[1]); `out` may be supplied."""
+    assert len(a.shape) == 2, "input `a` must be 2-D."
+    assert len(v.shape) == 2, "input `v` mus(t be 2-D."
+    assert (a.shape[0] == v.shape[0] or a.shape[0] == 1 or v.shape[0] == 1), (
+        "`a` and `v` must have the same number of rows or one of them must have only one ")
+    assert a.device == v.device, "`a` and `v` must be on the same device"
+    result_shape = (max(a.shape[0], v.shape[0]), v.shape[1])
+    if out is not None:
+        assert out.device == a.device, "`out` must be on the same device as `a`"
+        assert out.dtype == torch.long, "out.dtype must be torch.long"
+        assert out.shape == result_shape, "If the output tensor is provided, its shape must be correct."
+    else:
+        out = torch.empty(result_shape, device=v.device, dtype=torch.long)
+    _need_cuda("a", a)
+    _need_cuda("v", v)
+    if not a.is_contiguous() or not v.is_contiguous() or not out.is_contiguous():
+        # the reference's CUDA wrapper asserts contiguity (searchsorted_cuda_wrapper.cpp:5-7)
+        raise RuntimeError("searchsorted: a, v and out must be contiguous")
+    lib = _lib.load()
+    with torch.cuda.device(a.device):
+        check(lib.snerf_searchsorted_f32(ptr(a), a.shape[0], a.shape[1], ptr(v), v.shape[0], v.shape[1], ptr(out),
+                                         1 if side == "left" else 0, current_stream()), "snerf_searchsorted_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 PositionalEncoder
+# ------------------------------------------------------------------------------------------------
+class PositionalEncoder:
+    """utils.py:114-131.  `output_dim` counts embedding functions per input channel exactly like the
+    reference (train.py multiplies it by 3)."""
+
+    def __init__(self, number_frequencies, include_identity):
+        self.number_frequencies = int(number_frequencies)
+        self.include_identity = include_identity
+        self.output_dim = (1 if include_identity else 0) + 2 * self.number_frequencies
+
+    def encode(self, coordinate: torch.Tensor) -> torch.Tensor:
+        _need_cuda("coordinate", coordinate)
+        _no_grad_inputs(coordinate)
+        x = coordinate.contiguous()
+        c = x.shape[-1]
+        n = x.numel() // c if c else 0
+        out = torch.empty(x.shape[:-1] + (c * self.output_dim,), device=x.device, dtype=torch.float32)
+        if out.numel() == 0:
+            return out
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            check(lib.snerf_posenc_f32(ptr(x), n, c, self.number_frequencies, 1 if self.include_identity else 0,
+                                       ptr(out), current_stream()), "snerf_posenc_f32")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# a4 raw2outputs
+# ------------------------------------------------------------------------------------------------
+def _directions_arg(samples_directions: torch.Tensor, B: int, N: int):
+    """(tensor, per_sample flag).  The pipelines pass ray directions as an expanded [B,N,3] view
+    (models/nerf_pipeline.py:30-32); a zero stride over the sample axis is consumed as [B,3]."""
+    d = samples_directions
+    if d.dim() == 2 and d.shape == (B, 3):
+        return d.contiguous(), 0
+    if d.dim() == 3 and d.shape == (B, N, 3):
+        if N == 1 or d.stride(1) == 0:
+            return d[:, 0, :].contiguous(), 0
+        return d.contiguous(), 1
+    if d.dim() == 1 and d.shape[0] == 3:
+        return d.expand(B, 3).contiguous(), 0
+    raise RuntimeError(f"raw2outputs: samples_directions of shape {tuple(d.shape)} does not match raw [B={B}, N={N}]")
+
+
+def composite(raw, z_vals, samples_directions, white_background: bool, noise=None,
+              want_weights=True, want_alpha=True):
+    B, N = z_vals.shape
+    dirs, per_sample = _directions_arg(samples_directions, B, N)
+    raw = raw.contiguous()
+    z_vals = z_vals.contiguous()
+    dev = raw.device
+    rgb = torch.empty((B, 3), device=dev, dtype=torch.float32)
+    weights = torch.empty((B, N), device=dev, dtype=torch.float32) if want_weights else None
+    alpha = torch.empty((B, N), device=dev, dtype=torch.float32) if want_alpha else None
+    if noise is not None:
+        noise = noise.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(dev), _lib.timed(f"composite_fwd[N={N}]"):
+        check(lib.snerf_composite_fwd_f32(ptr(raw), ptr(z_vals), ptr(dirs), per_sample, ptr(noise), B, N,
+                                          1 if white_background else 0, ptr(rgb), ptr(weights), ptr(alpha),
+                                          current_stream()), "snerf_composite_fwd_f32")
+    return rgb, weights, alpha
+
+
+def raw2outputs(raw: torch.Tensor, z_vals: torch.Tensor, samples_directions: torch.Tensor,
+                args) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """utils.py:134-191: returns (rgb [B,3], weights [B,N], density/alpha [B,N]).  Reads
+    args.sigma_noise_std and args.white_background; the Gaussian sigma noise is drawn here with
+    torch.normal exactly where the reference draws it (utils.py:171-173) - also in eval mode."""
+    for nm, t in (("raw", raw), ("z_vals", z_vals), ("samples_directions", samples_directions)):
+        _need_cuda(nm, t)
+    _no_grad_inputs(raw, z_vals, samples_directions)
+    noise = None
+    if z_vals.shape[-1] > 1 and args.sigma_noise_std > 0.:
+        noise = torch.normal(0, args.sigma_noise_std, raw[..., 3].shape, device=raw.device)
+    return composite(raw, z_vals, samples_directions, bool(args.white_background), noise)
+
+
+# ------------------------------------------------------------------------------------------------
+# a5 sample_pdf / fine_sampling
+# ------------------------------------------------------------------------------------------------
+_U_CACHE = {}
+
+
+def uniform_u(n: int, device) -> torch.Tensor:
+    """u = torch.linspace(0., 1., steps=n) (utils.py:206), evaluated by the same torch CPU kernel the
+    reference's CPU path uses, then kept on the device."""
+    key = (int(n), str(device))
+    u = _U_CACHE.get(key)
+    if u is None:
+        u = torch.linspace(0., 1., steps=int(n)).to(device)
+        _U_CACHE[key] = u
+    return u
+
+
+def hierarchical_samples(ray_translation, ray_direction, z_vals, weights, number_fine_samples: int,
+                         want_inds=False, want_samples=False):
+    """One launch of snerf_sample_pdf_f32 -> dict(z_fine, pts, [inds], [z_samples])."""
+    B, Nc = z_vals.shape
+    Nf = int(number_fine_samples)
+    dev = z_vals.device
+    z_vals, weights = z_vals.contiguous(), weights.contiguous()
+    o, d = ray_translation.contiguous(), ray_direction.contiguous()
+    u = uniform_u(Nf, dev)
+    z_fine = torch.empty((B, Nc + Nf), device=dev, dtype=torch.float32)
+    pts = torch.empty((B, Nc + Nf, 3), device=dev, dtype=torch.float32)
+    inds = torch.empty((B, Nf), device=dev, dtype=torch.long) if want_inds else None
+    zs = torch.empty((B, Nf), device=dev, dtype=torch.float32) if want_samples else None
+    lib = _lib.load()
+    with torch.cuda.device(dev), _lib.timed("sample_pdf"):
+        check(lib.snerf_sample_pdf_f32(ptr(z_vals), ptr(weights), ptr(u), ptr(o), ptr(d), B, Nc, Nf, ptr(inds),
+                                       ptr(zs), ptr(z_fine), ptr(pts), current_stream()), "snerf_sample_pdf_f32")
+    return dict(z_fine=z_fine, pts=pts, inds=inds, z_samples=zs)
+
+
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, args) -> torch.Tensor:
+    """utils.py:194-228 with the reference's calling convention: bins [B,Nb] (the coarse midpoints),
+    weights [B,Nb-1] (the interior coarse weights).  Returns the Nf samples [B, Nf]."""
+    _need_cuda("bins", bins)
+    _need_cuda("weights", weights)
+    _no_grad_inputs(bins, weights)
+    B, Nb = bins.shape
+    assert weights.shape == (B, Nb - 1), "weights must have one entry less than bins"
+    Nf = int(args.number_fine_samples)
+    bins, weights = bins.contiguous(), weights.contiguous()
+    u = uniform_u(Nf, bins.device)
+    zs = torch.empty((B, Nf), device=bins.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(bins.device):
+        check(lib.snerf_sample_pdf_bins_f32(ptr(bins), ptr(weights), ptr(u), B, Nb, Nf, None, ptr(zs),
+                                            current_stream()), "snerf_sample_pdf_bins_f32")
+    return zs
+
+
+def fine_sampling(ray_translation: torch.Tensor, samples_directions: torch.Tensor, z_vals: torch.Tensor,
+                  weights: torch.Tensor, args) -> Tuple[torch.Tensor, torch.Tensor]:
+    """utils.py:231-264 -> (z_vals [B,Nc+Nf] ascending, ray_samples_fine [B,Nc+Nf,3]); the samples are
+    detached like in the reference (utils.py:260)."""
+    for nm, t in (("ray_translation", ray_translation), ("samples_directions", samples_directions),
+                  ("z_vals", z_vals), ("weights", weights)):
+        _need_cuda(nm, t)
+    r = hierarchical_samples(ray_translation.detach(), samples_directions.detach(), z_vals.detach(),
+                             weights.detach(), args.number_fine_samples)
+    return r["z_fine"], r["pts"]

@@ -1,0 +1,109 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every symbol the public header
+declares, and validates arguments before touching a device.  No GPU needed, no compute launched."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from smpl_nerf_amd import _lib, build
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "smplnerf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(snerf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(lib):
+    syms = header_symbols()
+    assert len(syms) >= 12
+    assert sorted(_lib.SIGNATURES) == syms          # the ctypes table lists exactly the header's functions
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/smplnerf.h but not exported"
+
+
+def test_version_and_error_string(lib):
+    assert lib.snerf_version() == 100
+    assert isinstance(lib.snerf_last_error_string(), bytes)
+    assert lib.snerf_device_count() >= 0
+
+
+def test_argument_validation_happens_on_the_host(lib):
+    # mismatched row counts (searchsorted.py:23-28) -> BADARG, nothing launched
+    rc = lib.snerf_searchsorted_f32(None, 3, 4, None, 2, 4, None, 0, None)
+    assert rc == -1 and b"rows" in lib.snerf_last_error_string()
+    assert lib.snerf_searchsorted_f32(None, 0, 4, None, 0, 4, None, 0, None) == 0      # empty is a no-op
+    assert lib.snerf_posenc_f32(None, 5, 0, 10, 0, None, None) == -1
+    assert lib.snerf_composite_fwd_f32(None, None, None, 0, None, 4, 0, 0, None, None, None, None) == -1
+    assert lib.snerf_sample_pdf_f32(None, None, None, None, None, 4, 2, 128, None, None, None, None, None) == -1
+    assert lib.snerf_sample_pdf_f32(None, None, None, None, None, 0, 64, 128, None, None, None, None, None) == 0
+
+
+def test_mlp_descriptor_arithmetic(lib):
+    d = _lib.MlpDesc(8, 256, 10, 0, 4, 0, 0, 1 << 4, 1)
+    assert lib.snerf_mlp_param_floats(d) == 610436        # skips=[4]
+    d0 = _lib.MlpDesc(8, 256, 10, 0, 4, 0, 0, 0, 1)
+    assert lib.snerf_mlp_param_floats(d0) == 595076       # skips=[]
+    # 151 slabs of 17 KiB + 3 pad slabs (mlp_plan.h)
+    assert lib.snerf_mlp_packed_floats(d) == (151 + 3) * 4352
+    bad = _lib.MlpDesc(8, 200, 10, 0, 4, 0, 0, 0, 1)
+    assert lib.snerf_mlp_param_floats(bad) < 0
+    assert lib.snerf_mlp_pack_f32(d, None, None, None) == -1
+
+
+def test_missing_library_is_a_hard_error(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsmplnerf_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    from smpl_nerf_amd import ops
+    a = torch.sort(torch.rand(4, 8), dim=1)[0]
+    v = torch.rand(4, 3)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.searchsorted(a, v)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.PositionalEncoder(4, 0).encode(torch.rand(5, 3))
+    with pytest.raises(AssertionError):
+        ops.searchsorted(torch.rand(3, 4), torch.rand(2, 4))       # reference's shape assert
+
+
+def test_directions_argument_views():
+    import torch
+    from smpl_nerf_amd import ops
+    d = torch.rand(5, 3)
+    t, per = ops._directions_arg(d[:, None, :].expand(5, 7, 3), 5, 7)
+    assert per == 0 and t.shape == (5, 3) and torch.equal(t, d)
+    t, per = ops._directions_arg(torch.rand(5, 7, 3), 5, 7)
+    assert per == 1 and t.shape == (5, 7, 3)
+    t, per = ops._directions_arg(d, 5, 7)
+    assert per == 0
+
+
+def test_render_ray_net_state_dict_contract():
+    """Checkpoints written by the reference (utils.py:282-283) must load: same keys, same shapes."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd import synthetic as syn
+    net = RenderRayNet(8, 256, 60, 24, skips=[4])
+    sd = net.state_dict()
+    expect = []
+    for name, fo, fi in syn.render_ray_net_shapes(skips=(4,)):
+        expect += [(name + ".weight", (fo, fi)), (name + ".bias", (fo,))]
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == expect
+    assert sum(v.numel() for v in sd.values()) == 610436
+    d = net.desc_for_encoded()
+    assert (d.pos_freqs, d.pos_identity, d.dir_freqs, d.dir_identity, d.add_dim, d.skip_mask) == (10, 0, 4, 0, 0, 16)
+    odd = RenderRayNet(4, 128, 5, 24, additional_input_dim=2, skips=[1])
+    d = odd.desc_for_encoded()
+    assert (d.pos_freqs, d.add_dim) == (0, 7)

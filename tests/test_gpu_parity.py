@@ -1,0 +1,394 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the drop-in Python mirror) against the CPU
+oracle on the same seeded inputs and against the golden vectors captured from the reference.
+
+Tolerances (written next to each assert):
+  * integer / index outputs: bit-exact;
+  * sampler floats: bit-exact against the oracle (same fp64-sum / fp32-op contract);
+  * fp32 elementwise + reductions: a few ulp;
+  * rendered RGB: 1e-4 absolute, PSNR 0.01 dB (BASELINE.json north_star).
+"""
+from itertools import product
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from smpl_nerf_amd import synthetic as syn
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from smpl_nerf_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+# ------------------------------------------------------------------------------------------ a6
+@pytest.mark.parametrize("Ba,Bv,A,V,side", list(product([1, 100, 200], [1, 100, 200], [1, 50, 500], [1, 12, 120],
+                                                        ["left", "right"])))
+def test_searchsorted_reference_grid(dev, Ba, Bv, A, V, side):
+    """The reference's own test grid (torchsearchsorted/test/test_searchsorted.py:27-44)."""
+    from smpl_nerf_amd.ops import searchsorted
+    if Ba > 1 and Bv > 1 and Ba != Bv:
+        pytest.skip("skipped by the reference too")
+    rng = np.random.default_rng(Ba + 3 * Bv + 5 * A + 7 * V)
+    for _ in range(4):
+        a = np.sort(rng.random((Ba, A), dtype=F32), axis=1)
+        v = rng.random((Bv, V), dtype=F32)
+        out = searchsorted(T(a, dev), T(v, dev), side=side)
+        assert out.dtype == torch.long
+        np.testing.assert_array_equal(N(out), O.searchsorted(a, v, side))
+
+
+def test_searchsorted_out_argument_and_goldens(dev):
+    from smpl_nerf_amd.ops import searchsorted
+    g = load_golden("g_searchsorted.npz")
+    for side in ("left", "right"):
+        np.testing.assert_array_equal(N(searchsorted(T(g["a"], dev), T(g["v"], dev), side=side)), g[f"out_{side}"])
+        out = torch.empty((7, 33), dtype=torch.long, device=dev)
+        r = searchsorted(T(g["a2"], dev), T(g["v2"], dev), out, side=side)
+        assert r is out
+        np.testing.assert_array_equal(N(out), g[f"out2_{side}"])
+    g4 = load_golden("g4_sampler.npz")
+    np.testing.assert_array_equal(N(searchsorted(T(g4["cdf"], dev), T(g4["u"], dev), side="right")), g4["inds"])
+    np.testing.assert_array_equal(N(searchsorted(T(g4["cdf"], dev), T(g4["u"][:1], dev), side="right")), g4["inds"])
+
+
+def test_searchsorted_large_shapes(dev):
+    """README benchmark shape class (50000x300 / 50000x1000) scaled to seconds, plus the long-row path."""
+    from smpl_nerf_amd.ops import searchsorted
+    rng = np.random.default_rng(0)
+    a = np.sort(rng.random((5000, 300), dtype=F32), axis=1)
+    v = rng.random((5000, 100), dtype=F32)
+    np.testing.assert_array_equal(N(searchsorted(T(a, dev), T(v, dev), side="left")), O._searchsorted_rows(a, v, "left"))
+    a = np.sort(rng.random((3, 20000), dtype=F32), axis=1)           # > LDS budget -> global bisection
+    v = rng.random((3, 1000), dtype=F32)
+    v[:, :10] = a[:, 5:15]
+    for side in ("left", "right"):
+        np.testing.assert_array_equal(N(searchsorted(T(a, dev), T(v, dev), side=side)), O.searchsorted(a, v, side))
+    # size-independent property at NeRF frame size: result is the insertion point
+    B = 16384
+    cdf = np.sort(rng.random((B, 63), dtype=F32), axis=1)
+    u = np.broadcast_to(O.linspace01(128), (B, 128)).copy()
+    inds = N(searchsorted(T(cdf, dev), T(u, dev), side="right"))
+    lo = np.take_along_axis(np.concatenate([np.full((B, 1), -np.inf, F32), cdf], 1), inds, 1)
+    hi = np.take_along_axis(np.concatenate([cdf, np.full((B, 1), np.inf, F32)], 1), inds, 1)
+    assert np.all(lo <= u) and np.all(u < hi)
+
+
+# ------------------------------------------------------------------------------------------ a1
+@pytest.mark.parametrize("L,ident", [(10, 0), (4, 0), (10, 1), (4, 1), (0, 1)])
+def test_posenc(dev, L, ident):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    g = load_golden("g1_posenc.npz")
+    enc = PositionalEncoder(L, ident)
+    assert enc.output_dim == O.PositionalEncoder(L, ident).output_dim
+    out = N(enc.encode(T(g["x"], dev)))
+    assert out.shape == g[f"enc_L{L}_id{ident}"].shape
+    assert maxabs(out, g[f"enc_L{L}_id{ident}"]) <= 4e-7        # sin/cos at |arg| <= 2e3: <= 2 ulp of 1 each side
+    x = np.random.default_rng(3).uniform(-4, 4, (1000, 77, 3)).astype(F32)   # ragged vs the 64-point tile
+    out = N(enc.encode(T(x, dev)))
+    assert maxabs(out, O.PositionalEncoder(L, ident).encode(x)) <= 4e-7
+
+
+def test_posenc_pose_channels(dev):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    g = load_golden("g1_posenc.npz")
+    assert maxabs(N(PositionalEncoder(10, 0).encode(T(g["pose2"], dev))), g["pose2_enc_L10_id0"]) <= 4e-7
+
+
+# ------------------------------------------------------------------------------------------ a4
+@pytest.mark.parametrize("Ns", [1, 2, 64, 192, 100])
+@pytest.mark.parametrize("wb", [0, 1])
+@pytest.mark.parametrize("mode", ["ray", "smp"])
+def test_raw2outputs(dev, Ns, wb, mode):
+    from smpl_nerf_amd.ops import raw2outputs
+    if Ns == 1 and mode == "smp":
+        pytest.skip("N==1 ignores directions")
+    g = load_golden("g3_raw2outputs.npz")
+    raw, z = g[f"raw_N{Ns}"], g[f"z_N{Ns}"]
+    B = raw.shape[0]
+    if mode == "ray":
+        d = T(g[f"dray_N{Ns}"], dev)[:, None, :].expand(B, Ns, 3)        # the pipeline's expanded view
+    else:
+        d = T(g[f"dsmp_N{Ns}"], dev)
+    args = O.Args(white_background=wb)
+    rgb, w, a = raw2outputs(T(raw, dev), T(z, dev), d, args)
+    dn = np.broadcast_to(g[f"dray_N{Ns}"][:, None, :], (B, Ns, 3)) if mode == "ray" else g[f"dsmp_N{Ns}"]
+    orgb, ow, oa = O.raw2outputs(raw, z, dn, wb)
+    for got, orc, gold, tol in ((rgb, orgb, g[f"rgb_N{Ns}_wb{wb}_{mode}"], 1e-6),
+                                (w, ow, g[f"weights_N{Ns}_wb{wb}_{mode}"], 5e-7),
+                                (a, oa, g[f"alpha_N{Ns}_wb{wb}_{mode}"], 5e-7)):
+        assert tuple(got.shape) == gold.shape
+        assert maxabs(N(got), orc) <= tol        # vs oracle
+        assert maxabs(N(got), gold) <= tol       # vs reference
+
+
+def test_raw2outputs_noise(dev):
+    from smpl_nerf_amd import ops
+    g = load_golden("g3_raw2outputs.npz")
+    rgb, w, a = ops.composite(T(g["raw_N64"], dev), T(g["z_N64"], dev), T(g["dray_N64"], dev), False,
+                              T(g["noise_N64"], dev))
+    assert maxabs(N(rgb), g["rgb_N64_noise"]) <= 1e-6
+    assert maxabs(N(w), g["weights_N64_noise"]) <= 5e-7
+    # sigma_noise_std > 0 draws noise (utils.py:171-173): result must differ from the noiseless one
+    args = O.Args(sigma_noise_std=1.0)
+    torch.manual_seed(0)
+    rgb_n, _, _ = ops.raw2outputs(T(g["raw_N64"], dev), T(g["z_N64"], dev), T(g["dray_N64"], dev), args)
+    assert maxabs(N(rgb_n), g["rgb_N64_wb0_ray"]) > 1e-4
+
+
+def test_composite_frame_size_properties(dev):
+    """Full 128x128 frame (16384 rays x 192): weights are a sub-probability vector, alpha in [0,1],
+    white background completes rgb to 1 - linearity in the colours."""
+    from smpl_nerf_amd import ops
+    rng = np.random.default_rng(5)
+    B, Ns = 16384, 192
+    raw = rng.normal(0, 2, (B, Ns, 4)).astype(F32)
+    z = np.sort(rng.uniform(1, 4, (B, Ns)).astype(F32), -1)
+    d = rng.normal(size=(B, 3)).astype(F32)
+    rgb, w, a = ops.composite(T(raw, dev), T(z, dev), T(d, dev), False)
+    rgb_w, _, _ = ops.composite(T(raw, dev), T(z, dev), T(d, dev), True)
+    w, a, rgb, rgb_w = N(w), N(a), N(rgb), N(rgb_w)
+    assert np.all(a >= 0) and np.all(a <= 1) and np.all(w >= 0)
+    acc = w.sum(-1, dtype=np.float64)
+    assert np.all(acc <= 1 + 1e-5)
+    np.testing.assert_allclose(rgb_w - rgb, np.broadcast_to((1 - acc)[:, None], (B, 3)), atol=2e-6)
+    sub = slice(0, 512)
+    orgb, ow, _ = O.raw2outputs(raw[sub], z[sub], np.broadcast_to(d[sub, None, :], (512, Ns, 3)), 0)
+    assert maxabs(rgb[sub], orgb) <= 1e-6 and maxabs(w[sub], ow) <= 5e-7
+
+
+# ------------------------------------------------------------------------------------------ a5
+def _check_sampler(dev, o, d, z, w, nf, u=None):
+    from smpl_nerf_amd import ops
+    if u is not None:
+        ops._U_CACHE[(nf, str(dev))] = T(u, dev)
+    try:
+        r = ops.hierarchical_samples(T(o, dev), T(d, dev), T(z, dev), T(w, dev), nf, want_inds=True, want_samples=True)
+    finally:
+        ops._U_CACHE.pop((nf, str(dev)), None)
+    uu = N(ops.uniform_u(nf, dev)) if u is None else u
+    z_mid = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
+    det = O.sample_pdf_detail(z_mid, w[:, 1:-1], nf, u=uu)
+    zf, pts = O.fine_sampling(o, d, z, w, nf, u=uu)
+    np.testing.assert_array_equal(N(r["inds"]), det["inds"])             # bit-exact indices
+    np.testing.assert_array_equal(N(r["z_samples"]), det["samples"])     # bit-exact fp32
+    np.testing.assert_array_equal(N(r["z_fine"]), zf)
+    np.testing.assert_array_equal(N(r["pts"]), pts)
+    return r
+
+
+def test_sampler_golden_inputs(dev):
+    g = load_golden("g4_sampler.npz")
+    r = _check_sampler(dev, g["o"], g["d"], g["z"], g["w"], 128, u=g["u"][0])
+    # and against the reference's own outputs, up to its sensitivity to the 1-ulp normalising sum
+    assert np.mean(N(r["inds"]) != g["inds"]) <= 5e-3
+    assert np.mean(np.abs(N(r["z_fine"]) - g["z_fine"]) > 5e-6) <= 5e-3
+    assert np.mean(np.abs(N(r["pts"]) - g["pts_fine"]) > 2e-5) <= 5e-3
+
+
+@pytest.mark.parametrize("nc,nf", [(16, 8), (32, 64), (64, 64), (48, 200), (3, 1), (200, 700)])
+def test_sampler_shapes(dev, nc, nf):
+    rng = np.random.default_rng(nc * 1000 + nf)
+    B = 301                                                              # ragged vs 4 rays per workgroup
+    o, d = syn.camera_rays(20, 20, syn.sphere_pose(10, 20, 2.4))
+    sel = rng.choice(o.shape[0], B, replace=False)
+    _, oo, dd, zz = syn.coarse_samples(o[sel], d[sel], 1.6, 3.1, nc, rng.random(B))
+    ww = (rng.random((B, nc)).astype(F32) ** 3)
+    ww[0] = 0
+    ww[1] = 1
+    _check_sampler(dev, oo, dd, zz, ww, nf)
+
+
+def test_sampler_unsorted_input_falls_back_to_exact_sort(dev):
+    rng = np.random.default_rng(11)
+    B, nc, nf = 64, 64, 128
+    z = rng.uniform(1, 4, (B, nc)).astype(F32)                           # NOT sorted
+    z[::2] = np.sort(z[::2], -1)
+    w = rng.random((B, nc)).astype(F32)
+    o = rng.normal(size=(B, 3)).astype(F32)
+    d = rng.normal(size=(B, 3)).astype(F32)
+    _check_sampler(dev, o, d, z, w, nf)
+
+
+def test_sample_pdf_and_fine_sampling_signatures(dev):
+    from smpl_nerf_amd import ops
+    g = load_golden("g4_sampler.npz")
+    args = O.Args(number_fine_samples=128)
+    ops._U_CACHE[(128, str(dev))] = T(g["u"][0], dev)
+    try:
+        z = g["z"]
+        z_mid = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
+        zs = ops.sample_pdf(T(z_mid, dev), T(g["w"][:, 1:-1].copy(), dev), args)
+        np.testing.assert_array_equal(N(zs), O.sample_pdf(z_mid, g["w"][:, 1:-1], 128, u=g["u"][0]))
+        zf, pts = ops.fine_sampling(T(g["o"], dev), T(g["d"], dev), T(z, dev), T(g["w"], dev), args)
+        ozf, opts = O.fine_sampling(g["o"], g["d"], z, g["w"], 128, u=g["u"][0])
+        np.testing.assert_array_equal(N(zf), ozf)
+        np.testing.assert_array_equal(N(pts), opts)
+    finally:
+        ops._U_CACHE.pop((128, str(dev)), None)
+
+
+def test_sampler_frame_size_properties(dev):
+    from smpl_nerf_amd import ops
+    rng = np.random.default_rng(2)
+    data = syn.frame_batch(128, 128, seed=3)
+    B = 16384
+    w = (rng.random((B, 64)).astype(F32) ** 6)
+    r = ops.hierarchical_samples(T(data[1], dev), T(data[2], dev), T(data[3], dev), T(w, dev), 128, want_samples=True)
+    zf, pts, zs = N(r["z_fine"]), N(r["pts"]), N(r["z_samples"])
+    assert np.all(np.diff(zf, axis=-1) >= 0)                             # sortedness
+    both = np.sort(np.concatenate([data[3], zs], -1), -1)
+    np.testing.assert_array_equal(zf, both)                              # a permutation of cat(z, samples)
+    np.testing.assert_array_equal(pts, data[1][:, None, :] + data[2][:, None, :] * zf[..., None])
+    assert np.all(zs >= data[3][:, :1]) and np.all(zs <= data[3][:, -1:])
+
+
+# ------------------------------------------------------------------------------------------ a2
+def _net(dev, params, **kw):
+    from smpl_nerf_amd.nets import RenderRayNet
+    net = RenderRayNet(n_layers=kw.get("n_layers", 8), width=kw.get("width", 256), positions_dim=60,
+                       directions_dim=24, additional_input_dim=kw.get("additional_input_dim", 0),
+                       skips=list(kw.get("skips", (4,))), use_directional_input=kw.get("use_directional_input", 1))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    return net.to(dev)
+
+
+@pytest.mark.parametrize("tag,kw,seed", [("skip4", dict(skips=(4,)), 11), ("noskip", dict(skips=()), 12),
+                                         ("d4w128", dict(n_layers=4, width=128, skips=(1,)), 13)])
+def test_render_ray_net_encoded_and_fused(dev, tag, kw, seed):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    g = load_golden("g2_mlp.npz")
+    params = syn.make_render_ray_net_params(seed, sigma_scale=30.0, rgb_scale=10.0, **kw)
+    net = _net(dev, params, **kw)
+    ref = g[f"raw_{tag}"]
+    tol = 4e-6 * max(1.0, float(np.max(np.abs(ref))))                   # fp32 round-off of a 10-layer chain
+    with torch.no_grad():
+        out = N(net(T(g["inputs"], dev)))                               # RenderRayNet.forward(x_enc)
+        assert out.shape == ref.shape
+        assert maxabs(out, ref) <= tol
+        fused = N(net.forward_fused(T(g["pts"], dev), T(g["dirs"], dev), 1, PositionalEncoder(10, 0),
+                                    PositionalEncoder(4, 0)))
+        assert maxabs(fused, ref) <= 4 * tol                            # + sin/cos ulps through 2^9 frequencies
+    fkw = {k: v for k, v in kw.items() if k != "width"}
+    assert maxabs(out, O.render_ray_net_forward(params, g["inputs"], **fkw)) <= tol
+
+
+def test_render_ray_net_additional_input_and_no_direction(dev):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    g = load_golden("g2_mlp.npz")
+    pe, de = O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0)
+    params = syn.make_render_ray_net_params(14, 30.0, 10.0, additional_input_dim=6, skips=(4,))
+    net = _net(dev, params, additional_input_dim=6, skips=(4,))
+    x = np.concatenate([pe.encode(g["pts"]), g["add6"], de.encode(g["dirs"])], -1)
+    with torch.no_grad():
+        assert maxabs(N(net(T(x, dev))), g["raw_add6"]) <= 1e-4
+        fused = net.forward_fused(T(g["pts"], dev), T(g["dirs"], dev), 1, PositionalEncoder(10, 0),
+                                  PositionalEncoder(4, 0), additional=T(g["add6"], dev))
+        assert maxabs(N(fused), g["raw_add6"]) <= 4e-4
+    params = syn.make_render_ray_net_params(15, 30.0, 10.0, skips=(4,), use_directional_input=0)
+    net = _net(dev, params, skips=(4,), use_directional_input=0)
+    with torch.no_grad():
+        assert maxabs(N(net(T(g["inputs"], dev))), g["raw_nodir"]) <= 1e-4
+
+
+def test_render_ray_net_ragged_and_ray_broadcast(dev):
+    """n not a multiple of the 64-sample workgroup tile; per-ray directions broadcast over samples."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(8)
+    params = syn.make_render_ray_net_params(31, 30.0, 10.0, skips=(4,))
+    net = _net(dev, params)
+    B, Ns = 37, 5
+    pts = rng.uniform(-2, 2, (B, Ns, 3)).astype(F32)
+    dray = rng.normal(size=(B, 3)).astype(F32)
+    pe, de = O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0)
+    dn = O._normalize(np.broadcast_to(dray[:, None, :], (B, Ns, 3)))
+    x = np.concatenate([pe.encode(pts), de.encode(dn)], -1).reshape(B * Ns, -1)
+    ref = O.render_ray_net_forward(params, x)
+    with torch.no_grad():
+        out = net.forward_fused(T(pts, dev), T(dray, dev), Ns, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    assert maxabs(N(out), ref) <= 2e-5 * max(1.0, float(np.max(np.abs(ref))))
+    # weights updated in place -> the packed stream must be rebuilt
+    with torch.no_grad():
+        net.rgb_out_layer.bias.add_(1.0)
+        out2 = net.forward_fused(T(pts, dev), T(dray, dev), Ns, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    np.testing.assert_allclose(N(out2)[:, :3], N(out)[:, :3] + 1.0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ a3
+def _pipeline(dev, wb=0, run_fine=1):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline
+    pc = syn.make_render_ray_net_params(101, 30.0, 10.0, skips=(4,))
+    pf = syn.make_render_ray_net_params(102, 30.0, 10.0, skips=(4,))
+    args = O.Args(white_background=wb, run_fine=run_fine)
+    return NerfPipeline(_net(dev, pc), _net(dev, pf), args, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+
+
+def psnr(img, gt):
+    return O.mse2psnr_img(np.mean((np.asarray(img, np.float64) - gt) ** 2))
+
+
+@pytest.mark.parametrize("tag,near,far,wb", [("nf14", 1.0, 4.0, 0), ("nf1631wb", 1.6, 3.1, 1)])
+def test_nerf_pipeline_full_frame_vs_reference(dev, tag, near, far, wb):
+    """BASELINE config 2: 128x128 frame, 64 coarse + 128 fine samples, netdepth 8 - against the frame
+    the reference itself rendered on CPU (tests/golden/g5)."""
+    g = load_golden("g5_nerf_pipeline.npz")
+    pipe = _pipeline(dev, wb=wb)
+    data = syn.frame_batch(128, 128, phi=0.0, theta=0.0, seed=7, near=near, far=far)
+    with torch.no_grad():
+        rgb, rgb_fine, pts_fine, alpha_fine = pipe([T(a, dev) for a in data])
+    rgb, rgb_fine, pts_fine, alpha_fine = N(rgb), N(rgb_fine), N(pts_fine), N(alpha_fine)
+    assert rgb.shape == (16384, 3) and pts_fine.shape == (16384, 192, 3) and alpha_fine.shape == (16384, 192)
+    assert maxabs(rgb, g[f"rgb_{tag}"]) <= 1e-4                          # coarse frame
+    assert maxabs(rgb_fine, g[f"rgb_fine_{tag}"]) <= 1e-4                # fine frame: north_star tolerance
+    gt = data[4]
+    assert abs(psnr(rgb_fine, gt) - psnr(g[f"rgb_fine_{tag}"], gt)) <= 0.01      # dB
+    assert psnr(rgb_fine, g[f"rgb_fine_{tag}"].astype(np.float64)) > 90.0
+    sub = g[f"sub_{tag}"]
+    assert np.mean(np.abs(pts_fine[sub] - g[f"pts_fine_sub_{tag}"]) > 1e-4) <= 0.02   # fp32 noise floor (H2)
+    assert np.mean(np.abs(alpha_fine[sub] - g[f"alpha_fine_sub_{tag}"]) > 1e-3) <= 0.02
+
+
+def test_nerf_pipeline_coarse_only_and_oracle(dev):
+    g = load_golden("g5_nerf_pipeline.npz")
+    data = syn.frame_batch(128, 128, phi=0.0, theta=0.0, seed=7, near=1.0, far=4.0)
+    sub = g["sub_nf14"]
+    pipe = _pipeline(dev, run_fine=0)
+    with torch.no_grad():
+        out = pipe([T(a[sub], dev) for a in data])
+    assert out[0] is out[1]                                             # quirk Q10
+    assert maxabs(N(out[0]), g["coarse_only_rgb"]) <= 1e-5
+    assert maxabs(N(out[3]), g["coarse_only_alpha"]) <= 1e-5
+    assert tuple(out[2].shape) == (256, 64, 3)
+    # full pipeline against the oracle on the same subset
+    pipe = _pipeline(dev)
+    pc = syn.make_render_ray_net_params(101, 30.0, 10.0, skips=(4,))
+    pf = syn.make_render_ray_net_params(102, 30.0, 10.0, skips=(4,))
+    with torch.no_grad():
+        got = pipe([T(a[sub], dev) for a in data])
+    from smpl_nerf_amd.ops import uniform_u
+    args = O.Args(u=N(uniform_u(128, dev)))
+    ref = O.nerf_pipeline_forward(pc, pf, args, O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0),
+                                  [a[sub] for a in data])
+    assert maxabs(N(got[0]), ref[0]) <= 1e-5
+    assert maxabs(N(got[1]), ref[1]) <= 1e-4
