@@ -36,7 +36,7 @@ def build_pipeline(dev):
     from smpl_nerf_amd.pipelines import NerfPipeline
     from oracle.nerf_oracle import Args  # plain namespace only (no compute)
 
-    params = [syn.make_render_ray_net_params(s, 30.0, 10.0, skips=(4,)) for s in (101, 102)]
+    params = list(syn.make_scene_nets(101))
     nets = []
     for p in params:
         m = RenderRayNet(8, 256, 60, 24, skips=[4])

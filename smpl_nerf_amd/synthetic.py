@@ -125,6 +125,75 @@ def make_render_ray_net_params(seed: int, sigma_scale: float = 1.0, rgb_scale: f
     return params
 
 
+def _probe_trunk(params, pts, dirs, n_layers=8, skips=(4,), pos_L=10, dir_L=4):
+    """Plain numpy evaluation of a RenderRayNet up to the two head inputs (used only to calibrate
+    the synthetic scene below; fp64, not a reference for anything)."""
+    def enc(x, L):
+        out = []
+        for k in range(L):
+            out += [np.sin(x * 2.0 ** k), np.cos(x * 2.0 ** k)]
+        return np.concatenate(out, -1)
+    P = {k: v.astype(np.float64) for k, v in params.items()}
+    pe, de = enc(pts.astype(np.float64), pos_L), enc(dirs.astype(np.float64), dir_L)
+    lin = lambda x, n: x @ P[n + ".weight"].T + P[n + ".bias"]
+    o = np.maximum(lin(pe, "positions_pose_input"), 0)
+    for i in range(n_layers - 1):
+        o = np.maximum(lin(np.concatenate([o, pe], -1) if i in skips else o, f"positional_net.{i}"), 0)
+    o = lin(o, "additional_linear_layer")
+    h = lin(np.concatenate([o, de], -1), "directional_input")
+    h = np.maximum(lin(h, "directional_net.0"), 0)
+    return o, h
+
+
+def make_scene_net_params(seed: int, sigma_std: float = 10.0, rgb_std: float = 1.5, gamma: float = 0.7,
+                          **net_kw) -> dict:
+    """A random-init RenderRayNet turned into a well-conditioned synthetic scene:
+
+    * the weight columns that read positional-encoding band k are damped by 2^(-gamma*k), so the
+      field is spatially smooth at the sample spacing (an undamped random init is white noise in
+      space: there even the reference's own fp32 and fp64 renderings differ by 6e-2, while a trained
+      NeRF - and this scene - sit at the 1e-6 fp32 round-off floor);
+    * the two heads are rescaled and re-centred so that over the camera frustum sigma ~ (0, sigma_std)
+      and the colour logits ~ (0, rgb_std): a semi-transparent volume with non-trivial compositing
+      weights (an untouched random init predicts a constant, usually negative sigma: an empty scene).
+    """
+    layers = render_ray_net_shapes(**net_kw)
+    params = init_linear_stack(layers, seed)
+    pos_dim = net_kw.get("positions_dim", 60)
+    width = net_kw.get("width", 256)
+    L = pos_dim // 6
+    scale = np.repeat(2.0 ** (-gamma * np.arange(L)), 6).astype(F32)
+    params["positions_pose_input.weight"][:, :pos_dim] *= scale
+    for i in net_kw.get("skips", (4,)):
+        params[f"positional_net.{i}.weight"][:, width:width + pos_dim] *= scale
+    rng = np.random.default_rng(seed + 7919)
+    pts = rng.uniform(-2.5, 2.5, (2048, 3))
+    dirs = rng.normal(size=(2048, 3))
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    o, h = _probe_trunk(params, pts, dirs, n_layers=net_kw.get("n_layers", 8), skips=net_kw.get("skips", (4,)))
+    w = params["sigma_out_layer.weight"].astype(np.float64)
+    s = o @ w.T
+    sc = sigma_std / s.std()
+    params["sigma_out_layer.weight"] = (w * sc).astype(F32)
+    params["sigma_out_layer.bias"] = np.asarray(-s.mean(0) * sc, F32)
+    w = params["rgb_out_layer.weight"].astype(np.float64)
+    c = h @ w.T
+    sc = rgb_std / c.std(0)
+    params["rgb_out_layer.weight"] = (w * sc[:, None]).astype(F32)
+    params["rgb_out_layer.bias"] = np.asarray(-c.mean(0) * sc, F32)
+    return params
+
+
+def make_scene_nets(seed: int, eps: float = 0.01, **kw):
+    """(coarse, fine) parameters of ONE scene: the fine net is the coarse net with a 1 % relative
+    perturbation of every weight, the way a trained coarse/fine pair describes the same volume (with
+    two unrelated random fields the hierarchical samples would land in arbitrary fine densities)."""
+    coarse = make_scene_net_params(seed, **kw)
+    rng = np.random.default_rng(seed + 104729)
+    fine = {k: (v * (1.0 + eps * rng.standard_normal(v.shape))).astype(F32) for k, v in coarse.items()}
+    return coarse, fine
+
+
 def make_warp_field_params(seed: int, positions_dim=60, pose_dim=40, width=256, out_scale=1.0) -> dict:
     """WarpFieldNet: linear1 (width, positions_dim+pose_dim), linear2 (3, width) (models/warp_field_net.py:14-15)."""
     params = init_linear_stack([("linear1", width, positions_dim + pose_dim), ("linear2", 3, width)], seed)

@@ -121,6 +121,9 @@ def main():
         net = load_params(RenderRayNet(n_layers=kw.get("n_layers", 8), width=kw.get("width", 256),
                                        positions_dim=60, directions_dim=24, skips=list(kw["skips"])), params)
         g2[f"raw_{tag}"] = net(inp).numpy()
+    params = syn.make_scene_nets(101)[1]
+    net = load_params(RenderRayNet(8, 256, 60, 24, skips=[4]), params)
+    g2["raw_scene101"] = net(inp).numpy()
     # additional per-ray input (append_smpl_params style, train.py:154-159) and no-direction ablation
     add = rng.uniform(-1, 1, (160, 6)).astype(F32)
     g2["add6"] = add
@@ -211,8 +214,7 @@ def main():
     save("g_searchsorted.npz", **gs)
 
     # ---- G5 NerfPipeline.forward (models/nerf_pipeline.py:14-67), 128x128 frame ----------------
-    pc = syn.make_render_ray_net_params(101, 30.0, 10.0, skips=(4,))
-    pf = syn.make_render_ray_net_params(102, 30.0, 10.0, skips=(4,))
+    pc, pf = syn.make_scene_nets(101)
     mc = load_params(RenderRayNet(8, 256, 60, 24, skips=[4]), pc)
     mf = load_params(RenderRayNet(8, 256, 60, 24, skips=[4]), pf)
     g5 = {}
@@ -242,8 +244,8 @@ def main():
     pose_enc = U.PositionalEncoder(10, 0)
     poses = syn.human_poses((41, 38), 0, 60, 10)
     data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
-    sub = np.arange(0, 16384, 128) + (np.arange(128) % 128)
-    gp = poses[np.arange(128) % 10]
+    sub = np.arange(0, 16384, 256) + (np.arange(64) * 5 % 128)
+    gp = poses[np.arange(64) % 10]
     g6 = {"sub": sub, "goal_pose": gp}
     for wb in (0, 1):
         pipe = SmplNerfPipeline(mc, mf, mw, Args(white_background=wb), pe, de, pose_enc)

@@ -293,6 +293,18 @@ def test_render_ray_net_encoded_and_fused(dev, tag, kw, seed):
     assert maxabs(out, O.render_ray_net_forward(params, g["inputs"], **fkw)) <= tol
 
 
+def test_render_ray_net_scene_weights(dev):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    g = load_golden("g2_mlp.npz")
+    net = _net(dev, syn.make_scene_nets(101)[1])
+    with torch.no_grad():
+        ref = g["raw_scene101"]
+        tol = 4e-6 * float(np.max(np.abs(ref)))                         # fp32 round-off times the head scale
+        assert maxabs(N(net(T(g["inputs"], dev))), ref) <= tol
+        fused = net.forward_fused(T(g["pts"], dev), T(g["dirs"], dev), 1, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        assert maxabs(N(fused), ref) <= 4 * tol
+
+
 def test_render_ray_net_additional_input_and_no_direction(dev):
     from smpl_nerf_amd.ops import PositionalEncoder
     g = load_golden("g2_mlp.npz")
@@ -338,8 +350,7 @@ def test_render_ray_net_ragged_and_ray_broadcast(dev):
 def _pipeline(dev, wb=0, run_fine=1):
     from smpl_nerf_amd.ops import PositionalEncoder
     from smpl_nerf_amd.pipelines import NerfPipeline
-    pc = syn.make_render_ray_net_params(101, 30.0, 10.0, skips=(4,))
-    pf = syn.make_render_ray_net_params(102, 30.0, 10.0, skips=(4,))
+    pc, pf = syn.make_scene_nets(101)
     args = O.Args(white_background=wb, run_fine=run_fine)
     return NerfPipeline(_net(dev, pc), _net(dev, pf), args, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
 
@@ -382,8 +393,7 @@ def test_nerf_pipeline_coarse_only_and_oracle(dev):
     assert tuple(out[2].shape) == (256, 64, 3)
     # full pipeline against the oracle on the same subset
     pipe = _pipeline(dev)
-    pc = syn.make_render_ray_net_params(101, 30.0, 10.0, skips=(4,))
-    pf = syn.make_render_ray_net_params(102, 30.0, 10.0, skips=(4,))
+    pc, pf = syn.make_scene_nets(101)
     with torch.no_grad():
         got = pipe([T(a[sub], dev) for a in data])
     from smpl_nerf_amd.ops import uniform_u

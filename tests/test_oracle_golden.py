@@ -44,6 +44,14 @@ def test_render_ray_net(tag, kw, seed):
     assert maxabs(out, ref) <= 2e-6 * max(scale, 1.0)
 
 
+def test_render_ray_net_scene_weights():
+    """The calibrated scene net used by the pipeline goldens / bench (large head scales)."""
+    g = load_golden("g2_mlp.npz")
+    out = O.render_ray_net_forward(syn.make_scene_nets(101)[1], g["inputs"], skips=(4,))
+    ref = g["raw_scene101"]
+    assert maxabs(out, ref) <= 4e-6 * float(np.max(np.abs(ref)))      # fp32 round-off times the head scale
+
+
 def test_render_ray_net_additional_input_and_nodir():
     g = load_golden("g2_mlp.npz")
     pe, de = O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0)
@@ -160,8 +168,7 @@ def test_fine_sampling_shapes(nc, nf):
 
 # ---------------------------------------------------------------- a3
 def _nerf_nets():
-    return (syn.make_render_ray_net_params(101, 30.0, 10.0, skips=(4,)),
-            syn.make_render_ray_net_params(102, 30.0, 10.0, skips=(4,)))
+    return syn.make_scene_nets(101)
 
 
 @pytest.mark.parametrize("tag,near,far,wb", [("nf14", 1.0, 4.0, 0), ("nf1631wb", 1.6, 3.1, 1)])
@@ -225,7 +232,7 @@ def test_smpl_nerf_pipeline_coarse_only():
     assert maxabs(out[0], g["coarse_rgb"]) <= 1e-5
     assert maxabs(out[2], g["coarse_warp"]) <= 2e-6
     assert maxabs(out[4], g["coarse_warped"]) <= 2e-6
-    assert maxabs(out[5], g["coarse_alpha"]) <= 1e-5
+    assert maxabs(out[5], g["coarse_alpha"]) <= 5e-5   # warp round-off (2e-6) re-enters the 2^9 band of the encoder
 
 
 # ---------------------------------------------------------------- adjacent: rays / coarse samples
