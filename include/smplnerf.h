@@ -73,6 +73,13 @@ int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs,
                             const float *noise, int64_t B, int N, int white_background,
                             float *rgb, float *weights, float *alpha, snerf_stream_t stream);
 
+/* Backward of the compositing w.r.t. raw: d_rgb [B,3] -> d_raw [B,N,4] (same raw/z/dirs/noise as the
+ * forward call; autograd through utils.py:161-191).  weights/alpha are treated as outputs without
+ * gradient (the pipeline detaches what it derives from them, utils.py:260).  N <= 1024. */
+int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+                            const float *noise, int64_t B, int N, int white_background,
+                            const float *d_rgb, float *d_raw, snerf_stream_t stream);
+
 /* ---- a5: inverse-CDF hierarchical sampling + merge + point generation ------------------------------
  * z [B, Nc] coarse depths (ascending), weights [B, Nc] from compositing, u [Nf] = linspace(0,1,Nf)
  * (passed in so that the caller controls its bits, see oracle/nerf_oracle.py:linspace01),
@@ -124,6 +131,25 @@ int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *params_flat, flo
 int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                       const float *dirs, int dirs_per_sample, const float *add,
                       int64_t n, int samples_per_ray, float *raw, snerf_stream_t stream);
+
+/* ---- a2 backward (training) ------------------------------------------------------------------------
+ * Buffer sizes for n samples: activations saved by the forward, per-layer output gradients, the
+ * transposed weight stream, the split-K partial gradients (gpart_count chunks). */
+int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
+                          int64_t *packed_t_floats, int64_t *gpart_floats, int32_t *gpart_count);
+/* snerf_mlp_fwd_f32 that also saves every layer input into `act` (act_floats). */
+int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
+                            const float *dirs, int dirs_per_sample, const float *add, int64_t n,
+                            int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
+/* params_flat -> transposed weight stream for the dgrad kernel (once per weight update). */
+int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed_t,
+                         snerf_stream_t stream);
+/* d_raw [n,4] -> flat_grad (snerf_mlp_param_floats floats, state_dict order, OVERWRITTEN): what
+ * autograd leaves in .grad of the 26 parameter tensors after (raw * d_raw).sum().backward().
+ * dy, gpart: scratch (snerf_mlp_train_sizes).  Three launches: dgrad, split-K wgrad, reduce. */
+int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
+                      const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
+                      snerf_stream_t stream);
 
 /* Same network on already-encoded rows x_enc [n, row_floats] (the literal RenderRayNet.forward(x)
  * signature): positions_pose = x[:, :positions_dim+add_dim], directions = x[:, -directions_dim:]

@@ -32,12 +32,18 @@ SIGNATURES = {
     "snerf_searchsorted_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
     "snerf_posenc_f32": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P]),
     "snerf_composite_fwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "snerf_composite_bwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "snerf_sample_pdf_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "snerf_sample_pdf_bins_f32": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "snerf_mlp_param_floats": (c_int64, [POINTER(MlpDesc)]),
     "snerf_mlp_packed_floats": (c_int64, [POINTER(MlpDesc)]),
     "snerf_mlp_pack_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
     "snerf_mlp_fwd_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P]),
+    "snerf_mlp_train_sizes": (c_int, [POINTER(MlpDesc), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
+                                      POINTER(c_int64), POINTER(c_int32)]),
+    "snerf_mlp_fwd_train_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P, _P]),
+    "snerf_mlp_pack_t_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
+    "snerf_mlp_bwd_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "snerf_mlp_fwd_encoded_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int64, c_int64, _P, _P]),
 }
 

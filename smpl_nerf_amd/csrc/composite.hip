@@ -98,6 +98,105 @@ __global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
     }
 }
 
+// ---- backward: d rgb [B,3] -> d raw [B,N,4] --------------------------------------------------------
+// With c = sigmoid(raw.rgb), a = alpha, om = 1-a+1e-10, T = exclusive cumprod(om), w = a*T:
+//   d c_i  = w_i * d rgb                      d raw.rgb_i = d c_i * c_i (1 - c_i)
+//   d w_i  = <d rgb, c_i> - [white bg] sum(d rgb)
+//   d a_j  = d w_j T_j - (sum_{i>j} d w_i w_i) / om_j        (T_i depends on om_j for every i > j)
+//   d sigma_j = d a_j * dist_j * exp(-relu(sigma_j) dist_j) * [sigma_j + noise_j > 0]
+// One wave per ray: a forward sweep records the transmittance carried into every 64-sample chunk, a
+// reverse sweep recomputes each chunk and runs the suffix sum as a reverse wavefront scan (fp64).
+// HBM: raw and z are read twice (40 B/sample), d raw written once (16 B/sample).
+constexpr int CP_MAX_CHUNKS = 16;  // N <= 1024
+
+__global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
+    const float4 *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs, int dirs_per_sample,
+    const float *__restrict__ noise, int64_t B, int N, int white_bg, const float *__restrict__ d_rgb,
+    float4 *__restrict__ d_raw) {
+    __shared__ double s_carry[CP_THREADS / WAVE][CP_MAX_CHUNKS];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * (CP_THREADS / WAVE) + wave;
+    if (ray >= B) return;
+    const int64_t base = ray * N;
+    const float gr = d_rgb[ray * 3 + 0], gg = d_rgb[ray * 3 + 1], gb = d_rgb[ray * 3 + 2];
+    if (N == 1) {  // rgb = sigmoid(raw.rgb); weights/alpha are constants (utils.py:168-169)
+        if (lane == 0) {
+            const float4 r = raw[base];
+            const float cr = sigmoidf_ref(r.x), cg = sigmoidf_ref(r.y), cb = sigmoidf_ref(r.z);
+            d_raw[base] = make_float4(gr * cr * (1.f - cr), gg * cg * (1.f - cg), gb * cb * (1.f - cb), 0.f);
+        }
+        return;
+    }
+    float ray_norm = 0.f;
+    if (!dirs_per_sample) {
+        const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+        ray_norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    }
+    auto sample = [&](int i, float4 &r, float &a, float &om, float &dist, float &sig, float &ex) {
+        r = raw[base + i];
+        const float zi = z[base + i];
+        float nrm = ray_norm;
+        if (dirs_per_sample) {
+            const float *dp = dirs + (base + i) * 3;
+            nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dp[0], dp[0]), __fmul_rn(dp[1], dp[1])), __fmul_rn(dp[2], dp[2])));
+        }
+        dist = (i + 1 < N) ? __fsub_rn(z[base + i + 1], zi) : 1e10f;
+        dist = __fmul_rn(dist, nrm);
+        sig = noise ? __fadd_rn(r.w, noise[base + i]) : r.w;
+        ex = expf(__fmul_rn(-fmaxf(sig, 0.f), dist));
+        a = __fsub_rn(1.0f, ex);
+        om = __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
+    };
+    // forward sweep: transmittance carried into each chunk
+    const int nchunk = (N + WAVE - 1) / WAVE;
+    double carry = 1.0;
+    for (int c = 0; c < nchunk; ++c) {
+        if (lane == 0) s_carry[wave][c] = carry;
+        const int i = c * WAVE + lane;
+        float om = 1.0f;
+        if (i < N) {
+            float4 r;
+            float a, dist, sig, ex;
+            sample(i, r, a, om, dist, sig, ex);
+        }
+        const double incl = wave_scan_mul((double)om, lane);
+        carry *= __shfl(incl, 63, 64);
+    }
+    const float gsum = white_bg ? (gr + gg + gb) : 0.f;
+    // reverse sweep
+    double suffix = 0.0;  // sum_{i > last sample of this chunk} d w_i * w_i
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int i = c * WAVE + lane;
+        const bool ok = i < N;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        float a = 0.f, om = 1.0f, dist = 0.f, sig = 0.f, ex = 1.0f;
+        if (ok) sample(i, r, a, om, dist, sig, ex);
+        const double incl = wave_scan_mul((double)om, lane);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(s_carry[wave][c] * excl);
+        const float w = a * T;
+        const float cr = sigmoidf_ref(r.x), cg = sigmoidf_ref(r.y), cb = sigmoidf_ref(r.z);
+        const float dw = ok ? (gr * cr + gg * cg + gb * cb - gsum) : 0.f;
+        const double q = (double)dw * (double)w;
+        // exclusive reverse scan of q over the lanes + what came from the later chunks
+        double incl_rev = q;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_down(incl_rev, off, 64);
+            if (lane + off < 64) incl_rev += t;
+        }
+        const double after = incl_rev - q + suffix;
+        suffix += __shfl(incl_rev, 0, 64);
+        if (ok) {
+            const float da = dw * T - (float)(after / (double)om);
+            const float dsig = sig > 0.f ? da * dist * ex : 0.f;  // ex = exp(-relu(sigma) dist)
+            d_raw[base + i] = make_float4(w * gr * cr * (1.f - cr), w * gg * cg * (1.f - cg), w * gb * cb * (1.f - cb), dsig);
+        }
+    }
+}
+
 }  // namespace snerf
 
 extern "C" int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
@@ -116,4 +215,22 @@ extern "C" int snerf_composite_fwd_f32(const float *raw, const float *z, const f
                        reinterpret_cast<const float4 *>(raw), z, dirs, dirs_per_sample ? 1 : 0, noise, B, N,
                        white_background ? 1 : 0, rgb, weights, alpha);
     return check_launch("composite_fwd");
+}
+
+extern "C" int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+                                       const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
+                                       float *d_raw, snerf_stream_t stream) {
+    using namespace snerf;
+    if (B < 0 || N < 1 || N > WAVE * CP_MAX_CHUNKS) return fail(SNERF_E_BADARG, "composite_bwd: need 1 <= N <= 1024");
+    if (B == 0) return SNERF_OK;
+    if (!raw || !z || !d_rgb || !d_raw) return fail(SNERF_E_BADARG, "composite_bwd: null pointer");
+    if (N > 1 && !dirs) return fail(SNERF_E_BADARG, "composite_bwd: dirs is null");
+    if (!aligned(raw, 16) || !aligned(d_raw, 16)) return fail(SNERF_E_ALIGN, "composite_bwd: raw/d_raw must be 16-byte aligned");
+    const int rays_per_block = CP_THREADS / WAVE;
+    const int64_t grid = (B + rays_per_block - 1) / rays_per_block;
+    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "composite_bwd: B too large");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)grid), dim3(CP_THREADS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(raw), z, dirs, dirs_per_sample ? 1 : 0, noise, B, N,
+                       white_background ? 1 : 0, d_rgb, reinterpret_cast<float4 *>(d_raw));
+    return check_launch("composite_bwd");
 }

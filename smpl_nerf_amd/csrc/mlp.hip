@@ -20,12 +20,9 @@
 //   * positional encodings are evaluated in registers, straight into B-operand layout, with
 //     full-range sincosf (arguments reach 2^9*|x|); they are recomputed at the skip layer instead of
 //     being kept live.
-#include "snerf_common.h"
-#include "mlp_plan.h"
+#include "mlp_device.h"
 
 namespace snerf {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // weight packing: params_flat (state_dict order) -> slab stream
@@ -56,24 +53,9 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(Plan P, const float *__re
             const int l = rem >> 2, r = rem & 3;
             const int i = l & 15, g = l >> 4;
             const int row = 16 * to + i;
-            int kb = sl * kps + kbl;
+            const int kb = sl * kps + kbl;
             if (kbl < kps && kb < Ly.nkb && row < Ly.n_out) {
-                int col = -1;
-                for (int s = 0; s < Ly.nseg; ++s) {
-                    const Seg &sg = Ly.seg[s];
-                    if (kb < sg.nkb) {
-                        int c;
-                        if (sg.type == SEG_PE) {
-                            c = pe_slot_col(sg.L, sg.ident, kb, g, r);
-                        } else {
-                            c = 16 * kb + 4 * g + r;
-                            if (c >= sg.ncols) c = -1;
-                        }
-                        col = c < 0 ? -1 : sg.col_off + c;
-                        break;
-                    }
-                    kb -= sg.nkb;
-                }
+                const int col = slot_to_col(Ly, kb, g, r);
                 if (col >= 0) val = Wm[(int64_t)row * Ly.n_in + col];
             }
         } else if (sl == 0) {
@@ -84,192 +66,8 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(Plan P, const float *__re
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// forward kernel
-// ------------------------------------------------------------------------------------------------
-struct FwdArgs {
-    const float *packed;
-    const float *x;      // [n,3] positions, or x_enc [n, enc_stride] when ENCODED
-    const float *dirs;   // [n/spr,3] or [n,3]
-    const float *add;    // [n/spr, add_dim] or null
-    float *raw;          // [n,4]
-    int64_t n;
-    int spr;             // samples per ray
-    int dirs_per_sample;
-    int n_hidden;        // positional_net layers
-    unsigned skip_mask;
-    int pos_L, pos_id, pos_nkb, pos_dim;
-    int dir_L, dir_id, dir_nkb, dir_dim;
-    int add_dim, add_nkb;
-    int use_dir;
-    int enc_stride;
-};
-
-// Streams the slab sequence global -> registers -> LDS ring (3 slots).
-template <int NT>
-struct SlabPipe {
-    static constexpr int NA = SLAB_A_FLOATS / 4 / NT;  // f4 per thread in the A region (NT=256: 4, 512: 2)
-    const f4 *g;   // this thread's read cursor in the packed stream
-    float *ring;
-    f4 st[NA], st_aux;
-    int tid, rd, wr;
-
-    __device__ __forceinline__ void load() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) st[i] = g[i * NT];
-        if (tid < 64) st_aux = g[SLAB_A_FLOATS / 4];
-        g += SLAB_FLOATS / 4;
-    }
-    __device__ __forceinline__ void store(int slot) {
-        f4 *d = reinterpret_cast<f4 *>(ring + slot * SLAB_FLOATS) + tid;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) d[i * NT] = st[i];
-        if (tid < 64) d[SLAB_A_FLOATS / 4] = st_aux;
-    }
-    __device__ __forceinline__ void prologue(const float *packed, float *ring_, int tid_) {
-        ring = ring_;
-        tid = tid_;
-        g = reinterpret_cast<const f4 *>(packed) + tid;
-        load(); store(0);
-        load(); store(1);
-        load();
-        rd = 0;
-        wr = 2;
-        __syncthreads();
-    }
-    __device__ __forceinline__ const float *acquire() const { return ring + rd * SLAB_FLOATS; }
-    __device__ __forceinline__ void release() {
-        store(wr);
-        load();
-        __syncthreads();
-        rd = rd == 2 ? 0 : rd + 1;
-        wr = wr == 2 ? 0 : wr + 1;
-    }
-};
-
-// per-lane view of the sample this lane works for
-struct SampleCtx {
-    float px, py, pz;  // position
-    float dx, dy, dz;  // normalised direction
-    const float *enc;  // row of x_enc (ENCODED) or null
-    const float *add;  // row of add or null
-    int g;
-};
-
-__device__ __forceinline__ void pe_unit(float x, float y, float z, int L, int ident, int p, float &a, float &b) {
-    const int nid = ident ? 3 : 0;
-    a = 0.f;
-    b = 0.f;
-    if (p < nid) {
-        a = p == 0 ? x : (p == 1 ? y : z);
-        return;
-    }
-    const int pp = p - nid;
-    if (pp >= 3 * L) return;
-    const int k = pp / 3, c = pp - 3 * k;
-    const float v = c == 0 ? x : (c == 1 ? y : z);
-    sincosf(ldexpf(v, k), &a, &b);  // 2^k * v is exact: same argument bits as utils.py:127
-}
-
-// B operand (4 k-steps) of PE k-block kb for this lane
-template <bool ENCODED>
-__device__ __forceinline__ f4 pe_operand(const SampleCtx &c, bool is_dir, int L, int ident, int kb, int enc_off) {
-    f4 b;
-    if (ENCODED) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = pe_slot_col(L, ident, kb, c.g, r);
-            b[r] = col >= 0 ? c.enc[enc_off + col] : 0.f;
-        }
-    } else {
-        const float x = is_dir ? c.dx : c.px, y = is_dir ? c.dy : c.py, z = is_dir ? c.dz : c.pz;
-        float s0, c0, s1, c1;
-        pe_unit(x, y, z, L, ident, 4 * (2 * kb) + c.g, s0, c0);
-        pe_unit(x, y, z, L, ident, 4 * (2 * kb + 1) + c.g, s1, c1);
-        b = f4{s0, c0, s1, c1};
-    }
-    return b;
-}
-
-__device__ __forceinline__ f4 add_operand(const SampleCtx &c, int add_dim, int kb) {
-    f4 b;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int col = 16 * kb + 4 * c.g + r;
-        b[r] = col < add_dim ? c.add[col] : 0.f;
-    }
-    return b;
-}
-
-// One k-block: T_OUT x (ds_read_b128 + 4 MFMA).  Tiles are walked in pairs so that consecutive MFMAs
-// never share an accumulator (dependent latency of 16x16x4 is 40 cycles vs 32 issue).
-template <int T_OUT>
-__device__ __forceinline__ void kblock(const float *a_kb, f4 b, f4 (&acc)[T_OUT], int lane) {
-    const f4 *ap = reinterpret_cast<const f4 *>(a_kb) + lane;
-    if constexpr (T_OUT == 1) {
-        const f4 a = ap[0];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[0], 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int to = 0; to < T_OUT; to += 2) {
-            const f4 a0 = ap[to * 64], a1 = ap[(to + 1) * 64];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], b[r], acc[to], 0, 0, 0);
-                acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], b[r], acc[to + 1], 0, 0, 0);
-            }
-        }
-    }
-}
-
-// Walks the k-blocks of one layer through the slab pipe.
-template <int T_OUT, int NT>
-struct LayerRun {
-    static constexpr int KPS = 16 / T_OUT;
-    SlabPipe<NT> &pipe;
-    const float *slab;
-    int kbl;  // k-block index inside the current slab
-    int lane;
-
-    __device__ __forceinline__ LayerRun(SlabPipe<NT> &p, int lane_) : pipe(p), slab(p.acquire()), kbl(0), lane(lane_) {}
-    // bias -> accumulator init (aux block of the layer's first slab: bias[16*to + 4*g + r])
-    __device__ __forceinline__ void init(f4 (&acc)[T_OUT]) {
-        const f4 *aux = reinterpret_cast<const f4 *>(slab + SLAB_A_FLOATS) + (lane >> 4);
-#pragma unroll
-        for (int to = 0; to < T_OUT; ++to) acc[to] = aux[to * 4];
-    }
-    __device__ __forceinline__ void step(f4 b, f4 (&acc)[T_OUT]) {
-        if (kbl == KPS) {
-            pipe.release();
-            slab = pipe.acquire();
-            kbl = 0;
-        }
-        kblock<T_OUT>(slab + kbl * (T_OUT * 256), b, acc, lane);
-        ++kbl;
-    }
-    __device__ __forceinline__ void finish() { pipe.release(); }
-};
-
-template <int N>
-__device__ __forceinline__ void relu_into(f4 (&dst)[N], const f4 (&src)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        dst[i][0] = fmaxf(src[i][0], 0.f);
-        dst[i][1] = fmaxf(src[i][1], 0.f);
-        dst[i][2] = fmaxf(src[i][2], 0.f);
-        dst[i][3] = fmaxf(src[i][3], 0.f);
-    }
-}
-template <int N>
-__device__ __forceinline__ void copy_into(f4 (&dst)[N], const f4 (&src)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) dst[i] = src[i];
-}
-
-template <int WIDTH, int NWAVES, bool ENCODED>
+// TRAIN additionally stores every layer input (post-activation) for the backward kernels.
+template <int WIDTH, int NWAVES, bool ENCODED, bool TRAIN>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;   // tiles of the trunk
@@ -313,8 +111,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     f4 in[T], acc[T];
 
     // extra input segments [PE(x) | add] of layer 0 and of the skip layers
-    auto pos_segments = [&](LayerRun<T, NT> &run) {
-        for (int kb = 0; kb < A.pos_nkb; ++kb) run.step(pe_operand<ENCODED>(c, false, A.pos_L, A.pos_id, kb, 0), acc);
+    auto pos_segments = [&](LayerRun<T, NT> &run, bool first) {
+        for (int kb = 0; kb < A.pos_nkb; ++kb) {
+            const f4 b = pe_operand<ENCODED>(c, false, A.pos_L, A.pos_id, kb, 0);
+            if (TRAIN && first && valid) store_tile(A.act, A.act_pe + kb, A.n, sample, c.g, b);
+            run.step(b, acc);
+        }
         for (int kb = 0; kb < A.add_nkb; ++kb) {
             f4 b;
             if (ENCODED) {
@@ -333,18 +135,20 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     {  // positions_pose_input + relu (models/render_ray_net.py:45)
         LayerRun<T, NT> run(pipe, lane);
         run.init(acc);
-        pos_segments(run);
+        pos_segments(run, true);
         run.finish();
         relu_into(in, acc);
+        if (TRAIN && valid) store_tiles(A.act, A.act_x1, A.n, sample, c.g, in);
     }
     for (int i = 0; i < A.n_hidden; ++i) {  // positional_net[i] + relu (:46-50)
         LayerRun<T, NT> run(pipe, lane);
         run.init(acc);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], acc);
-        if ((A.skip_mask >> i) & 1u) pos_segments(run);
+        if ((A.skip_mask >> i) & 1u) pos_segments(run, false);
         run.finish();
         relu_into(in, acc);
+        if (TRAIN && valid) store_tiles(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, in);
     }
     {  // additional_linear_layer, no activation (:51)
         LayerRun<T, NT> run(pipe, lane);
@@ -353,6 +157,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], acc);
         run.finish();
         copy_into(in, acc);
+        if (TRAIN && valid) store_tiles(A.act, A.act_o, A.n, sample, c.g, in);
     }
     f4 sig[1];
     {  // sigma_out_layer (:52): one padded tile, row 0 is sigma
@@ -368,10 +173,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         run.init(accd);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], accd);
-        for (int kb = 0; kb < A.dir_nkb; ++kb)
-            run.step(pe_operand<ENCODED>(c, true, A.dir_L, A.dir_id, kb, enc_dir_off), accd);
+        for (int kb = 0; kb < A.dir_nkb; ++kb) {
+            const f4 b = pe_operand<ENCODED>(c, true, A.dir_L, A.dir_id, kb, enc_dir_off);
+            if (TRAIN && valid) store_tile(A.act, A.act_dpe + kb, A.n, sample, c.g, b);
+            run.step(b, accd);
+        }
         run.finish();
         copy_into(ind, accd);
+        if (TRAIN && valid) store_tiles(A.act, A.act_h1, A.n, sample, c.g, ind);
     }
     {  // directional_net[0] + relu (:58-59)
         LayerRun<TD, NT> run(pipe, lane);
@@ -380,6 +189,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], accd);
         run.finish();
         relu_into(ind, accd);
+        if (TRAIN && valid) store_tiles(A.act, A.act_h2, A.n, sample, c.g, ind);
     }
     f4 rgb[1];
     {  // rgb_out_layer (:60): rows 0..2
@@ -418,15 +228,15 @@ static int fill_args(const snerf_mlp_desc *desc, Plan &P, FwdArgs &A) {
 
 constexpr int FWD_WAVES = 4;  // 64 samples per workgroup; several workgroups share a CU
 
-template <bool ENCODED>
+template <bool ENCODED, bool TRAIN>
 static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     const int64_t tile = FWD_WAVES * 16;
     const int64_t grid = (A.n + tile - 1) / tile;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd: n too large");
     if (P.width == 256)
-        hipLaunchKernelGGL((mlp_fwd_kernel<256, FWD_WAVES, ENCODED>), dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0, s, A);
+        hipLaunchKernelGGL((mlp_fwd_kernel<256, FWD_WAVES, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0, s, A);
     else
-        hipLaunchKernelGGL((mlp_fwd_kernel<128, FWD_WAVES, ENCODED>), dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0, s, A);
+        hipLaunchKernelGGL((mlp_fwd_kernel<128, FWD_WAVES, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0, s, A);
     return check_launch("mlp_fwd");
 }
 
@@ -484,7 +294,61 @@ extern "C" int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed
     A.n = n;
     A.spr = samples_per_ray;
     A.dirs_per_sample = dirs_per_sample ? 1 : 0;
-    return launch_fwd<false>(P, A, (hipStream_t)stream);
+    return launch_fwd<false, false>(P, A, (hipStream_t)stream);
+}
+
+extern "C" int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
+                                     int64_t *packed_t_floats, int64_t *gpart_floats, int32_t *gpart_count) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "mlp_train_sizes: desc is null");
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_train_sizes: %s", why);
+    if (n < 0) return fail(SNERF_E_BADARG, "mlp_train_sizes: negative n");
+    TrainLayout L;
+    make_train_layout(P, L);
+    if (act_floats) *act_floats = (int64_t)L.act_rows * n * 16;
+    if (dy_floats) *dy_floats = (int64_t)L.dy_rows * n * 16;
+    if (packed_t_floats) *packed_t_floats = (int64_t)(bwd_total_slabs(P) + SLAB_PAD) * SLAB_FLOATS;
+    const int G = wgrad_chunks(n);
+    if (gpart_count) *gpart_count = G;
+    if (gpart_floats) *gpart_floats = (int64_t)G * L.gp_floats;
+    return SNERF_OK;
+}
+
+extern "C" int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
+                                       const float *dirs, int dirs_per_sample, const float *add, int64_t n,
+                                       int samples_per_ray, float *raw, float *act, snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    FwdArgs A{};
+    int rc = fill_args(desc, P, A);
+    if (rc) return rc;
+    if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "mlp_fwd_train: bad n/samples_per_ray");
+    if (n == 0) return SNERF_OK;
+    if (!packed || !x || !raw || !act) return fail(SNERF_E_BADARG, "mlp_fwd_train: null pointer");
+    if (A.use_dir && !dirs) return fail(SNERF_E_BADARG, "mlp_fwd_train: dirs is null");
+    if (A.add_dim) return fail(SNERF_E_BADARG, "mlp_fwd_train: additional inputs are not supported in training yet");
+    if (!aligned(packed, 16) || !aligned(raw, 16) || !aligned(act, 16))
+        return fail(SNERF_E_ALIGN, "mlp_fwd_train: packed/raw/act must be 16-byte aligned");
+    TrainLayout L;
+    make_train_layout(P, L);
+    A.packed = packed;
+    A.x = x;
+    A.dirs = dirs;
+    A.add = add;
+    A.raw = raw;
+    A.n = n;
+    A.spr = samples_per_ray;
+    A.dirs_per_sample = dirs_per_sample ? 1 : 0;
+    A.act = act;
+    A.act_pe = L.pe;
+    A.act_dpe = L.dpe;
+    A.act_x1 = L.x[1];
+    A.act_o = L.o;
+    A.act_h1 = L.h1;
+    A.act_h2 = L.h2;
+    return launch_fwd<false, true>(P, A, (hipStream_t)stream);
 }
 
 extern "C" int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
@@ -506,5 +370,5 @@ extern "C" int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float
     A.raw = raw;
     A.n = n;
     A.spr = 1;
-    return launch_fwd<true>(P, A, (hipStream_t)stream);
+    return launch_fwd<true, false>(P, A, (hipStream_t)stream);
 }

@@ -1,0 +1,214 @@
+// Device-side building blocks shared by the forward (mlp.hip) and training (mlp_train.hip) kernels:
+// the slab pipe (L2 -> registers -> 3-slot LDS ring), the k-block MFMA step, the layer walker and the
+// in-register positional-encoding operands.  See mlp_plan.h for the operand algebra.
+#pragma once
+#include "snerf_common.h"
+#include "mlp_plan.h"
+
+namespace snerf {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// forward kernel
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float *packed;
+    const float *x;      // [n,3] positions, or x_enc [n, enc_stride] when ENCODED
+    const float *dirs;   // [n/spr,3] or [n,3]
+    const float *add;    // [n/spr, add_dim] or null
+    float *raw;          // [n,4]
+    int64_t n;
+    int spr;             // samples per ray
+    int dirs_per_sample;
+    int n_hidden;        // positional_net layers
+    unsigned skip_mask;
+    int pos_L, pos_id, pos_nkb, pos_dim;
+    int dir_L, dir_id, dir_nkb, dir_dim;
+    int add_dim, add_nkb;
+    int use_dir;
+    int enc_stride;
+    // training only: activation buffer in tile-row-major layout (mlp_plan.h TrainLayout)
+    float *act;
+    int act_pe, act_dpe, act_x1, act_o, act_h1, act_h2;
+};
+
+// one tile (16 features of this lane's sample) <-> the tile-row-major activation buffer
+__device__ __forceinline__ void store_tile(float *buf, int row, int64_t n, int64_t sample, int g, f4 v) {
+    *reinterpret_cast<f4 *>(buf + ((int64_t)row * n + sample) * 16 + 4 * g) = v;
+}
+template <int N>
+__device__ __forceinline__ void store_tiles(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&tiles)[N]) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) store_tile(buf, row0 + t, n, sample, g, tiles[t]);
+}
+__device__ __forceinline__ f4 load_tile(const float *buf, int row, int64_t n, int64_t sample, int g) {
+    return *reinterpret_cast<const f4 *>(buf + ((int64_t)row * n + sample) * 16 + 4 * g);
+}
+
+// Streams the slab sequence global -> registers -> LDS ring (3 slots).
+template <int NT>
+struct SlabPipe {
+    static constexpr int NA = SLAB_A_FLOATS / 4 / NT;  // f4 per thread in the A region (NT=256: 4, 512: 2)
+    const f4 *g;   // this thread's read cursor in the packed stream
+    float *ring;
+    f4 st[NA], st_aux;
+    int tid, rd, wr;
+
+    __device__ __forceinline__ void load() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) st[i] = g[i * NT];
+        if (tid < 64) st_aux = g[SLAB_A_FLOATS / 4];
+        g += SLAB_FLOATS / 4;
+    }
+    __device__ __forceinline__ void store(int slot) {
+        f4 *d = reinterpret_cast<f4 *>(ring + slot * SLAB_FLOATS) + tid;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) d[i * NT] = st[i];
+        if (tid < 64) d[SLAB_A_FLOATS / 4] = st_aux;
+    }
+    __device__ __forceinline__ void prologue(const float *packed, float *ring_, int tid_) {
+        ring = ring_;
+        tid = tid_;
+        g = reinterpret_cast<const f4 *>(packed) + tid;
+        load(); store(0);
+        load(); store(1);
+        load();
+        rd = 0;
+        wr = 2;
+        __syncthreads();
+    }
+    __device__ __forceinline__ const float *acquire() const { return ring + rd * SLAB_FLOATS; }
+    __device__ __forceinline__ void release() {
+        store(wr);
+        load();
+        __syncthreads();
+        rd = rd == 2 ? 0 : rd + 1;
+        wr = wr == 2 ? 0 : wr + 1;
+    }
+};
+
+// per-lane view of the sample this lane works for
+struct SampleCtx {
+    float px, py, pz;  // position
+    float dx, dy, dz;  // normalised direction
+    const float *enc;  // row of x_enc (ENCODED) or null
+    const float *add;  // row of add or null
+    int g;
+};
+
+__device__ __forceinline__ void pe_unit(float x, float y, float z, int L, int ident, int p, float &a, float &b) {
+    const int nid = ident ? 3 : 0;
+    a = 0.f;
+    b = 0.f;
+    if (p < nid) {
+        a = p == 0 ? x : (p == 1 ? y : z);
+        return;
+    }
+    const int pp = p - nid;
+    if (pp >= 3 * L) return;
+    const int k = pp / 3, c = pp - 3 * k;
+    const float v = c == 0 ? x : (c == 1 ? y : z);
+    sincosf(ldexpf(v, k), &a, &b);  // 2^k * v is exact: same argument bits as utils.py:127
+}
+
+// B operand (4 k-steps) of PE k-block kb for this lane
+template <bool ENCODED>
+__device__ __forceinline__ f4 pe_operand(const SampleCtx &c, bool is_dir, int L, int ident, int kb, int enc_off) {
+    f4 b;
+    if (ENCODED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = pe_slot_col(L, ident, kb, c.g, r);
+            b[r] = col >= 0 ? c.enc[enc_off + col] : 0.f;
+        }
+    } else {
+        const float x = is_dir ? c.dx : c.px, y = is_dir ? c.dy : c.py, z = is_dir ? c.dz : c.pz;
+        float s0, c0, s1, c1;
+        pe_unit(x, y, z, L, ident, 4 * (2 * kb) + c.g, s0, c0);
+        pe_unit(x, y, z, L, ident, 4 * (2 * kb + 1) + c.g, s1, c1);
+        b = f4{s0, c0, s1, c1};
+    }
+    return b;
+}
+
+__device__ __forceinline__ f4 add_operand(const SampleCtx &c, int add_dim, int kb) {
+    f4 b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = 16 * kb + 4 * c.g + r;
+        b[r] = col < add_dim ? c.add[col] : 0.f;
+    }
+    return b;
+}
+
+// One k-block: T_OUT x (ds_read_b128 + 4 MFMA).  Tiles are walked in pairs so that consecutive MFMAs
+// never share an accumulator (dependent latency of 16x16x4 is 40 cycles vs 32 issue).
+template <int T_OUT>
+__device__ __forceinline__ void kblock(const float *a_kb, f4 b, f4 (&acc)[T_OUT], int lane) {
+    const f4 *ap = reinterpret_cast<const f4 *>(a_kb) + lane;
+    if constexpr (T_OUT == 1) {
+        const f4 a = ap[0];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[0], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int to = 0; to < T_OUT; to += 2) {
+            const f4 a0 = ap[to * 64], a1 = ap[(to + 1) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], b[r], acc[to], 0, 0, 0);
+                acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], b[r], acc[to + 1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Walks the k-blocks of one layer through the slab pipe.
+template <int T_OUT, int NT>
+struct LayerRun {
+    static constexpr int KPS = 16 / T_OUT;
+    SlabPipe<NT> &pipe;
+    const float *slab;
+    int kbl;  // k-block index inside the current slab
+    int lane;
+
+    __device__ __forceinline__ LayerRun(SlabPipe<NT> &p, int lane_) : pipe(p), slab(p.acquire()), kbl(0), lane(lane_) {}
+    // bias -> accumulator init (aux block of the layer's first slab: bias[16*to + 4*g + r])
+    __device__ __forceinline__ void init(f4 (&acc)[T_OUT]) {
+        const f4 *aux = reinterpret_cast<const f4 *>(slab + SLAB_A_FLOATS) + (lane >> 4);
+#pragma unroll
+        for (int to = 0; to < T_OUT; ++to) acc[to] = aux[to * 4];
+    }
+    __device__ __forceinline__ void step(f4 b, f4 (&acc)[T_OUT]) {
+        if (kbl == KPS) {
+            pipe.release();
+            slab = pipe.acquire();
+            kbl = 0;
+        }
+        kblock<T_OUT>(slab + kbl * (T_OUT * 256), b, acc, lane);
+        ++kbl;
+    }
+    __device__ __forceinline__ void finish() { pipe.release(); }
+};
+
+template <int N>
+__device__ __forceinline__ void relu_into(f4 (&dst)[N], const f4 (&src)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        dst[i][0] = fmaxf(src[i][0], 0.f);
+        dst[i][1] = fmaxf(src[i][1], 0.f);
+        dst[i][2] = fmaxf(src[i][2], 0.f);
+        dst[i][3] = fmaxf(src[i][3], 0.f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void copy_into(f4 (&dst)[N], const f4 (&src)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) dst[i] = src[i];
+}
+
+
+}  // namespace snerf

@@ -153,4 +153,122 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why) {
     return 0;
 }
 
+// column of `Ly`'s weight matrix that feeds input slot (kb, g, r) (kb counted over the whole layer),
+// or -1 for padding.  Shared by the weight packer, the transposed packer and the gradient scatter.
+__host__ __device__ inline int slot_to_col(const Layer &Ly, int kb, int g, int r) {
+    for (int s = 0; s < Ly.nseg; ++s) {
+        const Seg &sg = Ly.seg[s];
+        if (kb < sg.nkb) {
+            int c;
+            if (sg.type == SEG_PE) {
+                c = pe_slot_col(sg.L, sg.ident, kb, g, r);
+            } else {
+                c = 16 * kb + 4 * g + r;
+                if (c >= sg.ncols) c = -1;
+            }
+            return c < 0 ? -1 : sg.col_off + c;
+        }
+        kb -= sg.nkb;
+    }
+    return -1;
+}
+
+// ---- training buffers ------------------------------------------------------------------------------
+// Activations and their gradients are kept in HBM between the forward, the dgrad and the wgrad
+// kernels in TILE-ROW-MAJOR layout: a tile-row is [n samples][16 features] fp32 (n*64 B); feature
+// 16*t + 4*g + r of sample s lives at ((row0 + t)*n + s)*16 + 4*g + r.  A wave stores/loads a tile
+// of its 16 samples as one fully coalesced 1 KiB access (f4 per lane), and the wgrad kernel reads
+// 4 samples x 16 features = 256 contiguous bytes straight into an MFMA A/B operand register.
+struct TrainLayout {
+    int T, TD, nh;
+    int pe, add, dpe;    // encoder inputs in slot order (pos_nkb / add_nkb / dir_nkb tile-rows)
+    int x[18];           // x[i], i = 1..nh+1: input of positional_net[i-1] / additional (post-ReLU), T rows each
+    int o, h1, h2;       // additional out (T), directional_input out (TD), directional_net[0] out post-ReLU (TD)
+    int act_rows;
+    int dy[MAX_LAYERS];  // dY of forward layer l (plan order): t_out tile-rows
+    int dy_rows;
+    int gp[MAX_LAYERS];  // offset of layer l in the slot-ordered gradient: dW [t_out][nkb][64 lanes][4] then db [t_out*16]
+    int gp_floats;
+};
+
+inline void make_train_layout(const Plan &P, TrainLayout &L) {
+    L.T = P.width / 16;
+    L.TD = P.width / 32;
+    L.nh = P.n_hidden;
+    int r = 0;
+    L.pe = r; r += P.pos_nkb;
+    L.add = r; r += P.add_nkb;
+    L.dpe = r; r += P.dir_nkb;
+    for (int i = 1; i <= L.nh + 1; ++i) { L.x[i] = r; r += L.T; }
+    L.o = r; r += L.T;
+    L.h1 = r; r += L.TD;
+    L.h2 = r; r += L.TD;
+    L.act_rows = r;
+    int d = 0, g = 0;
+    for (int l = 0; l < P.nlayers; ++l) {
+        L.dy[l] = d;
+        d += P.layer[l].t_out;
+        L.gp[l] = g;
+        g += P.layer[l].t_out * P.layer[l].nkb * 256 + P.layer[l].t_out * 16;
+    }
+    L.dy_rows = d;
+    L.gp_floats = g;
+}
+
+// first activation tile-row of input segment `s` of forward layer `l`
+__host__ __device__ inline int seg_act_row(const Plan &P, const TrainLayout &L, int l, int s) {
+    const Seg &sg = P.layer[l].seg[s];
+    const int nh = L.nh;
+    if (sg.type == SEG_ADD) return L.add;
+    if (sg.type == SEG_PE) return l == nh + 3 ? L.dpe : L.pe;
+    if (l >= 1 && l <= nh + 1) return L.x[l];  // positional_net[l-1] / additional
+    if (l == nh + 2 || l == nh + 3) return L.o;  // sigma head, directional_input
+    if (l == nh + 4) return L.h1;
+    return L.h2;                                 // rgb head
+}
+
+// ---- backward (dgrad) weight stream ---------------------------------------------------------------
+// The dgrad pass is the forward pass of the transposed network: dX^T[in feature, sample] = W^T * dY^T,
+// with the same in-register chaining.  Its slab stream holds W^T tiles in reverse layer order:
+//   A[(kb, to, lane (i,g), r)] = W_fwd[16*kb + 4*g + r][16*to + i]   (hidden input columns only)
+struct BwdLayer {
+    int fwd;      // forward layer (plan order) whose weight is transposed
+    int t_out;    // tiles of hidden input features produced
+    int nkb;      // k-blocks over the forward layer's output rows
+    int aux_fwd;  // forward layer whose weight row 0 is shipped in the aux block (sigma head), or -1
+    int first_slab, nslab;
+};
+struct BwdPlan {
+    int nl, total_slabs;
+    BwdLayer layer[MAX_LAYERS];
+};
+inline void make_bwd_plan(const Plan &P, BwdPlan &B) {
+    const int T = P.width / 16, TD = P.width / 32, nh = P.n_hidden;
+    int nl = 0, slab = 0;
+    auto add = [&](int fwd, int t_out, int nkb, int aux) {
+        BwdLayer &b = B.layer[nl++];
+        b = BwdLayer{fwd, t_out, nkb, aux, slab, 0};
+        const int kps = 16 / t_out;
+        b.nslab = (nkb + kps - 1) / kps;
+        slab += b.nslab;
+    };
+    add(nh + 5, TD, 1, -1);       // rgb head^T : d rgb (3) -> d h2
+    add(nh + 4, TD, TD, -1);      // directional_net[0]^T
+    add(nh + 3, T, TD, nh + 2);   // directional_input^T (hidden columns) + sigma head row via aux
+    add(nh + 1, T, T, -1);        // additional_linear_layer^T
+    for (int i = nh; i >= 1; --i) add(i, T, T, -1);  // positional_net[i-1]^T (hidden columns)
+    B.nl = nl;
+    B.total_slabs = slab;
+}
+inline int bwd_total_slabs(const Plan &P) {
+    BwdPlan B;
+    make_bwd_plan(P, B);
+    return B.total_slabs;
+}
+// number of K-splits (sample chunks) of the wgrad kernel for n samples
+inline int wgrad_chunks(int64_t n) {
+    int64_t g = (n + 2047) / 2048;
+    return (int)(g < 1 ? 1 : (g > 64 ? 64 : g));
+}
+
 }  // namespace snerf

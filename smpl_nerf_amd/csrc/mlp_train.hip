@@ -1,0 +1,404 @@
+// Backward of the fused RenderRayNet (a2 backward; gradients w.r.t. all weights and biases).
+//
+// The reference gets these from autograd over 13 nn.Linear calls (solver/nerf_solver.py:83-87,
+// loss.backward()).  Here a training step of one net is four kernels around HBM-resident, tile-row-major
+// activation buffers (mlp_plan.h: TrainLayout):
+//
+//   mlp_fwd_kernel<.., TRAIN>   forward, additionally stores every layer input X_l           (mlp.hip)
+//   mlp_bwd_kernel               dgrad: the forward pass of the TRANSPOSED network on d raw, with the same
+//                                register-resident chaining (dX^T = W^T dY^T is again "accumulator layout =
+//                                next B operand"); applies the ReLU masks from the stored X_l and stores
+//                                every dY_l
+//   mlp_wgrad_kernel             dW_l = dY_l X_l^T, db_l = sum_s dY_l: split-K MFMA GEMMs over the samples;
+//                                operands are read from HBM/L2 straight into MFMA registers (the tile-row
+//                                layout makes 4 samples x 16 features one 256 B wave access), each
+//                                workgroup owns a <=64x64 block of one dW and one chunk of samples and
+//                                writes a partial
+//   mlp_wgrad_reduce_kernel      sums the partials in a fixed order (deterministic) and scatters from slot
+//                                order to the reference's [out, in] weight layout
+//
+// All MFMA work is v_mfma_f32_16x16x4_f32 (exact fp32), like the forward.
+#include "mlp_device.h"
+
+namespace snerf {
+
+// ------------------------------------------------------------------------------------------------
+// transposed weight stream
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_pack_t_kernel(Plan P, BwdPlan B, const float *__restrict__ params,
+                                                         float *__restrict__ packed) {
+    const int slab = blockIdx.x;
+    float *dst = packed + (int64_t)slab * SLAB_FLOATS;
+    if (slab >= B.total_slabs) {
+        for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) dst[e] = 0.f;
+        return;
+    }
+    int bi = 0;
+    while (bi + 1 < B.nl && slab >= B.layer[bi + 1].first_slab) ++bi;
+    const BwdLayer &Bl = B.layer[bi];
+    const Layer &Ly = P.layer[Bl.fwd];
+    const int sl = slab - Bl.first_slab;
+    const int kps = 16 / Bl.t_out;
+    const float *Wm = params + Ly.w_off;
+    for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
+        float val = 0.f;
+        if (e < SLAB_A_FLOATS) {
+            const int per_kb = Bl.t_out * 256;
+            const int kbl = e / per_kb;
+            int rem = e - kbl * per_kb;
+            const int to = rem >> 8;
+            rem &= 255;
+            const int l = rem >> 2, r = rem & 3;
+            const int i = l & 15, g = l >> 4;
+            const int kb = sl * kps + kbl;
+            const int row = 16 * kb + 4 * g + r;  // forward output feature (contraction index)
+            const int col = 16 * to + i;          // forward hidden input feature (output of the transpose)
+            if (kb < Bl.nkb && row < Ly.n_out && col < Ly.seg[0].ncols) val = Wm[(int64_t)row * Ly.n_in + col];
+        } else if (sl == 0 && Bl.aux_fwd >= 0) {
+            const Layer &La = P.layer[Bl.aux_fwd];
+            const int jj = e - SLAB_A_FLOATS;
+            if (jj < La.seg[0].ncols) val = params[La.w_off + jj];  // row 0 of the sigma head
+        }
+        dst[e] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dgrad
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float *packed_t;
+    const float *act;
+    const float *d_raw;  // [n,4]
+    float *dy;
+    int64_t n;
+    int n_hidden;
+    int act_x1, act_h2;
+    int dy_sig, dy_din, dy_dn0, dy_rgb;  // dy of forward layer l <= nh+1 is l*T
+};
+
+template <int N>
+__device__ __forceinline__ void mask_into(f4 (&dst)[N], const f4 (&src)[N], const float *act, int row0, int64_t n,
+                                          int64_t sample, int g) {
+    f4 m[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) m[t] = load_tile(act, row0 + t, n, sample, g);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        dst[t][0] = m[t][0] > 0.f ? src[t][0] : 0.f;
+        dst[t][1] = m[t][1] > 0.f ? src[t][1] : 0.f;
+        dst[t][2] = m[t][2] > 0.f ? src[t][2] : 0.f;
+        dst[t][3] = m[t][3] > 0.f ? src[t][3] : 0.f;
+    }
+}
+
+template <int WIDTH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int T = WIDTH / 16;
+    constexpr int TD = WIDTH / 32;
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;
+    const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
+    const bool valid = sample < A.n;
+    const int64_t sc = valid ? sample : A.n - 1;
+    const int nh = A.n_hidden;
+
+    const f4 dr = *reinterpret_cast<const f4 *>(A.d_raw + sc * 4);
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+    // head gradients as tile-rows for the wgrad kernel (rows 0..2 = rgb, row 0 = sigma)
+    if (valid) {
+        store_tile(A.dy, A.dy_rgb, A.n, sample, g, g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero);
+        store_tile(A.dy, A.dy_sig, A.n, sample, g, g == 0 ? f4{dr[3], 0.f, 0.f, 0.f} : zero);
+    }
+
+    SlabPipe<NT> pipe;
+    pipe.prologue(A.packed_t, ring, tid);
+
+    f4 ind[TD], accd[TD];
+    {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
+        LayerRun<TD, NT> run(pipe, lane);
+        run.init(accd);
+        run.step(g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, accd);
+        run.finish();
+        mask_into(ind, accd, A.act, A.act_h2, A.n, sc, g);
+        if (valid) store_tiles(A.dy, A.dy_dn0, A.n, sample, g, ind);
+    }
+    {  // directional_net[0]^T; directional_input has no activation (:54-57)
+        LayerRun<TD, NT> run(pipe, lane);
+        run.init(accd);
+#pragma unroll
+        for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], accd);
+        run.finish();
+        copy_into(ind, accd);
+        if (valid) store_tiles(A.dy, A.dy_din, A.n, sample, g, ind);
+    }
+    f4 in[T], acc[T];
+    {  // d o = directional_input[:, :W]^T d h1 + sigma_out_layer^T d sigma; additional layer has no activation (:51-52)
+        LayerRun<T, NT> run(pipe, lane);
+        run.init(acc);  // aux block = sigma head weights
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc[t][0] *= dr[3];
+            acc[t][1] *= dr[3];
+            acc[t][2] *= dr[3];
+            acc[t][3] *= dr[3];
+        }
+#pragma unroll
+        for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], acc);
+        run.finish();
+        copy_into(in, acc);
+        if (valid) store_tiles(A.dy, (nh + 1) * T, A.n, sample, g, in);
+    }
+    // additional^T, positional_net[nh-1]^T ... positional_net[0]^T: forward layer l+1 transposed yields
+    // d X_{l+1}; masking with X_{l+1} > 0 gives d Y of forward layer l (:46-50)
+    for (int l = nh; l >= 0; --l) {
+        LayerRun<T, NT> run(pipe, lane);
+        run.init(acc);
+#pragma unroll
+        for (int kb = 0; kb < T; ++kb) run.step(in[kb], acc);
+        run.finish();
+        mask_into(in, acc, A.act, A.act_x1 + l * T, A.n, sc, g);
+        if (valid) store_tiles(A.dy, l * T, A.n, sample, g, in);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float *act;
+    const float *dy;
+    float *part;  // [G][gp_floats]
+    int64_t n;
+    int64_t chunk;  // samples per K-split, multiple of 16
+};
+
+constexpr int WG_THREADS = 256;
+
+__host__ __device__ inline int wgrad_jobs(const Plan &P) {
+    int jobs = 0;
+    for (int l = 0; l < P.nlayers; ++l)
+        for (int s = 0; s < P.layer[l].nseg; ++s)
+            jobs += ((P.layer[l].t_out + 3) / 4) * ((P.layer[l].seg[s].nkb + 3) / 4);
+    return jobs;
+}
+
+__global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayout L, WgradArgs A) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 16 * 256 + 3 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- decode the job: (layer, segment, 4x4-tile block) -----------------------------------------
+    int job = blockIdx.x, l = 0, s = 0, kb0 = 0, nbj = 1;
+    for (l = 0; l < P.nlayers; ++l) {
+        bool found = false;
+        kb0 = 0;
+        for (s = 0; s < P.layer[l].nseg; ++s) {
+            nbj = (P.layer[l].seg[s].nkb + 3) / 4;
+            const int cnt = ((P.layer[l].t_out + 3) / 4) * nbj;
+            if (job < cnt) { found = true; break; }
+            job -= cnt;
+            kb0 += P.layer[l].seg[s].nkb;
+        }
+        if (found) break;
+    }
+    const Layer &Ly = P.layer[l];
+    const int bi = job / nbj, bj = job - bi * nbj;
+    const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
+    const int64_t n = A.n;
+    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + lane;                 // + sample*16 via k
+    const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + lane;
+    const bool want_bias = (s == 0 && bj == 0);
+
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: base + s0*16 + lane
+    const int kslot = lane >> 4;
+    auto load_ab = [&](int64_t s0, float (&a)[4], float (&b)[4]) {
+        const bool ok = s0 + kslot < end;
+        const int64_t off = (ok ? s0 : (end - 1 - kslot)) * 16;  // clamped, in-bounds (finite data)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = (t < n_ti && ok) ? dyp[(int64_t)t * n * 16 + off] : 0.f;
+            b[t] = (t < n_tj) ? xp[(int64_t)t * n * 16 + (ok ? off : 0)] : 0.f;
+        }
+    };
+    float a0[4], b0[4], a1[4], b1[4];
+    int64_t s0 = begin + wave * 4;
+    if (s0 < end) load_ab(s0, a0, b0);
+    while (s0 < end) {
+        const int64_t s1 = s0 + 16;
+        if (s1 < end) load_ab(s1, a1, b1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < n_ti) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < n_tj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                bsum[i] += a0[i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a0[t] = a1[t];
+            b0[t] = b1[t];
+        }
+        s0 = s1;
+    }
+    // ---- reduce the 4 waves (fixed order) and write the partial ------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bsum[i] += __shfl_xor(bsum[i], 16, 64);
+        bsum[i] += __shfl_xor(bsum[i], 32, 64);
+    }
+    if (wave > 0) {
+        float *dst = red + (wave - 1) * (16 * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f4 *>(dst + ((i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+        if (lane < 16) {
+            float *bd = red + 3 * 16 * 256 + (wave - 1) * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bd[i * 16 + lane] = bsum[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n_ti) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= n_tj) continue;
+                f4 v = acc[i][j];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f4 *>(red + w * (16 * 256) + ((i * 4 + j) * 64 + lane) * 4);
+                const int ti = 4 * bi + i, tj = kb0 + 4 * bj + j;
+                *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = v;
+            }
+            if (want_bias && lane < 16) {
+                float v = bsum[i];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[3 * 16 * 256 + w * 64 + i * 16 + lane];
+                part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
+            }
+        }
+    }
+}
+
+// sum over the G partials and scatter slot order -> state_dict order
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayout L, const float *__restrict__ part,
+                                                               int G, float *__restrict__ flat_grad) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= L.gp_floats) return;
+    int l = 0;
+    while (l + 1 < P.nlayers && e >= L.gp[l + 1]) ++l;
+    const Layer &Ly = P.layer[l];
+    int rel = e - L.gp[l];
+    int64_t dst = -1;
+    const int nw = Ly.t_out * Ly.nkb * 256;
+    if (rel < nw) {
+        const int r = rel & 3, lane = (rel >> 2) & 63, tile = rel >> 8;
+        const int ti = tile / Ly.nkb, tj = tile - ti * Ly.nkb;
+        const int row = 16 * ti + 4 * (lane >> 4) + r;  // MFMA D layout: row = 4*(lane>>4)+r, col = lane&15
+        const int jj = lane & 15;
+        const int col = slot_to_col(Ly, tj, jj >> 2, jj & 3);
+        if (row < Ly.n_out && col >= 0) dst = Ly.w_off + (int64_t)row * Ly.n_in + col;
+    } else {
+        const int row = rel - nw;
+        if (row < Ly.n_out) dst = Ly.b_off + row;
+    }
+    if (dst < 0) return;
+    float sum = 0.f;
+    for (int c = 0; c < G; ++c) sum += part[(int64_t)c * L.gp_floats + e];
+    flat_grad[dst] = sum;
+}
+
+}  // namespace snerf
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed_t,
+                                    snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "mlp_pack_t: desc is null");
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_pack_t: %s", why);
+    if (!params_flat || !packed_t) return fail(SNERF_E_BADARG, "mlp_pack_t: null pointer");
+    if (!aligned(packed_t, 16)) return fail(SNERF_E_ALIGN, "mlp_pack_t: packed_t must be 16-byte aligned");
+    BwdPlan B;
+    make_bwd_plan(P, B);
+    hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(B.total_slabs + SLAB_PAD), dim3(256), 0, (hipStream_t)stream, P, B,
+                       params_flat, packed_t);
+    return check_launch("mlp_pack_t");
+}
+
+extern "C" int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
+                                 const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
+                                 snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "mlp_bwd: desc is null");
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_bwd: %s", why);
+    if (P.add_dim) return fail(SNERF_E_BADARG, "mlp_bwd: additional inputs are not supported in training yet");
+    if (n < 0) return fail(SNERF_E_BADARG, "mlp_bwd: negative n");
+    if (n == 0) return SNERF_OK;
+    if (!packed_t || !act || !d_raw || !dy || !gpart || !flat_grad) return fail(SNERF_E_BADARG, "mlp_bwd: null pointer");
+    if (!aligned(packed_t, 16) || !aligned(act, 16) || !aligned(d_raw, 16) || !aligned(dy, 16) || !aligned(gpart, 16))
+        return fail(SNERF_E_ALIGN, "mlp_bwd: buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    TrainLayout L;
+    make_train_layout(P, L);
+    const int nh = P.n_hidden;
+    BwdArgs A{};
+    A.packed_t = packed_t;
+    A.act = act;
+    A.d_raw = d_raw;
+    A.dy = dy;
+    A.n = n;
+    A.n_hidden = nh;
+    A.act_x1 = L.x[1];
+    A.act_h2 = L.h2;
+    A.dy_sig = L.dy[nh + 2];
+    A.dy_din = L.dy[nh + 3];
+    A.dy_dn0 = L.dy[nh + 4];
+    A.dy_rgb = L.dy[nh + 5];
+    constexpr int BW = 4;
+    const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
+    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
+    if (P.width == 256)
+        hipLaunchKernelGGL((mlp_bwd_kernel<256, BW>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+    else
+        hipLaunchKernelGGL((mlp_bwd_kernel<128, BW>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+    int rc = check_launch("mlp_bwd(dgrad)");
+    if (rc) return rc;
+
+    const int G = wgrad_chunks(n);
+    WgradArgs W{};
+    W.act = act;
+    W.dy = dy;
+    W.part = gpart;
+    W.n = n;
+    W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wgrad_jobs(P), G), dim3(WG_THREADS), 0, s, P, L, W);
+    rc = check_launch("mlp_bwd(wgrad)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G,
+                       flat_grad);
+    return check_launch("mlp_bwd(reduce)");
+}

@@ -6,6 +6,8 @@ The nn.Linear children only hold the parameters; they are never called.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -20,6 +22,56 @@ def _encoder_shape(dim: int):
     if dim >= 3 and (dim - 3) % 6 == 0:
         return (dim - 3) // 6, 1
     return None
+
+
+class _FusedMlpFn(torch.autograd.Function):
+    """raw = RenderRayNet(encode(x), encode(normalise(d))) with gradients for every weight and bias.
+    Forward saves the layer inputs in the tile-row-major activation buffer; backward = dgrad + split-K
+    wgrad + reduce (snerf_mlp_bwd_f32).  Positions and directions get no gradient (they are leaves in
+    NerfPipeline: the hierarchical samples are detached, utils.py:260)."""
+
+    @staticmethod
+    def forward(ctx, net, desc, x, d, per_sample, spr, *params):
+        lib = _lib.load()
+        n = x.shape[0]
+        dev = x.device
+        packed = net.packed_weights(desc)
+        sizes = [ctypes.c_int64() for _ in range(4)]
+        cnt = ctypes.c_int32()
+        check(lib.snerf_mlp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes], ctypes.byref(cnt)),
+              "snerf_mlp_train_sizes")
+        act = torch.empty(sizes[0].value, device=dev, dtype=torch.float32)
+        raw = torch.empty((n, 4), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev), _lib.timed(f"mlp_fwd_train[n={n}]"):
+            check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, None, n, int(spr),
+                                              ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
+        ctx.net, ctx.desc, ctx.n, ctx.act = net, desc, n, act
+        ctx.sizes = (sizes[1].value, sizes[3].value)
+        ctx.shapes = [p.shape for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        lib = _lib.load()
+        net, desc, n = ctx.net, ctx.desc, ctx.n
+        dev = d_raw.device
+        d_raw = d_raw.contiguous().float()
+        packed_t = net.packed_weights_t(desc)
+        dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
+        gpart = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
+        flat = torch.empty(lib.snerf_mlp_param_floats(desc), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev), _lib.timed(f"mlp_bwd[n={n}]"):
+            check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), n, ptr(dy), ptr(gpart),
+                                        ptr(flat), current_stream()), "snerf_mlp_bwd_f32")
+        ctx.act = None
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            k = 1
+            for v in shp:
+                k *= v
+            grads.append(flat[off:off + k].view(shp))
+            off += k
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class RenderRayNet(nn.Module):
@@ -54,6 +106,7 @@ class RenderRayNet(nn.Module):
             self.directional_net.append(torch.nn.Linear(directional_width, directional_width))
         self.rgb_out_layer = torch.nn.Linear(directional_width, 3)
         self._pack_cache = {}
+        self._pack_t_cache = {}
 
     # ------------------------------------------------------------------ parameter plumbing
     def _ordered_params(self):
@@ -124,6 +177,25 @@ class RenderRayNet(nn.Module):
         self._pack_cache = {key: (stamp, packed)}
         return packed
 
+    def packed_weights_t(self, desc: MlpDesc) -> torch.Tensor:
+        """Transposed weight stream for the dgrad kernel (same caching rule as packed_weights)."""
+        params = self._ordered_params()
+        dev = params[0].device
+        key = tuple(getattr(desc, f[0]) for f in desc._fields_)
+        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._pack_t_cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = _lib.load()
+        n_pack = ctypes.c_int64()
+        check(lib.snerf_mlp_train_sizes(desc, 0, None, None, ctypes.byref(n_pack), None, None), "snerf_mlp_train_sizes")
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        packed = torch.empty(n_pack.value, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(lib.snerf_mlp_pack_t_f32(desc, ptr(flat), ptr(packed), current_stream()), "snerf_mlp_pack_t_f32")
+        self._pack_t_cache = {key: (stamp, packed)}
+        return packed
+
     # ------------------------------------------------------------------ forward paths
     def forward(self, x):
         """x [..., positions_dim + additional_input_dim + directions_dim] -> [..., 4] = [rgb | sigma]
@@ -148,10 +220,7 @@ class RenderRayNet(nn.Module):
         """Encode + MLP in one launch.  positions [n,3] (samples of a ray contiguous), directions
         [n/samples_per_ray, 3] (per ray) or [n, 3] (per sample), un-normalised; additional: optional
         [n/samples_per_ray, additional_input_dim].  Returns raw [n, 4]."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("RenderRayNet: backward is not implemented yet; run under torch.no_grad()")
         desc = self.desc_for_encoders(position_encoder, direction_encoder)
-        packed = self.packed_weights(desc)
         x = positions.reshape(-1, 3).contiguous()
         n = x.shape[0]
         d = directions.reshape(-1, 3).contiguous()
@@ -166,6 +235,12 @@ class RenderRayNet(nn.Module):
             if additional is None:
                 raise RuntimeError("forward_fused: this net needs `additional` inputs")
             add = additional.reshape(-1, self.additional_input_dim).contiguous()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.additional_input_dim:
+                raise NotImplementedError("RenderRayNet: training with additional inputs is not implemented yet")
+            return _FusedMlpFn.apply(self, desc, x.detach(), d.detach(), per_sample, int(samples_per_ray),
+                                     *self._ordered_params())
+        packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
         lib = _lib.load()
         with torch.cuda.device(x.device), _lib.timed(f"mlp_fwd[n={n}]"):

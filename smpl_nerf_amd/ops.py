@@ -111,18 +111,62 @@ def _directions_arg(samples_directions: torch.Tensor, B: int, N: int):
     raise RuntimeError(f"raw2outputs: samples_directions of shape {tuple(d.shape)} does not match raw [B={B}, N={N}]")
 
 
+class _CompositeFn(torch.autograd.Function):
+    """Differentiable alpha compositing: d rgb -> d raw (snerf_composite_bwd_f32).  weights and alpha
+    are returned without gradient: in the pipeline they only feed the detached hierarchical sampler
+    (utils.py:260) and the tuple handed back to the caller."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, dirs, per_sample, white_background, noise, want_weights, want_alpha):
+        rgb, weights, alpha = _composite_launch(raw, z_vals, dirs, per_sample, white_background, noise,
+                                                want_weights, want_alpha)
+        ctx.save_for_backward(raw, z_vals, dirs, noise)
+        ctx.cfg = (per_sample, white_background)
+        ctx.set_materialize_grads(False)
+        outs = [rgb]
+        for t in (weights, alpha):
+            if t is not None:
+                ctx.mark_non_differentiable(t)
+            outs.append(t)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_w, d_a):
+        raw, z_vals, dirs, noise = ctx.saved_tensors
+        per_sample, wb = ctx.cfg
+        if d_rgb is None:
+            return (None,) * 8
+        B, N = z_vals.shape
+        d_rgb = d_rgb.contiguous().float()
+        d_raw = torch.empty_like(raw)
+        lib = _lib.load()
+        with torch.cuda.device(raw.device), _lib.timed(f"composite_bwd[N={N}]"):
+            check(lib.snerf_composite_bwd_f32(ptr(raw), ptr(z_vals), ptr(dirs), per_sample, ptr(noise), B, N,
+                                              1 if wb else 0, ptr(d_rgb), ptr(d_raw), current_stream()),
+                  "snerf_composite_bwd_f32")
+        return (d_raw,) + (None,) * 7
+
+
 def composite(raw, z_vals, samples_directions, white_background: bool, noise=None,
               want_weights=True, want_alpha=True):
     B, N = z_vals.shape
     dirs, per_sample = _directions_arg(samples_directions, B, N)
     raw = raw.contiguous()
     z_vals = z_vals.contiguous()
+    if noise is not None:
+        noise = noise.contiguous()
+    if torch.is_grad_enabled() and raw.requires_grad:
+        return _CompositeFn.apply(raw.view(B, N, 4), z_vals.detach(), dirs.detach(), per_sample, bool(white_background),
+                                  noise, want_weights, want_alpha)
+    return _composite_launch(raw, z_vals, dirs, per_sample, white_background, noise, want_weights, want_alpha)
+
+
+def _composite_launch(raw, z_vals, dirs, per_sample, white_background, noise, want_weights, want_alpha):
+    B, N = z_vals.shape
     dev = raw.device
     rgb = torch.empty((B, 3), device=dev, dtype=torch.float32)
     weights = torch.empty((B, N), device=dev, dtype=torch.float32) if want_weights else None
     alpha = torch.empty((B, N), device=dev, dtype=torch.float32) if want_alpha else None
-    if noise is not None:
-        noise = noise.contiguous()
     lib = _lib.load()
     with torch.cuda.device(dev), _lib.timed(f"composite_fwd[N={N}]"):
         check(lib.snerf_composite_fwd_f32(ptr(raw), ptr(z_vals), ptr(dirs), per_sample, ptr(noise), B, N,
@@ -138,7 +182,7 @@ def raw2outputs(raw: torch.Tensor, z_vals: torch.Tensor, samples_directions: tor
     torch.normal exactly where the reference draws it (utils.py:171-173) - also in eval mode."""
     for nm, t in (("raw", raw), ("z_vals", z_vals), ("samples_directions", samples_directions)):
         _need_cuda(nm, t)
-    _no_grad_inputs(raw, z_vals, samples_directions)
+    _no_grad_inputs(z_vals, samples_directions)
     noise = None
     if z_vals.shape[-1] > 1 and args.sigma_noise_std > 0.:
         noise = torch.normal(0, args.sigma_noise_std, raw[..., 3].shape, device=raw.device)

@@ -94,7 +94,7 @@ def save(name, **arrays):
 
 def main():
     U, RenderRayNet, NerfPipeline, SmplNerfPipeline, WarpFieldNet = _import_reference()
-    torch.set_grad_enabled(False)
+    torch.set_grad_enabled(False) if __name__ == "__main__" else None
     rng = np.random.default_rng(1234)
 
     # ---- G1 positional encoding (utils.py:114-131) ---------------------------------------------

@@ -1,0 +1,202 @@
+"""GPU parity of the backward kernels (compositing backward, MLP dgrad + wgrad) and of whole training
+steps, against gradients captured from the reference under autograd (g7_grads.npz) and against the
+pinned torch fp32 reference (tests/torch_ref.py) for full-tensor comparisons.
+
+Tolerances: gradients are sums of up to ~50k fp32 products in a different order than torch's
+(sequential MFMA chains + split-K partials vs MKL blocking): 2e-4 relative + an absolute term scaled by
+the tensor's own magnitude."""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as R
+from oracle import nerf_oracle as O
+from smpl_nerf_amd import synthetic as syn
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+def make_net(dev, params, **kw):
+    from smpl_nerf_amd.nets import RenderRayNet
+    net = RenderRayNet(n_layers=kw.get("n_layers", 8), width=kw.get("width", 256), positions_dim=60, directions_dim=24,
+                       skips=list(kw.get("skips", (4,))))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    return net.to(dev)
+
+
+# ------------------------------------------------------------------------------------------ a4 backward
+@pytest.mark.parametrize("N", [1, 2, 64, 192, 100])
+@pytest.mark.parametrize("wb", [0, 1])
+@pytest.mark.parametrize("mode", ["ray", "smp"])
+def test_composite_backward(dev, N, wb, mode):
+    from smpl_nerf_amd import ops
+    if N == 1 and mode == "smp":
+        pytest.skip("N==1 ignores directions")
+    g3, g7 = load_golden("g3_raw2outputs.npz"), load_golden("g7_grads.npz")
+    B = g3[f"raw_N{N}"].shape[0]
+    raw = T(g3[f"raw_N{N}"], dev).requires_grad_(True)
+    d = T(g3[f"dray_N{N}"], dev)[:, None, :].expand(B, N, 3) if mode == "ray" else T(g3[f"dsmp_N{N}"], dev)
+    rgb, w, a = ops.composite(raw, T(g3[f"z_N{N}"], dev), d, bool(wb))
+    assert not w.requires_grad and not a.requires_grad
+    (rgb * T(g7[f"c_gout_N{N}"], dev)).sum().backward()
+    close(raw.grad.cpu().numpy(), g7[f"c_draw_N{N}_wb{wb}_{mode}"], 2e-4, 2e-6)
+
+
+def test_composite_backward_frame_size_vs_torch(dev):
+    from smpl_nerf_amd import ops
+    rng = np.random.default_rng(12)
+    B, N = 4096, 192
+    raw_np = rng.normal(0, 2, (B, N, 4)).astype(F32)
+    z = np.sort(rng.uniform(1, 4, (B, N)).astype(F32), -1)
+    d = rng.normal(size=(B, 3)).astype(F32)
+    gout = rng.normal(size=(B, 3)).astype(F32)
+    raw = T(raw_np, dev).requires_grad_(True)
+    rgb, _, _ = ops.composite(raw, T(z, dev), T(d, dev), True)
+    (rgb * T(gout, dev)).sum().backward()
+    raw_c = torch.from_numpy(raw_np).requires_grad_(True)
+    rgb_c, _, _ = R.raw2outputs(raw_c, torch.from_numpy(z), torch.from_numpy(d)[:, None, :].expand(B, N, 3), 1)
+    (rgb_c * torch.from_numpy(gout)).sum().backward()
+    close(raw.grad.cpu().numpy(), raw_c.grad.numpy(), 2e-4, 2e-6)
+
+
+# ------------------------------------------------------------------------------------------ a2 backward
+def _mlp_grads(dev, params, x_pts, x_dirs, gout, **kw):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    net = make_net(dev, params, **kw)
+    raw = net.forward_fused(T(x_pts, dev), T(x_dirs, dev), 1, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    assert raw.requires_grad
+    (raw * T(gout, dev)).sum().backward()
+    return net, raw
+
+
+def test_mlp_backward_small_net_all_params(dev):
+    g2, g7 = load_golden("g2_mlp.npz"), load_golden("g7_grads.npz")
+    kw = dict(n_layers=4, width=128, skips=(1,))
+    params = syn.make_render_ray_net_params(13, 30.0, 10.0, **kw)
+    net, raw = _mlp_grads(dev, params, g2["pts"], g2["dirs"], g7["m_gout"], **kw)
+    close(raw.detach().cpu().numpy(), g2["raw_d4w128"], 0, 2e-4)
+    for k, p in net.named_parameters():
+        ref = g7[f"m_d4w128/{k}"]
+        assert p.grad is not None and p.grad.shape == p.shape
+        close(p.grad.cpu().numpy(), ref, 2e-4, 2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag", ["skip4", "noskip", "scene"])
+def test_mlp_backward_full_net(dev, tag):
+    g2, g7 = load_golden("g2_mlp.npz"), load_golden("g7_grads.npz")
+    params = {"skip4": lambda: syn.make_render_ray_net_params(11, 30.0, 10.0, skips=(4,)),
+              "noskip": lambda: syn.make_render_ray_net_params(12, 30.0, 10.0, skips=()),
+              "scene": lambda: syn.make_scene_nets(101)[1]}[tag]()
+    skips = () if tag == "noskip" else (4,)
+    net, _ = _mlp_grads(dev, params, g2["pts"], g2["dirs"], g7["m_gout"], skips=skips)
+    # digests captured from the reference
+    for k, p in net.named_parameters():
+        ref = g7[f"m_{tag}/{k}"]
+        close(R.digest(p.grad), ref, 5e-4, 5e-5 * max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel())))
+    # every element against the pinned torch reference
+    P = R.tparams(params)
+    out = R.render_ray_net(P, torch.from_numpy(g2["inputs"]), skips=skips)
+    (out * torch.from_numpy(g7["m_gout"])).sum().backward()
+    for k, p in net.named_parameters():
+        ref = P[k].grad.numpy()
+        close(p.grad.cpu().numpy(), ref, 5e-4, 5e-5 * np.abs(ref).max())
+
+
+def test_mlp_backward_many_samples_ragged(dev):
+    """n = 5003 samples (ragged vs the 64-sample tile, several split-K chunks), per-ray directions."""
+    rng = np.random.default_rng(77)
+    params = syn.make_scene_nets(101)[0]
+    B, Ns = 5003 // 7 + 1, 7
+    n = B * Ns
+    pts = rng.uniform(-2, 2, (B, Ns, 3)).astype(F32)
+    dray = rng.normal(size=(B, 3)).astype(F32)
+    gout = rng.normal(size=(n, 4)).astype(F32)
+    from smpl_nerf_amd.ops import PositionalEncoder
+    net = make_net(dev, params)
+    raw = net.forward_fused(T(pts, dev), T(dray, dev), Ns, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    (raw * T(gout, dev)).sum().backward()
+    P = R.tparams(params)
+    dn = torch.from_numpy(dray)[:, None, :].expand(B, Ns, 3)
+    dn = dn / torch.norm(dn, dim=-1, keepdim=True)
+    x = torch.cat([R.posenc(torch.from_numpy(pts), 10, 0), R.posenc(dn, 4, 0)], -1).view(n, -1)
+    (R.render_ray_net(P, x) * torch.from_numpy(gout)).sum().backward()
+    for k, p in net.named_parameters():
+        ref = P[k].grad.numpy()
+        close(p.grad.cpu().numpy(), ref, 1e-3, 1e-4 * np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------ training steps
+def _pipeline(dev, run_fine=1):
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline
+    pc, pf = syn.make_scene_nets(101)
+    mc, mf = make_net(dev, pc), make_net(dev, pf)
+    pipe = NerfPipeline(mc, mf, O.Args(run_fine=run_fine), PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    return pipe, mc, mf
+
+
+def test_three_adam_steps_match_the_reference(dev):
+    """solver/nerf_solver.py:83-87 with torch.optim.Adam exactly as NerfSolver builds it (:31-33)."""
+    g7 = load_golden("g7_grads.npz")
+    pipe, mc, mf = _pipeline(dev)
+    data = syn.frame_batch(128, 128, seed=7)
+    batch = [T(a[g7["t_sub"]], dev) for a in data]
+    optim = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4, betas=(0.9, 0.999), eps=1e-8,
+                             weight_decay=0)
+    loss_fn = torch.nn.MSELoss()
+    losses = []
+    for step in range(3):
+        rgb, rgb_fine, pts_fine, dens = pipe(batch)
+        optim.zero_grad()
+        loss = loss_fn(rgb, batch[-1]) + loss_fn(rgb_fine, batch[-1])
+        loss.backward()
+        if step == 0:
+            close(rgb.detach().cpu().numpy(), g7["t_rgb0"], 0, 1e-5)
+            close(rgb_fine.detach().cpu().numpy(), g7["t_rgb_fine0"], 0, 1e-4)
+            for name, m in (("coarse", mc), ("fine", mf)):
+                for k, p in m.named_parameters():
+                    ref = g7[f"t_grad0/{name}.{k}"]
+                    scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
+                    close(R.digest(p.grad), ref, 5e-3, 2e-3 * scale)
+        optim.step()
+        losses.append(loss.item())
+    close(losses, g7["t_losses"], 1e-4, 1e-6)
+    assert losses[2] < losses[0]
+    for name, m in (("coarse", mc), ("fine", mf)):
+        for k, p in m.named_parameters():
+            ref = g7[f"t_param3/{name}.{k}"]
+            # Adam normalises the step to ~lr: after 3 steps parameters agree to a fraction of 3*lr
+            close(R.digest(p)[2:], ref[2:], 0, 3e-4)
+
+
+def test_coarse_only_training_quirk(dev):
+    """run_fine=0: the pipeline returns rgb twice, loss = 2*MSE, fine net gets no gradient (Q10)."""
+    g7 = load_golden("g7_grads.npz")
+    pipe, mc, mf = _pipeline(dev, run_fine=0)
+    data = syn.frame_batch(128, 128, seed=7)
+    batch = [T(a[g7["t_sub"]], dev) for a in data]
+    rgb, rgb_fine, _, _ = pipe(batch)
+    loss = torch.nn.functional.mse_loss(rgb, batch[-1]) + torch.nn.functional.mse_loss(rgb_fine, batch[-1])
+    loss.backward()
+    close([loss.item()], g7["t_coarse_only_loss"], 1e-5, 1e-7)
+    assert all(p.grad is None for p in mf.parameters())
+    for k, p in mc.named_parameters():
+        ref = g7[f"t_coarse_only_grad/coarse.{k}"]
+        scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
+        close(R.digest(p.grad), ref, 5e-3, 2e-3 * scale)
