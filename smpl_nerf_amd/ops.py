@@ -123,12 +123,8 @@ class _CompositeFn(torch.autograd.Function):
         ctx.save_for_backward(raw, z_vals, dirs, noise)
         ctx.cfg = (per_sample, white_background)
         ctx.set_materialize_grads(False)
-        outs = [rgb]
-        for t in (weights, alpha):
-            if t is not None:
-                ctx.mark_non_differentiable(t)
-            outs.append(t)
-        return tuple(outs)
+        ctx.mark_non_differentiable(*[t for t in (weights, alpha) if t is not None])
+        return rgb, weights, alpha
 
     @staticmethod
     def backward(ctx, d_rgb, d_w, d_a):
