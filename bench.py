@@ -70,12 +70,61 @@ def cpu_baseline(params, data_np, n_rays, u):
     return n_rays * 256 / dt, dt, out
 
 
+def train_section(pipe, data, rays, steps, world, rank, dev):
+    """Secondary measurement (not `value`): data-parallel training steps - forward with saved
+    activations, MSE coarse+fine, HIP backward, one flat RCCL all-reduce of the gradients, Adam - on
+    `rays` rays per GPU drawn from this rank's frame (solver/nerf_solver.py:76-87)."""
+    from smpl_nerf_amd import _lib
+    from smpl_nerf_amd.dist import barrier, max_over_ranks
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    mc, mf = pipe.model_coarse, pipe.model_fine
+    for m in (mc, mf):
+        m.train()
+        for p in m.parameters():
+            p.requires_grad_(True)
+    tr = DataParallelTrainer(pipe, [mc, mf], lr=5e-4)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    n_total = data[0].shape[0]
+    batches = []
+    for _ in range(4):
+        idx = torch.randperm(n_total, generator=g)[:rays].to(dev)
+        batches.append([t[idx].contiguous() for t in data])
+    losses = []
+    for i in range(2):
+        losses.append(tr.step(batches[i % 4]))
+    barrier(dev)
+    torch.cuda.synchronize()
+    with _lib.profile() as prof:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            losses.append(tr.step(batches[i % 4]))
+        torch.cuda.synchronize()
+        barrier(dev)
+        dt = time.perf_counter() - t0
+    kern = prof.summary()
+    dt = max_over_ranks(dt, dev)
+    losses = [float(l) for l in losses]
+    evals = world * steps * rays * 256
+    bwd = {k: v for k, v in kern.items() if k.startswith("mlp_bwd")}
+    fwd = {k: v for k, v in kern.items() if k.startswith("mlp_fwd_train")}
+    flop_step = 3 * FLOP_PER_EVAL * rays * 256          # fwd + dgrad + wgrad
+    mlp_ms = (sum(v[1] for v in bwd.values()) + sum(v[1] for v in fwd.values())) / steps
+    return {"metric": "ray-samples/s, training step (fwd+bwd+all-reduce+Adam)", "value": evals / dt,
+            "rays_per_step_per_gpu": rays, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "loss_first": losses[0], "loss_last": losses[-1],
+            "mlp_kernels_ms_per_step": mlp_ms, "mlp_tflops": flop_step / (mlp_ms * 1e-3) / 1e12,
+            "kernels_ms_per_step": {k: v[1] / steps for k, v in sorted(kern.items())},
+            "collective": "one all-reduce of 1 220 872 fp32 gradients per step" if world > 1 else "none (1 GPU)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the frame the CPU baseline renders (0 = skip)")
+    ap.add_argument("--train-rays", type=int, default=4096, help="rays per GPU per training step (0 = skip the train section)")
+    ap.add_argument("--train-steps", type=int, default=10)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,6 +165,13 @@ def main():
         kern = prof.summary()
     elapsed = max_over_ranks(elapsed, dev)
 
+    train = None
+    if a.train_rays > 0:
+        try:
+            train = train_section(pipe, data, a.train_rays, a.train_steps, world, rank, dev)
+        except Exception as e:  # the render metric above stays valid
+            train = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         value = world * a.steps * evals_per_step / elapsed
         # dominant kernel = the fused encode+MLP kernel; it is launched twice per step (coarse: 16384*64
@@ -147,6 +203,8 @@ def main():
                                       "(PMC passes of this command), not measured live"},
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(kern.items())},
         }
+        if train is not None:
+            line["train"] = train
         if world == 1 and a.cpu_rays > 0:
             from smpl_nerf_amd.ops import uniform_u
             u = uniform_u(128, dev).cpu().numpy()

@@ -57,3 +57,58 @@ def _worker(rank, world, port, n):
 def test_two_rank_gloo_sharding_and_allreduce():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, 1001), nprocs=2, join=True)
+
+
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smpl_nerf_amd.trainer import DataParallelTrainer
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+        class Pipe(torch.nn.Module):          # stands in for NerfPipeline: (rgb, rgb_fine, ...) from a batch list
+            def forward(self, data):
+                y = torch.sigmoid(net(data[0]))
+                return y, y * 0.5
+
+        g = torch.Generator().manual_seed(1)
+        x, gt = torch.rand(64, 6, generator=g), torch.rand(64, 3, generator=g)
+        b, e = sd.shard_range(64, world, rank)
+        tr = DataParallelTrainer(Pipe(), [net], lr=1e-2, fused=False)
+        for _ in range(3):
+            tr.step([x[b:e], gt[b:e]])
+        if rank == 0:
+            q.put([p.detach().numpy().copy() for p in net.parameters()])   # by value
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_steps_equal_single_process_on_the_concatenated_batch():
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join()
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+    class Pipe(torch.nn.Module):
+        def forward(self, data):
+            y = torch.sigmoid(net(data[0]))
+            return y, y * 0.5
+
+    g = torch.Generator().manual_seed(1)
+    x, gt = torch.rand(64, 6, generator=g), torch.rand(64, 3, generator=g)
+    tr = DataParallelTrainer(Pipe(), [net], lr=1e-2, fused=False)
+    for _ in range(3):
+        tr.step([x, gt])
+    for a, b in zip(got, net.parameters()):
+        assert torch.allclose(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-6)
