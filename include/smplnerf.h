@@ -157,6 +157,28 @@ int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const f
 int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
                               int64_t n, int64_t row_floats, float *raw, snerf_stream_t stream);
 
+/* ---- a7: WarpFieldNet fused with x' = x + warp and the per-sample view direction ---------------------
+ * Mirrors WarpFieldNet.__init__ (models/warp_field_net.py:8-15): linear1 [width, positions_dim+pose_dim],
+ * linear2 [3, width]; positions_dim is expressed through the position encoder. */
+typedef struct snerf_warp_desc {
+    int32_t width;        /* 256 */
+    int32_t pos_freqs;    /* 10 */
+    int32_t pos_identity; /* 0 */
+    int32_t pose_dim;     /* 40 = encoded pose of the two joints (models/smpl_nerf_pipeline.py:28-30) */
+} snerf_warp_desc;
+int64_t snerf_warp_param_floats(const snerf_warp_desc *desc); /* linear1.weight, .bias, linear2.weight, .bias */
+int64_t snerf_warp_packed_floats(const snerf_warp_desc *desc);
+int snerf_warp_pack_f32(const snerf_warp_desc *desc, const float *params_flat, float *packed,
+                        snerf_stream_t stream);
+/* x [n,3], pose_enc [n/samples_per_ray, pose_dim], o [n/samples_per_ray, 3] ->
+ * warp [n,3] = net([PE(x) | pose_enc]) (models/warp_field_net.py:17-21),
+ * warped [n,3] = x + warp (models/smpl_nerf_pipeline.py:49), sdirs [n,3] = warped - o (:52-53).
+ * warped / sdirs nullable.  With pos_freqs = pos_identity = 0 the net reads only pose_enc rows
+ * (x may be NULL): the literal WarpFieldNet.forward(x_rows) with samples_per_ray = 1. */
+int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
+                       const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
+                       float *warp, float *warped, float *sdirs, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

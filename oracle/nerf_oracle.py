@@ -354,6 +354,47 @@ def smpl_nerf_pipeline_forward(params_coarse, params_fine, params_warp, args, po
 
 
 # ----------------------------------------------------------------------------------------------
+# a8  AppendVerticesPipeline.forward  (models/append_vertices_pipeline.py:16-94)
+# ----------------------------------------------------------------------------------------------
+def append_vertices_net_forward(params, x, n_layers=8, positions_dim=60, directions_dim=24, skips=(4,)):
+    """models/append_vertices_net.py:43-66.  positions = x[:, :positions_dim] (:44), directions =
+    x[:, -directions_dim:] (:47); `vertices_net` is evaluated by the reference and its result dropped
+    (:48-50), so it is not restated here (it cannot influence the output)."""
+    return render_ray_net_forward(params, x, n_layers=n_layers, positions_dim=positions_dim,
+                                  directions_dim=directions_dim, additional_input_dim=0, skips=skips)
+
+
+def append_vertices_pipeline_forward(params_coarse, params_fine, vertices, args, position_encoder,
+                                     direction_encoder, data, net_kw=None):
+    """models/append_vertices_pipeline.py:16-94 given the posed vertices [B, 6890, 3] the body model returned
+    (:38-40).  Rows are [vertices_flat | PE(x) | PE(d)] (:56-58); only the columns the net reads are built."""
+    net_kw = net_kw or {}
+    ray_samples, ray_translation, ray_direction, z_vals = [np.asarray(t, F32) for t in data[:4]]
+    B, Nc = ray_samples.shape[:2]
+    vflat = np.asarray(vertices, F32).reshape(B, -1)                                     # :41
+    pdim = net_kw.get("positions_dim", 60)
+    dirs = np.broadcast_to(ray_direction[:, None, :], (B, Nc, 3))
+    directions_encoding = direction_encoder.encode(_normalize(dirs))                     # :52-55
+
+    def rows(n):
+        head = np.broadcast_to(vflat[:, None, :pdim], (B, n, pdim))                      # first columns of the row
+        denc = np.broadcast_to(directions_encoding[:, :1, :], (B, n, directions_encoding.shape[-1]))
+        return np.concatenate([head.reshape(B * n, -1), denc.reshape(B * n, -1)], -1)
+
+    raw = append_vertices_net_forward(params_coarse, rows(Nc), **net_kw).reshape(B, Nc, 4)     # :59-62
+    rgb, weights, densities = raw2outputs(raw, z_vals, dirs, args.white_background)      # :63
+    if not args.run_fine:
+        return rgb, rgb, ray_samples, densities
+    z_f, pts_f = fine_sampling(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
+                               getattr(args, "u", None))                                 # :68
+    N = pts_f.shape[1]
+    raw_f = append_vertices_net_forward(params_fine, rows(N), **net_kw).reshape(B, N, 4)  # :84-88
+    dirs_f = np.broadcast_to(ray_direction[:, None, :], (B, N, 3))
+    rgb_fine, _, dens_f = raw2outputs(raw_f, z_f, dirs_f, args.white_background)         # :92
+    return rgb, rgb_fine, pts_f, dens_f
+
+
+# ----------------------------------------------------------------------------------------------
 # adjacent: rays + stratified coarse samples (utils.py:26-54, datasets/transforms.py:58-90)
 # ----------------------------------------------------------------------------------------------
 def get_rays(H, W, focal, camera_transform):

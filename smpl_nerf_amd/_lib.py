@@ -22,6 +22,11 @@ class MlpDesc(ctypes.Structure):
                 ("use_dir", c_int32)]
 
 
+class WarpDesc(ctypes.Structure):
+    """struct snerf_warp_desc - mirrors WarpFieldNet.__init__ (models/warp_field_net.py:8)."""
+    _fields_ = [("width", c_int32), ("pos_freqs", c_int32), ("pos_identity", c_int32), ("pose_dim", c_int32)]
+
+
 _P = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 # name -> (restype, argtypes); must list every symbol include/smplnerf.h declares
@@ -44,6 +49,10 @@ SIGNATURES = {
     "snerf_mlp_fwd_train_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P, _P]),
     "snerf_mlp_pack_t_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
     "snerf_mlp_bwd_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "snerf_warp_param_floats": (c_int64, [POINTER(WarpDesc)]),
+    "snerf_warp_packed_floats": (c_int64, [POINTER(WarpDesc)]),
+    "snerf_warp_pack_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P]),
+    "snerf_warp_fwd_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "snerf_mlp_fwd_encoded_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int64, c_int64, _P, _P]),
 }
 

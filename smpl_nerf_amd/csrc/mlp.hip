@@ -226,6 +226,11 @@ static int fill_args(const snerf_mlp_desc *desc, Plan &P, FwdArgs &A) {
     return SNERF_OK;
 }
 
+int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStream_t s, const char *what) {
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, s, P, params_flat, packed);
+    return check_launch(what);
+}
+
 constexpr int FWD_WAVES = 4;  // 64 samples per workgroup; several workgroups share a CU
 
 template <bool ENCODED, bool TRAIN>
@@ -267,9 +272,7 @@ extern "C" int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *param
     if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_pack: %s", why);
     if (!params_flat || !packed) return fail(SNERF_E_BADARG, "mlp_pack: null pointer");
     if (!aligned(packed, 16)) return fail(SNERF_E_ALIGN, "mlp_pack: packed must be 16-byte aligned");
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, (hipStream_t)stream, P,
-                       params_flat, packed);
-    return check_launch("mlp_pack");
+    return launch_pack(P, params_flat, packed, (hipStream_t)stream, "mlp_pack");
 }
 
 extern "C" int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x, const float *dirs,

@@ -9,6 +9,9 @@ namespace snerf {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// defined in mlp.hip: packs params_flat into the slab stream described by `P` (any plan)
+int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStream_t s, const char *what);
+
 // ------------------------------------------------------------------------------------------------
 // forward kernel
 // ------------------------------------------------------------------------------------------------

@@ -251,3 +251,142 @@ class RenderRayNet(nn.Module):
     @property
     def is_cuda(self):
         return next(self.parameters()).is_cuda
+
+
+class WarpFieldNet(nn.Module):
+    """models/warp_field_net.py:6-22 drop-in: linear1 (width, positions_dim+pose_dim) + ReLU + linear2
+    (3, width); `n_layers` is accepted and ignored exactly like the reference (:14-15).  forward(x) runs the
+    fused HIP kernel on already-encoded rows; forward_fused() also encodes the positions and returns the
+    warped samples and per-sample view directions (models/smpl_nerf_pipeline.py:38-53)."""
+
+    def __init__(self, n_layers=8, width=256, positions_dim=60, pose_dim=24):
+        super(WarpFieldNet, self).__init__()
+        self.positions_dim = positions_dim
+        self.direcions_dim = pose_dim  # (sic) reference attribute name, :12
+        self.width = width
+        self.linear1 = torch.nn.Linear(positions_dim + pose_dim, width)
+        self.linear2 = torch.nn.Linear(width, 3)
+        self._pack_cache = {}
+
+    def _params(self):
+        return [self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias]
+
+    def _packed(self, desc):
+        params = self._params()
+        dev = params[0].device
+        if not params[0].is_cuda:
+            raise RuntimeError("WarpFieldNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
+        key = tuple(getattr(desc, f[0]) for f in desc._fields_)
+        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = _lib.load()
+        n_param, n_pack = lib.snerf_warp_param_floats(desc), lib.snerf_warp_packed_floats(desc)
+        if n_param < 0 or n_pack < 0:
+            check(int(min(n_param, n_pack)), "snerf_warp_packed_floats")
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        if flat.numel() != n_param:
+            raise RuntimeError(f"WarpFieldNet: {flat.numel()} parameters but the descriptor expects {n_param}")
+        packed = torch.empty(n_pack, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(lib.snerf_warp_pack_f32(desc, ptr(flat), ptr(packed), current_stream()), "snerf_warp_pack_f32")
+        self._pack_cache = {key: (stamp, packed)}
+        return packed
+
+    def _no_grad(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("WarpFieldNet: backward is not implemented yet; run under torch.no_grad()")
+
+    def forward(self, x):
+        """x [..., positions_dim + pose_dim] (already encoded) -> warp [..., 3]."""
+        self._no_grad()
+        if not x.is_cuda:
+            raise RuntimeError("WarpFieldNet.forward: input must be on the GPU (no CPU path)")
+        rows = x.reshape(-1, x.shape[-1]).contiguous().float()
+        desc = _lib.WarpDesc(self.width, 0, 0, rows.shape[1])
+        packed = self._packed(desc)
+        n = rows.shape[0]
+        warp = torch.empty((n, 3), device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            check(lib.snerf_warp_fwd_f32(desc, ptr(packed), None, ptr(rows), None, n, 1, ptr(warp), None, None,
+                                         current_stream()), "snerf_warp_fwd_f32")
+        return warp.reshape(x.shape[:-1] + (3,))
+
+    def forward_fused(self, positions, pose_encoding, ray_translation, samples_per_ray, position_encoder):
+        """positions [n,3] (samples of a ray contiguous), pose_encoding [n/spr, pose_dim], ray_translation
+        [n/spr, 3] -> (warp, warped = positions + warp, sdirs = warped - ray_translation), each [n,3]."""
+        self._no_grad()
+        pos_L, pos_id = position_encoder.number_frequencies, 1 if position_encoder.include_identity else 0
+        if 3 * (pos_id + 2 * pos_L) != self.positions_dim or pose_encoding.shape[-1] != self.direcions_dim:
+            raise RuntimeError("WarpFieldNet: encoder output sizes do not match positions_dim/pose_dim")
+        desc = _lib.WarpDesc(self.width, pos_L, pos_id, self.direcions_dim)
+        packed = self._packed(desc)
+        x = positions.reshape(-1, 3).contiguous()
+        n = x.shape[0]
+        pe = pose_encoding.reshape(-1, self.direcions_dim).contiguous()
+        o = ray_translation.reshape(-1, 3).contiguous()
+        if pe.shape[0] * samples_per_ray != n or o.shape[0] * samples_per_ray != n:
+            raise RuntimeError("forward_fused: per-ray inputs do not match positions / samples_per_ray")
+        warp, warped, sdirs = (torch.empty((n, 3), device=x.device, dtype=torch.float32) for _ in range(3))
+        lib = _lib.load()
+        with torch.cuda.device(x.device), _lib.timed(f"warp_fwd[n={n}]"):
+            check(lib.snerf_warp_fwd_f32(desc, ptr(packed), ptr(x), ptr(pe), ptr(o), n, int(samples_per_ray), ptr(warp),
+                                         ptr(warped), ptr(sdirs), current_stream()), "snerf_warp_fwd_f32")
+        return warp, warped, sdirs
+
+    @property
+    def is_cuda(self):
+        return next(self.parameters()).is_cuda
+
+
+class AppendVerticesNet(RenderRayNet):
+    """models/append_vertices_net.py:6-66 drop-in.  The reference slices its input as
+    positions = x[:, :positions_dim], vertices = x[:, positions_dim:positions_dim+additional_input_dim],
+    directions = x[:, -directions_dim:] (:44-47), pushes `vertices` through `vertices_net` and never uses the
+    result (:48-50): the output is RenderRayNet(positions, directions) on the first positions_dim input
+    columns.  The parameters of `vertices_net` are kept (same state_dict) and, as in the reference, receive
+    no gradient; the dead branch is not evaluated."""
+
+    def __init__(self, n_layers=8, width=256, positions_dim=60, directions_dim=24, additional_input_dim=6980,
+                 additional_input_layers=1, skips=[4]):
+        super(AppendVerticesNet, self).__init__(n_layers, width, positions_dim, directions_dim, 0, skips, 1)
+        self.additional_input_dim = additional_input_dim
+        self.vertices_net = nn.ModuleList()
+        self.vertices_net.append(torch.nn.Linear(additional_input_dim, width))
+        for i in range(additional_input_layers):
+            self.vertices_net.append(torch.nn.Linear(width, width))
+
+    def desc_for_rows(self) -> MlpDesc:
+        """positions are plain per-ray columns (no encoder): pos_freqs = 0, add_dim = positions_dim."""
+        d = _encoder_shape(self.direcions_dim)
+        if d is None:
+            raise RuntimeError(f"AppendVerticesNet: directions_dim={self.direcions_dim} is not a 3-channel encoding")
+        return MlpDesc(self.n_layers, self.width, 0, 0, d[0], d[1], self.positions_dim, self._skip_mask(), 1)
+
+    def forward(self, x):
+        """x [..., positions_dim + additional_input_dim + directions_dim] -> [..., 4] (:43-66)."""
+        keep = self.additional_input_dim
+        try:
+            self.additional_input_dim = 0        # live columns: x[..., :positions_dim] and x[..., -directions_dim:]
+            return RenderRayNet.forward(self, x)
+        finally:
+            self.additional_input_dim = keep
+
+    def forward_rays(self, ray_inputs, directions, samples_per_ray, n):
+        """ray_inputs [B, positions_dim] (the first positions_dim columns of the reference's input rows, a
+        per-ray constant), directions [B,3] -> raw [n = B*samples_per_ray, 4]."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("AppendVerticesNet: backward is not implemented yet; run under torch.no_grad()")
+        desc = self.desc_for_rows()
+        packed = self.packed_weights(desc)
+        add = ray_inputs.reshape(-1, self.positions_dim).contiguous().float()
+        d = directions.reshape(-1, 3).contiguous()
+        dummy_x = torch.zeros((n, 3), device=add.device, dtype=torch.float32)   # no position encoder: never read for slots
+        raw = torch.empty((n, 4), device=add.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(add.device), _lib.timed(f"mlp_fwd[n={n}]"):
+            check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(dummy_x), ptr(d), 0, ptr(add), n, int(samples_per_ray),
+                                        ptr(raw), current_stream()), "snerf_mlp_fwd_f32")
+        return raw

@@ -57,3 +57,96 @@ class NerfPipeline(nn.Module):
         rgb_fine, _, densities_fine = ops.composite(raw_fine.view(B, N, 4), z_fine, ray_direction, wb,
                                                     self._noise((B, N), dev), want_weights=False)  # :65
         return rgb, rgb_fine, ray_samples_fine, densities_fine                                    # :67
+
+
+class SmplNerfPipeline(NerfPipeline):
+    """models/smpl_nerf_pipeline.py:7-100 drop-in: NerfPipeline with a pose-conditioned warp of the samples.
+
+    data = [ray_samples, ray_translation, ray_direction, z_vals, goal_pose[B,69], rgb_truth]; returns
+    (rgb, rgb_fine, warp_fine, ray_samples_fine, warped_samples_fine, densities_fine) or, with
+    run_fine = 0, (rgb, rgb, warp, ray_samples, warped_samples, densities).  Quirks kept: joints 38 and 41
+    are hard-coded (:28); the coarse compositing scales distances by |x' - o| per sample (:63) while the
+    fine one uses the ray direction (:95-98); hierarchical samples are drawn on the un-warped ray (:68).
+    Only human_pose_encoding = 1 is supported (with 0 the reference itself crashes once run_fine = 1, Q5).
+    """
+
+    def __init__(self, model_coarse, model_fine, model_warp_field, args, position_encoder, direction_encoder,
+                 human_pose_encoder):
+        super().__init__(model_coarse, model_fine, args, position_encoder, direction_encoder)
+        self.human_pose_encoder = human_pose_encoder
+        self.model_warp_field = model_warp_field
+
+    def _stage(self, net, samples, ray_translation, pose_enc, n_per_ray):
+        warp, warped, sdirs = self.model_warp_field.forward_fused(samples, pose_enc, ray_translation, n_per_ray,
+                                                                  self.position_encoder)
+        raw = net.forward_fused(warped, sdirs, n_per_ray, self.position_encoder, self.direction_encoder)
+        return warp, warped, sdirs, raw
+
+    def forward(self, data):
+        ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
+        args = self.args
+        if not args.human_pose_encoding:
+            raise NotImplementedError("SmplNerfPipeline: human_pose_encoding=0 is not supported (the reference "
+                                      "crashes in the fine branch in that mode, models/smpl_nerf_pipeline.py:71-77)")
+        B, Nc = z_vals.shape
+        wb = bool(args.white_background)
+        dev = ray_samples.device
+        goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)                      # :28
+        pose_enc = self.human_pose_encoder.encode(goal_pose.contiguous())                          # :30
+        warp, warped, sdirs, raw = self._stage(self.model_coarse, ray_samples, ray_translation, pose_enc, Nc)
+        rgb, weights, densities = ops.composite(raw.view(B, Nc, 4), z_vals, sdirs.view(B, Nc, 3), wb,
+                                                self._noise((B, Nc), dev))                        # :63
+        if not args.run_fine:
+            return rgb, rgb, warp.view(B, Nc, 3), ray_samples, warped.view(B, Nc, 3), densities   # :64-65
+        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples)
+        z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :68
+        N = z_fine.shape[1]
+        warp_f, warped_f, _, raw_f = self._stage(self.model_fine, ray_samples_fine, ray_translation, pose_enc, N)
+        rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
+                                                    self._noise((B, N), dev), want_weights=False)  # :95-98
+        return (rgb, rgb_fine, warp_f.view(B, N, 3), ray_samples_fine, warped_f.view(B, N, 3), densities_fine)  # :100
+
+
+class AppendVerticesPipeline(NerfPipeline):
+    """models/append_vertices_pipeline.py:7-94 drop-in.  data = [ray_samples, ray_translation, ray_direction,
+    z_vals, images (estimator input, e.g. image indices), rgb_truth]; `smpl_estimator(images)` returns
+    (goal_poses, betas) and `smpl_model(betas=, return_verts=True, body_pose=, global_orient=)` an object
+    with `.vertices [B, 6890, 3]` (smplx in the reference; any callable with that contract here).
+
+    The reference concatenates the 20 670 vertex floats IN FRONT of every sample's encoding (:56-58) and the
+    net reads its "positions" from the first positions_dim columns (models/append_vertices_net.py:44-47), so
+    the effective network input is a per-ray constant: the first positions_dim vertex floats and the encoded
+    ray direction.  That is what is evaluated here - without materialising the
+    [B*N, 20754] fp32 input rows (83 KB per sample in the reference)."""
+
+    def __init__(self, model_coarse, model_fine, smpl_estimator, smpl_model, args, position_encoder,
+                 direction_encoder):
+        super().__init__(model_coarse, model_fine, args, position_encoder, direction_encoder)
+        self.smpl_estimator = smpl_estimator
+        self.smpl_model = smpl_model
+
+    def forward(self, data):
+        ray_samples, ray_translation, ray_direction, z_vals, images, _ = data
+        args = self.args
+        B, Nc = z_vals.shape
+        wb = bool(args.white_background)
+        dev = ray_samples.device
+        goal_poses, betas = self.smpl_estimator(images)                                            # :30
+        global_orient = torch.zeros([1, 3], device=dev).expand(B, -1)                              # :13, :36
+        goal_models = self.smpl_model(betas=betas, return_verts=True, body_pose=goal_poses,
+                                      global_orient=global_orient)                                 # :38-39
+        vertices_flat = goal_models.vertices.reshape(B, -1)                                        # :41
+        pdim = self.model_coarse.positions_dim
+        ray_inputs = vertices_flat[:, :pdim]          # the columns AppendVerticesNet.forward actually reads
+        raw = self.model_coarse.forward_rays(ray_inputs, ray_direction, Nc, B * Nc)
+        rgb, weights, densities = ops.composite(raw.view(B, Nc, 4), z_vals, ray_direction, wb,
+                                                self._noise((B, Nc), dev))                        # :65
+        if not args.run_fine:
+            return rgb, rgb, ray_samples, densities                                               # :66-67
+        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples)
+        z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :70
+        N = z_fine.shape[1]
+        raw_f = self.model_fine.forward_rays(ray_inputs, ray_direction, N, B * N)
+        rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
+                                                    self._noise((B, N), dev), want_weights=False)  # :92
+        return rgb, rgb_fine, ray_samples_fine, densities_fine                                    # :94

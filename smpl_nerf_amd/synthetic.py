@@ -201,6 +201,33 @@ def make_warp_field_params(seed: int, positions_dim=60, pose_dim=40, width=256, 
     return params
 
 
+def append_vertices_shapes(n_layers=8, width=256, positions_dim=60, directions_dim=24, additional_input_dim=6890,
+                           additional_input_layers=1, skips=(4,)):
+    """AppendVerticesNet state_dict (name, fan_out, fan_in) in registration order
+    (models/append_vertices_net.py:19-41)."""
+    layers = [("positions_pose_input", width, positions_dim)]
+    for i in range(n_layers - 1):
+        layers.append((f"positional_net.{i}", width, width + positions_dim if i in skips else width))
+    layers.append(("additional_linear_layer", width, width))
+    layers.append(("sigma_out_layer", 1, width))
+    layers.append(("vertices_net.0", width, additional_input_dim))
+    for i in range(additional_input_layers):
+        layers.append((f"vertices_net.{i + 1}", width, width))
+    dw = width // 2
+    layers.append(("directional_input", dw, width + directions_dim))
+    layers.append(("directional_net.0", dw, dw))
+    layers.append(("rgb_out_layer", 3, dw))
+    return layers
+
+
+def make_append_vertices_params(seed: int, sigma_scale=30.0, rgb_scale=10.0, **kw) -> dict:
+    params = init_linear_stack(append_vertices_shapes(**kw), seed)
+    params["sigma_out_layer.weight"] = (params["sigma_out_layer.weight"] * F32(sigma_scale)).astype(F32)
+    params["sigma_out_layer.bias"] = (params["sigma_out_layer.bias"] + F32(2.0)).astype(F32)
+    params["rgb_out_layer.weight"] = (params["rgb_out_layer.weight"] * F32(rgb_scale)).astype(F32)
+    return params
+
+
 def human_poses(joints=(41, 38), start=0.0, end=60.0, steps=10) -> np.ndarray:
     """render.py:190-220 (get_human_poses) -> [steps, 69] fp32, radians at the listed joints."""
     angles = np.linspace(start, end, steps)

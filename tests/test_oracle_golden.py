@@ -235,6 +235,36 @@ def test_smpl_nerf_pipeline_coarse_only():
     assert maxabs(out[5], g["coarse_alpha"]) <= 5e-5   # warp round-off (2e-6) re-enters the 2^9 band of the encoder
 
 
+# ---------------------------------------------------------------- a8
+def _av_setup():
+    import torch
+    from smpl_nerf_amd.synthetic_smpl import LinearBodyModel
+    g = load_golden("g9_append_vertices.npz")
+    poses = syn.human_poses((41, 38), 0, 60, 10)
+    body = LinearBodyModel(seed=3)
+    verts = body(body_pose=torch.from_numpy(poses[g["images"]])).vertices.numpy()
+    data = syn.frame_batch(128, 128, phi=3.0, theta=-10.0, seed=11)
+    return g, verts, [a[g["sub"]] for a in data]
+
+
+@pytest.mark.parametrize("wb", [0, 1])
+def test_append_vertices_pipeline_coarse(wb):
+    g, verts, d = _av_setup()
+    assert g["reference_fine_branch_runs"][0] == 0      # the reference raises with run_fine=1 (pipeline.py:71)
+    pc, pf = syn.make_append_vertices_params(201), syn.make_append_vertices_params(202)
+    out = O.append_vertices_pipeline_forward(pc, pf, verts, O.Args(white_background=wb, run_fine=0),
+                                             O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0), d)
+    assert out[0] is out[1]
+    assert maxabs(out[0], g[f"coarse_rgb_wb{wb}"]) <= 1e-5
+    assert maxabs(out[3], g[f"coarse_alpha_wb{wb}"]) <= 1e-5
+
+
+def test_append_vertices_net_rows():
+    g = load_golden("g9_append_vertices.npz")
+    out = O.append_vertices_net_forward(syn.make_append_vertices_params(201), g["net_rows"])
+    assert maxabs(out, g["net_out"]) <= 2e-5 * max(1.0, float(np.abs(g["net_out"]).max()))
+
+
 # ---------------------------------------------------------------- adjacent: rays / coarse samples
 def test_rays_and_coarse_sampling():
     g = load_golden("g8_rays.npz")
