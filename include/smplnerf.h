@@ -113,6 +113,9 @@ typedef struct snerf_mlp_desc {
     int32_t add_dim;      /* 0 */
     uint32_t skip_mask;   /* bit i set <=> i in skips */
     int32_t use_dir;      /* 1 */
+    int32_t add_first;    /* 0: input columns [PE(x) | add] (RenderRayNet(additional_input_dim) fed by train.py:154-159
+                             style rows [samples_encoding | extra]); 1: [add | PE(x)], the order the append_smpl_params /
+                             append_to_nerf pipelines build (models/append_smpl_params_pipeline.py:49-51) */
 } snerf_mlp_desc;
 
 /* Number of floats in the flat parameter vector: weights and biases in state_dict order

@@ -354,6 +354,43 @@ def smpl_nerf_pipeline_forward(params_coarse, params_fine, params_warp, args, po
 
 
 # ----------------------------------------------------------------------------------------------
+# f-4  AppendSmplParamsPipeline / AppendToNerfPipeline  (models/append_smpl_params_pipeline.py:14-91,
+#      models/append_to_nerf_pipeline.py:14-90)
+# ----------------------------------------------------------------------------------------------
+def append_pose_pipeline_forward(params_coarse, params_fine, args, position_encoder, direction_encoder,
+                                 human_pose_encoder, data, two_joints=False, net_kw=None):
+    """Rows are [pose | PE(x) | PE(d)] (:49-51) fed to RenderRayNet(additional_input_dim = pose columns)."""
+    net_kw = dict(net_kw or {})
+    ray_samples, ray_translation, ray_direction, z_vals, goal_pose = [np.asarray(t, F32) for t in data[:5]]
+    if two_joints:
+        goal_pose = np.stack([goal_pose[:, 38], goal_pose[:, 41]], -1)                   # append_to_nerf :26
+    pose = human_pose_encoder.encode(goal_pose) if args.human_pose_encoding else goal_pose   # :29-37
+    net_kw["additional_input_dim"] = pose.shape[-1]
+    B, Nc = ray_samples.shape[:2]
+    dirs = np.broadcast_to(ray_direction[:, None, :], (B, Nc, 3))
+    directions_encoding = direction_encoder.encode(_normalize(dirs))
+
+    def rows(pts):
+        n = pts.shape[1]
+        pz = np.broadcast_to(pose[:, None, :], (B, n, pose.shape[-1]))
+        denc = np.broadcast_to(directions_encoding[:, :1, :], (B, n, directions_encoding.shape[-1]))
+        return np.concatenate([pz.reshape(B * n, -1), position_encoder.encode(pts).reshape(B * n, -1),
+                               denc.reshape(B * n, -1)], -1)
+
+    raw = render_ray_net_forward(params_coarse, rows(ray_samples), **net_kw).reshape(B, Nc, 4)
+    rgb, weights, densities = raw2outputs(raw, z_vals, dirs, args.white_background)      # :55
+    if not args.run_fine:
+        return rgb, rgb, ray_samples, densities
+    z_f, pts_f = fine_sampling(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
+                               getattr(args, "u", None))                                 # :60
+    N = pts_f.shape[1]
+    raw_f = render_ray_net_forward(params_fine, rows(pts_f), **net_kw).reshape(B, N, 4)
+    dirs_f = np.broadcast_to(ray_direction[:, None, :], (B, N, 3))
+    rgb_fine, _, dens_f = raw2outputs(raw_f, z_f, dirs_f, args.white_background)         # :89
+    return rgb, rgb_fine, pts_f, dens_f
+
+
+# ----------------------------------------------------------------------------------------------
 # a8  AppendVerticesPipeline.forward  (models/append_vertices_pipeline.py:16-94)
 # ----------------------------------------------------------------------------------------------
 def append_vertices_net_forward(params, x, n_layers=8, positions_dim=60, directions_dim=24, skips=(4,)):

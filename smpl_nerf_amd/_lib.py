@@ -19,7 +19,7 @@ class MlpDesc(ctypes.Structure):
     """struct snerf_mlp_desc (include/smplnerf.h) - mirrors RenderRayNet.__init__ (models/render_ray_net.py:8)."""
     _fields_ = [("n_layers", c_int32), ("width", c_int32), ("pos_freqs", c_int32), ("pos_identity", c_int32),
                 ("dir_freqs", c_int32), ("dir_identity", c_int32), ("add_dim", c_int32), ("skip_mask", c_uint32),
-                ("use_dir", c_int32)]
+                ("use_dir", c_int32), ("add_first", c_int32)]
 
 
 class WarpDesc(ctypes.Structure):

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         }
         if (A.add_dim) c.add = A.add + ray * A.add_dim;
     }
-    const int enc_add_off = A.pos_dim, enc_dir_off = A.enc_stride - A.dir_dim;  // directions = x[..., -dir_dim:] (:43)
+    const int enc_pos_off = A.add_first ? A.add_dim : 0, enc_add_off = A.add_first ? 0 : A.pos_dim;
+    const int enc_dir_off = A.enc_stride - A.dir_dim;  // directions = x[..., -dir_dim:] (:43)
 
     SlabPipe<NT> pipe;
     pipe.prologue(A.packed, ring, tid);
@@ -111,12 +112,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     f4 in[T], acc[T];
 
     // extra input segments [PE(x) | add] of layer 0 and of the skip layers
-    auto pos_segments = [&](LayerRun<T, NT> &run, bool first) {
+    auto pe_segment = [&](LayerRun<T, NT> &run, bool first) {
         for (int kb = 0; kb < A.pos_nkb; ++kb) {
-            const f4 b = pe_operand<ENCODED>(c, false, A.pos_L, A.pos_id, kb, 0);
+            const f4 b = pe_operand<ENCODED>(c, false, A.pos_L, A.pos_id, kb, enc_pos_off);
             if (TRAIN && first && valid) store_tile(A.act, A.act_pe + kb, A.n, sample, c.g, b);
             run.step(b, acc);
         }
+    };
+    auto add_segment = [&](LayerRun<T, NT> &run, bool first) {
         for (int kb = 0; kb < A.add_nkb; ++kb) {
             f4 b;
             if (ENCODED) {
@@ -128,8 +131,15 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
             } else {
                 b = add_operand(c, A.add_dim, kb);
             }
+            if (TRAIN && first && valid) store_tile(A.act, A.act_add + kb, A.n, sample, c.g, b);
             run.step(b, acc);
         }
+    };
+    // extra input segments of layer 0 and of the skip layers, in the column order of the weight matrix
+    auto pos_segments = [&](LayerRun<T, NT> &run, bool first) {
+        if (A.add_first) add_segment(run, first);
+        pe_segment(run, first);
+        if (!A.add_first) add_segment(run, first);
     };
 
     {  // positions_pose_input + relu (models/render_ray_net.py:45)
@@ -221,6 +231,7 @@ static int fill_args(const snerf_mlp_desc *desc, Plan &P, FwdArgs &A) {
     A.dir_dim = P.dir_dim;
     A.add_dim = P.add_dim;
     A.add_nkb = P.add_nkb;
+    A.add_first = (P.add_dim && desc->add_first) ? 1 : 0;
     A.use_dir = desc->use_dir ? 1 : 0;
     A.enc_stride = P.pos_dim + P.add_dim + (desc->use_dir ? P.dir_dim : 0);
     return SNERF_OK;
@@ -331,7 +342,7 @@ extern "C" int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *
     if (n == 0) return SNERF_OK;
     if (!packed || !x || !raw || !act) return fail(SNERF_E_BADARG, "mlp_fwd_train: null pointer");
     if (A.use_dir && !dirs) return fail(SNERF_E_BADARG, "mlp_fwd_train: dirs is null");
-    if (A.add_dim) return fail(SNERF_E_BADARG, "mlp_fwd_train: additional inputs are not supported in training yet");
+    if (A.add_dim && !add) return fail(SNERF_E_BADARG, "mlp_fwd_train: add is null");
     if (!aligned(packed, 16) || !aligned(raw, 16) || !aligned(act, 16))
         return fail(SNERF_E_ALIGN, "mlp_fwd_train: packed/raw/act must be 16-byte aligned");
     TrainLayout L;
@@ -346,6 +357,7 @@ extern "C" int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *
     A.dirs_per_sample = dirs_per_sample ? 1 : 0;
     A.act = act;
     A.act_pe = L.pe;
+    A.act_add = L.add;
     A.act_dpe = L.dpe;
     A.act_x1 = L.x[1];
     A.act_o = L.o;

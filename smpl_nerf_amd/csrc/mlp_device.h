@@ -28,12 +28,12 @@ struct FwdArgs {
     unsigned skip_mask;
     int pos_L, pos_id, pos_nkb, pos_dim;
     int dir_L, dir_id, dir_nkb, dir_dim;
-    int add_dim, add_nkb;
+    int add_dim, add_nkb, add_first;
     int use_dir;
     int enc_stride;
     // training only: activation buffer in tile-row-major layout (mlp_plan.h TrainLayout)
     float *act;
-    int act_pe, act_dpe, act_x1, act_o, act_h1, act_h2;
+    int act_pe, act_add, act_dpe, act_x1, act_o, act_h1, act_h2;
 };
 
 // one tile (16 features of this lane's sample) <-> the tile-row-major activation buffer

@@ -113,10 +113,15 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why) {
             col += hidden_cols;
         }
         if (extra == 1) {
+            if (P.add_dim && d.add_first) {
+                Seg &a = Ly.seg[Ly.nseg++];
+                a = Seg{SEG_ADD, col, P.add_dim, P.add_nkb, 0, 0};
+                col += P.add_dim;
+            }
             Seg &s = Ly.seg[Ly.nseg++];
             s = Seg{SEG_PE, col, P.pos_dim, P.pos_nkb, d.pos_freqs, pid};
             col += P.pos_dim;
-            if (P.add_dim) {
+            if (P.add_dim && !d.add_first) {
                 Seg &a = Ly.seg[Ly.nseg++];
                 a = Seg{SEG_ADD, col, P.add_dim, P.add_nkb, 0, 0};
                 col += P.add_dim;

@@ -355,7 +355,6 @@ extern "C" int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "mlp_bwd: desc is null");
     if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_bwd: %s", why);
-    if (P.add_dim) return fail(SNERF_E_BADARG, "mlp_bwd: additional inputs are not supported in training yet");
     if (n < 0) return fail(SNERF_E_BADARG, "mlp_bwd: negative n");
     if (n == 0) return SNERF_OK;
     if (!packed_t || !act || !d_raw || !dy || !gpart || !flat_grad) return fail(SNERF_E_BADARG, "mlp_bwd: null pointer");

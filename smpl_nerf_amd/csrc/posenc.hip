@@ -14,11 +14,11 @@ constexpr int PE_THREADS = 256;
 constexpr int PE_TILE = 64;
 
 __global__ __launch_bounds__(PE_THREADS) void posenc_kernel(const float *__restrict__ x, int64_t n, int c, int L,
-                                                           int identity, float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float s_out[];  // [PE_TILE][outdim]
+                                                           int identity, float *__restrict__ out, int tile) {
+    extern __shared__ __attribute__((aligned(16))) float s_out[];  // [tile][outdim]
     const int outdim = c * (identity + 2 * L);
-    const int64_t p0 = (int64_t)blockIdx.x * PE_TILE;
-    const int np = (int)min((int64_t)PE_TILE, n - p0);
+    const int64_t p0 = (int64_t)blockIdx.x * tile;
+    const int np = (int)min((int64_t)tile, n - p0);
     const int per_point = c * (L + identity);  // work items: (channel, k) pairs, k == L means identity
     for (int i = threadIdx.x; i < np * per_point; i += PE_THREADS) {
         const int p = i / per_point, r = i - p * per_point;
@@ -59,11 +59,15 @@ extern "C" int snerf_posenc_f32(const float *x, int64_t n, int c, int L, int ide
     const int outdim = c * (identity + 2 * L);
     if (n == 0 || outdim == 0) return SNERF_OK;
     if (!x || !out) return fail(SNERF_E_BADARG, "posenc: null pointer");
-    const size_t lds = (size_t)PE_TILE * outdim * sizeof(float);
-    if (lds > 64 * 1024) return fail(SNERF_E_BADARG, "posenc: c*(identity+2L) too large (%d)", outdim);
-    const int64_t grid = (n + PE_TILE - 1) / PE_TILE;
+    // points per workgroup: as many as fit 64 KiB of LDS, at most PE_TILE (wide rows, e.g. a 69-channel
+    // pose with L = 10 -> 1380 floats per point, get fewer points per group)
+    if (outdim > 16384) return fail(SNERF_E_BADARG, "posenc: c*(identity+2L) too large (%d)", outdim);
+    int tile = 16384 / outdim;
+    if (tile > PE_TILE) tile = PE_TILE;
+    const size_t lds = (size_t)tile * outdim * sizeof(float);
+    const int64_t grid = (n + tile - 1) / tile;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "posenc: n too large");
     hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)grid), dim3(PE_THREADS), lds, (hipStream_t)stream, x, n, c, L,
-                       identity, out);
+                       identity, out, tile);
     return check_launch("posenc");
 }

@@ -31,7 +31,7 @@ class _FusedMlpFn(torch.autograd.Function):
     NerfPipeline: the hierarchical samples are detached, utils.py:260)."""
 
     @staticmethod
-    def forward(ctx, net, desc, x, d, per_sample, spr, *params):
+    def forward(ctx, net, desc, x, d, per_sample, spr, add, *params):
         lib = _lib.load()
         n = x.shape[0]
         dev = x.device
@@ -43,7 +43,7 @@ class _FusedMlpFn(torch.autograd.Function):
         act = torch.empty(sizes[0].value, device=dev, dtype=torch.float32)
         raw = torch.empty((n, 4), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev), _lib.timed(f"mlp_fwd_train[n={n}]"):
-            check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, None, n, int(spr),
+            check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
                                               ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
         ctx.net, ctx.desc, ctx.n, ctx.act = net, desc, n, act
         ctx.sizes = (sizes[1].value, sizes[3].value)
@@ -71,7 +71,7 @@ class _FusedMlpFn(torch.autograd.Function):
                 k *= v
             grads.append(flat[off:off + k].view(shp))
             off += k
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None) + tuple(grads)
 
 
 class RenderRayNet(nn.Module):
@@ -127,18 +127,18 @@ class RenderRayNet(nn.Module):
                 mask |= 1 << i
         return mask
 
-    def make_desc(self, pos_L, pos_id, dir_L, dir_id, add_dim) -> MlpDesc:
+    def make_desc(self, pos_L, pos_id, dir_L, dir_id, add_dim, add_first=0) -> MlpDesc:
         return MlpDesc(self.n_layers, self.width, pos_L, pos_id, dir_L, dir_id, add_dim, self._skip_mask(),
-                       1 if self.use_directional_input else 0)
+                       1 if self.use_directional_input else 0, 1 if add_first else 0)
 
-    def desc_for_encoders(self, position_encoder, direction_encoder) -> MlpDesc:
+    def desc_for_encoders(self, position_encoder, direction_encoder, add_first=False) -> MlpDesc:
         """Descriptor of the fused (encode + MLP) path; checks that the encoders produce what this net
         was built for (train.py:102-107: positions_dim = 3 * encoder.output_dim)."""
         pos_L, pos_id = position_encoder.number_frequencies, 1 if position_encoder.include_identity else 0
         dir_L, dir_id = direction_encoder.number_frequencies, 1 if direction_encoder.include_identity else 0
         if 3 * (pos_id + 2 * pos_L) != self.positions_dim or 3 * (dir_id + 2 * dir_L) != self.direcions_dim:
             raise RuntimeError("RenderRayNet: encoder output sizes do not match positions_dim/directions_dim")
-        return self.make_desc(pos_L, pos_id, dir_L, dir_id, self.additional_input_dim)
+        return self.make_desc(pos_L, pos_id, dir_L, dir_id, self.additional_input_dim, add_first)
 
     def desc_for_encoded(self) -> MlpDesc:
         """Descriptor for forward(x) on already-encoded rows: any slot assignment of the position
@@ -216,11 +216,12 @@ class RenderRayNet(nn.Module):
         return raw.reshape(x.shape[:-1] + (4,))
 
     def forward_fused(self, positions, directions, samples_per_ray, position_encoder, direction_encoder,
-                      additional=None):
+                      additional=None, add_first=False):
         """Encode + MLP in one launch.  positions [n,3] (samples of a ray contiguous), directions
         [n/samples_per_ray, 3] (per ray) or [n, 3] (per sample), un-normalised; additional: optional
-        [n/samples_per_ray, additional_input_dim].  Returns raw [n, 4]."""
-        desc = self.desc_for_encoders(position_encoder, direction_encoder)
+        [n/samples_per_ray, additional_input_dim] per-ray constants whose weight columns sit after
+        (add_first=False) or before (add_first=True) the position-encoding columns.  Returns raw [n, 4]."""
+        desc = self.desc_for_encoders(position_encoder, direction_encoder, add_first)
         x = positions.reshape(-1, 3).contiguous()
         n = x.shape[0]
         d = directions.reshape(-1, 3).contiguous()
@@ -236,10 +237,8 @@ class RenderRayNet(nn.Module):
                 raise RuntimeError("forward_fused: this net needs `additional` inputs")
             add = additional.reshape(-1, self.additional_input_dim).contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.additional_input_dim:
-                raise NotImplementedError("RenderRayNet: training with additional inputs is not implemented yet")
             return _FusedMlpFn.apply(self, desc, x.detach(), d.detach(), per_sample, int(samples_per_ray),
-                                     *self._ordered_params())
+                                     None if add is None else add.detach(), *self._ordered_params())
         packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
         lib = _lib.load()
@@ -363,7 +362,7 @@ class AppendVerticesNet(RenderRayNet):
         d = _encoder_shape(self.direcions_dim)
         if d is None:
             raise RuntimeError(f"AppendVerticesNet: directions_dim={self.direcions_dim} is not a 3-channel encoding")
-        return MlpDesc(self.n_layers, self.width, 0, 0, d[0], d[1], self.positions_dim, self._skip_mask(), 1)
+        return MlpDesc(self.n_layers, self.width, 0, 0, d[0], d[1], self.positions_dim, self._skip_mask(), 1, 0)
 
     def forward(self, x):
         """x [..., positions_dim + additional_input_dim + directions_dim] -> [..., 4] (:43-66)."""

@@ -150,3 +150,48 @@ class AppendVerticesPipeline(NerfPipeline):
         rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
                                                     self._noise((B, N), dev), want_weights=False)  # :92
         return rgb, rgb_fine, ray_samples_fine, densities_fine                                    # :94
+
+
+class AppendSmplParamsPipeline(NerfPipeline):
+    """models/append_smpl_params_pipeline.py:7-91 drop-in (the paper's headline model): NerfPipeline whose nets
+    read [pose | PE(x) | PE(d)] rows, the pose being the 69 SMPL body-pose parameters of the ray's frame,
+    optionally encoded (args.human_pose_encoding).  The pose columns are per-ray constants: they are read as
+    the fused kernel's `additional` input (weight columns in front of the position encoding) instead of
+    being expanded to every sample."""
+
+    def __init__(self, model_coarse, model_fine, args, position_encoder, direction_encoder, human_pose_encoder):
+        super().__init__(model_coarse, model_fine, args, position_encoder, direction_encoder)
+        self.human_pose_encoder = human_pose_encoder
+
+    def _select(self, goal_pose):
+        return goal_pose
+
+    def forward(self, data):
+        ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
+        args = self.args
+        B, Nc = z_vals.shape
+        wb = bool(args.white_background)
+        dev = ray_samples.device
+        goal_pose = self._select(goal_pose).contiguous()
+        pose = self.human_pose_encoder.encode(goal_pose) if args.human_pose_encoding else goal_pose   # :29-37
+        raw = self.model_coarse.forward_fused(ray_samples, ray_direction, Nc, self.position_encoder,
+                                              self.direction_encoder, additional=pose, add_first=True)   # :49-52
+        rgb, weights, densities = ops.composite(raw.view(B, Nc, 4), z_vals, ray_direction, wb,
+                                                self._noise((B, Nc), dev))                             # :55
+        if not args.run_fine:
+            return rgb, rgb, ray_samples, densities                                                    # :56-57
+        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples)
+        z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                              # :60
+        N = z_fine.shape[1]
+        raw_f = self.model_fine.forward_fused(ray_samples_fine, ray_direction, N, self.position_encoder,
+                                              self.direction_encoder, additional=pose, add_first=True)  # :77-81
+        rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
+                                                    self._noise((B, N), dev), want_weights=False)       # :89
+        return rgb, rgb_fine, ray_samples_fine, densities_fine                                         # :91
+
+
+class AppendToNerfPipeline(AppendSmplParamsPipeline):
+    """models/append_to_nerf_pipeline.py:7-90 drop-in: the same with only joints 38 and 41 of the pose (:26)."""
+
+    def _select(self, goal_pose):
+        return torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)

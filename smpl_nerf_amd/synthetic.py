@@ -125,7 +125,7 @@ def make_render_ray_net_params(seed: int, sigma_scale: float = 1.0, rgb_scale: f
     return params
 
 
-def _probe_trunk(params, pts, dirs, n_layers=8, skips=(4,), pos_L=10, dir_L=4):
+def _probe_trunk(params, pts, dirs, n_layers=8, skips=(4,), pos_L=10, dir_L=4, add=None, add_first=False):
     """Plain numpy evaluation of a RenderRayNet up to the two head inputs (used only to calibrate
     the synthetic scene below; fp64, not a reference for anything)."""
     def enc(x, L):
@@ -135,6 +135,8 @@ def _probe_trunk(params, pts, dirs, n_layers=8, skips=(4,), pos_L=10, dir_L=4):
         return np.concatenate(out, -1)
     P = {k: v.astype(np.float64) for k, v in params.items()}
     pe, de = enc(pts.astype(np.float64), pos_L), enc(dirs.astype(np.float64), dir_L)
+    if add is not None:
+        pe = np.concatenate([add.astype(np.float64), pe] if add_first else [pe, add.astype(np.float64)], -1)
     lin = lambda x, n: x @ P[n + ".weight"].T + P[n + ".bias"]
     o = np.maximum(lin(pe, "positions_pose_input"), 0)
     for i in range(n_layers - 1):
@@ -146,7 +148,7 @@ def _probe_trunk(params, pts, dirs, n_layers=8, skips=(4,), pos_L=10, dir_L=4):
 
 
 def make_scene_net_params(seed: int, sigma_std: float = 10.0, rgb_std: float = 1.5, gamma: float = 0.7,
-                          **net_kw) -> dict:
+                          add_first: bool = False, **net_kw) -> dict:
     """A random-init RenderRayNet turned into a well-conditioned synthetic scene:
 
     * the weight columns that read positional-encoding band k are damped by 2^(-gamma*k), so the
@@ -163,14 +165,18 @@ def make_scene_net_params(seed: int, sigma_std: float = 10.0, rgb_std: float = 1
     width = net_kw.get("width", 256)
     L = pos_dim // 6
     scale = np.repeat(2.0 ** (-gamma * np.arange(L)), 6).astype(F32)
-    params["positions_pose_input.weight"][:, :pos_dim] *= scale
+    add_dim = net_kw.get("additional_input_dim", 0)
+    c0 = add_dim if add_first else 0            # [add | PE(x)] rows (append_* pipelines) vs [PE(x) | add]
+    params["positions_pose_input.weight"][:, c0:c0 + pos_dim] *= scale
     for i in net_kw.get("skips", (4,)):
-        params[f"positional_net.{i}.weight"][:, width:width + pos_dim] *= scale
+        params[f"positional_net.{i}.weight"][:, width + c0:width + c0 + pos_dim] *= scale
     rng = np.random.default_rng(seed + 7919)
     pts = rng.uniform(-2.5, 2.5, (2048, 3))
     dirs = rng.normal(size=(2048, 3))
     dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
-    o, h = _probe_trunk(params, pts, dirs, n_layers=net_kw.get("n_layers", 8), skips=net_kw.get("skips", (4,)))
+    add = rng.uniform(-1, 1, (2048, add_dim)) if add_dim else None
+    o, h = _probe_trunk(params, pts, dirs, n_layers=net_kw.get("n_layers", 8), skips=net_kw.get("skips", (4,)), add=add,
+                        add_first=add_first)
     w = params["sigma_out_layer.weight"].astype(np.float64)
     s = o @ w.T
     sc = sigma_std / s.std()

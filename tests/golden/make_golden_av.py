@@ -56,6 +56,43 @@ def main():
     g["net_out"] = mc(t(x)).numpy()
     MG.save("g9_append_vertices.npz", **g)
 
+    # ---- AppendSmplParamsPipeline / AppendToNerfPipeline (models/append_smpl_params_pipeline.py, append_to_nerf_pipeline.py)
+    from models.append_smpl_params_pipeline import AppendSmplParamsPipeline
+    from models.append_to_nerf_pipeline import AppendToNerfPipeline
+    h = {"sub": sub, "images": idx}
+    hpe = U.PositionalEncoder(10, 0)
+    gp = poses[idx] + 0.05 * torch.from_numpy(np.random.default_rng(9).normal(size=(B, 69)).astype(np.float32))
+    h["goal_pose"] = gp.numpy()
+    batch = [t(a[sub]) for a in data[:4]] + [gp, t(data[4][sub])]
+    for name, cls, npose in (("smpl", AppendSmplParamsPipeline, 69), ("two", AppendToNerfPipeline, 2)):
+        for enc in (0, 1):
+            add = npose * (20 if enc else 1)
+            pcs = syn.make_scene_net_params(301 + enc, add_first=True, additional_input_dim=add)
+            pfs = syn.make_scene_net_params(303 + enc, add_first=True, additional_input_dim=add)
+            mcs = MG.load_params(RenderRayNet(8, 256, 60, 24, add, skips=[4]), pcs)
+            mfs = MG.load_params(RenderRayNet(8, 256, 60, 24, add, skips=[4]), pfs)
+            pipe = cls(mcs, mfs, MG.Args(human_pose_encoding=enc), pe, de, hpe)
+            out = pipe(batch)
+            for nm, o in zip(("rgb", "rgb_fine", "pts_fine", "alpha_fine"), out):
+                h[f"{name}{enc}_{nm}"] = o.numpy()
+    # one training step of append_smpl_params (raw pose, 69 extra columns): loss + gradient digests
+    torch.set_grad_enabled(True)
+    import make_golden_grad as GG
+    pcs, pfs = (syn.make_scene_net_params(301, add_first=True, additional_input_dim=69),
+                syn.make_scene_net_params(303, add_first=True, additional_input_dim=69))
+    mcs = MG.load_params(RenderRayNet(8, 256, 60, 24, 69, skips=[4]), pcs)
+    mfs = MG.load_params(RenderRayNet(8, 256, 60, 24, 69, skips=[4]), pfs)
+    pipe = AppendSmplParamsPipeline(mcs, mfs, MG.Args(human_pose_encoding=0), pe, de, hpe)
+    rgb, rgb_fine, _, _ = pipe(batch)
+    loss = torch.nn.functional.mse_loss(rgb, batch[-1]) + torch.nn.functional.mse_loss(rgb_fine, batch[-1])
+    loss.backward()
+    h["train_loss"] = np.array([loss.item()])
+    for k, v in GG.param_digest((f"coarse.{k}", p.grad) for k, p in mcs.named_parameters()).items():
+        h[f"train_grad/{k}"] = v
+    for k, v in GG.param_digest((f"fine.{k}", p.grad) for k, p in mfs.named_parameters()).items():
+        h[f"train_grad/{k}"] = v
+    MG.save("g10_append_pose.npz", **h)
+
 
 if __name__ == "__main__":
     main()

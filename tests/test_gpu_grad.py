@@ -206,3 +206,31 @@ def test_coarse_only_training_quirk(dev):
         ref = g7[f"t_coarse_only_grad/coarse.{k}"]
         scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
         close(R.digest(p.grad), ref, 5e-3, 2e-3 * scale)
+
+
+def test_append_smpl_params_training_step(dev):
+    """One training step of the paper's headline model (69 raw pose columns in front of the encoding):
+    loss and every parameter-gradient digest against the reference under autograd."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline
+    g = load_golden("g10_append_pose.npz")
+    nets = []
+    for seed in (301, 303):
+        m = RenderRayNet(8, 256, 60, 24, 69, skips=[4])
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in
+                           syn.make_scene_net_params(seed, add_first=True, additional_input_dim=69).items()})
+        nets.append(m.to(dev))
+    pipe = AppendSmplParamsPipeline(nets[0], nets[1], O.Args(human_pose_encoding=0), PositionalEncoder(10, 0),
+                                    PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+    data = syn.frame_batch(128, 128, phi=3.0, theta=-10.0, seed=11)
+    d = [T(a[g["sub"]], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][g["sub"]], dev)]
+    rgb, rgb_fine, _, _ = pipe(d)
+    loss = torch.nn.functional.mse_loss(rgb, d[-1]) + torch.nn.functional.mse_loss(rgb_fine, d[-1])
+    loss.backward()
+    close([loss.item()], g["train_loss"], 1e-5, 1e-7)
+    for name, m in (("coarse", nets[0]), ("fine", nets[1])):
+        for k, p in m.named_parameters():
+            ref = g[f"train_grad/{name}.{k}"]
+            scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
+            close(R.digest(p.grad), ref, 5e-3, 2e-3 * scale)

@@ -526,3 +526,31 @@ def test_append_vertices_net_forward_rows(dev):
     assert maxabs(N(out), g["net_out"]) <= 2e-5 * max(1.0, float(np.abs(g["net_out"]).max()))
     sd = nets[0].state_dict()
     assert "vertices_net.0.weight" in sd and tuple(sd["vertices_net.0.weight"].shape) == (256, 6890)
+
+
+# ------------------------------------------------------------------------------------------ f-4
+@pytest.mark.parametrize("name,npose", [("smpl", 69), ("two", 2)])
+@pytest.mark.parametrize("enc", [0, 1])
+def test_append_pose_pipelines(dev, name, npose, enc):
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline
+    g = load_golden("g10_append_pose.npz")
+    add = npose * (20 if enc else 1)
+    nets = []
+    for seed in (301 + enc, 303 + enc):
+        m = RenderRayNet(8, 256, 60, 24, add, skips=[4])
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in
+                           syn.make_scene_net_params(seed, add_first=True, additional_input_dim=add).items()})
+        nets.append(m.to(dev))
+    cls = AppendSmplParamsPipeline if name == "smpl" else AppendToNerfPipeline
+    pipe = cls(nets[0], nets[1], O.Args(human_pose_encoding=enc), PositionalEncoder(10, 0), PositionalEncoder(4, 0),
+               PositionalEncoder(10, 0))
+    data = syn.frame_batch(128, 128, phi=3.0, theta=-10.0, seed=11)
+    d = [T(a[g["sub"]], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][g["sub"]], dev)]
+    with torch.no_grad():
+        out = pipe(d)
+    assert maxabs(N(out[0]), g[f"{name}{enc}_rgb"]) <= 1e-5
+    assert maxabs(N(out[1]), g[f"{name}{enc}_rgb_fine"]) <= 1e-4
+    assert np.mean(np.abs(N(out[2]) - g[f"{name}{enc}_pts_fine"]) > 1e-4) <= 0.02
+    assert tuple(out[3].shape) == g[f"{name}{enc}_alpha_fine"].shape

@@ -265,6 +265,24 @@ def test_append_vertices_net_rows():
     assert maxabs(out, g["net_out"]) <= 2e-5 * max(1.0, float(np.abs(g["net_out"]).max()))
 
 
+# ---------------------------------------------------------------- f-4 pose-append pipelines
+@pytest.mark.parametrize("name,npose", [("smpl", 69), ("two", 2)])
+@pytest.mark.parametrize("enc", [0, 1])
+def test_append_pose_pipelines(name, npose, enc):
+    g = load_golden("g10_append_pose.npz")
+    add = npose * (20 if enc else 1)
+    pc = syn.make_scene_net_params(301 + enc, add_first=True, additional_input_dim=add)
+    pf = syn.make_scene_net_params(303 + enc, add_first=True, additional_input_dim=add)
+    data = syn.frame_batch(128, 128, phi=3.0, theta=-10.0, seed=11)
+    d = [a[g["sub"]] for a in data[:4]] + [g["goal_pose"], data[4][g["sub"]]]
+    E = O.PositionalEncoder
+    out = O.append_pose_pipeline_forward(pc, pf, O.Args(human_pose_encoding=enc), E(10, 0), E(4, 0), E(10, 0), d,
+                                         two_joints=(name == "two"))
+    assert maxabs(out[0], g[f"{name}{enc}_rgb"]) <= 1e-5
+    assert maxabs(out[1], g[f"{name}{enc}_rgb_fine"]) <= 1e-4
+    assert np.mean(np.abs(out[2] - g[f"{name}{enc}_pts_fine"]) > 1e-4) <= 0.02
+
+
 # ---------------------------------------------------------------- adjacent: rays / coarse samples
 def test_rays_and_coarse_sampling():
     g = load_golden("g8_rays.npz")
