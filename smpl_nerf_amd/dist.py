@@ -44,7 +44,7 @@ def shard_rays(tensors, world: int = None, rank: int = None):
 
 def barrier(device=None):
     if is_dist():
-        if device is not None and device.type == "cuda":
+        if device is not None and device.type == "cuda" and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
