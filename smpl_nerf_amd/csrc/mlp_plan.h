@@ -272,8 +272,8 @@ inline int bwd_total_slabs(const Plan &P) {
 }
 // number of K-splits (sample chunks) of the wgrad kernel for n samples
 inline int wgrad_chunks(int64_t n) {
-    int64_t g = (n + 2047) / 2048;
-    return (int)(g < 1 ? 1 : (g > 64 ? 64 : g));
+    int64_t g = (n + 1023) / 1024;
+    return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
 }
 
 }  // namespace snerf

@@ -177,7 +177,8 @@ struct WgradArgs {
     int64_t chunk;  // samples per K-split, multiple of 16
 };
 
-constexpr int WG_THREADS = 256;
+constexpr int WG_THREADS = 64;  // one wavefront per workgroup: no LDS, no barrier, occupancy bound by VGPRs only
+constexpr int WG_PREFETCH = 4;  // k-steps (4 samples each) of operands in flight per wave
 
 __host__ __device__ inline int wgrad_jobs(const Plan &P) {
     int jobs = 0;
@@ -188,8 +189,7 @@ __host__ __device__ inline int wgrad_jobs(const Plan &P) {
 }
 
 __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayout L, WgradArgs A) {
-    __shared__ __attribute__((aligned(16))) float red[3 * 16 * 256 + 3 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     // ---- decode the job: (layer, segment, 4x4-tile block) -----------------------------------------
     int job = blockIdx.x, l = 0, s = 0, kb0 = 0, nbj = 1;
     for (l = 0; l < P.nlayers; ++l) {
@@ -208,9 +208,11 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     const int bi = job / nbj, bj = job - bi * nbj;
     const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
     const int64_t n = A.n;
-    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + lane;                 // + sample*16 via k
+    // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: base + s0*16 + lane
+    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + lane;
     const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + lane;
     const bool want_bias = (s == 0 && bj == 0);
+    const int kslot = lane >> 4;
 
     const int64_t begin = (int64_t)blockIdx.y * A.chunk;
     const int64_t end = min(n, begin + A.chunk);
@@ -222,78 +224,63 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: base + s0*16 + lane
-    const int kslot = lane >> 4;
     auto load_ab = [&](int64_t s0, float (&a)[4], float (&b)[4]) {
         const bool ok = s0 + kslot < end;
-        const int64_t off = (ok ? s0 : (end - 1 - kslot)) * 16;  // clamped, in-bounds (finite data)
+        const int64_t off = ok ? s0 * 16 : 0;  // masked lanes read sample 0 of the tile-row (finite data) and a = 0
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             a[t] = (t < n_ti && ok) ? dyp[(int64_t)t * n * 16 + off] : 0.f;
-            b[t] = (t < n_tj) ? xp[(int64_t)t * n * 16 + (ok ? off : 0)] : 0.f;
+            b[t] = (t < n_tj) ? xp[(int64_t)t * n * 16 + off] : 0.f;
         }
     };
-    float a0[4], b0[4], a1[4], b1[4];
-    int64_t s0 = begin + wave * 4;
-    if (s0 < end) load_ab(s0, a0, b0);
-    while (s0 < end) {
-        const int64_t s1 = s0 + 16;
-        if (s1 < end) load_ab(s1, a1, b1);
+    // software pipeline: WG_PREFETCH k-steps of operands in flight (register ring, statically indexed)
+    float ra[WG_PREFETCH][4], rb[WG_PREFETCH][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < n_ti) {
+    for (int p = 0; p < WG_PREFETCH; ++p) {
+        const int64_t sp = begin + 4 * p;
+        if (sp < end) load_ab(sp, ra[p], rb[p]);
+    }
+    for (int64_t s0 = begin; s0 < end; s0 += 4 * WG_PREFETCH) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < n_tj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
-                bsum[i] += a0[i];
+        for (int p = 0; p < WG_PREFETCH; ++p) {
+            const int64_t sc = s0 + 4 * p;
+            if (sc < end) {  // wave-uniform
+                float a0[4], b0[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a0[t] = ra[p][t];
+                    b0[t] = rb[p][t];
+                }
+                const int64_t sn = sc + 4 * WG_PREFETCH;
+                if (sn < end) load_ab(sn, ra[p], rb[p]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < n_ti) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < n_tj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        bsum[i] += a0[i];
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a0[t] = a1[t];
-            b0[t] = b1[t];
-        }
-        s0 = s1;
     }
-    // ---- reduce the 4 waves (fixed order) and write the partial ------------------------------------
+    // ---- write the partial of this (block, chunk) ---------------------------------------------------
+    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        bsum[i] += __shfl_xor(bsum[i], 16, 64);
-        bsum[i] += __shfl_xor(bsum[i], 32, 64);
-    }
-    if (wave > 0) {
-        float *dst = red + (wave - 1) * (16 * 256);
+        if (i >= n_ti) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f4 *>(dst + ((i * 4 + j) * 64 + lane) * 4) = acc[i][j];
-        if (lane < 16) {
-            float *bd = red + 3 * 16 * 256 + (wave - 1) * 64;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bd[i * 16 + lane] = bsum[i];
+        for (int j = 0; j < 4; ++j) {
+            if (j >= n_tj) continue;
+            const int ti = 4 * bi + i, tj = kb0 + 4 * bj + j;
+            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
         }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i >= n_ti) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j >= n_tj) continue;
-                f4 v = acc[i][j];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f4 *>(red + w * (16 * 256) + ((i * 4 + j) * 64 + lane) * 4);
-                const int ti = 4 * bi + i, tj = kb0 + 4 * bj + j;
-                *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = v;
-            }
-            if (want_bias && lane < 16) {
-                float v = bsum[i];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) v += red[3 * 16 * 256 + w * 64 + i * 16 + lane];
-                part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
-            }
+        if (want_bias) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
         }
     }
 }
