@@ -554,3 +554,40 @@ def test_append_pose_pipelines(dev, name, npose, enc):
     assert maxabs(N(out[1]), g[f"{name}{enc}_rgb_fine"]) <= 1e-4
     assert np.mean(np.abs(N(out[2]) - g[f"{name}{enc}_pts_fine"]) > 1e-4) <= 0.02
     assert tuple(out[3].shape) == g[f"{name}{enc}_alpha_fine"].shape
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+def test_empty_and_maximum_sizes(dev):
+    """Empty batches are no-ops; the sampler/compositor limits (Nc, Nf, N <= 1024) work at the limit."""
+    from smpl_nerf_amd import ops
+    z = torch.empty((0, 64), device=dev)
+    r = ops.hierarchical_samples(torch.empty((0, 3), device=dev), torch.empty((0, 3), device=dev), z, z.clone(), 128)
+    assert tuple(r["z_fine"].shape) == (0, 192) and tuple(r["pts"].shape) == (0, 192, 3)
+    rgb, w, a = ops.composite(torch.empty((0, 64, 4), device=dev), z, torch.empty((0, 3), device=dev), False)
+    assert tuple(rgb.shape) == (0, 3) and tuple(w.shape) == (0, 64)
+    out = ops.searchsorted(torch.empty((0, 5), device=dev), torch.empty((0, 7), device=dev))
+    assert tuple(out.shape) == (0, 7)
+    assert tuple(ops.PositionalEncoder(10, 0).encode(torch.empty((0, 3), device=dev)).shape) == (0, 60)
+    rng = np.random.default_rng(21)
+    B, nc, nf = 9, 1024, 1024
+    zz = np.sort(rng.uniform(1, 4, (B, nc)).astype(F32), -1)
+    ww = rng.random((B, nc)).astype(F32) ** 2
+    o = rng.normal(size=(B, 3)).astype(F32)
+    d = rng.normal(size=(B, 3)).astype(F32)
+    _check_sampler(dev, o, d, zz, ww, nf)
+    raw = rng.normal(0, 2, (B, 1024, 4)).astype(F32)
+    rgb, w, a = ops.composite(T(raw, dev), T(zz, dev), T(d, dev), True)
+    orgb, ow, oa = O.raw2outputs(raw, zz, np.broadcast_to(d[:, None, :], (B, 1024, 3)), 1)
+    assert maxabs(N(rgb), orgb) <= 2e-6 and maxabs(N(w), ow) <= 5e-7 and maxabs(N(a), oa) <= 5e-7
+    with pytest.raises(RuntimeError, match="1024"):
+        ops.hierarchical_samples(T(o, dev), T(d, dev), T(zz, dev), T(ww, dev), 1025)
+
+
+def test_searchsorted_ties_nan_free_duplicates(dev):
+    """Collisions: long runs of equal keys and queries equal to keys, both sides."""
+    from smpl_nerf_amd.ops import searchsorted
+    rng = np.random.default_rng(4)
+    a = np.sort(rng.integers(0, 8, (50, 63)).astype(F32), -1)            # many duplicates
+    v = rng.integers(-1, 9, (50, 128)).astype(F32)
+    for side in ("left", "right"):
+        np.testing.assert_array_equal(N(searchsorted(T(a, dev), T(v, dev), side=side)), O.searchsorted(a, v, side))
