@@ -182,6 +182,16 @@ int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const f
                        const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
                        float *warp, float *warped, float *sdirs, snerf_stream_t stream);
 
+/* ---- 8(f)-1: on-device ray generation + stratified coarse sampling --------------------------------------
+ * Replaces get_rays (utils.py:50-54) + CoarseSampling (datasets/transforms.py:80-89) + ToTensor (:13-21) for a
+ * batch of rays.  poses: fp64 [n_frames, 4, 4] camera-to-world; ray_index int64 [B] = frame*H*W + row*W + col;
+ * jitter fp64 [B] = the per-ray np.random.rand() scalar; lower/span fp64 [Nc] = the bin tables of
+ * CoarseSampling (lower, upper - lower).  fp64 arithmetic in the reference's order, one rounding to fp32:
+ * bit-identical to the numpy path.  Outputs: samples [B,Nc,3], o [B,3], d [B,3], z [B,Nc] fp32. */
+int snerf_raygen_f64(const double *poses, int64_t n_frames, int H, int W, double focal, const double *lower,
+                     const double *span, int Nc, const int64_t *ray_index, const double *jitter, int64_t B,
+                     float *samples, float *o, float *d, float *z, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsmplnerf_hip.so")
@@ -53,6 +53,7 @@ SIGNATURES = {
     "snerf_warp_packed_floats": (c_int64, [POINTER(WarpDesc)]),
     "snerf_warp_pack_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P]),
     "snerf_warp_fwd_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "snerf_raygen_f64": (c_int, [_P, c_int64, c_int, c_int, c_double, _P, _P, c_int, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "snerf_mlp_fwd_encoded_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int64, c_int64, _P, _P]),
 }
 

@@ -20,6 +20,8 @@
 //   * positional encodings are evaluated in registers, straight into B-operand layout, with
 //     full-range sincosf (arguments reach 2^9*|x|); they are recomputed at the skip layer instead of
 //     being kept live.
+#include <stdlib.h>
+
 #include "mlp_device.h"
 
 namespace snerf {
@@ -244,16 +246,28 @@ int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStrea
 
 constexpr int FWD_WAVES = 4;  // 64 samples per workgroup; several workgroups share a CU
 
-template <bool ENCODED, bool TRAIN>
-static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
-    const int64_t tile = FWD_WAVES * 16;
+template <int NW, bool ENCODED, bool TRAIN>
+static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
+    const int64_t tile = NW * 16;
     const int64_t grid = (A.n + tile - 1) / tile;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd: n too large");
     if (P.width == 256)
-        hipLaunchKernelGGL((mlp_fwd_kernel<256, FWD_WAVES, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0, s, A);
+        hipLaunchKernelGGL((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
     else
-        hipLaunchKernelGGL((mlp_fwd_kernel<128, FWD_WAVES, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0, s, A);
+        hipLaunchKernelGGL((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
     return check_launch("mlp_fwd");
+}
+
+template <bool ENCODED, bool TRAIN>
+static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
+    // 4 waves (64 samples) per workgroup, two workgroups per CU.  SNERF_FWD_WAVES=8 selects one 8-wave
+    // workgroup per CU instead (tuning knob, read once).
+    static const int nw = [] {
+        const char *e = getenv("SNERF_FWD_WAVES");
+        return (e && atoi(e) == 8) ? 8 : FWD_WAVES;
+    }();
+    if (nw == 8) return launch_fwd_nw<8, ENCODED, TRAIN>(P, A, s);
+    return launch_fwd_nw<FWD_WAVES, ENCODED, TRAIN>(P, A, s);
 }
 
 }  // namespace snerf

@@ -56,6 +56,7 @@ struct SlabPipe {
     const f4 *g;   // this thread's read cursor in the packed stream
     float *ring;
     f4 st[NA], st_aux;
+    f4 pa0, pa1;  // first A-operand pair of the next k-block, prefetched (see kblock)
     int tid, rd, wr;
 
     __device__ __forceinline__ void load() {
@@ -80,8 +81,12 @@ struct SlabPipe {
         rd = 0;
         wr = 2;
         __syncthreads();
+        const f4 *np = reinterpret_cast<const f4 *>(ring) + (tid & 63);
+        pa0 = np[0];
+        pa1 = np[64];
     }
     __device__ __forceinline__ const float *acquire() const { return ring + rd * SLAB_FLOATS; }
+    __device__ __forceinline__ const float *peek_next() const { return ring + (rd == 2 ? 0 : rd + 1) * SLAB_FLOATS; }
     __device__ __forceinline__ void release() {
         store(wr);
         load();
@@ -147,29 +152,60 @@ __device__ __forceinline__ f4 add_operand(const SampleCtx &c, int add_dim, int k
 
 // One k-block: T_OUT x (ds_read_b128 + 4 MFMA).  Tiles are walked in pairs so that consecutive MFMAs
 // never share an accumulator (dependent latency of 16x16x4 is 40 cycles vs 32 issue).
+// One k-block: T_OUT x (ds_read_b128 + 4 MFMA), software-pipelined: the A values of tile pair p+1 are read
+// from LDS while the 8 MFMAs of pair p issue, and the first pair of the NEXT k-block (`next`, possibly in the
+// next slab) is read during the last pair - so a wave never waits on an LDS read between MFMAs.  Tiles are
+// walked in pairs so that consecutive MFMAs never share an accumulator (dependent latency of 16x16x4 is 40
+// cycles vs 32 issue).  (pa0, pa1) carry the prefetched first pair from k-block to k-block.
 template <int T_OUT>
-__device__ __forceinline__ void kblock(const float *a_kb, f4 b, f4 (&acc)[T_OUT], int lane) {
+__device__ __forceinline__ void kblock(const float *a_kb, const float *a_next, f4 b, f4 (&acc)[T_OUT], f4 &pa0, f4 &pa1,
+                                       int lane) {
     const f4 *ap = reinterpret_cast<const f4 *>(a_kb) + lane;
+    const f4 *np = reinterpret_cast<const f4 *>(a_next) + lane;
     if constexpr (T_OUT == 1) {
-        const f4 a = ap[0];
+        const f4 a = pa0;
+        pa0 = np[0];
+        pa1 = np[64];
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[0], 0, 0, 0);
     } else {
+        f4 a0 = pa0, a1 = pa1;
 #pragma unroll
         for (int to = 0; to < T_OUT; to += 2) {
-            const f4 a0 = ap[to * 64], a1 = ap[(to + 1) * 64];
+            f4 n0, n1;
+            if (to + 2 < T_OUT) {
+                n0 = ap[(to + 2) * 64];
+                n1 = ap[(to + 3) * 64];
+            } else {
+                n0 = np[0];
+                n1 = np[64];
+            }
+            // pin the schedule: the two LDS reads of the NEXT pair issue first, then the 8 MFMAs of this pair
+            // alternating between the two accumulators (hipcc otherwise sinks the reads to their first use and
+            // groups the MFMAs by accumulator, which exposes both the LDS and the 40-cycle dependent latency)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], b[r], acc[to], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], b[r], acc[to + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
         }
+        pa0 = a0;
+        pa1 = a1;
     }
 }
 
-// Walks the k-blocks of one layer through the slab pipe.
+// Walks the k-blocks of one layer through the slab pipe.  A slab is released (staged slab written to LDS,
+// next global loads issued, workgroup barrier) as soon as its last k-block has been issued; the first A
+// pair of the following slab was read before that barrier - legal because slab p+1 has been resident and
+// visible since the barrier that ended slab p-1 (the ring holds p, p+1 and the slot being filled with p+2).
 template <int T_OUT, int NT>
 struct LayerRun {
     static constexpr int KPS = 16 / T_OUT;
@@ -186,15 +222,25 @@ struct LayerRun {
         for (int to = 0; to < T_OUT; ++to) acc[to] = aux[to * 4];
     }
     __device__ __forceinline__ void step(f4 b, f4 (&acc)[T_OUT]) {
-        if (kbl == KPS) {
+        const float *cur = slab + kbl * (T_OUT * 256);
+        const float *nxt = (kbl + 1 < KPS) ? cur + T_OUT * 256 : pipe.peek_next();
+        kblock<T_OUT>(cur, nxt, b, acc, pipe.pa0, pipe.pa1, lane);
+        if (++kbl == KPS) {
             pipe.release();
             slab = pipe.acquire();
             kbl = 0;
         }
-        kblock<T_OUT>(slab + kbl * (T_OUT * 256), b, acc, lane);
-        ++kbl;
     }
-    __device__ __forceinline__ void finish() { pipe.release(); }
+    // end of the layer: a partially consumed slab is dropped (its tail is padding) and the prefetched pair
+    // re-read from the slab the next layer starts in
+    __device__ __forceinline__ void finish() {
+        if (kbl != 0) {
+            const f4 *np = reinterpret_cast<const f4 *>(pipe.peek_next()) + lane;
+            pipe.pa0 = np[0];
+            pipe.pa1 = np[64];
+            pipe.release();
+        }
+    }
 };
 
 template <int N>

@@ -591,3 +591,39 @@ def test_searchsorted_ties_nan_free_duplicates(dev):
     v = rng.integers(-1, 9, (50, 128)).astype(F32)
     for side in ("left", "right"):
         np.testing.assert_array_equal(N(searchsorted(T(a, dev), T(v, dev), side=side)), O.searchsorted(a, v, side))
+
+
+# ------------------------------------------------------------------------------------------ 8(f)-1 ray generation
+def test_raygen_bit_exact_vs_reference_path(dev):
+    """get_rays + CoarseSampling + ToTensor of the reference (golden g8) reproduced on the device."""
+    from smpl_nerf_amd.raygen import RayGenerator
+    g = load_golden("g8_rays.npz")
+    gen = RayGenerator(g["pose"][None], 16, 24, np.pi / 3, 1.0, 4.0, 64, dev)
+    out = gen.batch(T(g["rows"].astype(np.int64), dev), T(g["jitter"], dev))
+    np.testing.assert_array_equal(N(out[0]), g["samples"])
+    np.testing.assert_array_equal(N(out[1]), g["o"])
+    np.testing.assert_array_equal(N(out[2]), g["d"])
+    np.testing.assert_array_equal(N(out[3]), g["z"])
+
+
+def test_raygen_frame_and_random_batches(dev):
+    """A whole 128x128 frame (several frames resident, ragged batch) equals the host path used by every other
+    test; random batches gather the matching ground-truth pixels."""
+    from smpl_nerf_amd.raygen import RayGenerator
+    poses = np.stack([syn.sphere_pose(7.0 * f, 25.0 * f, 2.4) for f in range(3)])
+    imgs = np.stack([syn.procedural_image(128, 128, 7.0 * f, 25.0 * f) for f in range(3)])
+    gen = RayGenerator(poses, 128, 128, np.pi / 3, 1.6, 3.1, 64, dev, images=imgs)
+    rng = np.random.default_rng(0)
+    jit = rng.random(16384)
+    out = gen.batch(torch.arange(16384, 2 * 16384, device=dev), T(jit, dev))      # frame 1
+    o, d = syn.camera_rays(128, 128, poses[1])
+    pts, o32, d32, z = syn.coarse_samples(o, d, 1.6, 3.1, 64, jit)
+    np.testing.assert_array_equal(N(out[0]), pts)
+    np.testing.assert_array_equal(N(out[1]), o32)
+    np.testing.assert_array_equal(N(out[2]), d32)
+    np.testing.assert_array_equal(N(out[3]), z)
+    np.testing.assert_array_equal(N(out[4]), imgs[1].reshape(-1, 3))
+    g = torch.Generator(device=dev).manual_seed(1)
+    b = gen.random_batch(1001, generator=g)
+    assert [tuple(t.shape) for t in b] == [(1001, 64, 3), (1001, 3), (1001, 3), (1001, 64), (1001, 3)]
+    assert bool(torch.all(b[3][:, 1:] > b[3][:, :-1]))

@@ -1,0 +1,52 @@
+"""On-disk formats: transforms.json + PNG round trip, checkpoint files, scores.  CPU only."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from smpl_nerf_amd import io as sio
+from smpl_nerf_amd import synthetic as syn
+
+
+def test_dataset_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    imgs_rgb = rng.integers(0, 256, (3, 8, 6, 3), dtype=np.uint8)
+    poses = np.stack([syn.sphere_pose(10.0 * i, -20.0 * i, 2.4) for i in range(3)])
+    hp = syn.human_poses((41, 38), 0, 60, 3)
+    names = sio.write_dataset(str(tmp_path), imgs_rgb, poses, np.pi / 3, human_poses=hp)
+    td = json.load(open(os.path.join(tmp_path, "transforms.json")))
+    assert set(td) == {"camera_angle_x", "image_transform_map", "image_pose_map", "betas", "expression"}
+    assert len(td["image_pose_map"][names[0]]) == 69 and len(td["betas"]) == 10
+    ds = sio.load_dataset(str(tmp_path))
+    assert ds["names"] == names
+    np.testing.assert_array_equal(ds["images"], imgs_rgb[..., ::-1])       # cv2.imread order: BGR
+    np.testing.assert_array_equal(ds["poses"], poses)                       # json round-trips doubles exactly
+    np.testing.assert_array_equal(ds["human_poses"], hp)
+    norm = sio.normalize_rgb(ds["images"])
+    assert norm.dtype == np.float32 and norm.max() <= 1.0
+    np.testing.assert_array_equal(sio.to_uint8_rgb(norm), imgs_rgb)         # inference.py:261-263 flips back
+
+
+def test_checkpoint_files_are_interchangeable(tmp_path):
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    mc, mw = RenderRayNet(8, 256, 60, 24, skips=[4]), WarpFieldNet(8, 256, 60, 40)
+    sio.save_run(str(tmp_path), [mc, mw], ["model_coarse.pt", "model_warp_field.pt"])
+    sd = torch.load(os.path.join(tmp_path, "model_coarse.pt"))
+    assert list(sd)[:2] == ["positions_pose_input.weight", "positions_pose_input.bias"]
+    assert list(torch.load(os.path.join(tmp_path, "model_warp_field.pt"))) == [
+        "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias"]
+    m2 = RenderRayNet(8, 256, 60, 24, skips=[4])
+    sio.load_run(str(tmp_path), [m2], ["model_coarse.pt"])
+    assert all(torch.equal(a, b) for a, b in zip(mc.state_dict().values(), m2.state_dict().values()))
+
+
+def test_scores():
+    x = np.full((4, 4, 3), 0.5)
+    y = x + 0.1
+    assert abs(sio.img2mse(x, y) - 0.01) < 1e-12
+    assert abs(sio.img2psnr(x, y) - 20.0) < 1e-9
+    assert sio.mse2psnr(0) == 50.0 and abs(sio.mse2psnr(0.01) - 20.0) < 1e-12
+    t = torch.tensor(0.01)
+    ref = (-10. * torch.log(t) / torch.log(torch.Tensor([10.]))).item()    # util/scores.py:47-48
+    assert abs(sio.img2psnr(x, y) - ref) < 1e-5
