@@ -198,7 +198,7 @@ def main():
                        "rays_per_step_per_gpu": rays, "ray_samples_per_ray": 256, "parallelism": f"dp{world} (rays of "
                        "independent frames per rank, no data-path collective)"},
             "rays_per_s": world * a.steps * rays / elapsed,
-            "roofline": {"bound": "mfma", "kernel": "snerf::mlp_fwd_kernel<256, 4, false> (coarse + fine launches)",
+            "roofline": {"bound": "mfma", "kernel": "snerf::mlp_fwd_kernel<256, 8, false, false> (coarse + fine launches)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": TRAFFIC_PER_LAUNCH,
                          "avg_launch_ms": avg_ms, "launches": calls, "flop_per_unit": FLOP_PER_EVAL,

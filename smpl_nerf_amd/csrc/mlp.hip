@@ -244,7 +244,7 @@ int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStrea
     return check_launch(what);
 }
 
-constexpr int FWD_WAVES = 4;  // 64 samples per workgroup; several workgroups share a CU
+constexpr int FWD_WAVES = 8;  // 128 samples per workgroup, one workgroup per CU (2 waves per SIMD)
 
 template <int NW, bool ENCODED, bool TRAIN>
 static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
@@ -260,13 +260,14 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
 
 template <bool ENCODED, bool TRAIN>
 static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
-    // 4 waves (64 samples) per workgroup, two workgroups per CU.  SNERF_FWD_WAVES=8 selects one 8-wave
-    // workgroup per CU instead (tuning knob, read once).
+    // 8 waves (128 samples) per workgroup = one workgroup per CU, 2 waves per SIMD (85.7 % of the fp32 MFMA
+    // peak on the 128x128 frame); SNERF_FWD_WAVES=4 selects two independent 4-wave workgroups per CU instead
+    // (83.1 %; twice the L2->LDS weight traffic).  Tuning knob, read once.
     static const int nw = [] {
         const char *e = getenv("SNERF_FWD_WAVES");
-        return (e && atoi(e) == 8) ? 8 : FWD_WAVES;
+        return (e && atoi(e) == 4) ? 4 : FWD_WAVES;
     }();
-    if (nw == 8) return launch_fwd_nw<8, ENCODED, TRAIN>(P, A, s);
+    if (nw == 4) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
     return launch_fwd_nw<FWD_WAVES, ENCODED, TRAIN>(P, A, s);
 }
 

@@ -364,7 +364,7 @@ extern "C" int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed
     A.dy_din = L.dy[nh + 3];
     A.dy_dn0 = L.dy[nh + 4];
     A.dy_rgb = L.dy[nh + 5];
-    constexpr int BW = 4;
+    constexpr int BW = 8;  // 8 waves = 128 samples per workgroup, like the forward
     const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
     if (P.width == 256)
