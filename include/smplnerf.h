@@ -78,7 +78,8 @@ int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs,
  * gradient (the pipeline detaches what it derives from them, utils.py:260).  N <= 1024. */
 int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
                             const float *noise, int64_t B, int N, int white_background,
-                            const float *d_rgb, float *d_raw, snerf_stream_t stream);
+                            const float *d_rgb, float *d_raw, float *d_dirs /* nullable, [B,N,3]: only with per-sample
+                            directions (dists are scaled by their norm, utils.py:165) */, snerf_stream_t stream);
 
 /* ---- a5: inverse-CDF hierarchical sampling + merge + point generation ------------------------------
  * z [B, Nc] coarse depths (ascending), weights [B, Nc] from compositing, u [Nf] = linspace(0,1,Nf)
@@ -144,15 +145,25 @@ int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_fl
 int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                             const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                             int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
-/* params_flat -> transposed weight stream for the dgrad kernel (once per weight update). */
+/* params_flat -> transposed weight stream for the dgrad kernel (once per weight update).  input_grad != 0
+ * adds the encoder-column transposes snerf_mlp_bwd_inputs_f32 consumes (a different stream: pack one per use). */
 int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed_t,
-                         snerf_stream_t stream);
+                         int input_grad, snerf_stream_t stream);
 /* d_raw [n,4] -> flat_grad (snerf_mlp_param_floats floats, state_dict order, OVERWRITTEN): what
  * autograd leaves in .grad of the 26 parameter tensors after (raw * d_raw).sum().backward().
  * dy, gpart: scratch (snerf_mlp_train_sizes).  Three launches: dgrad, split-K wgrad, reduce. */
 int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
                       const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
                       snerf_stream_t stream);
+
+/* snerf_mlp_bwd_f32 that also back-propagates into the inputs of snerf_mlp_fwd_train_f32: d_x [n,3] (through
+ * the position encoding of layer 0 and the skip layers) and d_dirs [n,3] (through the direction encoding and
+ * the normalisation d/|d|, models/smpl_nerf_pipeline.py:54-56).  Needs the input_grad=1 transposed stream;
+ * default encoders only (<= 4 position / 2 direction k-blocks). */
+int snerf_mlp_bwd_inputs_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
+                             const float *d_raw, const float *x, const float *dirs, int dirs_per_sample,
+                             int samples_per_ray, int64_t n, float *dy, float *gpart, float *flat_grad,
+                             float *d_x, float *d_dirs, snerf_stream_t stream);
 
 /* Same network on already-encoded rows x_enc [n, row_floats] (the literal RenderRayNet.forward(x)
  * signature): positions_pose = x[:, :positions_dim+add_dim], directions = x[:, -directions_dim:]
@@ -181,6 +192,20 @@ int snerf_warp_pack_f32(const snerf_warp_desc *desc, const float *params_flat, f
 int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
                        const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
                        float *warp, float *warped, float *sdirs, snerf_stream_t stream);
+
+/* Training of the warp net: forward that saves [PE(x) | pose | h] tile-rows, the transposed head, and the
+ * backward d_warp [n,3] (= d loss / d warp, the sum of what arrives through warp, warped and sdirs) ->
+ * flat_grad (snerf_warp_param_floats floats, state_dict order, overwritten).  Sizes as snerf_mlp_train_sizes. */
+int snerf_warp_train_sizes(const snerf_warp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
+                           int64_t *packed_t_floats, int64_t *gpart_floats);
+int snerf_warp_fwd_train_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
+                             const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
+                             float *warp, float *warped, float *sdirs, float *act, snerf_stream_t stream);
+int snerf_warp_pack_t_f32(const snerf_warp_desc *desc, const float *params_flat, float *packed_t,
+                          snerf_stream_t stream);
+int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *packed_t, const float *act,
+                       const float *d_warp, int64_t n, float *dy, float *gpart, float *flat_grad,
+                       snerf_stream_t stream);
 
 /* ---- 8(f)-1: on-device ray generation + stratified coarse sampling --------------------------------------
  * Replaces get_rays (utils.py:50-54) + CoarseSampling (datasets/transforms.py:80-89) + ToTensor (:13-21) for a

@@ -37,7 +37,7 @@ SIGNATURES = {
     "snerf_searchsorted_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
     "snerf_posenc_f32": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P]),
     "snerf_composite_fwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
-    "snerf_composite_bwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    "snerf_composite_bwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "snerf_sample_pdf_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "snerf_sample_pdf_bins_f32": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "snerf_mlp_param_floats": (c_int64, [POINTER(MlpDesc)]),
@@ -47,12 +47,19 @@ SIGNATURES = {
     "snerf_mlp_train_sizes": (c_int, [POINTER(MlpDesc), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
                                       POINTER(c_int64), POINTER(c_int32)]),
     "snerf_mlp_fwd_train_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P, _P]),
-    "snerf_mlp_pack_t_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
+    "snerf_mlp_pack_t_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int, _P]),
+    "snerf_mlp_bwd_inputs_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, _P, _P, c_int, c_int, c_int64, _P, _P, _P, _P, _P,
+                                         _P]),
     "snerf_mlp_bwd_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "snerf_warp_param_floats": (c_int64, [POINTER(WarpDesc)]),
     "snerf_warp_packed_floats": (c_int64, [POINTER(WarpDesc)]),
     "snerf_warp_pack_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P]),
     "snerf_warp_fwd_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "snerf_warp_train_sizes": (c_int, [POINTER(WarpDesc), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
+                                       POINTER(c_int64)]),
+    "snerf_warp_fwd_train_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P]),
+    "snerf_warp_pack_t_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P]),
+    "snerf_warp_bwd_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "snerf_raygen_f64": (c_int, [_P, c_int64, c_int, c_int, c_double, _P, _P, c_int, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "snerf_mlp_fwd_encoded_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int64, c_int64, _P, _P]),
 }

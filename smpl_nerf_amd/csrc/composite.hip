@@ -112,7 +112,7 @@ constexpr int CP_MAX_CHUNKS = 16;  // N <= 1024
 __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
     const float4 *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs, int dirs_per_sample,
     const float *__restrict__ noise, int64_t B, int N, int white_bg, const float *__restrict__ d_rgb,
-    float4 *__restrict__ d_raw) {
+    float4 *__restrict__ d_raw, float *__restrict__ d_dirs) {
     __shared__ double s_carry[CP_THREADS / WAVE][CP_MAX_CHUNKS];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
             const float cr = sigmoidf_ref(r.x), cg = sigmoidf_ref(r.y), cb = sigmoidf_ref(r.z);
             d_raw[base] = make_float4(gr * cr * (1.f - cr), gg * cg * (1.f - cg), gb * cb * (1.f - cb), 0.f);
         }
+        if (d_dirs && lane < 3) d_dirs[base * 3 + lane] = 0.f;
         return;
     }
     float ray_norm = 0.f;
@@ -133,16 +134,17 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
         const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
         ray_norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
     }
+    float delta = 0.f, nrm = 0.f;  // of the sample last evaluated by this lane
     auto sample = [&](int i, float4 &r, float &a, float &om, float &dist, float &sig, float &ex) {
         r = raw[base + i];
         const float zi = z[base + i];
-        float nrm = ray_norm;
+        nrm = ray_norm;
         if (dirs_per_sample) {
             const float *dp = dirs + (base + i) * 3;
             nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dp[0], dp[0]), __fmul_rn(dp[1], dp[1])), __fmul_rn(dp[2], dp[2])));
         }
-        dist = (i + 1 < N) ? __fsub_rn(z[base + i + 1], zi) : 1e10f;
-        dist = __fmul_rn(dist, nrm);
+        delta = (i + 1 < N) ? __fsub_rn(z[base + i + 1], zi) : 1e10f;
+        dist = __fmul_rn(delta, nrm);
         sig = noise ? __fadd_rn(r.w, noise[base + i]) : r.w;
         ex = expf(__fmul_rn(-fmaxf(sig, 0.f), dist));
         a = __fsub_rn(1.0f, ex);
@@ -193,6 +195,15 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
             const float da = dw * T - (float)(after / (double)om);
             const float dsig = sig > 0.f ? da * dist * ex : 0.f;  // ex = exp(-relu(sigma) dist)
             d_raw[base + i] = make_float4(w * gr * cr * (1.f - cr), w * gg * cg * (1.f - cg), w * gb * cb * (1.f - cb), dsig);
+            if (d_dirs) {  // per-sample directions: dist = delta * |dir|  =>  d dir = d dist * delta * dir / |dir|
+                const float ddist = sig > 0.f ? da * sig * ex : 0.f;
+                const float s = ddist * delta / nrm;
+                const float *dp = dirs + (base + i) * 3;
+                float *q = d_dirs + (base + i) * 3;
+                q[0] = s * dp[0];
+                q[1] = s * dp[1];
+                q[2] = s * dp[2];
+            }
         }
     }
 }
@@ -219,18 +230,19 @@ extern "C" int snerf_composite_fwd_f32(const float *raw, const float *z, const f
 
 extern "C" int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
                                        const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
-                                       float *d_raw, snerf_stream_t stream) {
+                                       float *d_raw, float *d_dirs, snerf_stream_t stream) {
     using namespace snerf;
     if (B < 0 || N < 1 || N > WAVE * CP_MAX_CHUNKS) return fail(SNERF_E_BADARG, "composite_bwd: need 1 <= N <= 1024");
     if (B == 0) return SNERF_OK;
     if (!raw || !z || !d_rgb || !d_raw) return fail(SNERF_E_BADARG, "composite_bwd: null pointer");
     if (N > 1 && !dirs) return fail(SNERF_E_BADARG, "composite_bwd: dirs is null");
+    if (d_dirs && !dirs_per_sample) return fail(SNERF_E_BADARG, "composite_bwd: d_dirs needs per-sample directions");
     if (!aligned(raw, 16) || !aligned(d_raw, 16)) return fail(SNERF_E_ALIGN, "composite_bwd: raw/d_raw must be 16-byte aligned");
     const int rays_per_block = CP_THREADS / WAVE;
     const int64_t grid = (B + rays_per_block - 1) / rays_per_block;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "composite_bwd: B too large");
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)grid), dim3(CP_THREADS), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4 *>(raw), z, dirs, dirs_per_sample ? 1 : 0, noise, B, N,
-                       white_background ? 1 : 0, d_rgb, reinterpret_cast<float4 *>(d_raw));
+                       white_background ? 1 : 0, d_rgb, reinterpret_cast<float4 *>(d_raw), d_dirs);
     return check_launch("composite_bwd");
 }

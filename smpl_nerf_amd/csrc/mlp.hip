@@ -338,7 +338,7 @@ extern "C" int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int6
     make_train_layout(P, L);
     if (act_floats) *act_floats = (int64_t)L.act_rows * n * 16;
     if (dy_floats) *dy_floats = (int64_t)L.dy_rows * n * 16;
-    if (packed_t_floats) *packed_t_floats = (int64_t)(bwd_total_slabs(P) + SLAB_PAD) * SLAB_FLOATS;
+    if (packed_t_floats) *packed_t_floats = (int64_t)(bwd_total_slabs(P, true) + SLAB_PAD) * SLAB_FLOATS;  // covers both streams
     const int G = wgrad_chunks(n);
     if (gpart_count) *gpart_count = G;
     if (gpart_floats) *gpart_floats = (int64_t)G * L.gp_floats;

@@ -194,6 +194,7 @@ struct TrainLayout {
     int dy_rows;
     int gp[MAX_LAYERS];  // offset of layer l in the slot-ordered gradient: dW [t_out][nkb][64 lanes][4] then db [t_out*16]
     int gp_floats;
+    short xrow[MAX_LAYERS][3];  // first activation tile-row of input segment s of forward layer l (wgrad B operand)
 };
 
 inline void make_train_layout(const Plan &P, TrainLayout &L) {
@@ -218,19 +219,23 @@ inline void make_train_layout(const Plan &P, TrainLayout &L) {
     }
     L.dy_rows = d;
     L.gp_floats = g;
+    const int nh = L.nh;
+    for (int l = 0; l < P.nlayers; ++l)
+        for (int sgi = 0; sgi < P.layer[l].nseg; ++sgi) {
+            const Seg &sg = P.layer[l].seg[sgi];
+            int row;
+            if (sg.type == SEG_ADD) row = L.add;
+            else if (sg.type == SEG_PE) row = (l == nh + 3) ? L.dpe : L.pe;
+            else if (l >= 1 && l <= nh + 1) row = L.x[l];        // positional_net[l-1] / additional
+            else if (l == nh + 2 || l == nh + 3) row = L.o;      // sigma head, directional_input
+            else if (l == nh + 4) row = L.h1;
+            else row = L.h2;                                     // rgb head
+            L.xrow[l][sgi] = (short)row;
+        }
 }
 
 // first activation tile-row of input segment `s` of forward layer `l`
-__host__ __device__ inline int seg_act_row(const Plan &P, const TrainLayout &L, int l, int s) {
-    const Seg &sg = P.layer[l].seg[s];
-    const int nh = L.nh;
-    if (sg.type == SEG_ADD) return L.add;
-    if (sg.type == SEG_PE) return l == nh + 3 ? L.dpe : L.pe;
-    if (l >= 1 && l <= nh + 1) return L.x[l];  // positional_net[l-1] / additional
-    if (l == nh + 2 || l == nh + 3) return L.o;  // sigma head, directional_input
-    if (l == nh + 4) return L.h1;
-    return L.h2;                                 // rgb head
-}
+__host__ __device__ inline int seg_act_row(const Plan &, const TrainLayout &L, int l, int s) { return L.xrow[l][s]; }
 
 // ---- backward (dgrad) weight stream ---------------------------------------------------------------
 // The dgrad pass is the forward pass of the transposed network: dX^T[in feature, sample] = W^T * dY^T,
@@ -238,36 +243,59 @@ __host__ __device__ inline int seg_act_row(const Plan &P, const TrainLayout &L, 
 //   A[(kb, to, lane (i,g), r)] = W_fwd[16*kb + 4*g + r][16*to + i]   (hidden input columns only)
 struct BwdLayer {
     int fwd;      // forward layer (plan order) whose weight is transposed
-    int t_out;    // tiles of hidden input features produced
+    int seg;      // input segment of that layer whose columns are produced (0 = hidden columns)
+    int t_out;    // tiles of input features produced
     int nkb;      // k-blocks over the forward layer's output rows
     int aux_fwd;  // forward layer whose weight row 0 is shipped in the aux block (sigma head), or -1
     int first_slab, nslab;
 };
+constexpr int MAX_BWD_LAYERS = 40;  // 4 + n_hidden + encoder-column transposes (<= n_hidden + 2)
 struct BwdPlan {
     int nl, total_slabs;
-    BwdLayer layer[MAX_LAYERS];
+    BwdLayer layer[MAX_BWD_LAYERS];
 };
-inline void make_bwd_plan(const Plan &P, BwdPlan &B) {
+// input_grad: also emit the transposes of the encoder-input columns (direction encoding of directional_input,
+// position encoding of the skip layers and of layer 0), which the dgrad kernel turns into d x / d dir.
+inline int pe_seg_of(const Layer &Ly) {
+    for (int s = 0; s < Ly.nseg; ++s)
+        if (Ly.seg[s].type == SEG_PE) return s;
+    return -1;
+}
+inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false) {
     const int T = P.width / 16, TD = P.width / 32, nh = P.n_hidden;
     int nl = 0, slab = 0;
-    auto add = [&](int fwd, int t_out, int nkb, int aux) {
+    auto add = [&](int fwd, int seg, int t_out, int nkb, int aux) {
         BwdLayer &b = B.layer[nl++];
-        b = BwdLayer{fwd, t_out, nkb, aux, slab, 0};
+        b = BwdLayer{fwd, seg, t_out, nkb, aux, slab, 0};
         const int kps = 16 / t_out;
         b.nslab = (nkb + kps - 1) / kps;
         slab += b.nslab;
     };
-    add(nh + 5, TD, 1, -1);       // rgb head^T : d rgb (3) -> d h2
-    add(nh + 4, TD, TD, -1);      // directional_net[0]^T
-    add(nh + 3, T, TD, nh + 2);   // directional_input^T (hidden columns) + sigma head row via aux
-    add(nh + 1, T, T, -1);        // additional_linear_layer^T
-    for (int i = nh; i >= 1; --i) add(i, T, T, -1);  // positional_net[i-1]^T (hidden columns)
+    auto add_pe = [&](int fwd, int nkb_out_rows) {
+        const int s = pe_seg_of(P.layer[fwd]);
+        if (input_grad && s >= 0 && P.layer[fwd].seg[s].nkb > 0) {
+            // t_out must divide 16: pad the tile count up to 1, 2, 4, 8 or 16
+            int t = P.layer[fwd].seg[s].nkb, tp = 1;
+            while (tp < t) tp *= 2;
+            add(fwd, s, tp, nkb_out_rows, -1);
+        }
+    };
+    add(nh + 5, 0, TD, 1, -1);       // rgb head^T : d rgb (3) -> d h2
+    add(nh + 4, 0, TD, TD, -1);      // directional_net[0]^T
+    add_pe(nh + 3, TD);              // directional_input^T, direction-encoding columns
+    add(nh + 3, 0, T, TD, nh + 2);   // directional_input^T (hidden columns) + sigma head row via aux
+    add(nh + 1, 0, T, T, -1);        // additional_linear_layer^T -> d Y of forward layer nh
+    add_pe(nh, T);
+    for (int i = nh; i >= 1; --i) {
+        add(i, 0, T, T, -1);         // positional_net[i-1]^T (hidden columns) -> d Y of forward layer i-1
+        add_pe(i - 1, T);            // ... whose position-encoding columns follow if it has any (skip / layer 0)
+    }
     B.nl = nl;
     B.total_slabs = slab;
 }
-inline int bwd_total_slabs(const Plan &P) {
+inline int bwd_total_slabs(const Plan &P, bool input_grad = false) {
     BwdPlan B;
-    make_bwd_plan(P, B);
+    make_bwd_plan(P, B, input_grad);
     return B.total_slabs;
 }
 // number of K-splits (sample chunks) of the wgrad kernel for n samples

@@ -52,8 +52,18 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(Plan P, BwdPlan B, cons
             const int i = l & 15, g = l >> 4;
             const int kb = sl * kps + kbl;
             const int row = 16 * kb + 4 * g + r;  // forward output feature (contraction index)
-            const int col = 16 * to + i;          // forward hidden input feature (output of the transpose)
-            if (kb < Bl.nkb && row < Ly.n_out && col < Ly.seg[0].ncols) val = Wm[(int64_t)row * Ly.n_in + col];
+            // forward input column produced by output row (to, i) of the transpose
+            const Seg &sg = Ly.seg[Bl.seg];
+            int col = -1;
+            if (sg.type == SEG_PE) {
+                if (to < sg.nkb) {  // slot (i>>2, i&3) of encoder k-block `to`
+                    const int c = pe_slot_col(sg.L, sg.ident, to, i >> 2, i & 3);
+                    if (c >= 0) col = sg.col_off + c;
+                }
+            } else if (16 * to + i < sg.ncols) {
+                col = sg.col_off + 16 * to + i;
+            }
+            if (kb < Bl.nkb && row < Ly.n_out && col >= 0) val = Wm[(int64_t)row * Ly.n_in + col];
         } else if (sl == 0 && Bl.aux_fwd >= 0) {
             const Layer &La = P.layer[Bl.aux_fwd];
             const int jj = e - SLAB_A_FLOATS;
@@ -75,7 +85,51 @@ struct BwdArgs {
     int n_hidden;
     int act_x1, act_h2;
     int dy_sig, dy_din, dy_dn0, dy_rgb;  // dy of forward layer l <= nh+1 is l*T
+    // input gradients (INPUT_GRAD kernels only)
+    const float *x, *dirs;  // forward inputs: positions [n,3], directions [n/spr,3] or [n,3]
+    float *d_x, *d_dirs;    // [n,3] each: d loss / d position, d loss / d (un-normalised) direction
+    int dirs_per_sample, spr;
+    unsigned skip_mask;
+    int pos_L, pos_id, pos_nkb, dir_L, dir_id, dir_nkb, use_dir;
 };
+
+// Backward of the positional encoding (utils.py:127-131) for the slots this lane holds: dpe[kb][2u], [2u+1] are
+// the gradients of (first, second) of unit p = 4*(2kb+u)+g.  Adds this lane's share to (dx, dy, dz).
+template <int NKB>
+__device__ __forceinline__ void pe_backward(const f4 (&dpe)[NKB], int nkb, float x, float y, float z, int L, int ident,
+                                            int g, float &dx, float &dy, float &dz) {
+    const int nid = ident ? 3 : 0;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb >= nkb) break;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = 4 * (2 * kb + u) + g;
+            const float d0 = dpe[kb][2 * u], d1 = dpe[kb][2 * u + 1];
+            float val = 0.f;
+            int c = -1;
+            if (p < nid) {
+                c = p;
+                val = d0;
+            } else if (p - nid < 3 * L) {
+                const int pp = p - nid, k = pp / 3;
+                c = pp - 3 * k;
+                const float v = c == 0 ? x : (c == 1 ? y : z);
+                float sn, cs;
+                sincosf(ldexpf(v, k), &sn, &cs);
+                val = ldexpf(cs * d0 - sn * d1, k);  // d/dv sin(2^k v) = 2^k cos, d/dv cos(2^k v) = -2^k sin
+            }
+            dx += c == 0 ? val : 0.f;
+            dy += c == 1 ? val : 0.f;
+            dz += c == 2 ? val : 0.f;
+        }
+    }
+}
+__device__ __forceinline__ float sum_over_g(float v) {  // the 4 lanes (g = 0..3) that share a sample
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 
 template <int N>
 __device__ __forceinline__ void mask_into(f4 (&dst)[N], const f4 (&src)[N], const float *act, int row0, int64_t n,
@@ -92,11 +146,15 @@ __device__ __forceinline__ void mask_into(f4 (&dst)[N], const f4 (&src)[N], cons
     }
 }
 
-template <int WIDTH, int NWAVES>
+// INPUT_GRAD: additionally back-propagates into the network inputs (SmplNerfPipeline: the warped samples and
+// their per-sample view directions are functions of the warp net, models/smpl_nerf_pipeline.py:49-56); only
+// for the default encoders (position k-blocks <= TPP = 4, direction k-blocks <= TPD = 2).
+template <int WIDTH, int NWAVES, bool INPUT_GRAD>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;
     constexpr int TD = WIDTH / 32;
+    constexpr int TPP = 4, TPD = 2;
     __shared__ __attribute__((aligned(16))) float ring[3 * SLAB_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -136,7 +194,48 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         copy_into(ind, accd);
         if (valid) store_tiles(A.dy, A.dy_din, A.n, sample, g, ind);
     }
+    if (INPUT_GRAD && A.use_dir && A.dir_nkb > 0) {
+        // d (direction encoding) = directional_input[:, W:]^T d h1, then encoder and normalisation backward
+        f4 ddpe[TPD];
+        LayerRun<TPD, NT> run(pipe, lane);
+        run.init(ddpe);
+#pragma unroll
+        for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], ddpe);
+        run.finish();
+        const float *dp = A.dirs + (A.dirs_per_sample ? sc : sc / A.spr) * 3;
+        const float ux = dp[0], uy = dp[1], uz = dp[2];
+        const float nrm = sqrtf(ux * ux + uy * uy + uz * uz);
+        const float nx = ux / nrm, ny = uy / nrm, nz = uz / nrm;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        pe_backward<TPD>(ddpe, A.dir_nkb, nx, ny, nz, A.dir_L, A.dir_id, g, gx, gy, gz);
+        gx = sum_over_g(gx);
+        gy = sum_over_g(gy);
+        gz = sum_over_g(gz);
+        if (valid && g == 0) {  // d (u/|u|) -> d u = (g - n (n.g)) / |u|   (models/smpl_nerf_pipeline.py:54-55)
+            const float dot = nx * gx + ny * gy + nz * gz;
+            float *q = A.d_dirs + sample * 3;
+            q[0] = (gx - nx * dot) / nrm;
+            q[1] = (gy - ny * dot) / nrm;
+            q[2] = (gz - nz * dot) / nrm;
+        }
+    }
     f4 in[T], acc[T];
+    f4 dpe[TPP];
+#pragma unroll
+    for (int t = 0; t < TPP; ++t) dpe[t] = f4{0.f, 0.f, 0.f, 0.f};
+    // position-encoding columns of forward layer l (layer 0 or a skip layer), given d Y_l in `in`
+    auto pe_columns = [&](int l) {
+        if (!INPUT_GRAD || A.pos_nkb <= 0) return;
+        if (!(l == 0 || ((A.skip_mask >> (l - 1)) & 1u))) return;
+        f4 t[TPP];
+        LayerRun<TPP, NT> run(pipe, lane);
+        run.init(t);
+#pragma unroll
+        for (int kb = 0; kb < T; ++kb) run.step(in[kb], t);
+        run.finish();
+#pragma unroll
+        for (int q = 0; q < TPP; ++q) dpe[q] += t[q];
+    };
     {  // d o = directional_input[:, :W]^T d h1 + sigma_out_layer^T d sigma; additional layer has no activation (:51-52)
         LayerRun<T, NT> run(pipe, lane);
         run.init(acc);  // aux block = sigma head weights
@@ -153,6 +252,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         copy_into(in, acc);
         if (valid) store_tiles(A.dy, (nh + 1) * T, A.n, sample, g, in);
     }
+    (void)0;
     // additional^T, positional_net[nh-1]^T ... positional_net[0]^T: forward layer l+1 transposed yields
     // d X_{l+1}; masking with X_{l+1} > 0 gives d Y of forward layer l (:46-50)
     for (int l = nh; l >= 0; --l) {
@@ -163,6 +263,23 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         run.finish();
         mask_into(in, acc, A.act, A.act_x1 + l * T, A.n, sc, g);
         if (valid) store_tiles(A.dy, l * T, A.n, sample, g, in);
+        pe_columns(l);
+    }
+    if (INPUT_GRAD) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (A.pos_nkb > 0) {
+            const float px = A.x[sc * 3 + 0], py = A.x[sc * 3 + 1], pz = A.x[sc * 3 + 2];
+            pe_backward<TPP>(dpe, A.pos_nkb, px, py, pz, A.pos_L, A.pos_id, g, gx, gy, gz);
+        }
+        gx = sum_over_g(gx);
+        gy = sum_over_g(gy);
+        gz = sum_over_g(gz);
+        if (valid && g == 0) {
+            float *q = A.d_x + sample * 3;
+            q[0] = gx;
+            q[1] = gy;
+            q[2] = gz;
+        }
     }
 }
 
@@ -313,13 +430,35 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
     flat_grad[dst] = sum;
 }
 
+int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, float *packed_t, hipStream_t s, const char *what) {
+    hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(B.total_slabs + SLAB_PAD), dim3(256), 0, s, P, B, params_flat, packed_t);
+    return check_launch(what);
+}
+
+// split-K wgrad + reduce for any (Plan, TrainLayout)
+int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
+                 float *flat_grad, hipStream_t s) {
+    const int G = wgrad_chunks(n);
+    WgradArgs W{};
+    W.act = act;
+    W.dy = dy;
+    W.part = gpart;
+    W.n = n;
+    W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wgrad_jobs(P), G), dim3(WG_THREADS), 0, s, P, L, W);
+    int rc = check_launch("wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, flat_grad);
+    return check_launch("wgrad_reduce");
+}
+
 }  // namespace snerf
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed_t,
-                                    snerf_stream_t stream) {
+                                    int input_grad, snerf_stream_t stream) {
     using namespace snerf;
     Plan P;
     const char *why;
@@ -328,16 +467,14 @@ extern "C" int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *par
     if (!params_flat || !packed_t) return fail(SNERF_E_BADARG, "mlp_pack_t: null pointer");
     if (!aligned(packed_t, 16)) return fail(SNERF_E_ALIGN, "mlp_pack_t: packed_t must be 16-byte aligned");
     BwdPlan B;
-    make_bwd_plan(P, B);
-    hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(B.total_slabs + SLAB_PAD), dim3(256), 0, (hipStream_t)stream, P, B,
-                       params_flat, packed_t);
-    return check_launch("mlp_pack_t");
+    make_bwd_plan(P, B, input_grad != 0);
+    return launch_pack_t(P, B, params_flat, packed_t, (hipStream_t)stream, "mlp_pack_t");
 }
 
-extern "C" int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
-                                 const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
-                                 snerf_stream_t stream) {
-    using namespace snerf;
+namespace snerf {
+static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n,
+                      float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample,
+                      int spr, float *d_x, float *d_dirs, snerf_stream_t stream) {
     Plan P;
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "mlp_bwd: desc is null");
@@ -347,6 +484,12 @@ extern "C" int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed
     if (!packed_t || !act || !d_raw || !dy || !gpart || !flat_grad) return fail(SNERF_E_BADARG, "mlp_bwd: null pointer");
     if (!aligned(packed_t, 16) || !aligned(act, 16) || !aligned(d_raw, 16) || !aligned(dy, 16) || !aligned(gpart, 16))
         return fail(SNERF_E_ALIGN, "mlp_bwd: buffers must be 16-byte aligned");
+    const bool input_grad = d_x != nullptr;
+    if (input_grad) {
+        if (!x || !d_dirs || (desc->use_dir && !dirs) || spr < 1) return fail(SNERF_E_BADARG, "mlp_bwd: input gradients need x, dirs, d_x, d_dirs");
+        if (P.pos_nkb > 4 || P.dir_nkb > 2)
+            return fail(SNERF_E_BADARG, "mlp_bwd: input gradients support at most 4 position / 2 direction encoder k-blocks");
+    }
     hipStream_t s = (hipStream_t)stream;
     TrainLayout L;
     make_train_layout(P, L);
@@ -364,27 +507,48 @@ extern "C" int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed
     A.dy_din = L.dy[nh + 3];
     A.dy_dn0 = L.dy[nh + 4];
     A.dy_rgb = L.dy[nh + 5];
+    A.x = x;
+    A.dirs = dirs;
+    A.d_x = d_x;
+    A.d_dirs = d_dirs;
+    A.dirs_per_sample = dirs_per_sample ? 1 : 0;
+    A.spr = spr < 1 ? 1 : spr;
+    A.skip_mask = desc->skip_mask;
+    A.pos_L = desc->pos_freqs;
+    A.pos_id = desc->pos_identity ? 1 : 0;
+    A.pos_nkb = P.pos_nkb;
+    A.dir_L = desc->dir_freqs;
+    A.dir_id = desc->dir_identity ? 1 : 0;
+    A.dir_nkb = P.dir_nkb;
+    A.use_dir = desc->use_dir ? 1 : 0;
     constexpr int BW = 8;  // 8 waves = 128 samples per workgroup, like the forward
     const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
-    if (P.width == 256)
-        hipLaunchKernelGGL((mlp_bwd_kernel<256, BW>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
-    else
-        hipLaunchKernelGGL((mlp_bwd_kernel<128, BW>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+    if (P.width == 256) {
+        if (input_grad) hipLaunchKernelGGL((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+        else hipLaunchKernelGGL((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+    } else {
+        if (input_grad) hipLaunchKernelGGL((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+        else hipLaunchKernelGGL((mlp_bwd_kernel<128, BW, false>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+    }
     int rc = check_launch("mlp_bwd(dgrad)");
     if (rc) return rc;
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);
+}
+}  // namespace snerf
 
-    const int G = wgrad_chunks(n);
-    WgradArgs W{};
-    W.act = act;
-    W.dy = dy;
-    W.part = gpart;
-    W.n = n;
-    W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wgrad_jobs(P), G), dim3(WG_THREADS), 0, s, P, L, W);
-    rc = check_launch("mlp_bwd(wgrad)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G,
-                       flat_grad);
-    return check_launch("mlp_bwd(reduce)");
+extern "C" int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
+                                 const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
+                                 snerf_stream_t stream) {
+    return snerf::launch_bwd(desc, packed_t, act, d_raw, n, dy, gpart, flat_grad, nullptr, nullptr, 0, 1, nullptr,
+                             nullptr, stream);
+}
+
+extern "C" int snerf_mlp_bwd_inputs_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
+                                        const float *d_raw, const float *x, const float *dirs, int dirs_per_sample,
+                                        int samples_per_ray, int64_t n, float *dy, float *gpart, float *flat_grad,
+                                        float *d_x, float *d_dirs, snerf_stream_t stream) {
+    if (!d_x) return snerf::fail(SNERF_E_BADARG, "mlp_bwd_inputs: d_x is null");
+    return snerf::launch_bwd(desc, packed_t, act, d_raw, n, dy, gpart, flat_grad, x, dirs, dirs_per_sample,
+                             samples_per_ray, d_x, d_dirs, stream);
 }

@@ -72,9 +72,33 @@ struct WarpArgs {
     int64_t n;
     int spr;
     int pos_L, pos_id, pos_nkb, add_dim, add_nkb;
+    float *act;  // training: tile-row-major [pe | pose | h] (see warp_train_layout)
 };
 
-template <int WIDTH, int NWAVES>
+// activation / gradient buffers of the 2-layer warp net in the generic training layout (mlp_plan.h)
+inline void warp_train_layout(const Plan &P, TrainLayout &L) {
+    const int T = P.width / 16;
+    L = TrainLayout{};
+    L.T = T;
+    L.pe = 0;
+    L.add = P.pos_nkb;
+    L.x[1] = P.pos_nkb + P.add_nkb;  // hidden activation h
+    L.act_rows = L.x[1] + T;
+    L.dy[0] = 0;
+    L.dy[1] = T;
+    L.dy_rows = T + 1;
+    int g = 0;
+    for (int l = 0; l < 2; ++l) {
+        L.gp[l] = g;
+        g += P.layer[l].t_out * P.layer[l].nkb * 256 + P.layer[l].t_out * 16;
+    }
+    L.gp_floats = g;
+    for (int sgi = 0; sgi < P.layer[0].nseg; ++sgi)
+        L.xrow[0][sgi] = (short)(P.layer[0].seg[sgi].type == SEG_PE ? L.pe : L.add);
+    L.xrow[1][0] = (short)L.x[1];
+}
+
+template <int WIDTH, int NWAVES, bool TRAIN>
 __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_kernel(WarpArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;
@@ -101,10 +125,19 @@ __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_kernel(WarpArgs A) {
     {
         LayerRun<T, NT> run(pipe, lane);
         run.init(acc);
-        for (int kb = 0; kb < A.pos_nkb; ++kb) run.step(pe_operand<false>(c, false, A.pos_L, A.pos_id, kb, 0), acc);
-        for (int kb = 0; kb < A.add_nkb; ++kb) run.step(add_operand(c, A.add_dim, kb), acc);
+        for (int kb = 0; kb < A.pos_nkb; ++kb) {
+            const f4 b = pe_operand<false>(c, false, A.pos_L, A.pos_id, kb, 0);
+            if (TRAIN && valid) store_tile(A.act, kb, A.n, sample, c.g, b);
+            run.step(b, acc);
+        }
+        for (int kb = 0; kb < A.add_nkb; ++kb) {
+            const f4 b = add_operand(c, A.add_dim, kb);
+            if (TRAIN && valid) store_tile(A.act, A.pos_nkb + kb, A.n, sample, c.g, b);
+            run.step(b, acc);
+        }
         run.finish();
         relu_into(in, acc);
+        if (TRAIN && valid) store_tiles(A.act, A.pos_nkb + A.add_nkb, A.n, sample, c.g, in);
     }
     f4 w[1];
     {
@@ -136,7 +169,111 @@ __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_kernel(WarpArgs A) {
     }
 }
 
+// backward: d warp [n,3] -> d h = linear2^T d warp masked by h > 0 (stored as the layer-0 dY tile-rows) and the
+// head's dY tile-row; the weight gradients then come from the generic split-K wgrad (mlp_train.hip).
+struct WarpBwdArgs {
+    const float *packed_t, *act, *d_warp;
+    float *dy;
+    int64_t n;
+    int h_row;
+};
+
+template <int WIDTH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void warp_bwd_kernel(WarpBwdArgs A) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int T = WIDTH / 16;
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
+    const bool valid = sample < A.n;
+    const int64_t sc = valid ? sample : A.n - 1;
+    const float *dp = A.d_warp + sc * 3;
+    const f4 dw = g == 0 ? f4{dp[0], dp[1], dp[2], 0.f} : f4{0.f, 0.f, 0.f, 0.f};
+    if (valid) store_tile(A.dy, T, A.n, sample, g, dw);
+    SlabPipe<NT> pipe;
+    pipe.prologue(A.packed_t, ring, tid);
+    f4 acc[T], dh[T];
+    LayerRun<T, NT> run(pipe, lane);
+    run.init(acc);
+    run.step(dw, acc);
+    run.finish();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const f4 m = load_tile(A.act, A.h_row + t, A.n, sc, g);
+        dh[t][0] = m[0] > 0.f ? acc[t][0] : 0.f;
+        dh[t][1] = m[1] > 0.f ? acc[t][1] : 0.f;
+        dh[t][2] = m[2] > 0.f ? acc[t][2] : 0.f;
+        dh[t][3] = m[3] > 0.f ? acc[t][3] : 0.f;
+    }
+    if (valid) store_tiles(A.dy, 0, A.n, sample, g, dh);
+}
+
+// in mlp_train.hip
+int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, float *packed_t, hipStream_t s, const char *what);
+
 }  // namespace snerf
+
+extern "C" int snerf_warp_train_sizes(const snerf_warp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
+                                      int64_t *packed_t_floats, int64_t *gpart_floats) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "warp_train_sizes: desc is null");
+    if (make_warp_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "warp_train_sizes: %s", why);
+    if (n < 0) return fail(SNERF_E_BADARG, "warp_train_sizes: negative n");
+    TrainLayout L;
+    warp_train_layout(P, L);
+    if (act_floats) *act_floats = (int64_t)L.act_rows * n * 16;
+    if (dy_floats) *dy_floats = (int64_t)L.dy_rows * n * 16;
+    if (packed_t_floats) *packed_t_floats = (int64_t)(1 + SLAB_PAD) * SLAB_FLOATS;
+    if (gpart_floats) *gpart_floats = (int64_t)wgrad_chunks(n) * L.gp_floats;
+    return SNERF_OK;
+}
+
+extern "C" int snerf_warp_pack_t_f32(const snerf_warp_desc *desc, const float *params_flat, float *packed_t,
+                                     snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "warp_pack_t: desc is null");
+    if (make_warp_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "warp_pack_t: %s", why);
+    if (!params_flat || !packed_t) return fail(SNERF_E_BADARG, "warp_pack_t: null pointer");
+    if (!aligned(packed_t, 16)) return fail(SNERF_E_ALIGN, "warp_pack_t: packed_t must be 16-byte aligned");
+    BwdPlan B;
+    B.nl = 1;
+    B.total_slabs = 1;
+    B.layer[0] = BwdLayer{1, 0, P.width / 16, 1, -1, 0, 1};  // linear2^T: 3 output rows -> width hidden columns
+    return launch_pack_t(P, B, params_flat, packed_t, (hipStream_t)stream, "warp_pack_t");
+}
+
+extern "C" int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *packed_t, const float *act,
+                                  const float *d_warp, int64_t n, float *dy, float *gpart, float *flat_grad,
+                                  snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "warp_bwd: desc is null");
+    if (make_warp_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "warp_bwd: %s", why);
+    if (n < 0) return fail(SNERF_E_BADARG, "warp_bwd: negative n");
+    if (n == 0) return SNERF_OK;
+    if (!packed_t || !act || !d_warp || !dy || !gpart || !flat_grad) return fail(SNERF_E_BADARG, "warp_bwd: null pointer");
+    if (!aligned(packed_t, 16) || !aligned(act, 16) || !aligned(dy, 16) || !aligned(gpart, 16))
+        return fail(SNERF_E_ALIGN, "warp_bwd: buffers must be 16-byte aligned");
+    TrainLayout L;
+    warp_train_layout(P, L);
+    WarpBwdArgs A{packed_t, act, d_warp, dy, n, L.x[1]};
+    constexpr int NW = 4;
+    const int64_t grid = (n + NW * 16 - 1) / (NW * 16);
+    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_bwd: n too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (P.width == 256)
+        hipLaunchKernelGGL((warp_bwd_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+    else
+        hipLaunchKernelGGL((warp_bwd_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+    int rc = check_launch("warp_bwd");
+    if (rc) return rc;
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);
+}
 
 extern "C" int64_t snerf_warp_param_floats(const snerf_warp_desc *desc) {
     using namespace snerf;
@@ -166,10 +303,25 @@ extern "C" int snerf_warp_pack_f32(const snerf_warp_desc *desc, const float *par
     return launch_pack(P, params_flat, packed, (hipStream_t)stream, "warp_pack");
 }
 
+namespace snerf {
+static int launch_warp_fwd(const snerf_warp_desc *desc, const float *packed, const float *x, const float *pose_enc,
+                           const float *o, int64_t n, int samples_per_ray, float *warp, float *warped, float *sdirs,
+                           float *act, snerf_stream_t stream);
+}
 extern "C" int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
                                   const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
                                   float *warp, float *warped, float *sdirs, snerf_stream_t stream) {
-    using namespace snerf;
+    return snerf::launch_warp_fwd(desc, packed, x, pose_enc, o, n, samples_per_ray, warp, warped, sdirs, nullptr, stream);
+}
+extern "C" int snerf_warp_fwd_train_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
+                                        const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
+                                        float *warp, float *warped, float *sdirs, float *act, snerf_stream_t stream) {
+    if (!act) return snerf::fail(SNERF_E_BADARG, "warp_fwd_train: act is null");
+    return snerf::launch_warp_fwd(desc, packed, x, pose_enc, o, n, samples_per_ray, warp, warped, sdirs, act, stream);
+}
+static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *packed, const float *x, const float *pose_enc,
+                                  const float *o, int64_t n, int samples_per_ray, float *warp, float *warped,
+                                  float *sdirs, float *act, snerf_stream_t stream) {
     Plan P;
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "warp_fwd: desc is null");
@@ -197,12 +349,17 @@ extern "C" int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *pack
     A.pos_nkb = P.pos_nkb;
     A.add_dim = P.add_dim;
     A.add_nkb = P.add_nkb;
+    A.act = act;
     constexpr int NW = 4;
     const int64_t grid = (n + NW * 16 - 1) / (NW * 16);
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_fwd: n too large");
-    if (P.width == 256)
-        hipLaunchKernelGGL((warp_fwd_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, (hipStream_t)stream, A);
-    else
-        hipLaunchKernelGGL((warp_fwd_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, (hipStream_t)stream, A);
+    hipStream_t s = (hipStream_t)stream;
+    if (P.width == 256) {
+        if (act) hipLaunchKernelGGL((warp_fwd_kernel<256, NW, true>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        else hipLaunchKernelGGL((warp_fwd_kernel<256, NW, false>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+    } else {
+        if (act) hipLaunchKernelGGL((warp_fwd_kernel<128, NW, true>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        else hipLaunchKernelGGL((warp_fwd_kernel<128, NW, false>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+    }
     return check_launch("warp_fwd");
 }

@@ -48,6 +48,9 @@ class _FusedMlpFn(torch.autograd.Function):
         ctx.net, ctx.desc, ctx.n, ctx.act = net, desc, n, act
         ctx.sizes = (sizes[1].value, sizes[3].value)
         ctx.shapes = [p.shape for p in params]
+        ctx.input_grad = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        if ctx.input_grad:       # SmplNerfPipeline: positions / per-sample directions depend on the warp net
+            ctx.xd = (x, d, per_sample, int(spr))
         return raw
 
     @staticmethod
@@ -56,13 +59,26 @@ class _FusedMlpFn(torch.autograd.Function):
         net, desc, n = ctx.net, ctx.desc, ctx.n
         dev = d_raw.device
         d_raw = d_raw.contiguous().float()
-        packed_t = net.packed_weights_t(desc)
+        packed_t = net.packed_weights_t(desc, ctx.input_grad)
         dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
         gpart = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
         flat = torch.empty(lib.snerf_mlp_param_floats(desc), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), _lib.timed(f"mlp_bwd[n={n}]"):
-            check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), n, ptr(dy), ptr(gpart),
-                                        ptr(flat), current_stream()), "snerf_mlp_bwd_f32")
+        d_x = d_d = None
+        if ctx.input_grad:
+            x, d, per_sample, spr = ctx.xd
+            d_x = torch.empty((n, 3), device=dev, dtype=torch.float32)
+            d_d = torch.zeros((n, 3), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev), _lib.timed(f"mlp_bwd_inputs[n={n}]"):
+                check(lib.snerf_mlp_bwd_inputs_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), ptr(x), ptr(d), per_sample,
+                                                   spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x), ptr(d_d),
+                                                   current_stream()), "snerf_mlp_bwd_inputs_f32")
+            if not per_sample:       # one direction per ray: sum the per-sample contributions
+                d_d = d_d.view(-1, spr, 3).sum(1)
+            ctx.xd = None
+        else:
+            with torch.cuda.device(dev), _lib.timed(f"mlp_bwd[n={n}]"):
+                check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), n, ptr(dy), ptr(gpart),
+                                            ptr(flat), current_stream()), "snerf_mlp_bwd_f32")
         ctx.act = None
         grads, off = [], 0
         for shp in ctx.shapes:
@@ -71,7 +87,7 @@ class _FusedMlpFn(torch.autograd.Function):
                 k *= v
             grads.append(flat[off:off + k].view(shp))
             off += k
-        return (None, None, None, None, None, None, None) + tuple(grads)
+        return (None, None, d_x, d_d, None, None, None) + tuple(grads)
 
 
 class RenderRayNet(nn.Module):
@@ -177,11 +193,11 @@ class RenderRayNet(nn.Module):
         self._pack_cache = {key: (stamp, packed)}
         return packed
 
-    def packed_weights_t(self, desc: MlpDesc) -> torch.Tensor:
+    def packed_weights_t(self, desc: MlpDesc, input_grad: bool = False) -> torch.Tensor:
         """Transposed weight stream for the dgrad kernel (same caching rule as packed_weights)."""
         params = self._ordered_params()
         dev = params[0].device
-        key = tuple(getattr(desc, f[0]) for f in desc._fields_)
+        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + (bool(input_grad),)
         stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_t_cache.get(key)
         if hit is not None and hit[0] == stamp:
@@ -192,8 +208,9 @@ class RenderRayNet(nn.Module):
         flat = torch.cat([p.detach().reshape(-1).float() for p in params])
         packed = torch.empty(n_pack.value, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
-            check(lib.snerf_mlp_pack_t_f32(desc, ptr(flat), ptr(packed), current_stream()), "snerf_mlp_pack_t_f32")
-        self._pack_t_cache = {key: (stamp, packed)}
+            check(lib.snerf_mlp_pack_t_f32(desc, ptr(flat), ptr(packed), 1 if input_grad else 0, current_stream()),
+                  "snerf_mlp_pack_t_f32")
+        self._pack_t_cache[key] = (stamp, packed)
         return packed
 
     # ------------------------------------------------------------------ forward paths
@@ -236,8 +253,9 @@ class RenderRayNet(nn.Module):
             if additional is None:
                 raise RuntimeError("forward_fused: this net needs `additional` inputs")
             add = additional.reshape(-1, self.additional_input_dim).contiguous()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _FusedMlpFn.apply(self, desc, x.detach(), d.detach(), per_sample, int(samples_per_ray),
+        if torch.is_grad_enabled() and (x.requires_grad or d.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            return _FusedMlpFn.apply(self, desc, x, d, per_sample, int(samples_per_ray),
                                      None if add is None else add.detach(), *self._ordered_params())
         packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
@@ -250,6 +268,63 @@ class RenderRayNet(nn.Module):
     @property
     def is_cuda(self):
         return next(self.parameters()).is_cuda
+
+
+class _WarpFn(torch.autograd.Function):
+    """(warp, warped, sdirs) = WarpFieldNet stage with gradients for linear1/linear2.  warped = x + warp and
+    sdirs = warped - o, so the three incoming gradients add up to d loss / d warp."""
+
+    @staticmethod
+    def forward(ctx, net, desc, x, pose_enc, o, spr, *params):
+        lib = _lib.load()
+        n = x.shape[0]
+        dev = x.device
+        packed = net._packed(desc)
+        sizes = [ctypes.c_int64() for _ in range(4)]
+        check(lib.snerf_warp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes]), "snerf_warp_train_sizes")
+        act = torch.empty(sizes[0].value, device=dev, dtype=torch.float32)
+        warp, warped, sdirs = (torch.empty((n, 3), device=dev, dtype=torch.float32) for _ in range(3))
+        with torch.cuda.device(dev), _lib.timed(f"warp_fwd_train[n={n}]"):
+            check(lib.snerf_warp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(pose_enc), ptr(o), n, int(spr), ptr(warp),
+                                               ptr(warped), ptr(sdirs), ptr(act), current_stream()),
+                  "snerf_warp_fwd_train_f32")
+        ctx.net, ctx.desc, ctx.n, ctx.act = net, desc, n, act
+        ctx.sizes = (sizes[1].value, sizes[2].value, sizes[3].value)
+        ctx.shapes = [p.shape for p in params]
+        ctx.set_materialize_grads(False)
+        return warp, warped, sdirs
+
+    @staticmethod
+    def backward(ctx, d_warp, d_warped, d_sdirs):
+        lib = _lib.load()
+        net, desc, n = ctx.net, ctx.desc, ctx.n
+        parts = [g for g in (d_warp, d_warped, d_sdirs) if g is not None]
+        if not parts:
+            return (None,) * (6 + len(ctx.shapes))
+        total = parts[0]
+        for g in parts[1:]:
+            total = total + g
+        total = total.contiguous().float()
+        dev = total.device
+        params = net._params()
+        flatp = torch.cat([p.detach().reshape(-1).float() for p in params])
+        packed_t = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
+        dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
+        gpart = torch.empty(ctx.sizes[2], device=dev, dtype=torch.float32)
+        flat = torch.empty(flatp.numel(), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev), _lib.timed(f"warp_bwd[n={n}]"):
+            check(lib.snerf_warp_pack_t_f32(desc, ptr(flatp), ptr(packed_t), current_stream()), "snerf_warp_pack_t_f32")
+            check(lib.snerf_warp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(total), n, ptr(dy), ptr(gpart), ptr(flat),
+                                         current_stream()), "snerf_warp_bwd_f32")
+        ctx.act = None
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            k = 1
+            for v in shp:
+                k *= v
+            grads.append(flat[off:off + k].view(shp))
+            off += k
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class WarpFieldNet(nn.Module):
@@ -316,7 +391,6 @@ class WarpFieldNet(nn.Module):
     def forward_fused(self, positions, pose_encoding, ray_translation, samples_per_ray, position_encoder):
         """positions [n,3] (samples of a ray contiguous), pose_encoding [n/spr, pose_dim], ray_translation
         [n/spr, 3] -> (warp, warped = positions + warp, sdirs = warped - ray_translation), each [n,3]."""
-        self._no_grad()
         pos_L, pos_id = position_encoder.number_frequencies, 1 if position_encoder.include_identity else 0
         if 3 * (pos_id + 2 * pos_L) != self.positions_dim or pose_encoding.shape[-1] != self.direcions_dim:
             raise RuntimeError("WarpFieldNet: encoder output sizes do not match positions_dim/pose_dim")
@@ -328,6 +402,8 @@ class WarpFieldNet(nn.Module):
         o = ray_translation.reshape(-1, 3).contiguous()
         if pe.shape[0] * samples_per_ray != n or o.shape[0] * samples_per_ray != n:
             raise RuntimeError("forward_fused: per-ray inputs do not match positions / samples_per_ray")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _WarpFn.apply(self, desc, x.detach(), pe.detach(), o.detach(), int(samples_per_ray), *self._params())
         warp, warped, sdirs = (torch.empty((n, 3), device=x.device, dtype=torch.float32) for _ in range(3))
         lib = _lib.load()
         with torch.cuda.device(x.device), _lib.timed(f"warp_fwd[n={n}]"):

@@ -121,7 +121,7 @@ class _CompositeFn(torch.autograd.Function):
         rgb, weights, alpha = _composite_launch(raw, z_vals, dirs, per_sample, white_background, noise,
                                                 want_weights, want_alpha)
         ctx.save_for_backward(raw, z_vals, dirs, noise)
-        ctx.cfg = (per_sample, white_background)
+        ctx.cfg = (per_sample, white_background, bool(ctx.needs_input_grad[2]) and bool(per_sample))
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*[t for t in (weights, alpha) if t is not None])
         return rgb, weights, alpha
@@ -129,18 +129,19 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_rgb, d_w, d_a):
         raw, z_vals, dirs, noise = ctx.saved_tensors
-        per_sample, wb = ctx.cfg
+        per_sample, wb, want_ddirs = ctx.cfg
         if d_rgb is None:
             return (None,) * 8
         B, N = z_vals.shape
         d_rgb = d_rgb.contiguous().float()
         d_raw = torch.empty_like(raw)
+        d_dirs = torch.empty_like(dirs) if want_ddirs else None
         lib = _lib.load()
         with torch.cuda.device(raw.device), _lib.timed(f"composite_bwd[N={N}]"):
             check(lib.snerf_composite_bwd_f32(ptr(raw), ptr(z_vals), ptr(dirs), per_sample, ptr(noise), B, N,
-                                              1 if wb else 0, ptr(d_rgb), ptr(d_raw), current_stream()),
+                                              1 if wb else 0, ptr(d_rgb), ptr(d_raw), ptr(d_dirs), current_stream()),
                   "snerf_composite_bwd_f32")
-        return (d_raw,) + (None,) * 7
+        return (d_raw, None, d_dirs) + (None,) * 5
 
 
 def composite(raw, z_vals, samples_directions, white_background: bool, noise=None,
@@ -152,7 +153,9 @@ def composite(raw, z_vals, samples_directions, white_background: bool, noise=Non
     if noise is not None:
         noise = noise.contiguous()
     if torch.is_grad_enabled() and raw.requires_grad:
-        return _CompositeFn.apply(raw.view(B, N, 4), z_vals.detach(), dirs.detach(), per_sample, bool(white_background),
+        # per-sample directions (SmplNerfPipeline's x' - o) carry gradient: dists are scaled by their norm
+        dirs_in = dirs if (per_sample and dirs.requires_grad) else dirs.detach()
+        return _CompositeFn.apply(raw.view(B, N, 4), z_vals.detach(), dirs_in, per_sample, bool(white_background),
                                   noise, want_weights, want_alpha)
     return _composite_launch(raw, z_vals, dirs, per_sample, white_background, noise, want_weights, want_alpha)
 

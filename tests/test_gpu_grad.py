@@ -234,3 +234,38 @@ def test_append_smpl_params_training_step(dev):
             ref = g[f"train_grad/{name}.{k}"]
             scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
             close(R.digest(p.grad), ref, 5e-3, 2e-3 * scale)
+
+
+@pytest.mark.parametrize("wb", [0, 1])
+def test_smpl_nerf_training_step(dev, wb):
+    """SmplNerfPipeline under autograd: gradients flow through the compositing's |x'-o| scaling, the direction
+    normalisation, both positional encodings and the fused MLP inputs into the warp net
+    (models/smpl_nerf_pipeline.py:38-63, 71-98).  Loss + all three nets' gradients vs the reference."""
+    from smpl_nerf_amd.nets import WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import SmplNerfPipeline
+    g6, g = load_golden("g6_smpl_nerf_pipeline.npz"), load_golden("g11_smpl_grads.npz")
+    pc, pf = syn.make_scene_nets(101)
+    mc, mf = make_net(dev, pc), make_net(dev, pf)
+    mw = WarpFieldNet(8, 256, 60, 40)
+    mw.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_params(103, out_scale=0.3).items()})
+    mw = mw.to(dev)
+    pipe = SmplNerfPipeline(mc, mf, mw, O.Args(white_background=wb), PositionalEncoder(10, 0), PositionalEncoder(4, 0),
+                            PositionalEncoder(10, 0))
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    d = [T(a[g6["sub"]], dev) for a in data[:4]] + [T(g6["goal_pose"], dev), T(data[4][g6["sub"]], dev)]
+    out = pipe(d)
+    loss = torch.nn.functional.mse_loss(out[0], d[-1]) + torch.nn.functional.mse_loss(out[1], d[-1])
+    loss.backward()
+    close([loss.item()], g[f"loss_wb{wb}"], 1e-5, 1e-7)
+    for name, m in (("coarse", mc), ("fine", mf), ("warp", mw)):
+        for k, p in m.named_parameters():
+            ref = g[f"grad_wb{wb}/{name}.{k}"]
+            assert p.grad is not None, (name, k)
+            scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
+            close(R.digest(p.grad), ref, 1e-2, 5e-3 * scale)
+    # every element of the warp net's gradient (the end of the longest chain)
+    for k, p in mw.named_parameters():
+        ref = g[f"warpfull_wb{wb}/{k}"].astype(np.float64)
+        got = p.grad.cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(got - ref) <= 1e-2 * np.linalg.norm(ref), (k, np.linalg.norm(got - ref) / np.linalg.norm(ref))
