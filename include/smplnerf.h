@@ -145,6 +145,10 @@ int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_fl
 int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                             const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                             int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
+/* The same for already-encoded rows (RenderRayNet.forward(x) under autograd). */
+int snerf_mlp_fwd_encoded_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
+                                    int64_t n, int64_t row_floats, float *raw, float *act,
+                                    snerf_stream_t stream);
 /* params_flat -> transposed weight stream for the dgrad kernel (once per weight update).  input_grad != 0
  * adds the encoder-column transposes snerf_mlp_bwd_inputs_f32 consumes (a different stream: pack one per use). */
 int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed_t,

@@ -381,6 +381,40 @@ extern "C" int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *
     return launch_fwd<false, true>(P, A, (hipStream_t)stream);
 }
 
+extern "C" int snerf_mlp_fwd_encoded_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
+                                               int64_t n, int64_t row_floats, float *raw, float *act,
+                                               snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    FwdArgs A{};
+    int rc = fill_args(desc, P, A);
+    if (rc) return rc;
+    if (n < 0) return fail(SNERF_E_BADARG, "mlp_fwd_encoded_train: bad n");
+    if (n == 0) return SNERF_OK;
+    if (!packed || !x_enc || !raw || !act) return fail(SNERF_E_BADARG, "mlp_fwd_encoded_train: null pointer");
+    if (!aligned(packed, 16) || !aligned(raw, 16) || !aligned(act, 16))
+        return fail(SNERF_E_ALIGN, "mlp_fwd_encoded_train: packed/raw/act must be 16-byte aligned");
+    if (row_floats < A.pos_dim + A.add_dim || row_floats < A.dir_dim || row_floats > 0x7fffffff)
+        return fail(SNERF_E_BADARG, "mlp_fwd_encoded_train: row of %lld floats is too short for this network", (long long)row_floats);
+    TrainLayout L;
+    make_train_layout(P, L);
+    A.enc_stride = (int)row_floats;
+    A.packed = packed;
+    A.x = x_enc;
+    A.raw = raw;
+    A.n = n;
+    A.spr = 1;
+    A.act = act;
+    A.act_pe = L.pe;
+    A.act_add = L.add;
+    A.act_dpe = L.dpe;
+    A.act_x1 = L.x[1];
+    A.act_o = L.o;
+    A.act_h1 = L.h1;
+    A.act_h2 = L.h2;
+    return launch_fwd<true, true>(P, A, (hipStream_t)stream);
+}
+
 extern "C" int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
                                          int64_t n, int64_t row_floats, float *raw, snerf_stream_t stream) {
     using namespace snerf;

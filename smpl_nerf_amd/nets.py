@@ -24,6 +24,9 @@ def _encoder_shape(dim: int):
     return None
 
 
+_ENCODED_ROWS = -1  # marker passed in the `per_sample` slot of _FusedMlpFn
+
+
 class _FusedMlpFn(torch.autograd.Function):
     """raw = RenderRayNet(encode(x), encode(normalise(d))) with gradients for every weight and bias.
     Forward saves the layer inputs in the tile-row-major activation buffer; backward = dgrad + split-K
@@ -43,12 +46,16 @@ class _FusedMlpFn(torch.autograd.Function):
         act = torch.empty(sizes[0].value, device=dev, dtype=torch.float32)
         raw = torch.empty((n, 4), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev), _lib.timed(f"mlp_fwd_train[n={n}]"):
-            check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
-                                              ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
+            if per_sample == _ENCODED_ROWS:      # x holds already-encoded rows (RenderRayNet.forward(x))
+                check(lib.snerf_mlp_fwd_encoded_train_f32(desc, ptr(packed), ptr(x), n, x.shape[1], ptr(raw), ptr(act),
+                                                          current_stream()), "snerf_mlp_fwd_encoded_train_f32")
+            else:
+                check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
+                                                  ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
         ctx.net, ctx.desc, ctx.n, ctx.act = net, desc, n, act
         ctx.sizes = (sizes[1].value, sizes[3].value)
         ctx.shapes = [p.shape for p in params]
-        ctx.input_grad = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        ctx.input_grad = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and per_sample != _ENCODED_ROWS
         if ctx.input_grad:       # SmplNerfPipeline: positions / per-sample directions depend on the warp net
             ctx.xd = (x, d, per_sample, int(spr))
         return raw
@@ -219,12 +226,15 @@ class RenderRayNet(nn.Module):
         (models/render_ray_net.py:42-61)."""
         if not x.is_cuda:
             raise RuntimeError("RenderRayNet.forward: input must be on the GPU (no CPU path)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("RenderRayNet: backward is not implemented yet; run under torch.no_grad()")
         desc = self.desc_for_encoded()
-        packed = self.packed_weights(desc)
         xf = x.reshape(-1, x.shape[-1]).contiguous().float()
         n = xf.shape[0]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # parameter gradients only: the encoded rows are treated as constants (the pipelines of this
+            # package differentiate through the fused path instead)
+            raw = _FusedMlpFn.apply(self, desc, xf.detach(), None, _ENCODED_ROWS, 1, None, *self._ordered_params())
+            return raw.reshape(x.shape[:-1] + (4,))
+        packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
         lib = _lib.load()
         with torch.cuda.device(x.device):
@@ -452,13 +462,14 @@ class AppendVerticesNet(RenderRayNet):
     def forward_rays(self, ray_inputs, directions, samples_per_ray, n):
         """ray_inputs [B, positions_dim] (the first positions_dim columns of the reference's input rows, a
         per-ray constant), directions [B,3] -> raw [n = B*samples_per_ray, 4]."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("AppendVerticesNet: backward is not implemented yet; run under torch.no_grad()")
         desc = self.desc_for_rows()
-        packed = self.packed_weights(desc)
         add = ray_inputs.reshape(-1, self.positions_dim).contiguous().float()
         d = directions.reshape(-1, 3).contiguous()
         dummy_x = torch.zeros((n, 3), device=add.device, dtype=torch.float32)   # no position encoder: never read for slots
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _FusedMlpFn.apply(self, desc, dummy_x, d.detach(), 0, int(samples_per_ray), add.detach(),
+                                     *self._ordered_params())
+        packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=add.device, dtype=torch.float32)
         lib = _lib.load()
         with torch.cuda.device(add.device), _lib.timed(f"mlp_fwd[n={n}]"):
