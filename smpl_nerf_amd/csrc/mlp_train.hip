@@ -328,7 +328,9 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: base + s0*16 + lane
     const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + lane;
     const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + lane;
-    const bool want_bias = (s == 0 && bj == 0);
+    int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
+    while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
+    const bool want_bias = (s == first_seg && bj == 0);
     const int kslot = lane >> 4;
 
     const int64_t begin = (int64_t)blockIdx.y * A.chunk;

@@ -323,4 +323,6 @@ def test_append_vertices_training_gradients(dev):
             continue
         ref = P[k].grad.numpy().astype(np.float64)
         got = p.grad.cpu().numpy().astype(np.float64)
-        assert np.linalg.norm(got - ref) <= 2e-3 * max(np.linalg.norm(ref), 1e-12), k
+        # relative in norm, with a floor for the tensors whose gradient is numerically zero in this degenerate
+        # model (the net's "positions" are per-ray constants, so most of the trunk saturates)
+        assert np.linalg.norm(got - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-8 * np.sqrt(ref.size), k
