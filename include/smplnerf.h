@@ -136,6 +136,18 @@ int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const flo
                       const float *dirs, int dirs_per_sample, const float *add,
                       int64_t n, int samples_per_ray, float *raw, snerf_stream_t stream);
 
+/* ---- a2 on the bf16 matrix cores with fp32-class accuracy (split-bf16, inference) -------------------------
+ * Every fp32 operand is split into nsplit bf16 parts and the cross terms are accumulated in fp32:
+ * nsplit = 3 (6 products, ~2^-24 relative: same parity class as the fp32 kernel, 2.7x less matrix-pipe time),
+ * nsplit = 2 (3 products, ~2^-16 relative: RGB within ~8e-5, 5.3x less).  Same inputs/outputs as
+ * snerf_mlp_fwd_f32; `packed` comes from snerf_mlp_pack_bf16 with the same nsplit.  Width 256 only. */
+int64_t snerf_mlp_packed_bf16_bytes(const snerf_mlp_desc *desc, int nsplit);
+int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed, int nsplit,
+                        snerf_stream_t stream);
+int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
+                           const float *dirs, int dirs_per_sample, const float *add, int64_t n,
+                           int samples_per_ray, float *raw, snerf_stream_t stream);
+
 /* ---- a2 backward (training) ------------------------------------------------------------------------
  * Buffer sizes for n samples: activations saved by the forward, per-layer output gradients, the
  * transposed weight stream, the split-K partial gradients (gpart_count chunks). */

@@ -58,6 +58,7 @@ struct Plan {
     int total_slabs;
     int width, n_hidden;  // n_hidden = n_layers - 1 positional_net layers
     int pos_nkb, dir_nkb, add_nkb;
+    int kw;  // features per k-block: 16 (fp32 MFMA 16x16x4 path) or 32 (split-bf16 MFMA 16x16x32 path)
     int pos_dim, dir_dim, add_dim;
     int64_t param_floats;
     Layer layer[MAX_LAYERS];
@@ -79,9 +80,27 @@ __host__ __device__ inline int pe_slot_col(int L, int ident, int kb, int g, int 
     return nid + 6 * k + ((r & 1) ? 3 : 0) + c;
 }
 
+// ---- 32-wide k-blocks (split-bf16 path): a lane holds 8 values per k-block, slot (kb, g, e), e = 0..7 ----
+//   HIDDEN / ADD  col = 32*kb + 16*(e>>2) + 4*g + (e&3)   (accumulators of tiles 2kb, 2kb+1 side by side)
+//   PE            unit p = 4*(4*kb + (e>>1)) + g, (first, second) = e&1
+__host__ __device__ inline int pe_nkb32(int L, int ident) {
+    const int per_lane = (pe_units(L, ident) + 3) / 4;
+    return (per_lane + 3) / 4;
+}
+__host__ __device__ inline int pe_slot_col32(int L, int ident, int kb, int g, int e) {
+    const int p = 4 * (4 * kb + (e >> 1)) + g;
+    const int nid = ident ? 3 : 0;
+    if (p < nid) return (e & 1) ? -1 : p;
+    const int pp = p - nid;
+    if (pp >= 3 * L) return -1;
+    const int k = pp / 3, c = pp - 3 * k;
+    return nid + 6 * k + ((e & 1) ? 3 : 0) + c;
+}
+
 // Builds the plan; returns 0 or a negative SNERF_E_* with `why` set.
-inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why) {
+inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw = 16) {
     why = "";
+    P.kw = kw;
     if (d.n_layers < 2 || d.n_layers > 16) { why = "n_layers must be in [2,16]"; return -1; }
     if (d.width != 256 && d.width != 128) { why = "width must be 256 or 128"; return -1; }
     if (d.pos_freqs < 0 || d.pos_freqs > 16 || d.dir_freqs < 0 || d.dir_freqs > 16) { why = "bad encoder frequencies"; return -1; }
@@ -95,9 +114,9 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why) {
     P.add_dim = d.add_dim;
     if (P.pos_dim + P.add_dim == 0) { why = "empty position input"; return -1; }
     if (d.use_dir && P.dir_dim == 0) { why = "empty direction encoding"; return -1; }
-    P.pos_nkb = pe_nkb(d.pos_freqs, pid);
-    P.dir_nkb = d.use_dir ? pe_nkb(d.dir_freqs, did) : 0;
-    P.add_nkb = (d.add_dim + 15) / 16;
+    P.pos_nkb = kw == 16 ? pe_nkb(d.pos_freqs, pid) : pe_nkb32(d.pos_freqs, pid);
+    P.dir_nkb = d.use_dir ? (kw == 16 ? pe_nkb(d.dir_freqs, did) : pe_nkb32(d.dir_freqs, did)) : 0;
+    P.add_nkb = (d.add_dim + kw - 1) / kw;
     const int pin = P.pos_dim + P.add_dim;
     int nl = 0, slab = 0;
     int64_t off = 0;
@@ -109,7 +128,7 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why) {
         int col = 0;
         if (hidden) {
             Seg &s = Ly.seg[Ly.nseg++];
-            s = Seg{SEG_HIDDEN, col, hidden_cols, hidden_cols / 16, 0, 0};
+            s = Seg{SEG_HIDDEN, col, hidden_cols, hidden_cols / kw, 0, 0};
             col += hidden_cols;
         }
         if (extra == 1) {
@@ -169,6 +188,25 @@ __host__ __device__ inline int slot_to_col(const Layer &Ly, int kb, int g, int r
                 c = pe_slot_col(sg.L, sg.ident, kb, g, r);
             } else {
                 c = 16 * kb + 4 * g + r;
+                if (c >= sg.ncols) c = -1;
+            }
+            return c < 0 ? -1 : sg.col_off + c;
+        }
+        kb -= sg.nkb;
+    }
+    return -1;
+}
+
+// 32-wide counterpart of slot_to_col
+__host__ __device__ inline int slot_to_col32(const Layer &Ly, int kb, int g, int e) {
+    for (int s = 0; s < Ly.nseg; ++s) {
+        const Seg &sg = Ly.seg[s];
+        if (kb < sg.nkb) {
+            int c;
+            if (sg.type == SEG_PE) {
+                c = pe_slot_col32(sg.L, sg.ident, kb, g, e);
+            } else {
+                c = 32 * kb + 16 * (e >> 2) + 4 * g + (e & 3);
                 if (c >= sg.ncols) c = -1;
             }
             return c < 0 ? -1 : sg.col_off + c;

@@ -17,6 +17,7 @@ inline int make_warp_plan(const snerf_warp_desc &d, Plan &P, const char *&why) {
     if (d.pose_dim < 0 || d.pose_dim > 4096) { why = "bad pose_dim"; return -1; }
     const int pid = d.pos_identity ? 1 : 0;
     P.width = d.width;
+    P.kw = 16;
     P.n_hidden = 0;
     P.pos_dim = 3 * (pid + 2 * d.pos_freqs);
     P.dir_dim = 0;

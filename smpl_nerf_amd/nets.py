@@ -7,6 +7,7 @@ The nn.Linear children only hold the parameters; they are never called.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -130,6 +131,9 @@ class RenderRayNet(nn.Module):
         self.rgb_out_layer = torch.nn.Linear(directional_width, 3)
         self._pack_cache = {}
         self._pack_t_cache = {}
+        # matrix-core arithmetic of the inference path: "fp32" (v_mfma_f32_16x16x4_f32) or split-bf16
+        # "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5 relative); training is always fp32
+        self.precision = os.environ.get("SNERF_PRECISION", "fp32")
 
     # ------------------------------------------------------------------ parameter plumbing
     def _ordered_params(self):
@@ -200,6 +204,28 @@ class RenderRayNet(nn.Module):
         self._pack_cache = {key: (stamp, packed)}
         return packed
 
+    def packed_weights_bf16(self, desc: MlpDesc, nsplit: int) -> torch.Tensor:
+        """Split-bf16 weight stream (snerf_mlp_pack_bf16), cached like packed_weights."""
+        params = self._ordered_params()
+        dev = params[0].device
+        if not params[0].is_cuda:
+            raise RuntimeError("RenderRayNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
+        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + ("bf16", nsplit)
+        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = _lib.load()
+        nbytes = lib.snerf_mlp_packed_bf16_bytes(desc, nsplit)
+        if nbytes < 0:
+            check(int(nbytes), "snerf_mlp_packed_bf16_bytes")
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            check(lib.snerf_mlp_pack_bf16(desc, ptr(flat), ptr(packed), nsplit, current_stream()), "snerf_mlp_pack_bf16")
+        self._pack_cache = {key: (stamp, packed)}
+        return packed
+
     def packed_weights_t(self, desc: MlpDesc, input_grad: bool = False) -> torch.Tensor:
         """Transposed weight stream for the dgrad kernel (same caching rule as packed_weights)."""
         params = self._ordered_params()
@@ -267,9 +293,16 @@ class RenderRayNet(nn.Module):
                                         any(p.requires_grad for p in self.parameters())):
             return _FusedMlpFn.apply(self, desc, x, d, per_sample, int(samples_per_ray),
                                      None if add is None else add.detach(), *self._ordered_params())
-        packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
         lib = _lib.load()
+        if self.precision in ("bf16x6", "bf16x3") and self.width == 256:
+            ns = 3 if self.precision == "bf16x6" else 2
+            packed = self.packed_weights_bf16(desc, ns)
+            with torch.cuda.device(x.device), _lib.timed(f"mlp_fwd[n={n}]"):
+                check(lib.snerf_mlp_fwd_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n,
+                                                 int(samples_per_ray), ptr(raw), current_stream()), "snerf_mlp_fwd_bf16_f32")
+            return raw
+        packed = self.packed_weights(desc)
         with torch.cuda.device(x.device), _lib.timed(f"mlp_fwd[n={n}]"):
             check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n,
                                         int(samples_per_ray), ptr(raw), current_stream()), "snerf_mlp_fwd_f32")

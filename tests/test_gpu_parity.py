@@ -627,3 +627,59 @@ def test_raygen_frame_and_random_batches(dev):
     b = gen.random_batch(1001, generator=g)
     assert [tuple(t.shape) for t in b] == [(1001, 64, 3), (1001, 3), (1001, 3), (1001, 64), (1001, 3)]
     assert bool(torch.all(b[3][:, 1:] > b[3][:, :-1]))
+
+
+# ------------------------------------------------------------------------------------------ split-bf16 MFMA modes
+@pytest.mark.parametrize("prec,tol_raw,tol_rgb", [("bf16x6", 1e-5, 1e-4), ("bf16x3", 2e-3, 2e-4)])
+def test_split_bf16_modes(dev, prec, tol_raw, tol_rgb):
+    """The bf16-matrix-core modes of the inference kernel: bf16x6 is in the fp32 kernel's parity class (RGB <= 1e-4
+    vs the reference's frame, raw <= 1e-5 * head scale), bf16x3 trades ~2^-16 relative error for speed."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    g = load_golden("g2_mlp.npz")
+    net = _net(dev, syn.make_scene_nets(101)[1])
+    net.precision = prec
+    ref = g["raw_scene101"]
+    with torch.no_grad():
+        fused = net.forward_fused(T(g["pts"], dev), T(g["dirs"], dev), 1, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    assert maxabs(N(fused), ref) <= 2 * tol_raw * float(np.max(np.abs(ref)))
+    # ragged n, per-ray directions broadcast over samples
+    rng = np.random.default_rng(8)
+    B, Ns = 37, 5
+    pts = rng.uniform(-2, 2, (B, Ns, 3)).astype(F32)
+    dray = rng.normal(size=(B, 3)).astype(F32)
+    with torch.no_grad():
+        out = net.forward_fused(T(pts, dev), T(dray, dev), Ns, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        net.precision = "fp32"
+        out32 = net.forward_fused(T(pts, dev), T(dray, dev), Ns, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    assert maxabs(N(out), N(out32)) <= 2 * tol_raw * float(np.abs(N(out32)).max())
+    # whole frame against the reference's rendering
+    g5 = load_golden("g5_nerf_pipeline.npz")
+    pipe = _pipeline(dev)
+    pipe.model_coarse.precision = pipe.model_fine.precision = prec
+    data = syn.frame_batch(128, 128, phi=0.0, theta=0.0, seed=7, near=1.0, far=4.0)
+    with torch.no_grad():
+        rgb, rgb_fine, _, _ = pipe([T(a, dev) for a in data])
+    assert maxabs(N(rgb), g5["rgb_nf14"]) <= tol_rgb
+    assert maxabs(N(rgb_fine), g5["rgb_fine_nf14"]) <= tol_rgb
+    assert abs(psnr(N(rgb_fine), data[4]) - psnr(g5["rgb_fine_nf14"], data[4])) <= 0.01
+
+
+def test_split_bf16_additional_inputs_and_per_sample_dirs(dev):
+    """bf16x6 with pose columns in front of the encoding (append_smpl_params) and with per-sample directions."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(3)
+    m = RenderRayNet(8, 256, 60, 24, 69, skips=[4])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in
+                       syn.make_scene_net_params(301, add_first=True, additional_input_dim=69).items()})
+    m = m.to(dev)
+    B, Ns = 33, 7
+    pts = rng.uniform(-2, 2, (B, Ns, 3)).astype(F32)
+    dsm = rng.normal(size=(B * Ns, 3)).astype(F32)
+    pose = rng.uniform(-1, 1, (B, 69)).astype(F32)
+    enc = (PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    with torch.no_grad():
+        a = m.forward_fused(T(pts, dev), T(dsm, dev), Ns, *enc, additional=T(pose, dev), add_first=True)
+        m.precision = "bf16x6"
+        b = m.forward_fused(T(pts, dev), T(dsm, dev), Ns, *enc, additional=T(pose, dev), add_first=True)
+    assert maxabs(N(a), N(b)) <= 2e-5 * float(np.abs(N(a)).max())
