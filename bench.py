@@ -27,6 +27,11 @@ import torch
 
 FLOP_PER_EVAL = 2 * 607872           # RenderRayNet 8x256, pos 60, dir 24, skips=[4]
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md)
+# precision modes of the inference kernel: (kernel name for rocprof, products per fp32-accurate MAC)
+MODES = {"fp32": ("snerf::mlp_fwd_kernel<256, 8, false, false>", 1),
+         "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3>", 6),
+         "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2>", 3)}
 # HBM bytes per average mlp_fwd launch from the rocprofv3 PMC passes committed under profiles/
 # (r01_pmc_summary.json: FETCH_SIZE as reported - the kernel's 4 B/lane strided reads are outside the
 # guide's x2 calibration - plus WRITE_SIZE); the kernel is MFMA-bound, this is informational.
@@ -38,20 +43,20 @@ except Exception:
     pass
 
 
-def build_pipeline(dev):
+def build_pipeline(dev, precision="fp32"):
     from smpl_nerf_amd import synthetic as syn
     from smpl_nerf_amd.nets import RenderRayNet
     from smpl_nerf_amd.ops import PositionalEncoder
-    from smpl_nerf_amd.pipelines import NerfPipeline
-    from oracle.nerf_oracle import Args  # plain namespace only (no compute)
+    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
 
     params = list(syn.make_scene_nets(101))
     nets = []
     for p in params:
         m = RenderRayNet(8, 256, 60, 24, skips=[4])
         m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+        m.precision = precision
         nets.append(m.to(dev).eval())
-    args = Args(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0)
+    args = PipelineArgs(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0)
     pipe = NerfPipeline(nets[0], nets[1], args, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
     return pipe, params
 
@@ -123,6 +128,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the frame the CPU baseline renders (0 = skip)")
+    ap.add_argument("--precision", choices=sorted(MODES), default="bf16x6",
+                    help="matrix-core arithmetic of the render kernel: bf16x6 (split-bf16, fp32-class accuracy, default), "
+                         "fp32 (v_mfma_f32_16x16x4_f32), bf16x3 (2-part split, ~1e-5 relative)")
     ap.add_argument("--train-rays", type=int, default=4096, help="rays per GPU per training step (0 = skip the train section)")
     ap.add_argument("--train-steps", type=int, default=10)
     a = ap.parse_args()
@@ -147,7 +155,7 @@ def main():
     from smpl_nerf_amd import _lib, synthetic as syn
     from smpl_nerf_amd.dist import barrier, max_over_ranks, shard_frames
 
-    pipe, params = build_pipeline(dev)
+    pipe, params = build_pipeline(dev, a.precision)
     # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
     frame_id = shard_frames(world, rank)
     data_np = syn.frame_batch(128, 128, phi=7.0 * frame_id, theta=25.0 * frame_id, seed=7 + frame_id)
@@ -170,6 +178,24 @@ def main():
         kern = prof.summary()
     elapsed = max_over_ranks(elapsed, dev)
 
+    alt = {}
+    if rank == 0 or world > 1:
+        with torch.no_grad():
+            for prec in sorted(MODES):
+                if prec == a.precision:
+                    continue
+                pipe.model_coarse.precision = pipe.model_fine.precision = prec
+                pipe(data)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    o2 = pipe(data)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 3
+                alt[prec] = {"ray_samples_per_s_per_gpu": evals_per_step / dt, "ms_per_step": dt * 1e3,
+                             "rgb_fine_max_abs_diff_vs_" + a.precision: float((o2[1] - out[1]).abs().max())}
+            pipe.model_coarse.precision = pipe.model_fine.precision = a.precision
+
     train = None
     if a.train_rays > 0:
         try:
@@ -188,26 +214,45 @@ def main():
         avg_ms = ms / calls
         units_per_launch = a.steps * evals_per_step / calls
         achieved = FLOP_PER_EVAL * units_per_launch / (avg_ms * 1e-3) / 1e12
+        kname, products = MODES[a.precision]
+        if a.precision == "fp32":
+            peak = PEAK_F32_MFMA_TFLOPS
+            roof_extra = {"peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32, 157.3 TFLOP/s"}
+            dtype = "f32"
+        else:
+            # split-bf16: every algorithmic fp32 MAC is `products` bf16 products on the bf16 matrix cores, accumulated
+            # in fp32.  `achieved` stays ALGORITHMIC (1 215 744 FLOP per ray-sample); the matrix pipe executes
+            # `products` times that, so the scheme tops out at 2500/products TFLOP/s algorithmic.
+            peak = PEAK_BF16_MFMA_TFLOPS
+            roof_extra = {"executed_mfma_tflops": achieved * products, "executed_frac": achieved * products / peak,
+                          "attainable_algorithmic_peak": peak / products,
+                          "frac_of_attainable": achieved * products / peak,
+                          "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                          "peak_note": f"dense bf16 MFMA peak 2500 TFLOP/s (v_mfma_f32_16x16x32_bf16); operands split into "
+                                       f"bf16 parts, {products} products per fp32-accurate MAC, fp32 accumulate"}
+            dtype = f"f32 via {a.precision} (split-bf16 operands, fp32 accumulate; RGB parity class of the fp32 kernel)" \
+                if a.precision == "bf16x6" else f"f32 via {a.precision} (split-bf16, ~2^-16 relative)"
         line = {
             "metric": "ray-samples/sec (coarse+fine) at 128^2 / 64+128 samples",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "nerf 128x128 frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, "
                                    "width 256, skips [4], forward render (BASELINE configs[1])",
                        "rays_per_step_per_gpu": rays, "ray_samples_per_ray": 256, "parallelism": f"dp{world} (rays of "
                        "independent frames per rank, no data-path collective)"},
             "rays_per_s": world * a.steps * rays / elapsed,
-            "roofline": {"bound": "mfma", "kernel": "snerf::mlp_fwd_kernel<256, 8, false, false> (coarse + fine launches)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": TRAFFIC_PER_LAUNCH,
-                         "avg_launch_ms": avg_ms, "launches": calls, "flop_per_unit": FLOP_PER_EVAL,
-                         "units_per_launch": units_per_launch,
-                         "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32, 157.3 TFLOP/s; "
-                                      "traffic = (FETCH_SIZE + WRITE_SIZE) per average launch from profiles/ "
-                                      "(PMC passes of this command), not measured live"},
+            "roofline": dict({"bound": "mfma", "kernel": kname + " (coarse + fine launches)",
+                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                              "frac": achieved / peak, "traffic": TRAFFIC_PER_LAUNCH,
+                              "avg_launch_ms": avg_ms, "launches": calls, "flop_per_unit": FLOP_PER_EVAL,
+                              "units_per_launch": units_per_launch,
+                              "traffic_note": "(FETCH_SIZE + WRITE_SIZE) per average launch from the PMC passes under "
+                                              "profiles/, not measured live"}, **roof_extra),
+            "precision": a.precision,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(kern.items())},
         }
+        line["other_precisions_1gpu"] = alt
         if train is not None:
             line["train"] = train
         if world == 1 and a.cpu_rays > 0:

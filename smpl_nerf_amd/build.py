@@ -18,6 +18,9 @@ SOURCES = ["api.hip", "searchsorted.hip", "posenc.hip", "composite.hip", "sample
 HEADERS = ["snerf_common.h", "mlp_plan.h", "mlp_device.h", os.path.join("..", "..", "include", "smplnerf.h")]
 # -ffp-contract=off: the HBM-bound ops reproduce the reference's eager (unfused) fp32 op order.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# mlp_bf16.hip: keep the operand-split subtractions scalar - SLP-packed v_pk_add_f32 beside MFMAs costs matrix-pipe
+# issue slots (MI355X_MICROARCH.md, per-instruction constants)
+EXTRA_FLAGS = {"mlp_bf16.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:
@@ -43,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -16,6 +16,8 @@
 // k-block x 16 output tiles x 3 parts), positional encodings are evaluated in registers.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mlp_device.h"
 
 namespace snerf {
@@ -71,47 +73,131 @@ __global__ __launch_bounds__(256) void mlp_pack_bf16_kernel(Plan P, int NS, cons
     for (int j = threadIdx.x; j < 256; j += 256) aux[j] = (sl == 0 && j < Ly.n_out) ? params[Ly.b_off + j] : 0.f;
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// A-operand loads are issued as inline asm: hipcc waits lgkmcnt(0) in front of every consumer of a ds_read
+// inside the (rolled) hidden-layer loop, i.e. right behind the prefetch of the NEXT tile pair, which exposes
+// a full LDS round trip every pair.  With the loads opaque to the compiler the counted waits below are the
+// only ones.  Rules that keep this sound:
+//   * a loaded register is consumed only through wait_pair(), whose "+v" operands make every consumer depend
+//     on the s_waitcnt;
+//   * LDS returns data in order, so lgkmcnt(n) with n = the loads issued after the wanted ones is exact; the
+//     compiler's own waits (bias loads in init()) can only be stricter;
+//   * `s_nop 7` in front of a load group covers the MFMA-SrcC -> LDS-write WAR distance the compiler would
+//     insert for a ds_read it knows (the allocator does recycle accumulator registers as load targets).
+template <int OFF>
+__device__ __forceinline__ void lds_load_a(bf8 &dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const char *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+template <int NS, int TO>
+__device__ __forceinline__ void issue_pair(uint32_t addr, bf8 (&x0)[NS], bf8 (&x1)[NS]) {
+    asm volatile("s_nop 7");
+    static_for<0, NS>([&](auto s) {
+        lds_load_a<(TO * NS + s) * 1024>(x0[s], addr);
+        lds_load_a<((TO + 1) * NS + s) * 1024>(x1[s], addr);
+    });
+}
+template <int NS, int LEFT>
+__device__ __forceinline__ void wait_pair(bf8 (&x0)[NS], bf8 (&x1)[NS]) {
+    static_assert(LEFT == 0 || LEFT == 4 || LEFT == 6, "lgkmcnt immediates used below");
+    if constexpr (NS == 3) {
+        if constexpr (LEFT == 6)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x0[0]), "+v"(x0[1]), "+v"(x0[2]), "+v"(x1[0]), "+v"(x1[1]), "+v"(x1[2]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0[0]), "+v"(x0[1]), "+v"(x0[2]), "+v"(x1[0]), "+v"(x1[1]), "+v"(x1[2]));
+    } else {
+        if constexpr (LEFT == 4)
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x0[0]), "+v"(x0[1]), "+v"(x1[0]), "+v"(x1[1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0[0]), "+v"(x0[1]), "+v"(x1[0]), "+v"(x1[1]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // slab pipe with a run-time slab size (dynamic LDS)
 // ------------------------------------------------------------------------------------------------
+// The slab stream goes L2 -> LDS by DMA (global_load_lds, 16 B per lane = 1 KiB per wave instruction), no VGPR
+// round trip: 3-slot ring, slab p is consumed while p+1 has landed and p+2 is in flight - two slab periods of
+// latency tolerance (the register-staged pipe of the fp32 kernel has one).  Per slab each wave issues
+// PIECES/NW pieces (+ the bias piece on wave 0); `s_waitcnt vmcnt(n)` with n = the pieces of the newest slab
+// retires exactly the previous slab's pieces, then one raw s_barrier publishes them to the workgroup.
 template <int NT, int NS>
 struct SlabPipe16 {
     static constexpr int SB = NS * 16384 + 1024;
-    static constexpr int NA = NS * 16384 / 16 / NT;
-    const f4 *g;
+    static constexpr int NW = NT / 64;
+    static constexpr int PER_WAVE = NS * 16 / NW;  // 1 KiB pieces of the A region per wave
+    static_assert(NS * 16 % NW == 0, "A region must split evenly over the waves");
+    const char *gsrc;  // packed + lane*16
     char *ring;
-    f4 st[NA], st_aux;
-    int tid, rd, wr;
-    __device__ __forceinline__ void load() {
+    int wave, rd, wr, next;  // next = slab index to issue
+    // A parts of the first tile pair of the k-block that runs next: issued one tile pair ahead like every other
+    // pair, i.e. during the last pair of the previous k-block - across slab and layer boundaries too
+    bf8 fa0[NS], fa1[NS];
+    uint32_t lane16;
+    __device__ __forceinline__ void prefetch_first(const char *at) { issue_pair<NS, 0>(lds_addr(at) + lane16, fa0, fa1); }
+
+    __device__ __forceinline__ void issue(int slot) {
+        const char *src = gsrc + (int64_t)next * SB;
+        char *dst = ring + slot * SB;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) st[i] = g[i * NT];
-        if (tid < 64) st_aux = g[NS * 1024];
-        g += SB / 16;
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int piece = wave * PER_WAVE + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+        }
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + NS * 16384),
+                                             (__attribute__((address_space(3))) void *)(dst + NS * 16384), 16, 0, 0);
+        ++next;
     }
-    __device__ __forceinline__ void store(int slot) {
-        f4 *d = reinterpret_cast<f4 *>(ring + slot * SB) + tid;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) d[i * NT] = st[i];
-        if (tid < 64) d[NS * 1024] = st_aux;
+    // all but the newest slab's pieces of this wave have landed
+    __device__ __forceinline__ void wait_prev() {
+        if (wave == 0) {
+            if constexpr (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if constexpr (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if constexpr (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-    __device__ __forceinline__ void prologue(const void *packed, char *ring_, int tid_) {
+    __device__ __forceinline__ void prologue(const void *packed, char *ring_, int tid) {
         ring = ring_;
-        tid = tid_;
-        g = reinterpret_cast<const f4 *>(packed) + tid;
-        load(); store(0);
-        load(); store(1);
-        load();
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        gsrc = reinterpret_cast<const char *>(packed) + (tid & 63) * 16;
+        next = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the per-sample input loads are done: only DMA below
+        issue(0);
+        issue(1);
+        wait_prev();  // slab 0 landed (this wave's pieces)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         rd = 0;
         wr = 2;
-        __syncthreads();
+        issue(2);
+        lane16 = (tid & 63) * 16;
+        prefetch_first(ring);
     }
     __device__ __forceinline__ const char *acquire() const { return ring + rd * SB; }
+    // done reading slab `rd`: make the next slab visible, then refill the slot just freed
     __device__ __forceinline__ void release() {
-        store(wr);
-        load();
-        __syncthreads();
+        wait_prev();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int freed = rd;
         rd = rd == 2 ? 0 : rd + 1;
-        wr = wr == 2 ? 0 : wr + 1;
+        issue(freed);
     }
 };
 
@@ -129,53 +215,146 @@ template <> struct Terms<3> {
 };
 
 // One 32-wide k-block: per output tile NS ds_read_b128 + Terms<NS>::N MFMAs; tiles in pairs so consecutive
-// MFMAs alternate accumulators; the A parts of the next pair are read while this pair's MFMAs issue.
-template <int T_OUT, int NS>
-__device__ __forceinline__ void kblock16(const char *a_kb, const bf8 (&b)[NS], f4 (&acc)[T_OUT], int lane) {
-    const bf8 *ap = reinterpret_cast<const bf8 *>(a_kb) + lane;  // [(to*NS + s)*64]
+// MFMAs alternate accumulators.  The stream is software-pipelined by hand and fenced with sched_barrier(0):
+// the A parts of pair p+1 are issued, then a counted wait retires pair p's, then pair p's 2N MFMAs run (the
+// LDS latency of p+1 hides behind them).  The pipeline runs across k-blocks: on entry (fa0, fa1) hold the
+// in-flight first pair of this k-block; in the last pair, after all of this k-block's loads have returned,
+// `boundary()` does the slab hand-over if one is due (counted vmcnt wait, barrier, refill of the freed slot)
+// and returns the LDS address of the next k-block, whose first pair is issued before the last pair's MFMAs -
+// so neither the barrier nor the first LDS round trip of a slab sits in front of an empty matrix pipe.
+// `b` holds this k-block's B operand parts (ready on entry).  `make_piece.make(i)`, i in [0, 4), is the VALU
+// work that prepares elements 2i, 2i+1 of the NEXT k-block's operand (splitting fp32 accumulators into bf16
+// parts); the pieces are spread over the pairs and interleaved with the MFMAs, so the split runs while the
+// matrix pipe works instead of in a serial phase between k-blocks (both waves of a SIMD belong to the same
+// workgroup and run close to lockstep, so a serial phase idles the matrix pipe).
+template <int T_OUT, int NS, class MakePiece, class Boundary>
+__device__ __forceinline__ void kblock16(uint32_t addr, bf8 (&fa0)[NS], bf8 (&fa1)[NS], const bf8 (&b)[NS],
+                                         MakePiece make_piece, f4 (&acc)[T_OUT], Boundary boundary) {
     using Tm = Terms<NS>;
     if constexpr (T_OUT == 1) {
         bf8 a[NS];
+        wait_pair<NS, 0>(fa0, fa1);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) a[s] = ap[s * 64];
+        for (int s = 0; s < NS; ++s) a[s] = fa0[s];
+        const uint32_t next = boundary();
+        issue_pair<NS, 0>(next, fa0, fa1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) make_piece.make(i);
 #pragma unroll
         for (int t = 0; t < Tm::N; ++t) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[Tm::A[t]], b[Tm::B[t]], acc[0], 0, 0, 0);
+        make_piece.touch();
+        __builtin_amdgcn_sched_barrier(0);
     } else {
+        constexpr int PAIRS = T_OUT / 2;
         bf8 a0[NS], a1[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            a0[s] = ap[s * 64];
-            a1[s] = ap[(NS + s) * 64];
+            a0[s] = fa0[s];
+            a1[s] = fa1[s];
         }
-#pragma unroll
-        for (int to = 0; to < T_OUT; to += 2) {
+        static_for<0, PAIRS>([&](auto pc) {
+            constexpr int p = decltype(pc)::value, to = 2 * p;
             bf8 n0[NS], n1[NS];
-            if (to + 2 < T_OUT) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    n0[s] = ap[((to + 2) * NS + s) * 64];
-                    n1[s] = ap[((to + 3) * NS + s) * 64];
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NS, 0);
+            if constexpr (p + 1 < PAIRS) {
+                issue_pair<NS, to + 2>(addr, n0, n1);
+                wait_pair<NS, 2 * NS>(a0, a1);
+            } else {
+                wait_pair<NS, 0>(a0, a1);
+                const uint32_t next = boundary();
+                issue_pair<NS, 0>(next, n0, n1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr bool has_piece = (p * 4) % PAIRS == 0 || PAIRS < 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i * PAIRS / 4 == p) make_piece.make(i);
 #pragma unroll
             for (int t = 0; t < Tm::N; ++t) {
                 acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[Tm::A[t]], b[Tm::B[t]], acc[to], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (to + 2 < T_OUT) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    a0[s] = n0[s];
-                    a1[s] = n1[s];
-                }
+            for (int t = 0; t < 2 * Tm::N; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
             }
+            if constexpr (has_piece) make_piece.touch();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                a0[s] = n0[s];
+                a1[s] = n1[s];
+            }
+        });
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            fa0[s] = a0[s];
+            fa1[s] = a1[s];
         }
     }
 }
+
+// elements e = 2i, 2i+1 (tile 2kb + (e >> 2), row e & 3) of the B operand of k-block kb.  PIN: the source values
+// pass through an empty volatile asm, which anchors the split's VALU work at this point of the asm-ordered
+// stream (the loads and waits of kblock16) - otherwise the compiler hoists it into one serial clump.
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+// (v0, v1) -> dword `i` (elements 2i, 2i+1) of the NS packed-bf16 parts.  Per part: one v_cvt_pk_bf16_f32 for both
+// values, a shift and a mask to widen the two halves back to fp32, and two scalar subtractions (kept scalar on
+// purpose: packed-fp32 VALU beside MFMAs costs matrix-pipe issue slots - MI355X_MICROARCH.md).
+template <int NS>
+__device__ __forceinline__ void split_pair_into(float v0, float v1, bf8 (&dst)[NS], int i) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{v0, v1}, bf2v));
+        u4v t = __builtin_bit_cast(u4v, dst[s]);
+        t[i] = u;
+        dst[s] = __builtin_bit_cast(bf8, t);
+        if (s + 1 < NS) {
+            v0 = v0 - __builtin_bit_cast(float, u << 16);
+            v1 = v1 - __builtin_bit_cast(float, u & 0xffff0000u);
+        }
+    }
+}
+// relu as exactly one v_max_f32 (fmaxf adds a canonicalising v_max in front)
+__device__ __forceinline__ float relu1(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+template <bool RELU, bool PIN, int T_SRC, int NS>
+__device__ __forceinline__ void split_piece(const f4 (&src)[T_SRC], int kb, int i, bf8 (&b)[NS]) {
+    float v0 = src[2 * kb + (i >> 1)][(2 * i) & 3], v1 = src[2 * kb + (i >> 1)][((2 * i) & 3) + 1];
+    if constexpr (PIN) asm volatile("" : "+v"(v0), "+v"(v1));
+    if constexpr (RELU) {
+        v0 = relu1(v0);
+        v1 = relu1(v1);
+    }
+    split_pair_into<NS>(v0, v1, b, i);
+}
+struct NoPiece {
+    __device__ __forceinline__ void make(int) const {}
+    __device__ __forceinline__ void touch() const {}
+};
+template <bool RELU, int T_SRC, int NS>
+struct NextPieceT {
+    const f4 (&src)[T_SRC];
+    bf8 (&bn)[NS];
+    int kb;  // the k-block being prepared (nothing to do past the last one)
+    __device__ __forceinline__ void make(int i) const {
+        if (kb < T_SRC / 2) split_piece<RELU, true>(src, kb, i, bn);
+    }
+    // keeps the piece's results inside the tile-pair region they were issued in
+    __device__ __forceinline__ void touch() const {
+        if (kb < T_SRC / 2) {
+            if constexpr (NS == 3) asm volatile("" ::"v"(bn[0]), "v"(bn[1]), "v"(bn[2]));
+            else asm volatile("" ::"v"(bn[0]), "v"(bn[1]));
+        }
+    }
+};
 
 template <int T_OUT, int NT, int NS>
 struct LayerRun16 {
@@ -189,37 +368,49 @@ struct LayerRun16 {
 #pragma unroll
         for (int to = 0; to < T_OUT; ++to) acc[to] = aux[to * 4];
     }
-    __device__ __forceinline__ void step(const bf8 (&b)[NS], f4 (&acc)[T_OUT]) {
-        if (kbl == KPS) {
-            pipe.release();
-            slab = pipe.acquire();
-            kbl = 0;
+    static constexpr int KB_BYTES = T_OUT * NS * 1024;
+    template <class MakePiece>
+    __device__ __forceinline__ void step(const bf8 (&b)[NS], MakePiece make_piece, f4 (&acc)[T_OUT]) {
+        kblock16<T_OUT, NS>(lds_addr(slab + kbl * KB_BYTES) + pipe.lane16, pipe.fa0, pipe.fa1, b, make_piece, acc,
+                            [&]() -> uint32_t {
+                                if (++kbl == KPS) {  // this k-block was the last of its slab
+                                    pipe.release();
+                                    slab = pipe.acquire();
+                                    kbl = 0;
+                                }
+                                return lds_addr(slab + kbl * KB_BYTES) + pipe.lane16;
+                            });
+    }
+    // operand computed up front (encoder / additional-input k-blocks)
+    template <class MakeB>
+    __device__ __forceinline__ void step_make(MakeB make_b, f4 (&acc)[T_OUT]) {
+        bf8 b[NS];
+        make_b(b);
+        step(b, NoPiece{}, acc);
+    }
+    // k-blocks fed by the accumulators of a previous layer: tiles 2kb, 2kb+1 are split just in time
+    template <bool RELU, int T_SRC>
+    __device__ __forceinline__ void run_hidden(const f4 (&src)[T_SRC], f4 (&acc)[T_OUT]) {
+        bf8 bc[NS], bn[NS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_piece<RELU, false>(src, 0, i, bc);  // the only split of the layer not hidden behind MFMAs
+#pragma unroll
+        for (int kb = 0; kb < T_SRC / 2; ++kb) {
+            step(bc, NextPieceT<RELU, T_SRC, NS>{src, bn, kb + 1}, acc);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) bc[s] = bn[s];
         }
-        kblock16<T_OUT, NS>(slab + kbl * (T_OUT * NS * 1024), b, acc, lane);
-        ++kbl;
     }
-    __device__ __forceinline__ void finish() { pipe.release(); }
+    // every layer starts on a fresh slab: hand over a partly used last slab and restart the first-pair prefetch
+    // (the one issued by the last k-block pointed into the unused part of the old slab)
+    __device__ __forceinline__ void finish() {
+        if (kbl != 0) {
+            wait_pair<NS, 0>(pipe.fa0, pipe.fa1);  // its registers stay live until the loads have landed
+            pipe.release();
+            pipe.prefetch_first(pipe.acquire());
+        }
+    }
 };
-
-// fp32 -> NS bf16 parts, element e of the packed B operand
-template <int NS>
-__device__ __forceinline__ void split_into(float v, bf8 (&dst)[NS], int e) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const __bf16 h = (__bf16)v;
-        dst[s][e] = h;
-        v = v - (float)h;
-    }
-}
-
-// accumulators of N tiles (optionally through ReLU) -> B operands of N/2 k-blocks
-template <int N, int NS, bool RELU>
-__device__ __forceinline__ void pack_acts(const f4 (&acc)[N], bf8 (&bin)[N / 2][NS]) {
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) split_into<NS>(RELU ? fmaxf(acc[t][r], 0.f) : acc[t][r], bin[t >> 1], 4 * (t & 1) + r);
-}
 
 // B operand of encoder k-block kb: 4 units (sin, cos pairs) per lane
 template <int NS>
@@ -229,16 +420,20 @@ __device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, in
     for (int u = 0; u < 4; ++u) {
         float s0, c0;
         pe_unit(x, y, z, L, ident, 4 * (4 * kb + u) + c.g, s0, c0);
-        split_into<NS>(s0, b, 2 * u);
-        split_into<NS>(c0, b, 2 * u + 1);
+        split_pair_into<NS>(s0, c0, b, u);
     }
 }
 template <int NS>
 __device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, int kb, bf8 (&b)[NS]) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int col = 32 * kb + 16 * (e >> 2) + 4 * c.g + (e & 3);
-        split_into<NS>(col < add_dim ? c.add[col] : 0.f, b, e);
+    for (int j = 0; j < 4; ++j) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = 2 * j + h, col = 32 * kb + 16 * (e >> 2) + 4 * c.g + (e & 3);
+            v[h] = col < add_dim ? c.add[col] : 0.f;
+        }
+        split_pair_into<NS>(v[0], v[1], b, j);
     }
 }
 
@@ -246,7 +441,6 @@ template <int WIDTH, int NWAVES, int NS>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16, TD = WIDTH / 32;
-    constexpr int KB = T / 2, KBD = TD / 2;
     extern __shared__ __attribute__((aligned(16))) char ring[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -271,94 +465,90 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         c.dz = __fdiv_rn(uz, nrm);
     }
     if (A.add_dim) c.add = A.add + ray * A.add_dim;
+    // make the compiler retire the input loads HERE: a later first use would put its s_waitcnt vmcnt(0) inside
+    // the slab loop and drain the in-flight weight DMA every time
+    asm volatile("" ::"v"(c.px), "v"(c.py), "v"(c.pz), "v"(c.dx), "v"(c.dy), "v"(c.dz));
 
     SlabPipe16<NT, NS> pipe;
     pipe.prologue(A.packed, ring, tid);
 
-    bf8 bin[KB][NS];
-    f4 acc[T];
-    auto pe_segment = [&](LayerRun16<T, NT, NS> &run) {
-        for (int kb = 0; kb < A.pos_nkb; ++kb) {
-            bf8 b[NS];
-            pe_operand16<NS>(c, false, A.pos_L, A.pos_id, kb, b);
-            run.step(b, acc);
-        }
+    // two accumulator sets ping-pong between consecutive layers: the finished set feeds the next layer's B
+    // operands (split just in time, k-block by k-block) while the other set accumulates
+    f4 accA[T], accB[T];
+    auto pos_segments = [&](LayerRun16<T, NT, NS> &run, f4(&acc)[T]) {
+        auto pe_segment = [&]() {
+            for (int kb = 0; kb < A.pos_nkb; ++kb)
+                run.step_make([&](bf8(&b)[NS]) { pe_operand16<NS>(c, false, A.pos_L, A.pos_id, kb, b); }, acc);
+        };
+        auto add_segment = [&]() {
+            for (int kb = 0; kb < A.add_nkb; ++kb)
+                run.step_make([&](bf8(&b)[NS]) { add_operand16<NS>(c, A.add_dim, kb, b); }, acc);
+        };
+        if (A.add_first) add_segment();
+        pe_segment();
+        if (!A.add_first) add_segment();
     };
-    auto add_segment = [&](LayerRun16<T, NT, NS> &run) {
-        for (int kb = 0; kb < A.add_nkb; ++kb) {
-            bf8 b[NS];
-            add_operand16<NS>(c, A.add_dim, kb, b);
-            run.step(b, acc);
-        }
-    };
-    auto pos_segments = [&](LayerRun16<T, NT, NS> &run) {
-        if (A.add_first) add_segment(run);
-        pe_segment(run);
-        if (!A.add_first) add_segment(run);
-    };
-    {  // positions_pose_input + relu
+    // positional_net[i] + relu: src (pre-activation of the previous layer) -> dst
+    auto hidden = [&](int i, const f4(&src)[T], f4(&dst)[T]) {
         LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(acc);
-        pos_segments(run);
+        run.init(dst);
+        run.template run_hidden<true>(src, dst);
+        if ((A.skip_mask >> i) & 1u) pos_segments(run, dst);
         run.finish();
-        pack_acts<T, NS, true>(acc, bin);
+    };
+    {  // positions_pose_input (its relu is applied when the next layer splits accA)
+        LayerRun16<T, NT, NS> run(pipe, lane);
+        run.init(accA);
+        pos_segments(run, accA);
+        run.finish();
     }
-    for (int i = 0; i < A.n_hidden; ++i) {  // positional_net[i] + relu
-        LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(acc);
+    for (int i = 0; i < A.n_hidden; i += 2) {
+        hidden(i, accA, accB);
+        if (i + 1 < A.n_hidden) {
+            hidden(i + 1, accB, accA);
+        } else {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) run.step(bin[kb], acc);
-        if ((A.skip_mask >> i) & 1u) pos_segments(run);
-        run.finish();
-        pack_acts<T, NS, true>(acc, bin);
+            for (int t = 0; t < T; ++t) accA[t] = accB[t];
+        }
     }
-    {  // additional_linear_layer (no activation)
+    {  // additional_linear_layer: relu(accA) -> accB (no activation on its output)
         LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(acc);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) run.step(bin[kb], acc);
+        run.init(accB);
+        run.template run_hidden<true>(accA, accB);
         run.finish();
-        pack_acts<T, NS, false>(acc, bin);
     }
     f4 sig[1];
     {
         LayerRun16<1, NT, NS> run(pipe, lane);
         run.init(sig);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) run.step(bin[kb], sig);
+        run.template run_hidden<false>(accB, sig);
         run.finish();
     }
-    bf8 bind[KBD][NS];
-    f4 accd[TD];
+    f4 accd[TD], acce[TD];
     {  // directional_input (no activation)
         LayerRun16<TD, NT, NS> run(pipe, lane);
         run.init(accd);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) run.step(bin[kb], accd);
-        for (int kb = 0; kb < A.dir_nkb; ++kb) {
-            bf8 b[NS];
-            pe_operand16<NS>(c, true, A.dir_L, A.dir_id, kb, b);
-            run.step(b, accd);
-        }
+        run.template run_hidden<false>(accB, accd);
+        for (int kb = 0; kb < A.dir_nkb; ++kb)
+            run.step_make([&](bf8(&b)[NS]) { pe_operand16<NS>(c, true, A.dir_L, A.dir_id, kb, b); }, accd);
         run.finish();
-        pack_acts<TD, NS, false>(accd, bind);
     }
-    {  // directional_net[0] + relu
+    {  // directional_net[0] (its relu is applied when the rgb head splits acce)
         LayerRun16<TD, NT, NS> run(pipe, lane);
-        run.init(accd);
-#pragma unroll
-        for (int kb = 0; kb < KBD; ++kb) run.step(bind[kb], accd);
+        run.init(acce);
+        run.template run_hidden<false>(accd, acce);
         run.finish();
-        pack_acts<TD, NS, true>(accd, bind);
     }
     f4 rgb[1];
     {
         LayerRun16<1, NT, NS> run(pipe, lane);
         run.init(rgb);
-#pragma unroll
-        for (int kb = 0; kb < KBD; ++kb) run.step(bind[kb], rgb);
+        run.template run_hidden<true>(acce, rgb);
         run.finish();
     }
+    // the last k-block prefetched past the end of the stream (padding slabs): retire those loads before their
+    // registers can be reused
+    wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
     if (valid && c.g == 0) reinterpret_cast<f4 *>(A.raw)[sample] = f4{rgb[0][0], rgb[0][1], rgb[0][2], sig[0][0]};
 }
 

@@ -19,6 +19,20 @@ from torch import nn
 from . import ops
 
 
+class PipelineArgs:
+    """The fields of the reference's argparse namespace (config_parser.py) that the pipelines read,
+    with the reference's defaults for them.  Any object with these attributes works as `args`."""
+
+    def __init__(self, **kw):
+        self.sigma_noise_std = 0.0
+        self.white_background = 0
+        self.run_fine = 1
+        self.number_fine_samples = 128
+        self.human_pose_encoding = 1
+        self.u = None  # optional explicit linspace(0, 1, number_fine_samples) buffer (ops.uniform_u)
+        self.__dict__.update(kw)
+
+
 class NerfPipeline(nn.Module):
 
     def __init__(self, model_coarse, model_fine, args, position_encoder, direction_encoder):

@@ -5,8 +5,7 @@ import numpy as np, torch
 from smpl_nerf_amd import synthetic as syn, _lib
 from smpl_nerf_amd.nets import RenderRayNet
 from smpl_nerf_amd.ops import PositionalEncoder
-from smpl_nerf_amd.pipelines import NerfPipeline
-from oracle.nerf_oracle import Args
+from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs as Args
 dev = torch.device("cuda:0")
 pc, pf = syn.make_scene_nets(101)
 def net(p):
