@@ -82,27 +82,58 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
+// cross terms (A part, B part), smallest first.  FIRST[s] = the A part whose first use is term s (s < NS): the A
+// loads of a tile are issued in that order, so term s can start once 2(s+1) loads of its pair have landed.
+template <int NS> struct Terms;
+template <> struct Terms<2> {
+    static constexpr int N = 3;
+    static constexpr int A[3] = {1, 0, 0};
+    static constexpr int B[3] = {0, 1, 0};
+    static constexpr int FIRST[2] = {1, 0};
+};
+template <> struct Terms<3> {
+    static constexpr int N = 6;
+    static constexpr int A[6] = {2, 0, 1, 1, 0, 0};
+    static constexpr int B[6] = {0, 2, 1, 0, 1, 0};
+    static constexpr int FIRST[3] = {2, 0, 1};
+};
+
 // A-operand loads are issued as inline asm: hipcc waits lgkmcnt(0) in front of every consumer of a ds_read
 // inside the (rolled) hidden-layer loop, i.e. right behind the prefetch of the NEXT tile pair, which exposes
 // a full LDS round trip every pair.  With the loads opaque to the compiler the counted waits below are the
 // only ones.  Rules that keep this sound:
-//   * a loaded register is consumed only through wait_pair(), whose "+v" operands make every consumer depend
-//     on the s_waitcnt;
+//   * a loaded register is consumed only through a wait asm whose "+v" operands make every consumer depend on
+//     the s_waitcnt;
+//   * a loaded register stays live (is named by a wait asm) until its load has returned, so the allocator
+//     cannot hand it out early;
 //   * LDS returns data in order, so lgkmcnt(n) with n = the loads issued after the wanted ones is exact; the
-//     compiler's own waits (bias loads in init()) can only be stricter;
-//   * `s_nop 7` in front of a load group covers the MFMA-SrcC -> LDS-write WAR distance the compiler would
-//     insert for a ds_read it knows (the allocator does recycle accumulator registers as load targets).
+//     compiler's own waits (bias loads in init()) and any younger loads can only make a wait stricter;
+//   * all A loads of a tile pair are issued in Terms::FIRST order, tile 0 before tile 1 per part.
 template <int OFF>
 __device__ __forceinline__ void lds_load_a(bf8 &dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
+// the same load pinned between two MFMAs by data dependences: after the MFMA that produced `after`, before the
+// next MFMA that accumulates into `before` - one load per MFMA gap instead of a clump of loads per tile pair
+// (both waves of a SIMD reach a clump together, and the matrix pipe idles for its length)
+template <int OFF>
+__device__ __forceinline__ void lds_load_between(bf8 &dst, uint32_t addr, const f4 &after, f4 &before) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3" : "=v"(dst), "+v"(before) : "v"(addr), "n"(OFF), "v"(after) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void wait_two(bf8 &x, bf8 &y) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(CNT));
+}
 __device__ __forceinline__ uint32_t lds_addr(const char *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
 }
+// tiles TO, TO+1 of a k-block, outside the MFMA stream (pipeline start-up).  `s_nop 7` covers the MFMA-SrcC ->
+// LDS-write WAR distance the compiler would insert for a ds_read it knows.
 template <int NS, int TO>
 __device__ __forceinline__ void issue_pair(uint32_t addr, bf8 (&x0)[NS], bf8 (&x1)[NS]) {
     asm volatile("s_nop 7");
-    static_for<0, NS>([&](auto s) {
+    static_for<0, NS>([&](auto i) __attribute__((always_inline)) {
+        constexpr int s = Terms<NS>::FIRST[decltype(i)::value];
         lds_load_a<(TO * NS + s) * 1024>(x0[s], addr);
         lds_load_a<((TO + 1) * NS + s) * 1024>(x1[s], addr);
     });
@@ -201,32 +232,20 @@ struct SlabPipe16 {
     }
 };
 
-// cross terms (A part, B part), smallest first
-template <int NS> struct Terms;
-template <> struct Terms<2> {
-    static constexpr int N = 3;
-    static constexpr int A[3] = {1, 0, 0};
-    static constexpr int B[3] = {0, 1, 0};
-};
-template <> struct Terms<3> {
-    static constexpr int N = 6;
-    static constexpr int A[6] = {2, 0, 1, 1, 0, 0};
-    static constexpr int B[6] = {0, 2, 1, 0, 1, 0};
-};
-
 // One 32-wide k-block: per output tile NS ds_read_b128 + Terms<NS>::N MFMAs; tiles in pairs so consecutive
-// MFMAs alternate accumulators.  The stream is software-pipelined by hand and fenced with sched_barrier(0):
-// the A parts of pair p+1 are issued, then a counted wait retires pair p's, then pair p's 2N MFMAs run (the
-// LDS latency of p+1 hides behind them).  The pipeline runs across k-blocks: on entry (fa0, fa1) hold the
-// in-flight first pair of this k-block; in the last pair, after all of this k-block's loads have returned,
-// `boundary()` does the slab hand-over if one is due (counted vmcnt wait, barrier, refill of the freed slot)
-// and returns the LDS address of the next k-block, whose first pair is issued before the last pair's MFMAs -
-// so neither the barrier nor the first LDS round trip of a slab sits in front of an empty matrix pipe.
-// `b` holds this k-block's B operand parts (ready on entry).  `make_piece.make(i)`, i in [0, 4), is the VALU
-// work that prepares elements 2i, 2i+1 of the NEXT k-block's operand (splitting fp32 accumulators into bf16
-// parts); the pieces are spread over the pairs and interleaved with the MFMAs, so the split runs while the
-// matrix pipe works instead of in a serial phase between k-blocks (both waves of a SIMD belong to the same
-// workgroup and run close to lockstep, so a serial phase idles the matrix pipe).
+// MFMAs alternate accumulators.  The instruction stream is laid out by hand:
+//   * while pair p's MFMAs run, the 2*NS A parts of pair p+1 are issued one per MFMA gap (behind the first 2*NS
+//     MFMAs), in the order pair p+1 will first use them; term s of pair p+1 waits lgkmcnt(2*NS-2), i.e. only for
+//     its own two parts (the later parts of its pair and the loads already issued for pair p+2 stay in flight);
+//   * the pipeline runs across k-blocks, slabs and layers: on entry (fa0, fa1) hold the in-flight first pair of
+//     this k-block; in the last pair, once this k-block's loads have all returned, `boundary()` does the slab
+//     hand-over if one is due (counted vmcnt wait, barrier, refill of the freed slot) and returns the LDS
+//     address of the next k-block, whose first pair then streams in behind the last pair's MFMAs - neither the
+//     barrier nor the first LDS round trip of a slab sits in front of an empty matrix pipe;
+//   * `make_piece.make(i)`, i in [0, 4), is the VALU work that prepares elements 2i, 2i+1 of the NEXT k-block's
+//     B operand (splitting fp32 accumulators into bf16 parts); the pieces are spread over the pairs and float
+//     between that pair's MFMAs instead of forming a serial phase between k-blocks.
+// `b` holds this k-block's B operand parts (ready on entry).
 template <int T_OUT, int NS, class MakePiece, class Boundary>
 __device__ __forceinline__ void kblock16(uint32_t addr, bf8 (&fa0)[NS], bf8 (&fa1)[NS], const bf8 (&b)[NS],
                                          MakePiece make_piece, f4 (&acc)[T_OUT], Boundary boundary) {
@@ -253,32 +272,35 @@ __device__ __forceinline__ void kblock16(uint32_t addr, bf8 (&fa0)[NS], bf8 (&fa
             a0[s] = fa0[s];
             a1[s] = fa1[s];
         }
-        static_for<0, PAIRS>([&](auto pc) {
+        static_for<0, PAIRS>([&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value, to = 2 * p;
+            constexpr bool LAST = p + 1 == PAIRS;
+            constexpr int NEXT_TILE = LAST ? 0 : to + 2;  // of the next k-block when LAST
             bf8 n0[NS], n1[NS];
-            if constexpr (p + 1 < PAIRS) {
-                issue_pair<NS, to + 2>(addr, n0, n1);
-                wait_pair<NS, 2 * NS>(a0, a1);
-            } else {
+            uint32_t src = addr;
+            if constexpr (LAST) {
                 wait_pair<NS, 0>(a0, a1);
-                const uint32_t next = boundary();
-                issue_pair<NS, 0>(next, n0, n1);
+                src = boundary();
             }
             __builtin_amdgcn_sched_barrier(0);
             constexpr bool has_piece = (p * 4) % PAIRS == 0 || PAIRS < 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i * PAIRS / 4 == p) make_piece.make(i);
-#pragma unroll
-            for (int t = 0; t < Tm::N; ++t) {
-                acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[Tm::A[t]], b[Tm::B[t]], acc[to], 0, 0, 0);
-                acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 2 * Tm::N; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
-            }
+            static_for<0, Tm::N>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t < NS) {
+                    constexpr int s = Tm::FIRST[t];
+                    wait_two<2 * NS - 2>(a0[s], a1[s]);
+                    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[Tm::A[t]], b[Tm::B[t]], acc[to], 0, 0, 0);
+                    lds_load_between<(NEXT_TILE * NS + s) * 1024>(n0[s], src, acc[to], acc[to + 1]);
+                    acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1], 0, 0, 0);
+                    lds_load_between<((NEXT_TILE + 1) * NS + s) * 1024>(n1[s], src, acc[to + 1], acc[to]);
+                } else {
+                    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[Tm::A[t]], b[Tm::B[t]], acc[to], 0, 0, 0);
+                    acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1], 0, 0, 0);
+                }
+            });
             if constexpr (has_piece) make_piece.touch();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -295,9 +317,6 @@ __device__ __forceinline__ void kblock16(uint32_t addr, bf8 (&fa0)[NS], bf8 (&fa
     }
 }
 
-// elements e = 2i, 2i+1 (tile 2kb + (e >> 2), row e & 3) of the B operand of k-block kb.  PIN: the source values
-// pass through an empty volatile asm, which anchors the split's VALU work at this point of the asm-ordered
-// stream (the loads and waits of kblock16) - otherwise the compiler hoists it into one serial clump.
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -372,7 +391,7 @@ struct LayerRun16 {
     template <class MakePiece>
     __device__ __forceinline__ void step(const bf8 (&b)[NS], MakePiece make_piece, f4 (&acc)[T_OUT]) {
         kblock16<T_OUT, NS>(lds_addr(slab + kbl * KB_BYTES) + pipe.lane16, pipe.fa0, pipe.fa1, b, make_piece, acc,
-                            [&]() -> uint32_t {
+                            [&]() __attribute__((always_inline)) -> uint32_t {
                                 if (++kbl == KPS) {  // this k-block was the last of its slab
                                     pipe.release();
                                     slab = pipe.acquire();
@@ -475,21 +494,21 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // two accumulator sets ping-pong between consecutive layers: the finished set feeds the next layer's B
     // operands (split just in time, k-block by k-block) while the other set accumulates
     f4 accA[T], accB[T];
-    auto pos_segments = [&](LayerRun16<T, NT, NS> &run, f4(&acc)[T]) {
-        auto pe_segment = [&]() {
+    auto pos_segments = [&](LayerRun16<T, NT, NS> &run, f4(&acc)[T]) __attribute__((always_inline)) {
+        auto pe_segment = [&]() __attribute__((always_inline)) {
             for (int kb = 0; kb < A.pos_nkb; ++kb)
-                run.step_make([&](bf8(&b)[NS]) { pe_operand16<NS>(c, false, A.pos_L, A.pos_id, kb, b); }, acc);
+                run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) { pe_operand16<NS>(c, false, A.pos_L, A.pos_id, kb, b); }, acc);
         };
-        auto add_segment = [&]() {
+        auto add_segment = [&]() __attribute__((always_inline)) {
             for (int kb = 0; kb < A.add_nkb; ++kb)
-                run.step_make([&](bf8(&b)[NS]) { add_operand16<NS>(c, A.add_dim, kb, b); }, acc);
+                run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) { add_operand16<NS>(c, A.add_dim, kb, b); }, acc);
         };
         if (A.add_first) add_segment();
         pe_segment();
         if (!A.add_first) add_segment();
     };
     // positional_net[i] + relu: src (pre-activation of the previous layer) -> dst
-    auto hidden = [&](int i, const f4(&src)[T], f4(&dst)[T]) {
+    auto hidden = [&](int i, const f4(&src)[T], f4(&dst)[T]) __attribute__((always_inline)) {
         LayerRun16<T, NT, NS> run(pipe, lane);
         run.init(dst);
         run.template run_hidden<true>(src, dst);
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         run.init(accd);
         run.template run_hidden<false>(accB, accd);
         for (int kb = 0; kb < A.dir_nkb; ++kb)
-            run.step_make([&](bf8(&b)[NS]) { pe_operand16<NS>(c, true, A.dir_L, A.dir_id, kb, b); }, accd);
+            run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) { pe_operand16<NS>(c, true, A.dir_L, A.dir_id, kb, b); }, accd);
         run.finish();
     }
     {  // directional_net[0] (its relu is applied when the rgb head splits acce)
