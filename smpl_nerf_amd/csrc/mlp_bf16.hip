@@ -159,71 +159,68 @@ __device__ __forceinline__ void wait_pair(bf8 (&x0)[NS], bf8 (&x1)[NS]) {
 // ------------------------------------------------------------------------------------------------
 // The slab stream goes L2 -> LDS by DMA (global_load_lds, 16 B per lane = 1 KiB per wave instruction), no VGPR
 // round trip: 3-slot ring, slab p is consumed while p+1 has landed and p+2 is in flight - two slab periods of
-// latency tolerance (the register-staged pipe of the fp32 kernel has one).  Per slab each wave issues
-// PIECES/NW pieces (+ the bias piece on wave 0); `s_waitcnt vmcnt(n)` with n = the pieces of the newest slab
-// retires exactly the previous slab's pieces, then one raw s_barrier publishes them to the workgroup.
+// latency tolerance (the register-staged pipe of the fp32 kernel has one).
+// Issuing a piece costs a wave ~60 issue cycles, and all waves reach the hand-over of a slab together: if every
+// wave issued its share there, both waves of each SIMD would be busy with DMA at the same moment and the matrix
+// pipe would idle for the length of the clump.  So the two halves of the workgroup (waves 0..3 / 4..7 - wave w
+// and w+4 share a SIMD) take turns: slab s is issued entirely by half s & 1, while the other half goes straight
+// on with its MFMAs.  The half that issued a slab is also the only one that has to wait for it, two hand-overs
+// later, and by then it has nothing younger in flight: `s_waitcnt vmcnt(0)`, then one raw s_barrier publishes
+// the slab to the workgroup.
 template <int NT, int NS>
 struct SlabPipe16 {
     static constexpr int SB = NS * 16384 + 1024;
     static constexpr int NW = NT / 64;
-    static constexpr int PER_WAVE = NS * 16 / NW;  // 1 KiB pieces of the A region per wave
-    static_assert(NS * 16 % NW == 0, "A region must split evenly over the waves");
+    static constexpr int HALF = NW / 2;
+    static constexpr int PER_WAVE = NS * 16 / HALF;  // 1 KiB pieces of the A region per issuing wave
+    static_assert(NS * 16 % HALF == 0, "A region must split evenly over the issuing waves");
     const char *gsrc;  // packed + lane*16
     char *ring;
-    int wave, rd, wr, next;  // next = slab index to issue
+    int wave, rd, next;  // next = slab index to issue
     // A parts of the first tile pair of the k-block that runs next: issued one tile pair ahead like every other
     // pair, i.e. during the last pair of the previous k-block - across slab and layer boundaries too
     bf8 fa0[NS], fa1[NS];
     uint32_t lane16;
     __device__ __forceinline__ void prefetch_first(const char *at) { issue_pair<NS, 0>(lds_addr(at) + lane16, fa0, fa1); }
 
+    __device__ __forceinline__ bool my_turn() const { return (wave >= HALF) == ((next & 1) != 0); }
+    // slab `next` -> ring slot `slot`, by the half whose turn it is
     __device__ __forceinline__ void issue(int slot) {
-        const char *src = gsrc + (int64_t)next * SB;
-        char *dst = ring + slot * SB;
+        if (my_turn()) {
+            const char *src = gsrc + (int64_t)next * SB;
+            char *dst = ring + slot * SB;
+            const int w = wave >= HALF ? wave - HALF : wave;
 #pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i) {
-            const int piece = wave * PER_WAVE + i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+            for (int i = 0; i < PER_WAVE; ++i) {
+                const int piece = w * PER_WAVE + i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+            }
+            if (w == 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + NS * 16384),
+                                                 (__attribute__((address_space(3))) void *)(dst + NS * 16384), 16, 0, 0);
         }
-        if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + NS * 16384),
-                                             (__attribute__((address_space(3))) void *)(dst + NS * 16384), 16, 0, 0);
         ++next;
-    }
-    // all but the newest slab's pieces of this wave have landed
-    __device__ __forceinline__ void wait_prev() {
-        if (wave == 0) {
-            if constexpr (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else if constexpr (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if constexpr (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
     }
     __device__ __forceinline__ void prologue(const void *packed, char *ring_, int tid) {
         ring = ring_;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         gsrc = reinterpret_cast<const char *>(packed) + (tid & 63) * 16;
         next = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the per-sample input loads are done: only DMA below
         issue(0);
         issue(1);
-        wait_prev();  // slab 0 landed (this wave's pieces)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slabs 0, 1 (and the per-sample input loads)
         __builtin_amdgcn_s_barrier();
         rd = 0;
-        wr = 2;
         issue(2);
         lane16 = (tid & 63) * 16;
         prefetch_first(ring);
     }
     __device__ __forceinline__ const char *acquire() const { return ring + rd * SB; }
-    // done reading slab `rd`: make the next slab visible, then refill the slot just freed
+    // done reading slab `rd`: make the next slab visible, then refill the slot just freed.  The slab published
+    // here is slab next-2, issued by the same half that now issues slab `next`.
     __device__ __forceinline__ void release() {
-        wait_prev();
+        if (my_turn()) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int freed = rd;
