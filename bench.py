@@ -32,13 +32,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 matrix peak (MI355X_MIC
 MODES = {"fp32": ("snerf::mlp_fwd_kernel<256, 8, false, false>", 1),
          "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3>", 6),
          "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2>", 3)}
-# HBM bytes per average mlp_fwd launch from the rocprofv3 PMC passes committed under profiles/
-# (r01_pmc_summary.json: FETCH_SIZE as reported - the kernel's 4 B/lane strided reads are outside the
-# guide's x2 calibration - plus WRITE_SIZE); the kernel is MFMA-bound, this is informational.
-TRAFFIC_PER_LAUNCH = None
+# HBM bytes per average launch of the MLP kernel, per precision mode, from the rocprofv3 PMC passes committed under
+# profiles/ (FETCH_SIZE as reported plus WRITE_SIZE); the kernels are MFMA-bound, this is informational.
+TRAFFIC_PER_LAUNCH = {}
 try:
     with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as _f:
-        TRAFFIC_PER_LAUNCH = json.load(_f)["mlp_fwd_avg_launch"]["hbm_bytes"]
+        TRAFFIC_PER_LAUNCH = {k: v["avg_launch"]["hbm_bytes"] for k, v in json.load(_f)["kernels"].items()}
 except Exception:
     pass
 
@@ -192,8 +191,17 @@ def main():
                     o2 = pipe(data)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / 3
+                with _lib.profile() as p2:
+                    pipe(data)
+                k2 = {k: v for k, v in p2.summary().items() if k.startswith("mlp_fwd")}
+                mlp_s = sum(v[1] for v in k2.values()) * 1e-3
+                prod = MODES[prec][1]
+                pk = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+                tf = FLOP_PER_EVAL * prod * evals_per_step / mlp_s / 1e12
                 alt[prec] = {"ray_samples_per_s_per_gpu": evals_per_step / dt, "ms_per_step": dt * 1e3,
-                             "rgb_fine_max_abs_diff_vs_" + a.precision: float((o2[1] - out[1]).abs().max())}
+                             "rgb_fine_max_abs_diff_vs_" + a.precision: float((o2[1] - out[1]).abs().max()),
+                             "mlp_kernel": MODES[prec][0], "mlp_kernel_ms_per_step": mlp_s * 1e3,
+                             "mfma_tflops": tf, "mfma_peak": pk, "mfma_frac": tf / pk}
             pipe.model_coarse.precision = pipe.model_fine.precision = a.precision
 
     train = None
@@ -213,23 +221,28 @@ def main():
         ms = sum(v[1] for v in mlp.values())
         avg_ms = ms / calls
         units_per_launch = a.steps * evals_per_step / calls
-        achieved = FLOP_PER_EVAL * units_per_launch / (avg_ms * 1e-3) / 1e12
         kname, products = MODES[a.precision]
+        alg_tflops = FLOP_PER_EVAL * units_per_launch / (avg_ms * 1e-3) / 1e12    # fp32 MACs of the network
         if a.precision == "fp32":
             peak = PEAK_F32_MFMA_TFLOPS
+            achieved = alg_tflops
+            flop_per_unit = FLOP_PER_EVAL
             roof_extra = {"peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32, 157.3 TFLOP/s"}
             dtype = "f32"
         else:
-            # split-bf16: every algorithmic fp32 MAC is `products` bf16 products on the bf16 matrix cores, accumulated
-            # in fp32.  `achieved` stays ALGORITHMIC (1 215 744 FLOP per ray-sample); the matrix pipe executes
-            # `products` times that, so the scheme tops out at 2500/products TFLOP/s algorithmic.
+            # split-bf16: every fp32 MAC of the network is `products` exact bf16 products on the bf16 matrix cores,
+            # accumulated in fp32 - that is the algorithm of this kernel, so its flop count per ray-sample is
+            # products x 1 215 744 and its roofline is the dense bf16 MFMA peak.  The fp32-equivalent rate
+            # (`fp32_equivalent_tflops`, what the network needs) is reported beside it.
             peak = PEAK_BF16_MFMA_TFLOPS
-            roof_extra = {"executed_mfma_tflops": achieved * products, "executed_frac": achieved * products / peak,
-                          "attainable_algorithmic_peak": peak / products,
-                          "frac_of_attainable": achieved * products / peak,
-                          "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+            achieved = alg_tflops * products
+            flop_per_unit = FLOP_PER_EVAL * products
+            roof_extra = {"fp32_equivalent_tflops": alg_tflops,
+                          "fp32_equivalent_vs_fp32_mfma_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
+                          "bf16_products_per_fp32_mac": products,
                           "peak_note": f"dense bf16 MFMA peak 2500 TFLOP/s (v_mfma_f32_16x16x32_bf16); operands split into "
-                                       f"bf16 parts, {products} products per fp32-accurate MAC, fp32 accumulate"}
+                                       f"bf16 parts, {products} bf16 products per fp32 MAC, fp32 accumulate; padded tiles "
+                                       f"(84->96, 280->288 inputs, 4-wide heads) are not counted"}
             dtype = f"f32 via {a.precision} (split-bf16 operands, fp32 accumulate; RGB parity class of the fp32 kernel)" \
                 if a.precision == "bf16x6" else f"f32 via {a.precision} (split-bf16, ~2^-16 relative)"
         line = {
@@ -244,8 +257,8 @@ def main():
             "rays_per_s": world * a.steps * rays / elapsed,
             "roofline": dict({"bound": "mfma", "kernel": kname + " (coarse + fine launches)",
                               "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                              "frac": achieved / peak, "traffic": TRAFFIC_PER_LAUNCH,
-                              "avg_launch_ms": avg_ms, "launches": calls, "flop_per_unit": FLOP_PER_EVAL,
+                              "frac": achieved / peak, "traffic": TRAFFIC_PER_LAUNCH.get(a.precision),
+                              "avg_launch_ms": avg_ms, "launches": calls, "flop_per_unit": flop_per_unit,
                               "units_per_launch": units_per_launch,
                               "traffic_note": "(FETCH_SIZE + WRITE_SIZE) per average launch from the PMC passes under "
                                               "profiles/, not measured live"}, **roof_extra),

@@ -233,6 +233,23 @@ int snerf_raygen_f64(const double *poses, int64_t n_frames, int H, int W, double
                      const double *span, int Nc, const int64_t *ray_index, const double *jitter, int64_t B,
                      float *samples, float *o, float *d, float *z, snerf_stream_t stream);
 
+/* ---- a3: the whole NerfPipeline.forward for inference in one call (models/nerf_pipeline.py:14-67) -------------
+ * Five launches on `stream`: fused encode+MLP (coarse) -> composite -> inverse-CDF sampler + merge + points ->
+ * fused encode+MLP (fine) -> composite.  precision: 0 = fp32 kernel (packed_* from snerf_mlp_pack_f32), 2 / 3 =
+ * split-bf16 with that nsplit (packed_* from snerf_mlp_pack_bf16).  Inputs as the Solver hands them over
+ * (solver/nerf_solver.py:77-81): ray_samples [B,Nc,3], rays_o [B,3], rays_d [B,3], z_vals [B,Nc]; u [Nf] =
+ * linspace(0,1,Nf) (utils.py:204-205); noise_coarse [B,Nc] / noise_fine [B,Nc+Nf] nullable (sigma noise,
+ * utils.py:171-173).  Nf == 0 is run_fine = 0: the fine outputs are copies of the coarse ones (:43-44).
+ * workspace: snerf_render_rays_workspace_bytes(B, Nc, Nf) bytes, 16-byte aligned.  Outputs: rgb [B,3],
+ * rgb_fine [B,3], samples_fine [B,Nc+Nf,3], densities_fine [B,Nc+Nf] (the `alpha` of utils.py:169). */
+int64_t snerf_render_rays_workspace_bytes(int64_t B, int Nc, int Nf);
+int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+                          const snerf_mlp_desc *desc_fine, const void *packed_fine, int precision,
+                          const float *ray_samples, const float *rays_o, const float *rays_d, const float *z_vals,
+                          const float *u, const float *noise_coarse, const float *noise_fine, int64_t B, int Nc,
+                          int Nf, int white_background, void *workspace, float *rgb, float *rgb_fine,
+                          float *samples_fine, float *densities_fine, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -467,9 +467,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     c.g = lane >> 4;
     c.enc = nullptr;
     c.add = nullptr;
-    c.px = A.x[sc * 3 + 0];
-    c.py = A.x[sc * 3 + 1];
-    c.pz = A.x[sc * 3 + 2];
+    // read-once / write-once streams bypass L2 retention: the 2.4 - 3.6 MB weight stream that every workgroup
+    // re-reads is what each XCD's 4 MB L2 should keep
+    c.px = __builtin_nontemporal_load(A.x + sc * 3 + 0);
+    c.py = __builtin_nontemporal_load(A.x + sc * 3 + 1);
+    c.pz = __builtin_nontemporal_load(A.x + sc * 3 + 2);
     c.dx = c.dy = c.dz = 0.f;
     const int64_t ray = sc / A.spr;
     if (A.use_dir) {
@@ -565,7 +567,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // the last k-block prefetched past the end of the stream (padding slabs): retire those loads before their
     // registers can be reused
     wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
-    if (valid && c.g == 0) reinterpret_cast<f4 *>(A.raw)[sample] = f4{rgb[0][0], rgb[0][1], rgb[0][2], sig[0][0]};
+    if (valid && c.g == 0)
+        __builtin_nontemporal_store(f4{rgb[0][0], rgb[0][1], rgb[0][2], sig[0][0]}, reinterpret_cast<f4 *>(A.raw) + sample);
 }
 
 static int plan16(const snerf_mlp_desc *desc, Plan &P, const char *what) {

@@ -1,0 +1,91 @@
+// snerf_render_rays_f32: NerfPipeline.forward (models/nerf_pipeline.py:14-67) for inference as one C-ABI call.
+// Pure sequencing of the library's own entry points on the caller's stream; the workspace holds what the
+// reference keeps as temporaries (raw, weights, z_fine) - [B*N, 84] encodings and [B*N, 256] activations never
+// exist in HBM.
+#include "snerf_common.h"
+
+namespace snerf {
+
+struct RenderWs {
+    int64_t raw_c, weights_c, alpha_c, z_samples, z_fine, raw_f, total;
+};
+static int64_t align16(int64_t b) { return (b + 15) & ~int64_t(15); }
+static RenderWs render_ws(int64_t B, int Nc, int Nf) {
+    RenderWs w{};
+    const int64_t N = Nc + Nf;
+    int64_t off = 0;
+    w.raw_c = off, off += align16(B * Nc * 4 * 4);
+    w.weights_c = off, off += align16(B * Nc * 4);
+    w.alpha_c = off, off += align16(B * Nc * 4);
+    w.z_samples = off, off += align16(B * (Nf > 0 ? Nf : 1) * 4);
+    w.z_fine = off, off += align16(B * N * 4);
+    w.raw_f = off, off += align16(B * N * 4 * 4);
+    w.total = off;
+    return w;
+}
+
+static int mlp(const snerf_mlp_desc *desc, const void *packed, int precision, const float *x, const float *dirs,
+               int64_t n, int spr, float *raw, snerf_stream_t stream) {
+    if (precision == 0)
+        return snerf_mlp_fwd_f32(desc, reinterpret_cast<const float *>(packed), x, dirs, 0, nullptr, n, spr, raw, stream);
+    return snerf_mlp_fwd_bf16_f32(desc, packed, precision, x, dirs, 0, nullptr, n, spr, raw, stream);
+}
+
+}  // namespace snerf
+
+extern "C" int64_t snerf_render_rays_workspace_bytes(int64_t B, int Nc, int Nf) {
+    using namespace snerf;
+    if (B < 0 || Nc < 1 || Nf < 0) return fail(SNERF_E_BADARG, "render_rays_workspace_bytes: bad B/Nc/Nf");
+    return render_ws(B, Nc, Nf).total;
+}
+
+extern "C" int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+                                     const snerf_mlp_desc *desc_fine, const void *packed_fine, int precision,
+                                     const float *ray_samples, const float *rays_o, const float *rays_d,
+                                     const float *z_vals, const float *u, const float *noise_coarse,
+                                     const float *noise_fine, int64_t B, int Nc, int Nf, int white_background,
+                                     void *workspace, float *rgb, float *rgb_fine, float *samples_fine,
+                                     float *densities_fine, snerf_stream_t stream) {
+    using namespace snerf;
+    if (precision != 0 && precision != 2 && precision != 3)
+        return fail(SNERF_E_BADARG, "render_rays: precision must be 0 (fp32), 2 (bf16x3) or 3 (bf16x6)");
+    if (B < 0 || Nc < 1 || Nf < 0) return fail(SNERF_E_BADARG, "render_rays: bad B/Nc/Nf");
+    if (B == 0) return SNERF_OK;
+    if (!desc_coarse || !packed_coarse || !ray_samples || !rays_d || !z_vals || !workspace || !rgb || !rgb_fine ||
+        !samples_fine || !densities_fine)
+        return fail(SNERF_E_BADARG, "render_rays: null pointer");
+    if (Nf > 0 && (!desc_fine || !packed_fine || !rays_o || !u))
+        return fail(SNERF_E_BADARG, "render_rays: the fine pass needs desc_fine, packed_fine, rays_o and u");
+    if ((desc_coarse->add_dim) || (Nf > 0 && desc_fine->add_dim))
+        return fail(SNERF_E_BADARG, "render_rays: nets with additional inputs go through snerf_mlp_fwd_* directly");
+    if (!aligned(workspace, 16)) return fail(SNERF_E_ALIGN, "render_rays: workspace must be 16-byte aligned");
+    const RenderWs w = render_ws(B, Nc, Nf);
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *raw_c = reinterpret_cast<float *>(ws + w.raw_c), *weights_c = reinterpret_cast<float *>(ws + w.weights_c);
+    float *alpha_c = reinterpret_cast<float *>(ws + w.alpha_c), *z_samples = reinterpret_cast<float *>(ws + w.z_samples);
+    float *z_fine = reinterpret_cast<float *>(ws + w.z_fine), *raw_f = reinterpret_cast<float *>(ws + w.raw_f);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    // coarse net on the given samples, then compositing (:29-42)
+    if ((rc = mlp(desc_coarse, packed_coarse, precision, ray_samples, rays_d, B * Nc, Nc, raw_c, stream))) return rc;
+    if (Nf == 0) {  // run_fine = 0 (:43-44): (rgb, rgb, ray_samples, alpha)
+        if ((rc = snerf_composite_fwd_f32(raw_c, z_vals, rays_d, 0, noise_coarse, B, Nc, white_background, rgb, weights_c,
+                                          densities_fine, stream)))
+            return rc;
+        if (hipMemcpyAsync(rgb_fine, rgb, B * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(samples_fine, ray_samples, B * Nc * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "render_rays: device copy failed");
+        return SNERF_OK;
+    }
+    if ((rc = snerf_composite_fwd_f32(raw_c, z_vals, rays_d, 0, noise_coarse, B, Nc, white_background, rgb, weights_c,
+                                      alpha_c, stream)))
+        return rc;
+    // hierarchical samples (:47) and the fine net on them (:49-65)
+    if ((rc = snerf_sample_pdf_f32(z_vals, weights_c, u, rays_o, rays_d, B, Nc, Nf, nullptr, z_samples, z_fine,
+                                   samples_fine, stream)))
+        return rc;
+    const int N = Nc + Nf;
+    if ((rc = mlp(desc_fine, packed_fine, precision, samples_fine, rays_d, B * N, N, raw_f, stream))) return rc;
+    return snerf_composite_fwd_f32(raw_f, z_fine, rays_d, 0, noise_fine, B, N, white_background, rgb_fine, nullptr,
+                                   densities_fine, stream);
+}

@@ -683,3 +683,23 @@ def test_split_bf16_additional_inputs_and_per_sample_dirs(dev):
         m.precision = "bf16x6"
         b = m.forward_fused(T(pts, dev), T(dsm, dev), Ns, *enc, additional=T(pose, dev), add_first=True)
     assert maxabs(N(a), N(b)) <= 2e-5 * float(np.abs(N(a)).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("run_fine,white", [(1, 0), (1, 1), (0, 0)])
+def test_render_rays_single_call(dev, prec, run_fine, white):
+    """snerf_render_rays_f32 (the whole NerfPipeline.forward behind one C-ABI call) returns exactly what the five
+    separate entry points return through NerfPipeline.forward - same kernels, same order, same stream."""
+    pipe = _pipeline(dev)
+    pipe.args.run_fine, pipe.args.white_background = run_fine, white
+    pipe.model_coarse.precision = pipe.model_fine.precision = prec
+    data = syn.frame_batch(128, 128, phi=20.0, theta=10.0, seed=3, near=1.0, far=4.0)
+    sub = np.arange(0, 16384, 37)  # ragged: 443 rays
+    batch = [T(a[sub], dev) for a in data]
+    with torch.no_grad():
+        ref = pipe(batch)
+        out = pipe.render_rays(batch)
+    for a, b in zip(ref, out):
+        assert a.shape == b.shape
+        assert torch.equal(a, b)

@@ -1,0 +1,53 @@
+"""profiles/<round>_pmc_summary.json from the three rocprofv3 --pmc passes of bench.py (SQ/GRBM, FETCH_SIZE,
+WRITE_SIZE - separate runs, as MI355X_MICROARCH.md prescribes).
+
+    python tools/make_pmc_profile.py <sq_dir> <fetch_dir> <write_dir> > profiles/rNN_pmc_summary.json
+"""
+import json
+import sys
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from pmc_summary import summarise
+
+KERNELS = {"fp32": "mlp_fwd_kernel<256, 8, false, false>", "bf16x6": "mlp_fwd_bf16_kernel<256, 8, 3>",
+           "bf16x3": "mlp_fwd_bf16_kernel<256, 8, 2>"}
+ALG_BYTES = {1048576: 1048576 * (12 + 16) + 16384 * 12, 3145728: 3145728 * (12 + 16) + 16384 * 12}  # x, raw, dirs
+
+
+def main(sq, fetch, write):
+    out = {"command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --steps 3 --warmup 1 --cpu-rays 0 "
+                      "--train-rays 0 (three separate passes: SQ/GRBM, FETCH_SIZE, WRITE_SIZE)",
+           "note": "FETCH_SIZE/WRITE_SIZE are KB; mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * "
+                   "1024 SIMDs); effective clock = GRBM_GUI_ACTIVE / 8 / duration.  MI355X_MICROARCH.md: FETCH_SIZE "
+                   "under-reports wide 16 B/lane streams by 2x; these kernels read 4 B/lane inputs and take their weights "
+                   "from L2 (the stream is re-read by every workgroup and stays on chip), so the figure is reported as is.",
+           "kernels": {}}
+    for prec, name in KERNELS.items():
+        a, f, w = (summarise(name, [d]) for d in (sq, fetch, write))
+        launches = {}
+        tot_f = tot_w = tot_n = 0
+        for key, e in a.items():
+            n = int(key.split("grid=")[1]) // 512 * 128  # 512 threads per workgroup, 128 samples
+            c = e["counters"]
+            fk, wk = f[key]["counters"]["FETCH_SIZE"], w[key]["counters"]["WRITE_SIZE"]
+            launches[f"n={n}"] = {"duration_ms": e["avg_seconds"] * 1e3, "effective_clock_GHz": e["effective_clock_ghz"],
+                                  "mfma_pipe_busy_frac": e["mfma_busy_frac"],
+                                  "wave_cycles_parked_frac": e.get("sq_wait_any_per_wave_cycle"),
+                                  "wave_cycles_issue_stall_frac": e.get("sq_wait_inst_any_per_wave_cycle"),
+                                  "wave_cycles_issuing_frac": e.get("sq_active_inst_any_per_wave_cycle"),
+                                  "SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"],
+                                  "GRBM_GUI_ACTIVE_sum_over_8_XCD": c["GRBM_GUI_ACTIVE"],
+                                  "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "algorithmic_bytes": ALG_BYTES.get(n)}
+            tot_f += fk * 1024
+            tot_w += wk * 1024
+            tot_n += 1
+        if tot_n:
+            out["kernels"][prec] = {"kernel": "snerf::" + name, "launches": launches,
+                                    "avg_launch": {"fetch_bytes_as_reported": tot_f / tot_n, "write_bytes": tot_w / tot_n,
+                                                   "hbm_bytes": (tot_f + tot_w) / tot_n,
+                                                   "algorithmic_bytes": sum(ALG_BYTES.values()) / 2}}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
