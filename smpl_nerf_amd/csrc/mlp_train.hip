@@ -294,27 +294,137 @@ struct WgradArgs {
     int64_t chunk;  // samples per K-split, multiple of 16
 };
 
-constexpr int WG_THREADS = 64;  // one wavefront per workgroup: no LDS, no barrier, occupancy bound by VGPRs only
-constexpr int WG_PREFETCH = 4;  // k-steps (4 samples each) of operands in flight per wave
+// One workgroup = 16 waves = one (layer, input segment, <=16 input k-blocks) job x one chunk of samples: the whole
+// <=256x256 block of dW.  Wave (bi, bj) owns the 64x64 sub-block of output tiles 4bi.. x input tiles 4bj.. (4x4
+// accumulator tiles, 64 VGPRs).  Operands reach the matrix cores through LDS: a stage is 16 samples of every
+// tile-row of the job (<=16 rows of dY, <=16 of X; one tile-row x 16 samples = 1 KiB contiguous in the tile-row
+// layout = one global_load_lds per wave), 3-slot ring, one barrier per stage = per 64 MFMAs per wave.  Every byte
+// of dY and X is read from HBM once per job instead of once per 64x64 block (4x fewer operand bytes than the
+// one-wave-per-block kernel this replaces, which ran at 51 % of the fp32 MFMA peak on L2/HBM operand traffic).
+constexpr int WL_WAVES = 16, WL_THREADS = WL_WAVES * 64;
+constexpr int WL_STAGE = 16;                      // samples per stage (4 MFMA k-steps)
+constexpr int WL_ROW_FLOATS = WL_STAGE * 16;      // one tile-row of a stage: 1 KiB
+constexpr int WL_SLOT_FLOATS = 32 * WL_ROW_FLOATS;  // 16 dY rows + 16 X rows
+constexpr int WL_LDS_BYTES = 3 * WL_SLOT_FLOATS * 4;
 
 __host__ __device__ inline int wgrad_jobs(const Plan &P) {
     int jobs = 0;
     for (int l = 0; l < P.nlayers; ++l)
-        for (int s = 0; s < P.layer[l].nseg; ++s)
-            jobs += ((P.layer[l].t_out + 3) / 4) * ((P.layer[l].seg[s].nkb + 3) / 4);
+        for (int s = 0; s < P.layer[l].nseg; ++s) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
     return jobs;
 }
 
-__global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayout L, WgradArgs A) {
-    const int lane = threadIdx.x;
-    // ---- decode the job: (layer, segment, 4x4-tile block) -----------------------------------------
-    int job = blockIdx.x, l = 0, s = 0, kb0 = 0, nbj = 1;
+// the stage loop and the epilogue for one wave that owns TI x TJ accumulator tiles
+template <int TI, int TJ>
+__device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L, const WgradArgs &A, float *ring, int l,
+                                           int kb0, int jb, int n_rows_y, int n_rows_x, bool bias_job,
+                                           const float *const (&row_src)[2], int wave, int lane) {
+    const int nbj = (n_rows_x + TJ - 1) / TJ, nbi = (n_rows_y + TI - 1) / TI;
+    const int bi = wave / nbj, bj = wave - bi * nbj;
+    const bool active = bi < nbi;
+    const int n_ti = active ? min(TI, n_rows_y - TI * bi) : 0, n_tj = min(TJ, n_rows_x - TJ * bj);
+    const bool want_bias = bias_job && bj == 0;
+    const int kslot = lane >> 4;
+    const int64_t n = A.n;
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+    const int nstages = begin < end ? (int)((end - begin + WL_STAGE - 1) / WL_STAGE) : 0;
+
+    auto issue = [&](int stage, int slot) {
+        // lane covers 16 B: features 4*(lane&3).. of sample (lane>>2) of the stage; clamped at the end of the buffer
+        const int64_t smp = min(begin + (int64_t)stage * WL_STAGE + (lane >> 2), n - 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(row_src[q] + smp * 16 + (lane & 3) * 4),
+                (__attribute__((address_space(3))) void *)(ring + slot * WL_SLOT_FLOATS + (2 * wave + q) * WL_ROW_FLOATS), 16, 0, 0);
+    };
+
+    f4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
+
+    if (nstages > 0) {
+        issue(0, 0);
+        if (nstages > 1) issue(1, 1);
+        if (nstages > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nstages > 2) issue(2, 2);
+    }
+    int slot = 0;
+    for (int st = 0; st < nstages; ++st) {
+        if (active) {
+            const float *ya = ring + slot * WL_SLOT_FLOATS + (TI * bi) * WL_ROW_FLOATS + lane;
+            const float *xb = ring + slot * WL_SLOT_FLOATS + (16 + TJ * bj) * WL_ROW_FLOATS + lane;
+            const int64_t s0 = begin + (int64_t)st * WL_STAGE;
+            // branch-free: tiles past the edge of the job run with a = 0 and are not stored; their LDS rows hold
+            // finite filler data
+#pragma unroll
+            for (int step = 0; step < WL_STAGE / 4; ++step) {
+                const bool ok = s0 + 4 * step + kslot < end;  // masked samples contribute a = 0 (b is finite data)
+                float a[TI], b[TJ];
+#pragma unroll
+                for (int t = 0; t < TI; ++t) {
+                    const float va = ya[t * WL_ROW_FLOATS + 64 * step];
+                    a[t] = (t < n_ti && ok) ? va : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < TJ; ++t) b[t] = xb[t * WL_ROW_FLOATS + 64 * step];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    bsum[i] += a[i];
+                }
+            }
+        }
+        if (st + 1 < nstages) {
+            // stage st+1 landed (this wave's pieces; st+2 may stay in flight), everyone done reading `slot`
+            if (st + 2 < nstages) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (st + 3 < nstages) issue(st + 3, slot);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (!active) return;
+    // ---- write the partial of this (block, chunk) ---------------------------------------------------
+    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        if (i >= n_ti) continue;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            if (j >= n_tj) continue;
+            const int ti = TI * bi + i, tj = kb0 + 16 * jb + TJ * bj + j;
+            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
+        }
+        if (want_bias) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (TI * bi + i) * 16 + lane] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayout L, WgradArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- decode the job: (layer, segment, group of 16 input k-blocks) --------------------------------
+    int job = blockIdx.x, l = 0, s = 0, kb0 = 0;
     for (l = 0; l < P.nlayers; ++l) {
         bool found = false;
         kb0 = 0;
         for (s = 0; s < P.layer[l].nseg; ++s) {
-            nbj = (P.layer[l].seg[s].nkb + 3) / 4;
-            const int cnt = ((P.layer[l].t_out + 3) / 4) * nbj;
+            const int cnt = (P.layer[l].seg[s].nkb + 15) / 16;
             if (job < cnt) { found = true; break; }
             job -= cnt;
             kb0 += P.layer[l].seg[s].nkb;
@@ -322,86 +432,45 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
         if (found) break;
     }
     const Layer &Ly = P.layer[l];
-    const int bi = job / nbj, bj = job - bi * nbj;
-    const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
+    const int jb = job;                                    // k-blocks 16*jb .. of the segment
+    const int n_rows_y = Ly.t_out, n_rows_x = min(16, Ly.seg[s].nkb - 16 * jb);
     const int64_t n = A.n;
-    // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: base + s0*16 + lane
-    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + lane;
-    const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + lane;
     int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
     while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
-    const bool want_bias = (s == first_seg && bj == 0);
-    const int kslot = lane >> 4;
+    const bool bias_job = (s == first_seg && jb == 0);
 
-    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
-    const int64_t end = min(n, begin + A.chunk);
-
-    f4 acc[4][4];
+    // ---- stage loader: this wave brings LDS rows 2*wave, 2*wave+1 (rows 0..15 = dY, 16..31 = X) ----------
+    // rows the job does not have re-load row 0 of dY, so that every wave issues exactly two pieces per stage
+    // and one counted vmcnt serves all waves
+    const float *row_src[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
-    auto load_ab = [&](int64_t s0, float (&a)[4], float (&b)[4]) {
-        const bool ok = s0 + kslot < end;
-        const int64_t off = ok ? s0 * 16 : 0;  // masked lanes read sample 0 of the tile-row (finite data) and a = 0
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = (t < n_ti && ok) ? dyp[(int64_t)t * n * 16 + off] : 0.f;
-            b[t] = (t < n_tj) ? xp[(int64_t)t * n * 16 + off] : 0.f;
-        }
-    };
-    // software pipeline: WG_PREFETCH k-steps of operands in flight (register ring, statically indexed)
-    float ra[WG_PREFETCH][4], rb[WG_PREFETCH][4];
-#pragma unroll
-    for (int p = 0; p < WG_PREFETCH; ++p) {
-        const int64_t sp = begin + 4 * p;
-        if (sp < end) load_ab(sp, ra[p], rb[p]);
-    }
-    for (int64_t s0 = begin; s0 < end; s0 += 4 * WG_PREFETCH) {
-#pragma unroll
-        for (int p = 0; p < WG_PREFETCH; ++p) {
-            const int64_t sc = s0 + 4 * p;
-            if (sc < end) {  // wave-uniform
-                float a0[4], b0[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a0[t] = ra[p][t];
-                    b0[t] = rb[p][t];
-                }
-                const int64_t sn = sc + 4 * WG_PREFETCH;
-                if (sn < end) load_ab(sn, ra[p], rb[p]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < n_ti) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < n_tj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
-                        bsum[i] += a0[i];
-                    }
-                }
-            }
+    for (int q = 0; q < 2; ++q) {
+        const int r = 2 * wave + q;
+        int64_t grow = L.dy[l];
+        if (r < 16) {
+            if (r < n_rows_y) grow = L.dy[l] + r;
+            row_src[q] = A.dy + grow * n * 16;
+        } else if (r - 16 < n_rows_x) {
+            row_src[q] = A.act + (int64_t)(seg_act_row(P, L, l, s) + 16 * jb + (r - 16)) * n * 16;
+        } else {
+            row_src[q] = A.dy + grow * n * 16;
         }
     }
-    // ---- write the partial of this (block, chunk) ---------------------------------------------------
-    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i >= n_ti) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j >= n_tj) continue;
-            const int ti = 4 * bi + i, tj = kb0 + 4 * bj + j;
-            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
-        }
-        if (want_bias) {
-            float v = bsum[i];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
-        }
-    }
+    // wave block shape: the job's <=16 x <=16 tiles are cut so that (up to) all 16 waves own a block
+    const int ti = n_rows_y > 8 ? 4 : (n_rows_y > 4 ? 2 : 1), tj = n_rows_x > 8 ? 4 : (n_rows_x > 4 ? 2 : 1);
+#define SNERF_WG_CASE(TI_, TJ_)                                                                                       \
+    if (ti == TI_ && tj == TJ_)                                                                                       \
+        return wgrad_wave<TI_, TJ_>(Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, wave, lane);
+    SNERF_WG_CASE(4, 4)
+    SNERF_WG_CASE(4, 2)
+    SNERF_WG_CASE(4, 1)
+    SNERF_WG_CASE(2, 4)
+    SNERF_WG_CASE(2, 2)
+    SNERF_WG_CASE(2, 1)
+    SNERF_WG_CASE(1, 4)
+    SNERF_WG_CASE(1, 2)
+    SNERF_WG_CASE(1, 1)
+#undef SNERF_WG_CASE
 }
 
 // sum over the G partials and scatter slot order -> state_dict order
@@ -447,7 +516,14 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     W.part = gpart;
     W.n = n;
     W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wgrad_jobs(P), G), dim3(WG_THREADS), 0, s, P, L, W);
+    static bool attr = false;  // idempotent; a race only repeats the call
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WL_LDS_BYTES) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "wgrad: cannot raise the dynamic LDS limit to %d bytes", WL_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wgrad_jobs(P), G), dim3(WL_THREADS), WL_LDS_BYTES, s, P, L, W);
     int rc = check_launch("wgrad");
     if (rc) return rc;
     hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, flat_grad);
