@@ -147,6 +147,12 @@ int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, vo
 int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
                            const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                            int samples_per_ray, float *raw, snerf_stream_t stream);
+/* The same forward for training: additionally saves every layer input into `act`, in exactly the layout
+ * snerf_mlp_fwd_train_f32 writes (act_floats of snerf_mlp_train_sizes), so that snerf_mlp_bwd_f32 /
+ * snerf_mlp_bwd_inputs_f32 run on it unchanged (the backward stays exact fp32). */
+int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
+                                 const float *dirs, int dirs_per_sample, const float *add, int64_t n,
+                                 int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
 
 /* ---- a2 backward (training) ------------------------------------------------------------------------
  * Buffer sizes for n samples: activations saved by the forward, per-layer output gradients, the

@@ -429,18 +429,23 @@ struct LayerRun16 {
 };
 
 // B operand of encoder k-block kb: 4 units (sin, cos pairs) per lane
+// `half[h]` = the fp32 values of 16-wide k-block 2kb + h in the fp32 kernel's layout (mlp_device.h pe_operand): what
+// the training forward stores for the backward kernels
 template <int NS>
-__device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, int L, int ident, int kb, bf8 (&b)[NS]) {
+__device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, int L, int ident, int kb, bf8 (&b)[NS],
+                                             f4 (&half)[2]) {
     const float x = is_dir ? c.dx : c.px, y = is_dir ? c.dy : c.py, z = is_dir ? c.dz : c.pz;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         float s0, c0;
         pe_unit(x, y, z, L, ident, 4 * (4 * kb + u) + c.g, s0, c0);
+        half[u >> 1][2 * (u & 1)] = s0;
+        half[u >> 1][2 * (u & 1) + 1] = c0;
         split_pair_into<NS>(s0, c0, b, u);
     }
 }
 template <int NS>
-__device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, int kb, bf8 (&b)[NS]) {
+__device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, int kb, bf8 (&b)[NS], f4 (&half)[2]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v[2];
@@ -448,12 +453,28 @@ __device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, i
         for (int h = 0; h < 2; ++h) {
             const int e = 2 * j + h, col = 32 * kb + 16 * (e >> 2) + 4 * c.g + (e & 3);
             v[h] = col < add_dim ? c.add[col] : 0.f;
+            half[e >> 2][e & 3] = v[h];
         }
         split_pair_into<NS>(v[0], v[1], b, j);
     }
 }
+// post-activation tiles -> the tile-row-major activation buffer
+template <bool RELU, int N>
+__device__ __forceinline__ void store_act(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&t)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        f4 v = t[i];
+        if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        store_tile(buf, row0 + i, n, sample, g, v);
+    }
+}
 
-template <int WIDTH, int NWAVES, int NS>
+// TRAIN additionally stores every layer input (post-activation, fp32, the fp32 kernel's layout) for the backward
+// kernels of mlp_train.hip.
+template <int WIDTH, int NWAVES, int NS, bool TRAIN>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16, TD = WIDTH / 32;
@@ -493,14 +514,28 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // two accumulator sets ping-pong between consecutive layers: the finished set feeds the next layer's B
     // operands (split just in time, k-block by k-block) while the other set accumulates
     f4 accA[T], accB[T];
-    auto pos_segments = [&](LayerRun16<T, NT, NS> &run, f4(&acc)[T]) __attribute__((always_inline)) {
+    auto pos_segments = [&](LayerRun16<T, NT, NS> &run, f4(&acc)[T], bool first) __attribute__((always_inline)) {
         auto pe_segment = [&]() __attribute__((always_inline)) {
             for (int kb = 0; kb < A.pos_nkb; ++kb)
-                run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) { pe_operand16<NS>(c, false, A.pos_L, A.pos_id, kb, b); }, acc);
+                run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) {
+                    f4 half[2];
+                    pe_operand16<NS>(c, false, A.pos_L, A.pos_id, kb, b, half);
+                    if (TRAIN && first && valid) {
+                        store_tile(A.act, A.act_pe + 2 * kb, A.n, sample, c.g, half[0]);
+                        if (2 * kb + 1 < A.pos_nkb16) store_tile(A.act, A.act_pe + 2 * kb + 1, A.n, sample, c.g, half[1]);
+                    }
+                }, acc);
         };
         auto add_segment = [&]() __attribute__((always_inline)) {
             for (int kb = 0; kb < A.add_nkb; ++kb)
-                run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) { add_operand16<NS>(c, A.add_dim, kb, b); }, acc);
+                run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) {
+                    f4 half[2];
+                    add_operand16<NS>(c, A.add_dim, kb, b, half);
+                    if (TRAIN && first && valid) {
+                        store_tile(A.act, A.act_add + 2 * kb, A.n, sample, c.g, half[0]);
+                        if (2 * kb + 1 < A.add_nkb16) store_tile(A.act, A.act_add + 2 * kb + 1, A.n, sample, c.g, half[1]);
+                    }
+                }, acc);
         };
         if (A.add_first) add_segment();
         pe_segment();
@@ -511,14 +546,16 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         LayerRun16<T, NT, NS> run(pipe, lane);
         run.init(dst);
         run.template run_hidden<true>(src, dst);
-        if ((A.skip_mask >> i) & 1u) pos_segments(run, dst);
+        if ((A.skip_mask >> i) & 1u) pos_segments(run, dst, false);
         run.finish();
+        if (TRAIN && valid) store_act<true>(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, dst);
     };
     {  // positions_pose_input (its relu is applied when the next layer splits accA)
         LayerRun16<T, NT, NS> run(pipe, lane);
         run.init(accA);
-        pos_segments(run, accA);
+        pos_segments(run, accA, true);
         run.finish();
+        if (TRAIN && valid) store_act<true>(A.act, A.act_x1, A.n, sample, c.g, accA);
     }
     for (int i = 0; i < A.n_hidden; i += 2) {
         hidden(i, accA, accB);
@@ -534,6 +571,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         run.init(accB);
         run.template run_hidden<true>(accA, accB);
         run.finish();
+        if (TRAIN && valid) store_act<false>(A.act, A.act_o, A.n, sample, c.g, accB);
     }
     f4 sig[1];
     {
@@ -548,14 +586,23 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         run.init(accd);
         run.template run_hidden<false>(accB, accd);
         for (int kb = 0; kb < A.dir_nkb; ++kb)
-            run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) { pe_operand16<NS>(c, true, A.dir_L, A.dir_id, kb, b); }, accd);
+            run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) {
+                f4 half[2];
+                pe_operand16<NS>(c, true, A.dir_L, A.dir_id, kb, b, half);
+                if (TRAIN && valid) {
+                    store_tile(A.act, A.act_dpe + 2 * kb, A.n, sample, c.g, half[0]);
+                    if (2 * kb + 1 < A.dir_nkb16) store_tile(A.act, A.act_dpe + 2 * kb + 1, A.n, sample, c.g, half[1]);
+                }
+            }, accd);
         run.finish();
+        if (TRAIN && valid) store_act<false>(A.act, A.act_h1, A.n, sample, c.g, accd);
     }
     {  // directional_net[0] (its relu is applied when the rgb head splits acce)
         LayerRun16<TD, NT, NS> run(pipe, lane);
         run.init(acce);
         run.template run_hidden<false>(accd, acce);
         run.finish();
+        if (TRAIN && valid) store_act<true>(A.act, A.act_h2, A.n, sample, c.g, acce);
     }
     f4 rgb[1];
     {
@@ -579,21 +626,84 @@ static int plan16(const snerf_mlp_desc *desc, Plan &P, const char *what) {
     return SNERF_OK;
 }
 
-template <int NS>
+template <int NS, bool TRAIN>
 static int launch_bf16(const FwdArgs &A, hipStream_t s) {
     constexpr int NW = 8;
     const int lds = 3 * slab16_bytes(NS);
     static bool attr = false;  // idempotent; a race only repeats the call
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_bf16_kernel<256, NW, NS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_bf16_kernel<256, NW, NS, TRAIN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return fail(SNERF_E_LAUNCH, "mlp_fwd_bf16: cannot raise the dynamic LDS limit to %d bytes", lds);
         attr = true;
     }
     const int64_t grid = (A.n + NW * 16 - 1) / (NW * 16);
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: n too large");
-    hipLaunchKernelGGL((mlp_fwd_bf16_kernel<256, NW, NS>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
+    hipLaunchKernelGGL((mlp_fwd_bf16_kernel<256, NW, NS, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_fwd_bf16");
+}
+
+// argument checks + FwdArgs shared by the inference and the training forward; act == nullptr: inference
+static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x, const float *dirs,
+                    int dirs_per_sample, const float *add, int64_t n, int samples_per_ray, float *raw, float *act,
+                    bool train, snerf_stream_t stream, const char *what) {
+    Plan P;
+    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "%s: nsplit must be 2 or 3", what);
+    int rc = plan16(desc, P, what);
+    if (rc) return rc;
+    if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "%s: bad n/samples_per_ray", what);
+    if (n == 0) return SNERF_OK;
+    if (!packed || !x || !raw || (train && !act)) return fail(SNERF_E_BADARG, "%s: null pointer", what);
+    if (desc->use_dir && !dirs) return fail(SNERF_E_BADARG, "%s: dirs is null", what);
+    if (P.add_dim && !add) return fail(SNERF_E_BADARG, "%s: add is null", what);
+    if (!aligned(packed, 16) || !aligned(raw, 16) || (train && !aligned(act, 16)))
+        return fail(SNERF_E_ALIGN, "%s: packed/raw/act must be 16-byte aligned", what);
+    FwdArgs A{};
+    A.packed = reinterpret_cast<const float *>(packed);
+    A.x = x;
+    A.dirs = dirs;
+    A.add = add;
+    A.raw = raw;
+    A.n = n;
+    A.spr = samples_per_ray;
+    A.dirs_per_sample = dirs_per_sample ? 1 : 0;
+    A.n_hidden = P.n_hidden;
+    A.skip_mask = desc->skip_mask;
+    A.pos_L = desc->pos_freqs;
+    A.pos_id = desc->pos_identity ? 1 : 0;
+    A.pos_nkb = P.pos_nkb;
+    A.pos_dim = P.pos_dim;
+    A.dir_L = desc->dir_freqs;
+    A.dir_id = desc->dir_identity ? 1 : 0;
+    A.dir_nkb = P.dir_nkb;
+    A.dir_dim = P.dir_dim;
+    A.add_dim = P.add_dim;
+    A.add_nkb = P.add_nkb;
+    A.add_first = (P.add_dim && desc->add_first) ? 1 : 0;
+    A.use_dir = desc->use_dir ? 1 : 0;
+    if (train) {
+        // the activation buffer has the layout of the 16-wide plan the backward kernels are built on
+        Plan Q;
+        const char *why;
+        if (make_plan(*desc, Q, why) != 0) return fail(SNERF_E_BADARG, "%s: %s", what, why);
+        TrainLayout L;
+        make_train_layout(Q, L);
+        A.act = act;
+        A.act_pe = L.pe;
+        A.act_add = L.add;
+        A.act_dpe = L.dpe;
+        A.act_x1 = L.x[1];
+        A.act_o = L.o;
+        A.act_h1 = L.h1;
+        A.act_h2 = L.h2;
+        A.pos_nkb16 = Q.pos_nkb;
+        A.add_nkb16 = Q.add_nkb;
+        A.dir_nkb16 = Q.dir_nkb;
+        if (nsplit == 3) return launch_bf16<3, true>(A, (hipStream_t)stream);
+        return launch_bf16<2, true>(A, (hipStream_t)stream);
+    }
+    if (nsplit == 3) return launch_bf16<3, false>(A, (hipStream_t)stream);
+    return launch_bf16<2, false>(A, (hipStream_t)stream);
 }
 
 }  // namespace snerf
@@ -624,40 +734,13 @@ extern "C" int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *para
 extern "C" int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
                                       const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                                       int samples_per_ray, float *raw, snerf_stream_t stream) {
-    using namespace snerf;
-    Plan P;
-    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: nsplit must be 2 or 3");
-    int rc = plan16(desc, P, "mlp_fwd_bf16");
-    if (rc) return rc;
-    if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: bad n/samples_per_ray");
-    if (n == 0) return SNERF_OK;
-    if (!packed || !x || !raw) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: null pointer");
-    if (desc->use_dir && !dirs) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: dirs is null");
-    if (P.add_dim && !add) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: add is null");
-    if (!aligned(packed, 16) || !aligned(raw, 16)) return fail(SNERF_E_ALIGN, "mlp_fwd_bf16: packed/raw must be 16-byte aligned");
-    FwdArgs A{};
-    A.packed = reinterpret_cast<const float *>(packed);
-    A.x = x;
-    A.dirs = dirs;
-    A.add = add;
-    A.raw = raw;
-    A.n = n;
-    A.spr = samples_per_ray;
-    A.dirs_per_sample = dirs_per_sample ? 1 : 0;
-    A.n_hidden = P.n_hidden;
-    A.skip_mask = desc->skip_mask;
-    A.pos_L = desc->pos_freqs;
-    A.pos_id = desc->pos_identity ? 1 : 0;
-    A.pos_nkb = P.pos_nkb;
-    A.pos_dim = P.pos_dim;
-    A.dir_L = desc->dir_freqs;
-    A.dir_id = desc->dir_identity ? 1 : 0;
-    A.dir_nkb = P.dir_nkb;
-    A.dir_dim = P.dir_dim;
-    A.add_dim = P.add_dim;
-    A.add_nkb = P.add_nkb;
-    A.add_first = (P.add_dim && desc->add_first) ? 1 : 0;
-    A.use_dir = desc->use_dir ? 1 : 0;
-    if (nsplit == 3) return launch_bf16<3>(A, (hipStream_t)stream);
-    return launch_bf16<2>(A, (hipStream_t)stream);
+    return snerf::fwd_bf16(desc, packed, nsplit, x, dirs, dirs_per_sample, add, n, samples_per_ray, raw, nullptr, false,
+                           stream, "mlp_fwd_bf16");
+}
+
+extern "C" int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
+                                            const float *dirs, int dirs_per_sample, const float *add, int64_t n,
+                                            int samples_per_ray, float *raw, float *act, snerf_stream_t stream) {
+    return snerf::fwd_bf16(desc, packed, nsplit, x, dirs, dirs_per_sample, add, n, samples_per_ray, raw, act, true, stream,
+                           "mlp_fwd_train_bf16");
 }

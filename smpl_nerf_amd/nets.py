@@ -39,7 +39,8 @@ class _FusedMlpFn(torch.autograd.Function):
         lib = _lib.load()
         n = x.shape[0]
         dev = x.device
-        packed = net.packed_weights(desc)
+        ns = {"bf16x6": 3, "bf16x3": 2}.get(net.precision, 0) if (net.width == 256 and per_sample != _ENCODED_ROWS) else 0
+        packed = net.packed_weights_bf16(desc, ns) if ns else net.packed_weights(desc)
         sizes = [ctypes.c_int64() for _ in range(4)]
         cnt = ctypes.c_int32()
         check(lib.snerf_mlp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes], ctypes.byref(cnt)),
@@ -50,6 +51,10 @@ class _FusedMlpFn(torch.autograd.Function):
             if per_sample == _ENCODED_ROWS:      # x holds already-encoded rows (RenderRayNet.forward(x))
                 check(lib.snerf_mlp_fwd_encoded_train_f32(desc, ptr(packed), ptr(x), n, x.shape[1], ptr(raw), ptr(act),
                                                           current_stream()), "snerf_mlp_fwd_encoded_train_f32")
+            elif ns:                             # forward on the bf16 matrix cores; the backward stays exact fp32
+                check(lib.snerf_mlp_fwd_train_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n,
+                                                       int(spr), ptr(raw), ptr(act), current_stream()),
+                      "snerf_mlp_fwd_train_bf16_f32")
             else:
                 check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
                                                   ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
@@ -131,8 +136,9 @@ class RenderRayNet(nn.Module):
         self.rgb_out_layer = torch.nn.Linear(directional_width, 3)
         self._pack_cache = {}
         self._pack_t_cache = {}
-        # matrix-core arithmetic of the inference path: "fp32" (v_mfma_f32_16x16x4_f32) or split-bf16
-        # "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5 relative); training is always fp32
+        # matrix-core arithmetic of the forward pass (inference and training): "fp32" (v_mfma_f32_16x16x4_f32) or
+        # split-bf16 "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5 relative); the backward
+        # kernels are always exact fp32
         self.precision = os.environ.get("SNERF_PRECISION", "fp32")
 
     # ------------------------------------------------------------------ parameter plumbing

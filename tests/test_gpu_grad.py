@@ -37,7 +37,14 @@ def make_net(dev, params, **kw):
     net = RenderRayNet(n_layers=kw.get("n_layers", 8), width=kw.get("width", 256), positions_dim=60, directions_dim=24,
                        skips=list(kw.get("skips", (4,))))
     net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    if kw.get("precision"):
+        net.precision = kw["precision"]
     return net.to(dev)
+
+
+# forward arithmetic of the training step: exact fp32 MFMA, or split-bf16 with fp32-class accuracy (the backward
+# kernels are fp32 in both); both are held to the same tolerances
+PRECISIONS = ["fp32", "bf16x6"]
 
 
 # ------------------------------------------------------------------------------------------ a4 backward
@@ -97,14 +104,15 @@ def test_mlp_backward_small_net_all_params(dev):
         close(p.grad.cpu().numpy(), ref, 2e-4, 2e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("tag", ["skip4", "noskip", "scene"])
-def test_mlp_backward_full_net(dev, tag):
+def test_mlp_backward_full_net(dev, tag, prec):
     g2, g7 = load_golden("g2_mlp.npz"), load_golden("g7_grads.npz")
     params = {"skip4": lambda: syn.make_render_ray_net_params(11, 30.0, 10.0, skips=(4,)),
               "noskip": lambda: syn.make_render_ray_net_params(12, 30.0, 10.0, skips=()),
               "scene": lambda: syn.make_scene_nets(101)[1]}[tag]()
     skips = () if tag == "noskip" else (4,)
-    net, _ = _mlp_grads(dev, params, g2["pts"], g2["dirs"], g7["m_gout"], skips=skips)
+    net, _ = _mlp_grads(dev, params, g2["pts"], g2["dirs"], g7["m_gout"], skips=skips, precision=prec)
     # digests captured from the reference
     for k, p in net.named_parameters():
         ref = g7[f"m_{tag}/{k}"]
@@ -118,7 +126,8 @@ def test_mlp_backward_full_net(dev, tag):
         close(p.grad.cpu().numpy(), ref, 5e-4, 5e-5 * np.abs(ref).max())
 
 
-def test_mlp_backward_many_samples_ragged(dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_mlp_backward_many_samples_ragged(dev, prec):
     """n = 5003 samples (ragged vs the 64-sample tile, several split-K chunks), per-ray directions."""
     rng = np.random.default_rng(77)
     params = syn.make_scene_nets(101)[0]
@@ -128,7 +137,7 @@ def test_mlp_backward_many_samples_ragged(dev):
     dray = rng.normal(size=(B, 3)).astype(F32)
     gout = rng.normal(size=(n, 4)).astype(F32)
     from smpl_nerf_amd.ops import PositionalEncoder
-    net = make_net(dev, params)
+    net = make_net(dev, params, precision=prec)
     raw = net.forward_fused(T(pts, dev), T(dray, dev), Ns, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
     (raw * T(gout, dev)).sum().backward()
     P = R.tparams(params)
@@ -148,19 +157,20 @@ def test_mlp_backward_many_samples_ragged(dev):
 
 
 # ------------------------------------------------------------------------------------------ training steps
-def _pipeline(dev, run_fine=1):
+def _pipeline(dev, run_fine=1, precision=None):
     from smpl_nerf_amd.ops import PositionalEncoder
     from smpl_nerf_amd.pipelines import NerfPipeline
     pc, pf = syn.make_scene_nets(101)
-    mc, mf = make_net(dev, pc), make_net(dev, pf)
+    mc, mf = make_net(dev, pc, precision=precision), make_net(dev, pf, precision=precision)
     pipe = NerfPipeline(mc, mf, O.Args(run_fine=run_fine), PositionalEncoder(10, 0), PositionalEncoder(4, 0))
     return pipe, mc, mf
 
 
-def test_three_adam_steps_match_the_reference(dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_three_adam_steps_match_the_reference(dev, prec):
     """solver/nerf_solver.py:83-87 with torch.optim.Adam exactly as NerfSolver builds it (:31-33)."""
     g7 = load_golden("g7_grads.npz")
-    pipe, mc, mf = _pipeline(dev)
+    pipe, mc, mf = _pipeline(dev, precision=prec)
     data = syn.frame_batch(128, 128, seed=7)
     batch = [T(a[g7["t_sub"]], dev) for a in data]
     optim = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4, betas=(0.9, 0.999), eps=1e-8,
@@ -236,8 +246,9 @@ def test_append_smpl_params_training_step(dev):
             close(R.digest(p.grad), ref, 5e-3, 2e-3 * scale)
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("wb", [0, 1])
-def test_smpl_nerf_training_step(dev, wb):
+def test_smpl_nerf_training_step(dev, wb, prec):
     """SmplNerfPipeline under autograd: gradients flow through the compositing's |x'-o| scaling, the direction
     normalisation, both positional encodings and the fused MLP inputs into the warp net
     (models/smpl_nerf_pipeline.py:38-63, 71-98).  Loss + all three nets' gradients vs the reference."""
@@ -246,7 +257,7 @@ def test_smpl_nerf_training_step(dev, wb):
     from smpl_nerf_amd.pipelines import SmplNerfPipeline
     g6, g = load_golden("g6_smpl_nerf_pipeline.npz"), load_golden("g11_smpl_grads.npz")
     pc, pf = syn.make_scene_nets(101)
-    mc, mf = make_net(dev, pc), make_net(dev, pf)
+    mc, mf = make_net(dev, pc, precision=prec), make_net(dev, pf, precision=prec)
     mw = WarpFieldNet(8, 256, 60, 40)
     mw.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_params(103, out_scale=0.3).items()})
     mw = mw.to(dev)
