@@ -154,6 +154,20 @@ int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed,
                                  const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                                  int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
 
+/* The backward on the bf16 matrix cores: dgrad (the transposed network) with split-bf16 operands, fp32 accumulate
+ * and fp32 stored d Y; the wgrad GEMMs stay exact fp32.  Same buffers as snerf_mlp_bwd_f32 / _bwd_inputs_f32
+ * (sizes from snerf_mlp_train_sizes) except the transposed weight stream, which comes from snerf_mlp_pack_t_bf16. */
+int64_t snerf_mlp_packed_t_bf16_bytes(const snerf_mlp_desc *desc, int nsplit, int input_grad);
+int snerf_mlp_pack_t_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed_t, int nsplit,
+                          int input_grad, snerf_stream_t stream);
+int snerf_mlp_bwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+                           const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
+                           snerf_stream_t stream);
+int snerf_mlp_bwd_inputs_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+                                  const float *d_raw, const float *x, const float *dirs, int dirs_per_sample,
+                                  int samples_per_ray, int64_t n, float *dy, float *gpart, float *flat_grad,
+                                  float *d_x, float *d_dirs, snerf_stream_t stream);
+
 /* ---- a2 backward (training) ------------------------------------------------------------------------
  * Buffer sizes for n samples: activations saved by the forward, per-layer output gradients, the
  * transposed weight stream, the split-K partial gradients (gpart_count chunks). */

@@ -48,6 +48,11 @@ SIGNATURES = {
     "snerf_mlp_pack_bf16": (c_int, [POINTER(MlpDesc), _P, _P, c_int, _P]),
     "snerf_mlp_fwd_bf16_f32": (c_int, [POINTER(MlpDesc), _P, c_int, _P, _P, c_int, _P, c_int64, c_int, _P, _P]),
     "snerf_mlp_fwd_train_bf16_f32": (c_int, [POINTER(MlpDesc), _P, c_int, _P, _P, c_int, _P, c_int64, c_int, _P, _P, _P]),
+    "snerf_mlp_packed_t_bf16_bytes": (c_int64, [POINTER(MlpDesc), c_int, c_int]),
+    "snerf_mlp_pack_t_bf16": (c_int, [POINTER(MlpDesc), _P, _P, c_int, c_int, _P]),
+    "snerf_mlp_bwd_bf16_f32": (c_int, [POINTER(MlpDesc), _P, c_int, _P, _P, c_int64, _P, _P, _P, _P]),
+    "snerf_mlp_bwd_inputs_bf16_f32": (c_int, [POINTER(MlpDesc), _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int64, _P, _P, _P,
+                                              _P, _P, _P]),
     "snerf_mlp_train_sizes": (c_int, [POINTER(MlpDesc), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
                                       POINTER(c_int64), POINTER(c_int32)]),
     "snerf_mlp_fwd_train_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P, _P]),

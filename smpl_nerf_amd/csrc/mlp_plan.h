@@ -299,10 +299,14 @@ inline int pe_seg_of(const Layer &Ly) {
         if (Ly.seg[s].type == SEG_PE) return s;
     return -1;
 }
-inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false) {
+// kw = 16: the fp32 stream (k-blocks of 16 forward output rows); kw = 32: the split-bf16 stream (k-blocks of 32;
+// the output tiles stay 16 wide).  P is always the 16-wide plan.
+inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false, int kw = 16) {
     const int T = P.width / 16, TD = P.width / 32, nh = P.n_hidden;
+    const int kdiv = kw / 16;
     int nl = 0, slab = 0;
-    auto add = [&](int fwd, int seg, int t_out, int nkb, int aux) {
+    auto add = [&](int fwd, int seg, int t_out, int nkb16, int aux) {
+        const int nkb = (nkb16 + kdiv - 1) / kdiv;
         BwdLayer &b = B.layer[nl++];
         b = BwdLayer{fwd, seg, t_out, nkb, aux, slab, 0};
         const int kps = 16 / t_out;
@@ -331,9 +335,9 @@ inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false) {
     B.nl = nl;
     B.total_slabs = slab;
 }
-inline int bwd_total_slabs(const Plan &P, bool input_grad = false) {
+inline int bwd_total_slabs(const Plan &P, bool input_grad = false, int kw = 16) {
     BwdPlan B;
-    make_bwd_plan(P, B, input_grad);
+    make_bwd_plan(P, B, input_grad, kw);
     return B.total_slabs;
 }
 // number of K-splits (sample chunks) of the wgrad kernel for n samples

@@ -18,7 +18,7 @@
 //                                order to the reference's [out, in] weight layout
 //
 // All MFMA work is v_mfma_f32_16x16x4_f32 (exact fp32), like the forward.
-#include "mlp_device.h"
+#include "mlp_train_device.h"
 
 namespace snerf {
 
@@ -76,61 +76,6 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(Plan P, BwdPlan B, cons
 // ------------------------------------------------------------------------------------------------
 // dgrad
 // ------------------------------------------------------------------------------------------------
-struct BwdArgs {
-    const float *packed_t;
-    const float *act;
-    const float *d_raw;  // [n,4]
-    float *dy;
-    int64_t n;
-    int n_hidden;
-    int act_x1, act_h2;
-    int dy_sig, dy_din, dy_dn0, dy_rgb;  // dy of forward layer l <= nh+1 is l*T
-    // input gradients (INPUT_GRAD kernels only)
-    const float *x, *dirs;  // forward inputs: positions [n,3], directions [n/spr,3] or [n,3]
-    float *d_x, *d_dirs;    // [n,3] each: d loss / d position, d loss / d (un-normalised) direction
-    int dirs_per_sample, spr;
-    unsigned skip_mask;
-    int pos_L, pos_id, pos_nkb, dir_L, dir_id, dir_nkb, use_dir;
-};
-
-// Backward of the positional encoding (utils.py:127-131) for the slots this lane holds: dpe[kb][2u], [2u+1] are
-// the gradients of (first, second) of unit p = 4*(2kb+u)+g.  Adds this lane's share to (dx, dy, dz).
-template <int NKB>
-__device__ __forceinline__ void pe_backward(const f4 (&dpe)[NKB], int nkb, float x, float y, float z, int L, int ident,
-                                            int g, float &dx, float &dy, float &dz) {
-    const int nid = ident ? 3 : 0;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb >= nkb) break;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int p = 4 * (2 * kb + u) + g;
-            const float d0 = dpe[kb][2 * u], d1 = dpe[kb][2 * u + 1];
-            float val = 0.f;
-            int c = -1;
-            if (p < nid) {
-                c = p;
-                val = d0;
-            } else if (p - nid < 3 * L) {
-                const int pp = p - nid, k = pp / 3;
-                c = pp - 3 * k;
-                const float v = c == 0 ? x : (c == 1 ? y : z);
-                float sn, cs;
-                sincosf(ldexpf(v, k), &sn, &cs);
-                val = ldexpf(cs * d0 - sn * d1, k);  // d/dv sin(2^k v) = 2^k cos, d/dv cos(2^k v) = -2^k sin
-            }
-            dx += c == 0 ? val : 0.f;
-            dy += c == 1 ? val : 0.f;
-            dz += c == 2 ? val : 0.f;
-        }
-    }
-}
-__device__ __forceinline__ float sum_over_g(float v) {  // the 4 lanes (g = 0..3) that share a sample
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 template <int N>
 __device__ __forceinline__ void mask_into(f4 (&dst)[N], const f4 (&src)[N], const float *act, int row0, int64_t n,
                                           int64_t sample, int g) {

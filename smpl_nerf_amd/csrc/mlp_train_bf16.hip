@@ -1,0 +1,355 @@
+// dgrad of RenderRayNet on the bf16 matrix cores (split-bf16, fp32-class accuracy): the transposed network of
+// mlp_train.hip's mlp_bwd_kernel run with the machinery of mlp_bf16.hip.
+//
+//   * same program: rgb head^T -> mask(h2) -> directional_net[0]^T -> directional_input^T + sigma head row ->
+//     additional^T -> positional_net[i]^T with the ReLU masks taken from the saved activations; every d Y_l is
+//     stored (fp32, the tile-row layout) for the wgrad kernel, which stays fp32;
+//   * the transposed weights are pre-split into NS bf16 parts (snerf_mlp_pack_t_bf16): k-blocks of 32 forward
+//     output rows x 16-wide output tiles, slabs of NS x 16 KiB + 1 KiB (the fp32 sigma-head row rides in the 1 KiB
+//     block and initialises the accumulators exactly like the fp32 kernel);
+//   * gradients are split just in time into NS parts (6 or 3 products per fp32 MAC, fp32 accumulate);
+//   * the ReLU mask is applied in place on the accumulators (4 tiles at a time: the mask loads must not cost 64
+//     more registers), then the masked tiles are stored and feed the next transposed layer.
+#include "mlp_bf16_device.h"
+#include "mlp_train_device.h"
+
+namespace snerf {
+
+// ------------------------------------------------------------------------------------------------
+// transposed weight stream, split-bf16:  slab = [k-block in slab][output tile][part][lane][8 bf16] then 256 fp32 aux
+//   A[(kb, to, s, lane (i,g), e)] = part_s(W_fwd[32*kb + 16*(e>>2) + 4*g + (e&3)][col(to, i)])
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_pack_t_bf16_kernel(Plan P, BwdPlan B, int NS, const float *__restrict__ params,
+                                                              unsigned char *__restrict__ packed) {
+    const int slab = blockIdx.x;
+    const int SB = slab16_bytes(NS);
+    unsigned char *dst = packed + (int64_t)slab * SB;
+    if (slab >= B.total_slabs) {
+        for (int e = threadIdx.x; e < SB / 4; e += 256) reinterpret_cast<float *>(dst)[e] = 0.f;
+        return;
+    }
+    int bi = 0;
+    while (bi + 1 < B.nl && slab >= B.layer[bi + 1].first_slab) ++bi;
+    const BwdLayer &Bl = B.layer[bi];
+    const Layer &Ly = P.layer[Bl.fwd];
+    const Seg &sg = Ly.seg[Bl.seg];
+    const int sl = slab - Bl.first_slab;
+    const int kps = 16 / Bl.t_out;
+    const float *Wm = params + Ly.w_off;
+    __bf16 *a = reinterpret_cast<__bf16 *>(dst);
+    const int per_kb = Bl.t_out * NS * 512;
+    for (int q = threadIdx.x; q < NS * 8192; q += 256) {
+        const int kbl = q / per_kb;
+        int rem = q - kbl * per_kb;
+        const int to = rem / (NS * 512);
+        rem -= to * NS * 512;
+        const int s = rem >> 9;
+        rem &= 511;
+        const int lane = rem >> 3, e = rem & 7;
+        const int i = lane & 15, g = lane >> 4;
+        const int kb = sl * kps + kbl;
+        const int row = 32 * kb + 16 * (e >> 2) + 4 * g + (e & 3);  // forward output feature (contraction index)
+        int col = -1;                                               // forward input column produced by output row (to, i)
+        if (sg.type == SEG_PE) {
+            if (to < sg.nkb) {  // slot (i>>2, i&3) of encoder k-block `to` (16-wide plan)
+                const int c = pe_slot_col(sg.L, sg.ident, to, i >> 2, i & 3);
+                if (c >= 0) col = sg.col_off + c;
+            }
+        } else if (16 * to + i < sg.ncols) {
+            col = sg.col_off + 16 * to + i;
+        }
+        float w = 0.f;
+        if (kb < Bl.nkb && row < Ly.n_out && col >= 0) w = Wm[(int64_t)row * Ly.n_in + col];
+        __bf16 h = (__bf16)w;
+        for (int t = 0; t < s; ++t) {
+            w = w - (float)h;
+            h = (__bf16)w;
+        }
+        a[q] = h;
+    }
+    float *aux = reinterpret_cast<float *>(dst + NS * 16384);
+    for (int j = threadIdx.x; j < 256; j += 256) {
+        float v = 0.f;
+        if (sl == 0 && Bl.aux_fwd >= 0) {
+            const Layer &La = P.layer[Bl.aux_fwd];
+            if (j < La.seg[0].ncols) v = params[La.w_off + j];  // row 0 of the sigma head
+        }
+        aux[j] = v;
+    }
+}
+
+// t[i] = m > 0 ? t[i] : 0 with m = the saved activation tile, four tiles at a time; then store t as d Y tile-rows
+template <int N>
+__device__ __forceinline__ void mask_store(f4 (&t)[N], const float *act, int act_row0, float *dy, int dy_row0, int64_t n,
+                                           int64_t sc, int64_t sample, bool valid, int g) {
+    constexpr int CH = N < 4 ? N : 4;
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        f4 m[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) m[q] = load_tile(act, act_row0 + c0 + q, n, sc, g);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[c0 + q][r] = m[q][r] > 0.f ? t[c0 + q][r] : 0.f;
+            if (valid) store_tile(dy, dy_row0 + c0 + q, n, sample, g, t[c0 + q]);
+        }
+    }
+}
+
+template <int WIDTH, int NWAVES, int NS, bool INPUT_GRAD>
+__global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int T = WIDTH / 16, TD = WIDTH / 32;
+    constexpr int TPP = 4, TPD = 2;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
+    const bool valid = sample < A.n;
+    const int64_t sc = valid ? sample : A.n - 1;
+    const int nh = A.n_hidden;
+
+    f4 dr = *reinterpret_cast<const f4 *>(A.d_raw + sc * 4);
+    asm volatile("" : "+v"(dr));  // retire the load here, before the weight DMA starts (cf. mlp_fwd_bf16_kernel)
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+    // head gradients as tile-rows for the wgrad kernel (rows 0..2 = rgb, row 0 = sigma)
+    if (valid) {
+        store_tile(A.dy, A.dy_rgb, A.n, sample, g, g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero);
+        store_tile(A.dy, A.dy_sig, A.n, sample, g, g == 0 ? f4{dr[3], 0.f, 0.f, 0.f} : zero);
+    }
+
+    SlabPipe16<NT, NS> pipe;
+    pipe.prologue(A.packed_t, ring, tid);
+
+    f4 accd[TD], acce[TD];
+    {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
+        LayerRun16<TD, NT, NS> run(pipe, lane);
+        run.init(accd);
+        const f4 src[2] = {g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, zero};
+        run.template run_hidden<false>(src, accd);
+        run.finish();
+        mask_store(accd, A.act, A.act_h2, A.dy, A.dy_dn0, A.n, sc, sample, valid, g);
+    }
+    {  // directional_net[0]^T; directional_input has no activation (:54-57)
+        LayerRun16<TD, NT, NS> run(pipe, lane);
+        run.init(acce);
+        run.template run_hidden<false>(accd, acce);
+        run.finish();
+        if (valid) store_tiles(A.dy, A.dy_din, A.n, sample, g, acce);
+    }
+    if (INPUT_GRAD && A.use_dir && A.dir_nkb > 0) {
+        // d (direction encoding) = directional_input[:, W:]^T d h1, then encoder and normalisation backward
+        f4 ddpe[TPD];
+        LayerRun16<TPD, NT, NS> run(pipe, lane);
+        run.init(ddpe);
+        run.template run_hidden<false>(acce, ddpe);
+        run.finish();
+        const float *dp = A.dirs + (A.dirs_per_sample ? sc : sc / A.spr) * 3;
+        const float ux = dp[0], uy = dp[1], uz = dp[2];
+        const float nrm = sqrtf(ux * ux + uy * uy + uz * uz);
+        const float nx = ux / nrm, ny = uy / nrm, nz = uz / nrm;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        pe_backward<TPD>(ddpe, A.dir_nkb, nx, ny, nz, A.dir_L, A.dir_id, g, gx, gy, gz);
+        gx = sum_over_g(gx);
+        gy = sum_over_g(gy);
+        gz = sum_over_g(gz);
+        if (valid && g == 0) {  // d (u/|u|) -> d u = (g - n (n.g)) / |u|   (models/smpl_nerf_pipeline.py:54-55)
+            const float dot = nx * gx + ny * gy + nz * gz;
+            float *q = A.d_dirs + sample * 3;
+            q[0] = (gx - nx * dot) / nrm;
+            q[1] = (gy - ny * dot) / nrm;
+            q[2] = (gz - nz * dot) / nrm;
+        }
+    }
+    f4 accA[T], accB[T];
+    f4 dpe[TPP];
+#pragma unroll
+    for (int t = 0; t < TPP; ++t) dpe[t] = zero;
+    // position-encoding columns of forward layer l (layer 0 or a skip layer), given d Y_l in `cur`
+    auto pe_columns = [&](int l, const f4(&cur)[T]) __attribute__((always_inline)) {
+        if (!INPUT_GRAD || A.pos_nkb <= 0) return;
+        if (!(l == 0 || ((A.skip_mask >> (l - 1)) & 1u))) return;
+        f4 t[TPP];
+        LayerRun16<TPP, NT, NS> run(pipe, lane);
+        run.init(t);
+        run.template run_hidden<false>(cur, t);
+        run.finish();
+#pragma unroll
+        for (int q = 0; q < TPP; ++q) dpe[q] += t[q];
+    };
+    {  // d o = directional_input[:, :W]^T d h1 + sigma_out_layer^T d sigma; additional layer has no activation (:51-52)
+        LayerRun16<T, NT, NS> run(pipe, lane);
+        run.init(accA);  // aux block = sigma head weights (fp32)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            accA[t][0] *= dr[3];
+            accA[t][1] *= dr[3];
+            accA[t][2] *= dr[3];
+            accA[t][3] *= dr[3];
+        }
+        run.template run_hidden<false>(acce, accA);
+        run.finish();
+        if (valid) store_tiles(A.dy, (nh + 1) * T, A.n, sample, g, accA);
+    }
+    // additional^T, positional_net[nh-1]^T ... positional_net[0]^T: forward layer l+1 transposed yields
+    // d X_{l+1}; masking with X_{l+1} > 0 gives d Y of forward layer l (:46-50).  Two accumulator sets ping-pong.
+    auto layer = [&](int l, const f4(&src)[T], f4(&dst)[T]) __attribute__((always_inline)) {
+        LayerRun16<T, NT, NS> run(pipe, lane);
+        run.init(dst);
+        run.template run_hidden<false>(src, dst);
+        run.finish();
+        mask_store(dst, A.act, A.act_x1 + l * T, A.dy, l * T, A.n, sc, sample, valid, g);
+        pe_columns(l, dst);
+    };
+    for (int l = nh; l >= 0; l -= 2) {
+        layer(l, accA, accB);
+        if (l - 1 >= 0) {
+            layer(l - 1, accB, accA);
+        }
+    }
+    // the last k-block prefetched past the end of the stream (padding slabs): retire those loads before their
+    // registers can be reused
+    wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
+    if (INPUT_GRAD) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (A.pos_nkb > 0) {
+            const float px = A.x[sc * 3 + 0], py = A.x[sc * 3 + 1], pz = A.x[sc * 3 + 2];
+            pe_backward<TPP>(dpe, A.pos_nkb, px, py, pz, A.pos_L, A.pos_id, g, gx, gy, gz);
+        }
+        gx = sum_over_g(gx);
+        gy = sum_over_g(gy);
+        gz = sum_over_g(gz);
+        if (valid && g == 0) {
+            float *q = A.d_x + sample * 3;
+            q[0] = gx;
+            q[1] = gy;
+            q[2] = gz;
+        }
+    }
+}
+
+static int plans_t(const snerf_mlp_desc *desc, Plan &P, const char *what) {
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "%s: desc is null", what);
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "%s: %s", what, why);
+    if (P.width != 256) return fail(SNERF_E_BADARG, "%s: the split-bf16 path supports width 256 only", what);
+    return SNERF_OK;
+}
+
+template <int NS, bool INPUT_GRAD>
+static int launch_dgrad_bf16(const BwdArgs &A, hipStream_t s) {
+    constexpr int NW = 8;
+    const int lds = 3 * slab16_bytes(NS);
+    static bool attr = false;  // idempotent; a race only repeats the call
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "mlp_bwd_bf16: cannot raise the dynamic LDS limit to %d bytes", lds);
+        attr = true;
+    }
+    const int64_t grid = (A.n + NW * 16 - 1) / (NW * 16);
+    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: n too large");
+    hipLaunchKernelGGL((mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
+    return check_launch("mlp_bwd_bf16(dgrad)");
+}
+
+static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+                           const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad, const float *x,
+                           const float *dirs, int dirs_per_sample, int spr, float *d_x, float *d_dirs,
+                           snerf_stream_t stream) {
+    Plan P;
+    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: nsplit must be 2 or 3");
+    int rc = plans_t(desc, P, "mlp_bwd_bf16");
+    if (rc) return rc;
+    if (n < 0) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: negative n");
+    if (n == 0) return SNERF_OK;
+    if (!packed_t || !act || !d_raw || !dy || !gpart || !flat_grad) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: null pointer");
+    if (!aligned(packed_t, 16) || !aligned(act, 16) || !aligned(d_raw, 16) || !aligned(dy, 16) || !aligned(gpart, 16))
+        return fail(SNERF_E_ALIGN, "mlp_bwd_bf16: buffers must be 16-byte aligned");
+    const bool input_grad = d_x != nullptr;
+    if (input_grad) {
+        if (!x || !d_dirs || (desc->use_dir && !dirs) || spr < 1)
+            return fail(SNERF_E_BADARG, "mlp_bwd_bf16: input gradients need x, dirs, d_x, d_dirs");
+        if (P.pos_nkb > 4 || P.dir_nkb > 2)
+            return fail(SNERF_E_BADARG, "mlp_bwd_bf16: input gradients support at most 4 position / 2 direction encoder k-blocks");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    TrainLayout L;
+    make_train_layout(P, L);
+    const int nh = P.n_hidden;
+    BwdArgs A{};
+    A.packed_t = reinterpret_cast<const float *>(packed_t);
+    A.act = act;
+    A.d_raw = d_raw;
+    A.dy = dy;
+    A.n = n;
+    A.n_hidden = nh;
+    A.act_x1 = L.x[1];
+    A.act_h2 = L.h2;
+    A.dy_sig = L.dy[nh + 2];
+    A.dy_din = L.dy[nh + 3];
+    A.dy_dn0 = L.dy[nh + 4];
+    A.dy_rgb = L.dy[nh + 5];
+    A.x = x;
+    A.dirs = dirs;
+    A.d_x = d_x;
+    A.d_dirs = d_dirs;
+    A.dirs_per_sample = dirs_per_sample ? 1 : 0;
+    A.spr = spr < 1 ? 1 : spr;
+    A.skip_mask = desc->skip_mask;
+    A.pos_L = desc->pos_freqs;
+    A.pos_id = desc->pos_identity ? 1 : 0;
+    A.pos_nkb = P.pos_nkb;
+    A.dir_L = desc->dir_freqs;
+    A.dir_id = desc->dir_identity ? 1 : 0;
+    A.dir_nkb = P.dir_nkb;
+    A.use_dir = desc->use_dir ? 1 : 0;
+    if (nsplit == 3) rc = input_grad ? launch_dgrad_bf16<3, true>(A, s) : launch_dgrad_bf16<3, false>(A, s);
+    else rc = input_grad ? launch_dgrad_bf16<2, true>(A, s) : launch_dgrad_bf16<2, false>(A, s);
+    if (rc) return rc;
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);  // fp32
+}
+
+}  // namespace snerf
+
+extern "C" int64_t snerf_mlp_packed_t_bf16_bytes(const snerf_mlp_desc *desc, int nsplit, int input_grad) {
+    using namespace snerf;
+    Plan P;
+    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_packed_t_bf16_bytes: nsplit must be 2 or 3");
+    int rc = plans_t(desc, P, "mlp_packed_t_bf16_bytes");
+    if (rc) return rc;
+    return (int64_t)(bwd_total_slabs(P, input_grad != 0, 32) + SLAB_PAD) * slab16_bytes(nsplit);
+}
+
+extern "C" int snerf_mlp_pack_t_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed_t, int nsplit,
+                                     int input_grad, snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_pack_t_bf16: nsplit must be 2 or 3");
+    int rc = plans_t(desc, P, "mlp_pack_t_bf16");
+    if (rc) return rc;
+    if (!params_flat || !packed_t) return fail(SNERF_E_BADARG, "mlp_pack_t_bf16: null pointer");
+    if (!aligned(packed_t, 16)) return fail(SNERF_E_ALIGN, "mlp_pack_t_bf16: packed_t must be 16-byte aligned");
+    BwdPlan B;
+    make_bwd_plan(P, B, input_grad != 0, 32);
+    hipLaunchKernelGGL(mlp_pack_t_bf16_kernel, dim3(B.total_slabs + SLAB_PAD), dim3(256), 0, (hipStream_t)stream, P, B, nsplit,
+                       params_flat, reinterpret_cast<unsigned char *>(packed_t));
+    return check_launch("mlp_pack_t_bf16");
+}
+
+extern "C" int snerf_mlp_bwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+                                      const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
+                                      snerf_stream_t stream) {
+    return snerf::launch_bwd_bf16(desc, packed_t, nsplit, act, d_raw, n, dy, gpart, flat_grad, nullptr, nullptr, 0, 1,
+                                  nullptr, nullptr, stream);
+}
+
+extern "C" int snerf_mlp_bwd_inputs_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+                                             const float *d_raw, const float *x, const float *dirs, int dirs_per_sample,
+                                             int samples_per_ray, int64_t n, float *dy, float *gpart, float *flat_grad,
+                                             float *d_x, float *d_dirs, snerf_stream_t stream) {
+    if (!d_x) return snerf::fail(SNERF_E_BADARG, "mlp_bwd_inputs_bf16: d_x is null");
+    return snerf::launch_bwd_bf16(desc, packed_t, nsplit, act, d_raw, n, dy, gpart, flat_grad, x, dirs, dirs_per_sample,
+                                  samples_per_ray, d_x, d_dirs, stream);
+}

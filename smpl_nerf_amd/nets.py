@@ -58,7 +58,7 @@ class _FusedMlpFn(torch.autograd.Function):
             else:
                 check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
                                                   ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
-        ctx.net, ctx.desc, ctx.n, ctx.act = net, desc, n, act
+        ctx.net, ctx.desc, ctx.n, ctx.act, ctx.ns = net, desc, n, act, ns
         ctx.sizes = (sizes[1].value, sizes[3].value)
         ctx.shapes = [p.shape for p in params]
         ctx.input_grad = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and per_sample != _ENCODED_ROWS
@@ -72,7 +72,8 @@ class _FusedMlpFn(torch.autograd.Function):
         net, desc, n = ctx.net, ctx.desc, ctx.n
         dev = d_raw.device
         d_raw = d_raw.contiguous().float()
-        packed_t = net.packed_weights_t(desc, ctx.input_grad)
+        ns = ctx.ns      # split-bf16 dgrad (the wgrad GEMMs are fp32 either way) when the forward ran in that mode
+        packed_t = net.packed_weights_t_bf16(desc, ns, ctx.input_grad) if ns else net.packed_weights_t(desc, ctx.input_grad)
         dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
         gpart = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
         flat = torch.empty(lib.snerf_mlp_param_floats(desc), device=dev, dtype=torch.float32)
@@ -82,16 +83,25 @@ class _FusedMlpFn(torch.autograd.Function):
             d_x = torch.empty((n, 3), device=dev, dtype=torch.float32)
             d_d = torch.zeros((n, 3), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev), _lib.timed(f"mlp_bwd_inputs[n={n}]"):
-                check(lib.snerf_mlp_bwd_inputs_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), ptr(x), ptr(d), per_sample,
-                                                   spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x), ptr(d_d),
-                                                   current_stream()), "snerf_mlp_bwd_inputs_f32")
+                if ns:
+                    check(lib.snerf_mlp_bwd_inputs_bf16_f32(desc, ptr(packed_t), ns, ptr(ctx.act), ptr(d_raw), ptr(x), ptr(d),
+                                                            per_sample, spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x),
+                                                            ptr(d_d), current_stream()), "snerf_mlp_bwd_inputs_bf16_f32")
+                else:
+                    check(lib.snerf_mlp_bwd_inputs_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), ptr(x), ptr(d),
+                                                       per_sample, spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x),
+                                                       ptr(d_d), current_stream()), "snerf_mlp_bwd_inputs_f32")
             if not per_sample:       # one direction per ray: sum the per-sample contributions
                 d_d = d_d.view(-1, spr, 3).sum(1)
             ctx.xd = None
         else:
             with torch.cuda.device(dev), _lib.timed(f"mlp_bwd[n={n}]"):
-                check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), n, ptr(dy), ptr(gpart),
-                                            ptr(flat), current_stream()), "snerf_mlp_bwd_f32")
+                if ns:
+                    check(lib.snerf_mlp_bwd_bf16_f32(desc, ptr(packed_t), ns, ptr(ctx.act), ptr(d_raw), n, ptr(dy),
+                                                     ptr(gpart), ptr(flat), current_stream()), "snerf_mlp_bwd_bf16_f32")
+                else:
+                    check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), n, ptr(dy), ptr(gpart),
+                                                ptr(flat), current_stream()), "snerf_mlp_bwd_f32")
         ctx.act = None
         grads, off = [], 0
         for shp in ctx.shapes:
@@ -249,6 +259,27 @@ class RenderRayNet(nn.Module):
         with torch.cuda.device(dev):
             check(lib.snerf_mlp_pack_t_f32(desc, ptr(flat), ptr(packed), 1 if input_grad else 0, current_stream()),
                   "snerf_mlp_pack_t_f32")
+        self._pack_t_cache[key] = (stamp, packed)
+        return packed
+
+    def packed_weights_t_bf16(self, desc: MlpDesc, nsplit: int, input_grad: bool = False) -> torch.Tensor:
+        """Split-bf16 transposed weight stream for the bf16 dgrad kernel (snerf_mlp_pack_t_bf16)."""
+        params = self._ordered_params()
+        dev = params[0].device
+        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + (bool(input_grad), "bf16", nsplit)
+        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._pack_t_cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = _lib.load()
+        nbytes = lib.snerf_mlp_packed_t_bf16_bytes(desc, nsplit, 1 if input_grad else 0)
+        if nbytes < 0:
+            check(int(nbytes), "snerf_mlp_packed_t_bf16_bytes")
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            check(lib.snerf_mlp_pack_t_bf16(desc, ptr(flat), ptr(packed), nsplit, 1 if input_grad else 0, current_stream()),
+                  "snerf_mlp_pack_t_bf16")
         self._pack_t_cache[key] = (stamp, packed)
         return packed
 
