@@ -30,8 +30,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X fp32 matrix peak (MI355X_MICROARCH
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md)
 # precision modes of the inference kernel: (kernel name for rocprof, products per fp32-accurate MAC)
 MODES = {"fp32": ("snerf::mlp_fwd_kernel<256, 8, false, false>", 1),
-         "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3>", 6),
-         "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2>", 3)}
+         "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3, false>", 6),
+         "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false>", 3)}
 # HBM bytes per average launch of the MLP kernel, per precision mode, from the rocprofv3 PMC passes committed under
 # profiles/ (FETCH_SIZE as reported plus WRITE_SIZE); the kernels are MFMA-bound, this is informational.
 TRAFFIC_PER_LAUNCH = {}

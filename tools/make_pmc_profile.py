@@ -9,8 +9,11 @@ import sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 from pmc_summary import summarise
 
-KERNELS = {"fp32": "mlp_fwd_kernel<256, 8, false, false>", "bf16x6": "mlp_fwd_bf16_kernel<256, 8, 3>",
-           "bf16x3": "mlp_fwd_bf16_kernel<256, 8, 2>"}
+KERNELS = {"fp32": "mlp_fwd_kernel<256, 8, false, false>", "bf16x6": "mlp_fwd_bf16_kernel<256, 8, 3, false>",
+           "bf16x3": "mlp_fwd_bf16_kernel<256, 8, 2, false>"}
+TRAIN_KERNELS = {"fwd_train_bf16x6": "mlp_fwd_bf16_kernel<256, 8, 3, true>", "dgrad_bf16x6": "mlp_bwd_bf16_kernel<256, 8, 3, false>",
+                 "wgrad_fp32": "mlp_wgrad_kernel", "fwd_train_fp32": "mlp_fwd_kernel<256, 8, false, true>",
+                 "dgrad_fp32": "mlp_bwd_kernel<256, 8, false>"}
 ALG_BYTES = {1048576: 1048576 * (12 + 16) + 16384 * 12, 3145728: 3145728 * (12 + 16) + 16384 * 12}  # x, raw, dirs
 
 
@@ -46,6 +49,16 @@ def main(sq, fetch, write):
                                     "avg_launch": {"fetch_bytes_as_reported": tot_f / tot_n, "write_bytes": tot_w / tot_n,
                                                    "hbm_bytes": (tot_f + tot_w) / tot_n,
                                                    "algorithmic_bytes": sum(ALG_BYTES.values()) / 2}}
+    out["training_kernels"] = {}
+    for tag, name in TRAIN_KERNELS.items():
+        a, f, w = (summarise(name, [d]) for d in (sq, fetch, write))
+        for key, e in a.items():
+            c = e["counters"]
+            out["training_kernels"][f"{tag} grid={key.split('grid=')[1]}"] = {
+                "kernel": "snerf::" + name, "duration_ms": e["avg_seconds"] * 1e3, "effective_clock_GHz": e["effective_clock_ghz"],
+                "mfma_pipe_busy_frac": e["mfma_busy_frac"], "wave_cycles_parked_frac": e.get("sq_wait_any_per_wave_cycle"),
+                "FETCH_SIZE_KB": f.get(key, {}).get("counters", {}).get("FETCH_SIZE"),
+                "WRITE_SIZE_KB": w.get(key, {}).get("counters", {}).get("WRITE_SIZE")}
     print(json.dumps(out, indent=1))
 
 
