@@ -243,14 +243,15 @@ struct WgradArgs {
 // <=256x256 block of dW.  Wave (bi, bj) owns the 64x64 sub-block of output tiles 4bi.. x input tiles 4bj.. (4x4
 // accumulator tiles, 64 VGPRs).  Operands reach the matrix cores through LDS: a stage is 16 samples of every
 // tile-row of the job (<=16 rows of dY, <=16 of X; one tile-row x 16 samples = 1 KiB contiguous in the tile-row
-// layout = one global_load_lds per wave), 3-slot ring, one barrier per stage = per 64 MFMAs per wave.  Every byte
+// layout = one global_load_lds per wave), 4-slot ring, one barrier per stage = per 64 MFMAs per wave.  Every byte
 // of dY and X is read from HBM once per job instead of once per 64x64 block (4x fewer operand bytes than the
 // one-wave-per-block kernel this replaces, which ran at 51 % of the fp32 MFMA peak on L2/HBM operand traffic).
 constexpr int WL_WAVES = 16, WL_THREADS = WL_WAVES * 64;
 constexpr int WL_STAGE = 16;                      // samples per stage (4 MFMA k-steps)
 constexpr int WL_ROW_FLOATS = WL_STAGE * 16;      // one tile-row of a stage: 1 KiB
 constexpr int WL_SLOT_FLOATS = 32 * WL_ROW_FLOATS;  // 16 dY rows + 16 X rows
-constexpr int WL_LDS_BYTES = 3 * WL_SLOT_FLOATS * 4;
+constexpr int WL_SLOTS = 4;                          // ring depth: up to WL_SLOTS - 2 stages in flight behind the one awaited
+constexpr int WL_LDS_BYTES = WL_SLOTS * WL_SLOT_FLOATS * 4;
 
 __host__ __device__ inline int wgrad_jobs(const Plan &P) {
     int jobs = 0;
@@ -294,16 +295,26 @@ __device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L
 #pragma unroll
     for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
 
-    if (nstages > 0) {
-        issue(0, 0);
-        if (nstages > 1) issue(1, 1);
-        if (nstages > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // stage st lives in slot st % WL_SLOTS.  Every wave issues exactly two pieces per stage, so `vmcnt(2k)` leaves the
+    // k newest stages in flight.
+    auto wait_landed = [&](int k) {  // k = stages allowed to stay in flight, 0 .. WL_SLOTS - 2
+        if (k >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (k == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(WL_SLOTS == 4, "wait_landed covers k <= 2");
+    if (nstages > 0) {
+#pragma unroll
+        for (int q = 0; q < WL_SLOTS - 1; ++q)
+            if (q < nstages) issue(q, q);
+        wait_landed(min(nstages, WL_SLOTS - 1) - 1);
         __builtin_amdgcn_s_barrier();
-        if (nstages > 2) issue(2, 2);
     }
     int slot = 0;
     for (int st = 0; st < nstages; ++st) {
+        // the slot of stage st-1 was freed by the barrier that ended the previous iteration (st = 0: the one slot the
+        // prologue left empty)
+        if (st + WL_SLOTS - 1 <= nstages - 1) issue(st + WL_SLOTS - 1, slot == 0 ? WL_SLOTS - 1 : slot - 1);
         if (active) {
             const float *ya = ring + slot * WL_SLOT_FLOATS + (TI * bi) * WL_ROW_FLOATS + lane;
             const float *xb = ring + slot * WL_SLOT_FLOATS + (16 + TJ * bj) * WL_ROW_FLOATS + lane;
@@ -330,13 +341,12 @@ __device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L
             }
         }
         if (st + 1 < nstages) {
-            // stage st+1 landed (this wave's pieces; st+2 may stay in flight), everyone done reading `slot`
-            if (st + 2 < nstages) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // stage st+1 landed (this wave's pieces); the stages issued after it may stay in flight; everyone is done
+            // reading `slot`
+            wait_landed(min(st + WL_SLOTS - 1, nstages - 1) - (st + 1));
             __builtin_amdgcn_s_barrier();
-            if (st + 3 < nstages) issue(st + 3, slot);
         }
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == WL_SLOTS - 1 ? 0 : slot + 1;
     }
     if (!active) return;
     // ---- write the partial of this (block, chunk) ---------------------------------------------------
