@@ -107,3 +107,28 @@ def test_render_ray_net_state_dict_contract():
     odd = RenderRayNet(4, 128, 5, 24, additional_input_dim=2, skips=[1])
     d = odd.desc_for_encoded()
     assert (d.pos_freqs, d.add_dim) == (0, 7)
+
+
+def test_torchsearchsorted_shim_imports_and_has_no_cpu_path():
+    """shims/torchsearchsorted is the package reference code imports (utils.py:14); on CPU tensors it must raise -
+    the product has no CPU fallback."""
+    import importlib
+    import sys
+    import numpy as np
+    import pytest
+    import torch
+    shims = os.path.join(ROOT, "shims")
+    sys.path.insert(0, shims)
+    try:
+        sys.modules.pop("torchsearchsorted", None)
+        mod = importlib.import_module("torchsearchsorted")
+        assert mod.__file__.startswith(shims)
+        a = torch.from_numpy(np.sort(np.random.default_rng(0).random((3, 9)).astype(np.float32), 1))
+        v = torch.rand(3, 5)
+        with pytest.raises(RuntimeError):
+            mod.searchsorted(a, v, side="right")
+        with pytest.raises(AssertionError):          # the reference's own shape asserts come first
+            mod.searchsorted(a[0], v)
+    finally:
+        sys.path.remove(shims)
+        sys.modules.pop("torchsearchsorted", None)

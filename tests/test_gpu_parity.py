@@ -7,6 +7,7 @@ Tolerances (written next to each assert):
   * fp32 elementwise + reductions: a few ulp;
   * rendered RGB: 1e-4 absolute, PSNR 0.01 dB (BASELINE.json north_star).
 """
+import os
 from itertools import product
 
 import numpy as np
@@ -772,3 +773,26 @@ def test_split_bf16_stress_against_fp32_kernel(dev):
             assert np.isfinite(outs["bf16x6"]).all() and np.isfinite(outs["bf16x3"]).all()
             assert e6 <= 2.0 * e32 + 1e-5 * scale, (kw, B, Ns, e32, e6)
             assert e3 <= 300.0 * e32 + 2e-3 * scale, (kw, B, Ns, e32, e3)
+
+
+@pytest.mark.gpu
+def test_torchsearchsorted_shim_on_gpu(dev):
+    """`from torchsearchsorted import searchsorted` as written in the reference (utils.py:14, :212) resolves to the HIP
+    kernel through shims/ and reproduces numpy.searchsorted (the reference's test oracle)."""
+    import importlib
+    import sys
+    shims = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shims")
+    sys.path.insert(0, shims)
+    try:
+        sys.modules.pop("torchsearchsorted", None)
+        searchsorted = importlib.import_module("torchsearchsorted").searchsorted
+        rng = np.random.default_rng(5)
+        a = np.sort(rng.random((300, 63)).astype(F32), 1)
+        v = rng.random((300, 128)).astype(F32)
+        for side in ("left", "right"):
+            got = N(searchsorted(T(a, dev), T(v, dev), side=side))
+            want = np.stack([np.searchsorted(a[i], v[i], side=side) for i in range(a.shape[0])])
+            assert got.dtype == np.int64 and np.array_equal(got, want)
+    finally:
+        sys.path.remove(shims)
+        sys.modules.pop("torchsearchsorted", None)
