@@ -796,3 +796,46 @@ def test_torchsearchsorted_shim_on_gpu(dev):
     finally:
         sys.path.remove(shims)
         sys.modules.pop("torchsearchsorted", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [0, 3])
+def test_c_host_example(dev, tmp_path, precision):
+    """examples/c_host/render_rays.c - plain C99, the C-ABI of include/smplnerf.h plus the HIP runtime, no Python in
+    the process - renders the same rays as NerfPipeline.forward, bit for bit."""
+    import shutil
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("gcc") or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("gcc / ROCm headers not available")
+    exe = str(tmp_path / "render_rays")
+    lib = os.path.join(root, "smpl_nerf_amd", "csrc", "libsmplnerf_hip.so")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_host", "render_rays.c"), lib, "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True)
+    pipe = _pipeline(dev)
+    prec = {0: "fp32", 3: "bf16x6"}[precision]
+    pipe.model_coarse.precision = pipe.model_fine.precision = prec
+    data = syn.frame_batch(128, 128, phi=10.0, theta=5.0, seed=11, near=1.0, far=4.0)
+    sub = np.arange(0, 16384, 29)
+    batch = [np.ascontiguousarray(a[sub]) for a in data]
+    B, Nc, Nf = batch[3].shape[0], batch[3].shape[1], 128
+    from smpl_nerf_amd.ops import uniform_u
+    blob = struct.pack("<5i", 0x534e5246, B, Nc, Nf, 0)
+    for m in (pipe.model_coarse, pipe.model_fine):
+        blob += bytes(m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder, False))
+    for m in (pipe.model_coarse, pipe.model_fine):
+        blob += torch.cat([p.detach().reshape(-1).float() for p in m._ordered_params()]).cpu().numpy().tobytes()
+    for a in batch[:4]:
+        blob += a.astype(F32).tobytes()
+    blob += uniform_u(Nf, dev).cpu().numpy().astype(F32).tobytes()
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(blob)
+    r = subprocess.run([exe, str(fin), str(fout), str(precision)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(fout.read_bytes(), dtype=F32)
+    with torch.no_grad():
+        ref = pipe([T(a, dev) for a in batch])
+    want = np.concatenate([N(t).reshape(-1) for t in ref])
+    assert got.shape == want.shape and np.array_equal(got, want)
