@@ -39,8 +39,9 @@ class _FusedMlpFn(torch.autograd.Function):
         lib = _lib.load()
         n = x.shape[0]
         dev = x.device
+        net._begin_training_forward()
         ns = {"bf16x6": 3, "bf16x3": 2}.get(net.precision, 0) if (net.width == 256 and per_sample != _ENCODED_ROWS) else 0
-        packed = net.packed_weights_bf16(desc, ns) if ns else net.packed_weights(desc)
+        packed = net.packed_weights_bf16(desc, ns, training=True) if ns else net.packed_weights(desc, training=True)
         sizes = [ctypes.c_int64() for _ in range(4)]
         cnt = ctypes.c_int32()
         check(lib.snerf_mlp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes], ctypes.byref(cnt)),
@@ -113,7 +114,28 @@ class _FusedMlpFn(torch.autograd.Function):
         return (None, None, d_x, d_d, None, None, None) + tuple(grads)
 
 
-class RenderRayNet(nn.Module):
+
+class _PackedWeightsEpoch:
+    """The packed weight streams are cached against (data_ptr, autograd version) of every parameter.  Not every
+    in-place update bumps the version counter - torch.optim.Adam(fused=True) does not - so the caches also carry an
+    epoch: every training forward starts a new one (an optimiser step is expected to follow), the first inference call
+    after a training forward starts another, and whoever updates weights behind autograd's back calls
+    mark_weights_changed() (DataParallelTrainer.step does after every optimiser step)."""
+
+    def mark_weights_changed(self):
+        self._weights_epoch += 1
+
+    def _begin_training_forward(self):
+        self._weights_epoch += 1
+        self._trained_since_pack = True
+
+    def _begin_inference(self):
+        if self._trained_since_pack:
+            self._weights_epoch += 1
+            self._trained_since_pack = False
+
+
+class RenderRayNet(_PackedWeightsEpoch, nn.Module):
 
     def __init__(self, n_layers=8, width=256, positions_dim=60, directions_dim=24, additional_input_dim=0,
                  skips=[4], use_directional_input=1):
@@ -146,6 +168,8 @@ class RenderRayNet(nn.Module):
         self.rgb_out_layer = torch.nn.Linear(directional_width, 3)
         self._pack_cache = {}
         self._pack_t_cache = {}
+        self._weights_epoch = 0            # see mark_weights_changed()
+        self._trained_since_pack = False
         # matrix-core arithmetic of the forward pass (inference and training): "fp32" (v_mfma_f32_16x16x4_f32) or
         # split-bf16 "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5 relative); the backward
         # kernels are always exact fp32
@@ -195,14 +219,16 @@ class RenderRayNet(nn.Module):
             return self.make_desc(0, 0, d[0], d[1], self.positions_dim + self.additional_input_dim)
         return self.make_desc(p[0], p[1], d[0], d[1], self.additional_input_dim)
 
-    def packed_weights(self, desc: MlpDesc) -> torch.Tensor:
+    def packed_weights(self, desc: MlpDesc, training: bool = False) -> torch.Tensor:
         """MFMA-ordered weight stream for `desc`, re-packed only when a parameter changed."""
+        if not training:
+            self._begin_inference()
         params = self._ordered_params()
         dev = params[0].device
         if not params[0].is_cuda:
             raise RuntimeError("RenderRayNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
         key = tuple(getattr(desc, f[0]) for f in desc._fields_)
-        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -220,14 +246,16 @@ class RenderRayNet(nn.Module):
         self._pack_cache = {key: (stamp, packed)}
         return packed
 
-    def packed_weights_bf16(self, desc: MlpDesc, nsplit: int) -> torch.Tensor:
+    def packed_weights_bf16(self, desc: MlpDesc, nsplit: int, training: bool = False) -> torch.Tensor:
         """Split-bf16 weight stream (snerf_mlp_pack_bf16), cached like packed_weights."""
+        if not training:
+            self._begin_inference()
         params = self._ordered_params()
         dev = params[0].device
         if not params[0].is_cuda:
             raise RuntimeError("RenderRayNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
         key = tuple(getattr(desc, f[0]) for f in desc._fields_) + ("bf16", nsplit)
-        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -247,7 +275,7 @@ class RenderRayNet(nn.Module):
         params = self._ordered_params()
         dev = params[0].device
         key = tuple(getattr(desc, f[0]) for f in desc._fields_) + (bool(input_grad),)
-        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_t_cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -267,7 +295,7 @@ class RenderRayNet(nn.Module):
         params = self._ordered_params()
         dev = params[0].device
         key = tuple(getattr(desc, f[0]) for f in desc._fields_) + (bool(input_grad), "bf16", nsplit)
-        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_t_cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -359,7 +387,8 @@ class _WarpFn(torch.autograd.Function):
         lib = _lib.load()
         n = x.shape[0]
         dev = x.device
-        packed = net._packed(desc)
+        net._begin_training_forward()
+        packed = net._packed(desc, training=True)
         sizes = [ctypes.c_int64() for _ in range(4)]
         check(lib.snerf_warp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes]), "snerf_warp_train_sizes")
         act = torch.empty(sizes[0].value, device=dev, dtype=torch.float32)
@@ -407,7 +436,7 @@ class _WarpFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads)
 
 
-class WarpFieldNet(nn.Module):
+class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
     """models/warp_field_net.py:6-22 drop-in: linear1 (width, positions_dim+pose_dim) + ReLU + linear2
     (3, width); `n_layers` is accepted and ignored exactly like the reference (:14-15).  forward(x) runs the
     fused HIP kernel on already-encoded rows; forward_fused() also encodes the positions and returns the
@@ -421,17 +450,21 @@ class WarpFieldNet(nn.Module):
         self.linear1 = torch.nn.Linear(positions_dim + pose_dim, width)
         self.linear2 = torch.nn.Linear(width, 3)
         self._pack_cache = {}
+        self._weights_epoch = 0
+        self._trained_since_pack = False
 
     def _params(self):
         return [self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias]
 
-    def _packed(self, desc):
+    def _packed(self, desc, training: bool = False):
+        if not training:
+            self._begin_inference()
         params = self._params()
         dev = params[0].device
         if not params[0].is_cuda:
             raise RuntimeError("WarpFieldNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
         key = tuple(getattr(desc, f[0]) for f in desc._fields_)
-        stamp = (str(dev),) + tuple((p.data_ptr(), p._version) for p in params)
+        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -475,7 +508,6 @@ class WarpFieldNet(nn.Module):
         if 3 * (pos_id + 2 * pos_L) != self.positions_dim or pose_encoding.shape[-1] != self.direcions_dim:
             raise RuntimeError("WarpFieldNet: encoder output sizes do not match positions_dim/pose_dim")
         desc = _lib.WarpDesc(self.width, pos_L, pos_id, self.direcions_dim)
-        packed = self._packed(desc)
         x = positions.reshape(-1, 3).contiguous()
         n = x.shape[0]
         pe = pose_encoding.reshape(-1, self.direcions_dim).contiguous()
@@ -484,6 +516,7 @@ class WarpFieldNet(nn.Module):
             raise RuntimeError("forward_fused: per-ray inputs do not match positions / samples_per_ray")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _WarpFn.apply(self, desc, x.detach(), pe.detach(), o.detach(), int(samples_per_ray), *self._params())
+        packed = self._packed(desc)
         warp, warped, sdirs = (torch.empty((n, 3), device=x.device, dtype=torch.float32) for _ in range(3))
         lib = _lib.load()
         with torch.cuda.device(x.device), _lib.timed(f"warp_fwd[n={n}]"):

@@ -13,9 +13,13 @@ single-process gradient of the concatenated batch.
 """
 from __future__ import annotations
 
+import os
+import time
+
 import torch
 
 from . import dist as sdist
+from . import io as sio
 
 
 class DataParallelTrainer:
@@ -23,6 +27,7 @@ class DataParallelTrainer:
 
     def __init__(self, pipeline, models, lr: float = 5e-4, weight_decay: float = 0.0, loss_func=None, fused=None):
         self.pipeline = pipeline
+        self.models = list(models)
         self.params = [p for m in models for p in m.parameters()]
         args = dict(self.default_adam_args)
         args.update({"lr": lr, "weight_decay": weight_decay})
@@ -64,4 +69,122 @@ class DataParallelTrainer:
         loss.backward()
         self.sync_gradients()
         self.optim.step()
+        # fused optimisers update the parameters without bumping autograd's version counters, which the nets' packed
+        # weight caches key on: tell them
+        for m in self.models:
+            if hasattr(m, "mark_weights_changed"):
+                m.mark_weights_changed()
         return loss.detach()
+
+    # ------------------------------------------------------------------ the Solver loop (solver/nerf_solver.py:54-163)
+    @torch.no_grad()
+    def validate(self, val_loader, h: int = 0, w: int = 0):
+        """Validation pass of NerfSolver.train (:107-150) under no_grad: mean loss over the loader, the re-rendered
+        frames (rgb_fine reshaped to [-1, h, w, 3] when whole frames were covered, :143-145) and their PSNR
+        (util/scores.py:47-48).  Returns (val_loss, psnr or None, frames or None)."""
+        for m in self.models:
+            m.eval()
+        total, count, renders, truths = 0.0, 0, [], []
+        for data in val_loader:
+            out = self.pipeline(data)
+            total += float(self.loss(out[0], out[1], data[-1]))
+            count += 1
+            renders.append(out[1].detach())
+            truths.append(data[-1].detach())
+        val_loss = total / (count or 1)                                   # :152 (guards the empty loader the same way)
+        frames = psnr = None
+        if count and h and w:
+            r, t = torch.cat(renders).cpu().numpy(), torch.cat(truths).cpu().numpy()
+            if r.shape[0] % (h * w) == 0:
+                frames = r.reshape(-1, h, w, 3)
+                psnr = sio.img2psnr(frames, t.reshape(-1, h, w, 3))
+        return val_loss, psnr, frames
+
+    def save_checkpoint(self, save_dir: str, model_names, epoch: int, history=None):
+        """utils.save_run's per-model state_dict files (utils.py:282-283), plus what the reference does not keep: the
+        optimiser state and the epoch counter, so that a run can be resumed.  Rank 0 writes."""
+        if self.rank != 0:
+            return
+        sio.save_run(save_dir, self.models, model_names)
+        torch.save({"optim": self.optim.state_dict(), "epoch": int(epoch), "history": history or {}},
+                   os.path.join(save_dir, "trainer_state.pt"))
+
+    def load_checkpoint(self, load_dir: str, model_names) -> int:
+        """Restores models and optimiser; returns the number of finished epochs."""
+        dev = self.params[0].device
+        sio.load_run(load_dir, self.models, model_names, map_location=dev)
+        state = torch.load(os.path.join(load_dir, "trainer_state.pt"), map_location=dev)
+        self.optim.load_state_dict(state["optim"])
+        return int(state["epoch"])
+
+    def fit(self, train_loader, val_loader=(), num_epochs: int = 1, h: int = 0, w: int = 0, save_dir: str = None,
+            model_names=("model_coarse.pt", "model_fine.pt"), log_iterations: int = 0, start_epoch: int = 0, log=print):
+        """NerfSolver.train (solver/nerf_solver.py:54-163) on this trainer: per epoch - the training batches of
+        `train_loader` (any iterable of pipeline input lists, rgb_truth last; tensors are moved to the models' device
+        like :78-79), the average training loss (:105), a no_grad validation pass with re-rendered frames and PSNR, a
+        checkpoint per epoch (:160-161).  Adds throughput (rays/s over the epoch's training steps, all ranks) to the
+        log.  Returns the history dict."""
+        dev = self.params[0].device
+        hist = {"train_loss": [], "val_loss": [], "val_psnr": [], "rays_per_s": []}
+        for epoch in range(start_epoch, num_epochs):
+            for m in self.models:
+                m.train()
+            losses, rays = [], 0
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i, data in enumerate(train_loader):
+                data = [e.to(dev) for e in data]
+                losses.append(self.step(data))
+                rays += int(data[-1].shape[0])
+                if log_iterations and i % log_iterations == log_iterations - 1 and self.rank == 0:
+                    log("[Epoch %d, Iteration %5d] TRAIN loss: %.7f" % (epoch + 1, i + 1, float(losses[-1])))
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            dt = max(time.perf_counter() - t0, 1e-9)
+            train_loss = float(torch.stack(losses).mean()) if losses else 0.0
+            val_loss, psnr, _ = self.validate([[e.to(dev) for e in d] for d in val_loader], h, w)
+            hist["train_loss"].append(train_loss)
+            hist["val_loss"].append(val_loss)
+            hist["val_psnr"].append(psnr)
+            hist["rays_per_s"].append(self.world * rays / dt)
+            if self.rank == 0:
+                log("[Epoch %d] Average loss of Epoch: %.7f | VAL loss: %.7f%s | %.3e rays/s" %
+                    (epoch + 1, train_loss, val_loss, "" if psnr is None else " PSNR %.2f dB" % psnr, hist["rays_per_s"][-1]))
+            if save_dir:
+                self.save_checkpoint(save_dir, model_names, epoch + 1, hist)
+        return hist
+
+
+class RayBatchLoader:
+    """The shuffled DataLoader over RaysFromImagesDataset (train.py:96-100) with the rays generated on the device
+    (raygen.RayGenerator): `iterations` batches of `batch_size` uniformly drawn rays per epoch; each rank draws from its
+    own generator seed (base + rank), so ranks see different rays."""
+
+    def __init__(self, ray_generator, batch_size: int, iterations: int, seed: int = 0):
+        self.gen, self.batch_size, self.iterations = ray_generator, int(batch_size), int(iterations)
+        _, rank = sdist.world_rank()
+        self.rng = torch.Generator(device=ray_generator.device)
+        self.rng.manual_seed(int(seed) + rank)
+
+    def __len__(self):
+        return self.iterations
+
+    def __iter__(self):
+        for _ in range(self.iterations):
+            yield self.gen.random_batch(self.batch_size, generator=self.rng)
+
+
+class FrameLoader:
+    """Validation loader: whole frames of a RayGenerator in row-major ray order, `batch_size` rays at a time, jitter
+    0.5 (the deterministic mid-bin samples render.py uses)."""
+
+    def __init__(self, ray_generator, frames, batch_size: int):
+        self.gen, self.frames, self.batch_size = ray_generator, list(frames), int(batch_size)
+
+    def __iter__(self):
+        hw = self.gen.h * self.gen.w
+        for f in self.frames:
+            for r0 in range(0, hw, self.batch_size):
+                idx = torch.arange(f * hw + r0, f * hw + min(r0 + self.batch_size, hw), device=self.gen.device)
+                yield self.gen.batch(idx, torch.full((idx.shape[0],), 0.5, dtype=torch.float64, device=self.gen.device))

@@ -337,3 +337,81 @@ def test_append_vertices_training_gradients(dev):
         # relative in norm, with a floor for the tensors whose gradient is numerically zero in this degenerate
         # model (the net's "positions" are per-ray constants, so most of the trunk saturates)
         assert np.linalg.norm(got - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-8 * np.sqrt(ref.size), k
+
+
+# ------------------------------------------------------------------------------------------ 8(f)-2: the Solver loop
+def test_trainer_fit_validate_checkpoint_resume(dev, tmp_path):
+    """DataParallelTrainer.fit = NerfSolver.train's epoch structure (solver/nerf_solver.py:54-163) on device-generated ray
+    batches: loss goes down, validation re-renders whole frames under no_grad with a PSNR, every epoch leaves
+    model_coarse.pt / model_fine.pt (utils.save_run format) plus the optimiser state, and a resumed run continues
+    bit-identically."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+    from smpl_nerf_amd.raygen import RayGenerator
+    from smpl_nerf_amd.trainer import DataParallelTrainer, FrameLoader, RayBatchLoader
+    h = w = 32
+    poses = np.stack([syn.sphere_pose(phi, 10.0, 2.4) for phi in (0.0, 40.0, 80.0)])
+    images = np.stack([syn.procedural_image(h, w, phi, 10.0) for phi in (0.0, 40.0, 80.0)]).astype(F32)
+    gen = RayGenerator(poses, h, w, np.pi / 3, 1.0, 4.0, 64, dev, images=images)
+    names = ("model_coarse.pt", "model_fine.pt")
+
+    def fresh():
+        pc, pf = syn.make_scene_nets(101)
+        mc, mf = make_net(dev, pc, precision="bf16x6"), make_net(dev, pf, precision="bf16x6")
+        pipe = NerfPipeline(mc, mf, PipelineArgs(), PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        return DataParallelTrainer(pipe, [mc, mf], lr=5e-4), mc, mf
+
+    logs = []
+    tr, mc, mf = fresh()
+    val = FrameLoader(gen, [2], 512)
+    hist = tr.fit(RayBatchLoader(gen, 256, 12, seed=1), val, num_epochs=2, h=h, w=w, save_dir=str(tmp_path / "run"),
+                  model_names=names, log_iterations=5, log=logs.append)
+    assert len(hist["train_loss"]) == 2 and hist["train_loss"][1] < hist["train_loss"][0]
+    assert all(np.isfinite(v) for v in hist["val_loss"]) and all(p is not None and np.isfinite(p) for p in hist["val_psnr"])
+    assert hist["rays_per_s"][0] > 0 and any("TRAIN loss" in l for l in logs) and any("VAL loss" in l for l in logs)
+    for f in names + ("trainer_state.pt",):
+        assert (tmp_path / "run" / f).exists()
+    # the per-model files are plain state_dicts with the reference's keys
+    sd = torch.load(tmp_path / "run" / "model_coarse.pt", map_location="cpu")
+    assert list(sd.keys())[:2] == ["positions_pose_input.weight", "positions_pose_input.bias"]
+    # continue for a third epoch ...
+    tr.fit(RayBatchLoader(gen, 256, 6, seed=7), (), num_epochs=3, start_epoch=2)
+    want = [p.detach().clone() for p in tr.params]
+    # ... and do the same from the checkpoint with fresh objects
+    tr2, _, _ = fresh()
+    assert tr2.load_checkpoint(str(tmp_path / "run"), names) == 2
+    tr2.fit(RayBatchLoader(gen, 256, 6, seed=7), (), num_epochs=3, start_epoch=2)
+    for a, b in zip(want, tr2.params):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_packed_weight_cache_follows_fused_optimizer_updates(dev, prec):
+    """torch.optim.Adam(fused=True) updates parameters without bumping autograd's version counters; the packed weight
+    streams must still follow (training forwards always re-pack, the first inference after one re-packs, the trainer
+    marks the nets after every step).  Reference point: the same steps with the unfused optimiser."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    data = syn.frame_batch(128, 128, seed=7)
+    sub = np.arange(0, 16384, 64)
+    batch = [T(a[sub], dev) for a in data]
+    finals = {}
+    for fused in (False, True):
+        pc, pf = syn.make_scene_nets(101)
+        mc, mf = make_net(dev, pc, precision=prec), make_net(dev, pf, precision=prec)
+        pipe = NerfPipeline(mc, mf, PipelineArgs(), PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        tr = DataParallelTrainer(pipe, [mc, mf], lr=5e-3, fused=fused)
+        losses = [float(tr.step(batch)) for _ in range(4)]
+        with torch.no_grad():
+            rgb = pipe(batch)[1]
+            # weights moved behind autograd's back once more, without a trainer: the documented escape hatch
+            for p in mf.parameters():
+                p.mul_(1.0)
+            mf.mark_weights_changed()
+            rgb2 = pipe(batch)[1]
+        assert torch.equal(rgb, rgb2)
+        finals[fused] = (losses, rgb.cpu().numpy())
+    assert finals[True][0][3] < finals[True][0][0]                       # it does learn
+    close(finals[True][0], finals[False][0], 1e-4, 1e-6)                 # like the unfused optimiser
+    assert float(np.abs(finals[True][1] - finals[False][1]).max()) <= 5e-4   # and inference sees the trained weights
