@@ -253,10 +253,22 @@ constexpr int WL_SLOT_FLOATS = 32 * WL_ROW_FLOATS;  // 16 dY rows + 16 X rows
 constexpr int WL_SLOTS = 4;                          // ring depth: up to WL_SLOTS - 2 stages in flight behind the one awaited
 constexpr int WL_LDS_BYTES = WL_SLOTS * WL_SLOT_FLOATS * 4;
 
-__host__ __device__ inline int wgrad_jobs(const Plan &P) {
+// A (layer, input segment) pair is "wide" when it fills the 16-wave workgroup of mlp_wgrad_kernel with real work
+// (the 256x256 layers and the 128x256 one); the narrow pairs - encoder columns, heads, the 128x128 layer: 15 % of
+// the FLOPs - go to mlp_wgrad_direct_kernel, whose independent single-wave workgroups have no per-stage barrier.
+__host__ __device__ inline bool wgrad_wide(const Layer &Ly, int s) { return Ly.t_out >= 8 && Ly.seg[s].nkb >= 16; }
+__host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups of <= 16 input k-blocks
     int jobs = 0;
     for (int l = 0; l < P.nlayers; ++l)
-        for (int s = 0; s < P.layer[l].nseg; ++s) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
+        for (int s = 0; s < P.layer[l].nseg; ++s)
+            if (wgrad_wide(P.layer[l], s)) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
+    return jobs;
+}
+__host__ __device__ inline int wgrad_direct_jobs(const Plan &P) {  // narrow jobs: 4x4-tile blocks
+    int jobs = 0;
+    for (int l = 0; l < P.nlayers; ++l)
+        for (int s = 0; s < P.layer[l].nseg; ++s)
+            if (!wgrad_wide(P.layer[l], s)) jobs += ((P.layer[l].t_out + 3) / 4) * ((P.layer[l].seg[s].nkb + 3) / 4);
     return jobs;
 }
 
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
         bool found = false;
         kb0 = 0;
         for (s = 0; s < P.layer[l].nseg; ++s) {
-            const int cnt = (P.layer[l].seg[s].nkb + 15) / 16;
+            const int cnt = wgrad_wide(P.layer[l], s) ? (P.layer[l].seg[s].nkb + 15) / 16 : 0;
             if (job < cnt) { found = true; break; }
             job -= cnt;
             kb0 += P.layer[l].seg[s].nkb;
@@ -426,6 +438,111 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     SNERF_WG_CASE(1, 2)
     SNERF_WG_CASE(1, 1)
 #undef SNERF_WG_CASE
+}
+
+// The narrow (layer, segment) pairs: one wave per workgroup owns a <= 4x4-tile block of dW and one chunk of samples;
+// operands go straight from L2/HBM into MFMA registers (4 samples x 16 features = one 256 B access per tile-row),
+// WG_PREFETCH k-steps in flight; no LDS, no barrier - occupancy bound by VGPRs only.
+constexpr int WG_THREADS = 64;
+constexpr int WG_PREFETCH = 4;  // k-steps (4 samples each) of operands in flight per wave
+
+__global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_direct_kernel(Plan P, TrainLayout L, WgradArgs A) {
+    const int lane = threadIdx.x;
+    // ---- decode the job: (narrow layer, segment, 4x4-tile block) -------------------------------------
+    int job = blockIdx.x, l = 0, s = 0, kb0 = 0, nbj = 1;
+    for (l = 0; l < P.nlayers; ++l) {
+        bool found = false;
+        kb0 = 0;
+        for (s = 0; s < P.layer[l].nseg; ++s) {
+            nbj = (P.layer[l].seg[s].nkb + 3) / 4;
+            const int cnt = wgrad_wide(P.layer[l], s) ? 0 : ((P.layer[l].t_out + 3) / 4) * nbj;
+            if (job < cnt) { found = true; break; }
+            job -= cnt;
+            kb0 += P.layer[l].seg[s].nkb;
+        }
+        if (found) break;
+    }
+    const Layer &Ly = P.layer[l];
+    const int bi = job / nbj, bj = job - bi * nbj;
+    const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
+    const int64_t n = A.n;
+    // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: base + s0*16 + lane
+    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + lane;
+    const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + lane;
+    int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
+    while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
+    const bool want_bias = (s == first_seg && bj == 0);
+    const int kslot = lane >> 4;
+
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_ab = [&](int64_t s0, float (&a)[4], float (&b)[4]) {
+        const bool ok = s0 + kslot < end;
+        const int64_t off = ok ? s0 * 16 : 0;  // masked lanes read sample 0 of the tile-row (finite data) and a = 0
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = (t < n_ti && ok) ? dyp[(int64_t)t * n * 16 + off] : 0.f;
+            b[t] = (t < n_tj) ? xp[(int64_t)t * n * 16 + off] : 0.f;
+        }
+    };
+    // software pipeline: WG_PREFETCH k-steps of operands in flight (register ring, statically indexed)
+    float ra[WG_PREFETCH][4], rb[WG_PREFETCH][4];
+#pragma unroll
+    for (int p = 0; p < WG_PREFETCH; ++p) {
+        const int64_t sp = begin + 4 * p;
+        if (sp < end) load_ab(sp, ra[p], rb[p]);
+    }
+    for (int64_t s0 = begin; s0 < end; s0 += 4 * WG_PREFETCH) {
+#pragma unroll
+        for (int p = 0; p < WG_PREFETCH; ++p) {
+            const int64_t sc = s0 + 4 * p;
+            if (sc < end) {  // wave-uniform
+                float a0[4], b0[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a0[t] = ra[p][t];
+                    b0[t] = rb[p][t];
+                }
+                const int64_t sn = sc + 4 * WG_PREFETCH;
+                if (sn < end) load_ab(sn, ra[p], rb[p]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < n_ti) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < n_tj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        bsum[i] += a0[i];
+                    }
+                }
+            }
+        }
+    }
+    // ---- write the partial of this (block, chunk) ---------------------------------------------------
+    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i >= n_ti) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= n_tj) continue;
+            const int ti = 4 * bi + i, tj = kb0 + 4 * bj + j;
+            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
+        }
+        if (want_bias) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
+        }
+    }
 }
 
 // sum over the G partials and scatter slot order -> state_dict order
@@ -478,9 +595,15 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             return fail(SNERF_E_LAUNCH, "wgrad: cannot raise the dynamic LDS limit to %d bytes", WL_LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wgrad_jobs(P), G), dim3(WL_THREADS), WL_LDS_BYTES, s, P, L, W);
-    int rc = check_launch("wgrad");
-    if (rc) return rc;
+    int rc;
+    if (const int jobs = wgrad_jobs(P)) {
+        hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(jobs, G), dim3(WL_THREADS), WL_LDS_BYTES, s, P, L, W);
+        if ((rc = check_launch("wgrad"))) return rc;
+    }
+    if (const int jobs = wgrad_direct_jobs(P)) {
+        hipLaunchKernelGGL(mlp_wgrad_direct_kernel, dim3(jobs, G), dim3(WG_THREADS), 0, s, P, L, W);
+        if ((rc = check_launch("wgrad_direct"))) return rc;
+    }
     hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, flat_grad);
     return check_launch("wgrad_reduce");
 }
