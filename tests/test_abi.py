@@ -132,3 +132,38 @@ def test_torchsearchsorted_shim_imports_and_has_no_cpu_path():
     finally:
         sys.path.remove(shims)
         sys.modules.pop("torchsearchsorted", None)
+
+
+def test_split_bf16_and_render_entry_points_validate_on_the_host(lib):
+    """Host-side argument checks of the entry points added for the bf16 matrix-core path, the training variants and the
+    one-call renderer: descriptor arithmetic, nsplit / precision ranges, null pointers - nothing is launched."""
+    d = _lib.MlpDesc(8, 256, 10, 0, 4, 0, 0, 1 << 4, 1)
+    # slab = one 32-wide k-block x 16 tiles x nsplit parts (+1 KiB bias): 79 slabs + 3 pad slabs for this net
+    b3, b2 = lib.snerf_mlp_packed_bf16_bytes(d, 3), lib.snerf_mlp_packed_bf16_bytes(d, 2)
+    assert b3 % (3 * 16384 + 1024) == 0 and b2 % (2 * 16384 + 1024) == 0
+    assert b3 // (3 * 16384 + 1024) == b2 // (2 * 16384 + 1024) > 3
+    assert lib.snerf_mlp_packed_bf16_bytes(d, 4) == -1 and b"nsplit" in lib.snerf_last_error_string()
+    narrow = _lib.MlpDesc(4, 128, 10, 0, 4, 0, 0, 2, 1)
+    assert lib.snerf_mlp_packed_bf16_bytes(narrow, 3) == -1 and b"256" in lib.snerf_last_error_string()
+    assert lib.snerf_mlp_packed_t_bf16_bytes(d, 3, 0) > 0
+    assert lib.snerf_mlp_packed_t_bf16_bytes(d, 3, 1) > lib.snerf_mlp_packed_t_bf16_bytes(d, 3, 0)   # + encoder columns
+    assert lib.snerf_mlp_packed_t_bf16_bytes(d, 1, 0) == -1
+    assert lib.snerf_mlp_pack_bf16(d, None, None, 3, None) == -1
+    assert lib.snerf_mlp_pack_t_bf16(d, None, None, 3, 0, None) == -1
+    assert lib.snerf_mlp_fwd_bf16_f32(d, None, 3, None, None, 0, None, 0, 64, None, None) == 0        # n = 0: no-op
+    assert lib.snerf_mlp_fwd_bf16_f32(d, None, 3, None, None, 0, None, 128, 64, None, None) == -1     # null pointers
+    assert lib.snerf_mlp_fwd_train_bf16_f32(d, None, 5, None, None, 0, None, 128, 64, None, None, None) == -1
+    assert lib.snerf_mlp_bwd_bf16_f32(d, None, 3, None, None, 0, None, None, None, None) == 0
+    assert lib.snerf_mlp_bwd_bf16_f32(d, None, 3, None, None, 128, None, None, None, None) == -1
+    assert lib.snerf_mlp_bwd_inputs_bf16_f32(d, None, 3, None, None, None, None, 0, 1, 128, None, None, None, None, None,
+                                             None) == -1
+    # one-call renderer
+    ws = lib.snerf_render_rays_workspace_bytes(16384, 64, 128)
+    assert ws >= 16384 * (64 * 16 + 64 * 8 + 128 * 4 + 192 * 4 + 192 * 16) and ws % 16 == 0
+    assert lib.snerf_render_rays_workspace_bytes(16384, 0, 128) == -1
+    args = [d, None, d, None, 3] + [None] * 7 + [0, 64, 128, 0, None, None, None, None, None, None]
+    assert lib.snerf_render_rays_f32(*args) == 0                                                         # B = 0: no-op
+    args[12] = 4
+    assert lib.snerf_render_rays_f32(*args) == -1 and b"null" in lib.snerf_last_error_string()
+    args[4] = 1
+    assert lib.snerf_render_rays_f32(*args) == -1 and b"precision" in lib.snerf_last_error_string()
