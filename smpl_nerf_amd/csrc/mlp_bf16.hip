@@ -120,7 +120,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
+    // Persistent workgroups: one per CU (the LDS ring allows no more), each walking the sample tiles
+    // blockIdx.x, blockIdx.x + gridDim.x, ...  The weight ring keeps rolling from one tile into the next (the stream
+    // wraps around), so only the first tile of a workgroup pays the pipeline fill.
+    SlabPipe16<NT, NS> pipe;
+    for (int64_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
     const int64_t sc = valid ? sample : A.n - 1;
     SampleCtx c;
@@ -147,8 +152,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // the slab loop and drain the in-flight weight DMA every time
     asm volatile("" ::"v"(c.px), "v"(c.py), "v"(c.pz), "v"(c.dx), "v"(c.dy), "v"(c.dz));
 
-    SlabPipe16<NT, NS> pipe;
-    pipe.prologue(A.packed, ring, tid);
+    if (tile == blockIdx.x) pipe.prologue(A.packed, ring, tid, A.total_slabs);
 
     // two accumulator sets ping-pong between consecutive layers: the finished set feeds the next layer's B
     // operands (split just in time, k-block by k-block) while the other set accumulates
@@ -250,11 +254,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         run.template run_hidden<true>(acce, rgb);
         run.finish();
     }
-    // the last k-block prefetched past the end of the stream (padding slabs): retire those loads before their
-    // registers can be reused
-    wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
     if (valid && c.g == 0)
         __builtin_nontemporal_store(f4{rgb[0][0], rgb[0][1], rgb[0][2], sig[0][0]}, reinterpret_cast<f4 *>(A.raw) + sample);
+    }  // tiles
+    // the last k-block prefetched the first tile pair of the wrapped-around stream: retire those loads before their
+    // registers can be reused
+    if (blockIdx.x < A.n_tiles) wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
 }
 
 static int plan16(const snerf_mlp_desc *desc, Plan &P, const char *what) {
@@ -276,7 +281,17 @@ static int launch_bf16(const FwdArgs &A, hipStream_t s) {
             return fail(SNERF_E_LAUNCH, "mlp_fwd_bf16: cannot raise the dynamic LDS limit to %d bytes", lds);
         attr = true;
     }
-    const int64_t grid = (A.n + NW * 16 - 1) / (NW * 16);
+    static int n_cu = 0;  // one persistent workgroup per CU
+    if (!n_cu) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            return fail(SNERF_E_LAUNCH, "mlp_fwd_bf16: cannot query the CU count");
+        n_cu = cus;
+    }
+    // SNERF_BF16_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
+    static const bool persistent = !(getenv("SNERF_BF16_PERSISTENT") && atoi(getenv("SNERF_BF16_PERSISTENT")) == 0);
+    const int64_t grid = (persistent && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: n too large");
     hipLaunchKernelGGL((mlp_fwd_bf16_kernel<256, NW, NS, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_fwd_bf16");
@@ -320,6 +335,8 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
     A.add_nkb = P.add_nkb;
     A.add_first = (P.add_dim && desc->add_first) ? 1 : 0;
     A.use_dir = desc->use_dir ? 1 : 0;
+    A.total_slabs = P.total_slabs;
+    A.n_tiles = (n + 8 * 16 - 1) / (8 * 16);
     if (train) {
         // the activation buffer has the layout of the 16-wide plan the backward kernels are built on
         Plan Q;

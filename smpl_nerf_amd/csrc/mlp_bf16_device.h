@@ -115,7 +115,8 @@ struct SlabPipe16 {
     static_assert(NS * 16 % HALF == 0, "A region must split evenly over the issuing waves");
     const char *gsrc;  // packed + lane*16
     char *ring;
-    int wave, rd, next;  // next = slab index to issue
+    int wave, rd, next;  // next = running index of the slab to issue (its parity picks the issuing half)
+    int src_slab, total;  // stream position of that slab: persistent kernels wrap around after `total` slabs
     // A parts of the first tile pair of the k-block that runs next: issued one tile pair ahead like every other
     // pair, i.e. during the last pair of the previous k-block - across slab and layer boundaries too
     bf8 fa0[NS], fa1[NS];
@@ -126,7 +127,7 @@ struct SlabPipe16 {
     // slab `next` -> ring slot `slot`, by the half whose turn it is
     __device__ __forceinline__ void issue(int slot) {
         if (my_turn()) {
-            const char *src = gsrc + (int64_t)next * SB;
+            const char *src = gsrc + (int64_t)src_slab * SB;
             char *dst = ring + slot * SB;
             const int w = wave >= HALF ? wave - HALF : wave;
 #pragma unroll
@@ -140,12 +141,17 @@ struct SlabPipe16 {
                                                  (__attribute__((address_space(3))) void *)(dst + NS * 16384), 16, 0, 0);
         }
         ++next;
+        src_slab = src_slab + 1 == total ? 0 : src_slab + 1;
     }
-    __device__ __forceinline__ void prologue(const void *packed, char *ring_, int tid) {
+    // total_slabs: length of the stream for kernels that run it repeatedly (one pass per sample tile); a one-pass
+    // kernel leaves the default and reads on into the zero padding slabs
+    __device__ __forceinline__ void prologue(const void *packed, char *ring_, int tid, int total_slabs = 0x7fffffff) {
         ring = ring_;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         gsrc = reinterpret_cast<const char *>(packed) + (tid & 63) * 16;
         next = 0;
+        src_slab = 0;
+        total = total_slabs;
         issue(0);
         issue(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slabs 0, 1 (and the per-sample input loads)

@@ -41,6 +41,8 @@ struct FwdArgs {
     // split-bf16 training forward only: encoder / additional k-block counts of the 16-wide (fp32) plan, which
     // defines the activation layout the backward kernels read
     int pos_nkb16, add_nkb16, dir_nkb16;
+    int total_slabs;   // split-bf16 kernels: slabs of the weight stream (persistent workgroups wrap around)
+    int64_t n_tiles;   // split-bf16 kernels: 128-sample tiles
 };
 
 // one tile (16 features of this lane's sample) <-> the tile-row-major activation buffer
