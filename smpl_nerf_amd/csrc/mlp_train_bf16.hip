@@ -10,6 +10,8 @@
 //   * gradients are split just in time into NS parts (6 or 3 products per fp32 MAC, fp32 accumulate);
 //   * the ReLU mask is applied in place on the accumulators (4 tiles at a time: the mask loads must not cost 64
 //     more registers), then the masked tiles are stored and feed the next transposed layer.
+#include <stdlib.h>
+
 #include "mlp_bf16_device.h"
 #include "mlp_train_device.h"
 
@@ -105,7 +107,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
-    const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
+    // persistent workgroups over the sample tiles, like mlp_fwd_bf16_kernel: the weight ring rolls on from tile to tile
+    SlabPipe16<NT, NS> pipe;
+    for (int64_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
     const int64_t sc = valid ? sample : A.n - 1;
     const int nh = A.n_hidden;
@@ -119,8 +124,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         store_tile(A.dy, A.dy_sig, A.n, sample, g, g == 0 ? f4{dr[3], 0.f, 0.f, 0.f} : zero);
     }
 
-    SlabPipe16<NT, NS> pipe;
-    pipe.prologue(A.packed_t, ring, tid);
+    if (tile == blockIdx.x) pipe.prologue(A.packed_t, ring, tid, A.total_slabs);
 
     f4 accd[TD], acce[TD];
     {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
@@ -208,9 +212,6 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
             layer(l - 1, accB, accA);
         }
     }
-    // the last k-block prefetched past the end of the stream (padding slabs): retire those loads before their
-    // registers can be reused
-    wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
     if (INPUT_GRAD) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
         if (A.pos_nkb > 0) {
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
             q[2] = gz;
         }
     }
+    }  // tiles
+    // the last k-block prefetched the first tile pair of the wrapped-around stream: retire those loads before their
+    // registers can be reused
+    if (blockIdx.x < A.n_tiles) wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
 }
 
 static int plans_t(const snerf_mlp_desc *desc, Plan &P, const char *what) {
@@ -248,7 +253,16 @@ static int launch_dgrad_bf16(const BwdArgs &A, hipStream_t s) {
             return fail(SNERF_E_LAUNCH, "mlp_bwd_bf16: cannot raise the dynamic LDS limit to %d bytes", lds);
         attr = true;
     }
-    const int64_t grid = (A.n + NW * 16 - 1) / (NW * 16);
+    static int n_cu = 0;  // one persistent workgroup per CU
+    if (!n_cu) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            return fail(SNERF_E_LAUNCH, "mlp_bwd_bf16: cannot query the CU count");
+        n_cu = cus;
+    }
+    static const bool persistent = !(getenv("SNERF_BF16_PERSISTENT") && atoi(getenv("SNERF_BF16_PERSISTENT")) == 0);
+    const int64_t grid = (persistent && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: n too large");
     hipLaunchKernelGGL((mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_bwd_bf16(dgrad)");
@@ -305,6 +319,8 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
     A.dir_id = desc->dir_identity ? 1 : 0;
     A.dir_nkb = P.dir_nkb;
     A.use_dir = desc->use_dir ? 1 : 0;
+    A.total_slabs = bwd_total_slabs(P, input_grad, 32);
+    A.n_tiles = (n + 8 * 16 - 1) / (8 * 16);
     if (nsplit == 3) rc = input_grad ? launch_dgrad_bf16<3, true>(A, s) : launch_dgrad_bf16<3, false>(A, s);
     else rc = input_grad ? launch_dgrad_bf16<2, true>(A, s) : launch_dgrad_bf16<2, false>(A, s);
     if (rc) return rc;

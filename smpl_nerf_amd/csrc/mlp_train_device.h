@@ -20,6 +20,8 @@ struct BwdArgs {
     int dirs_per_sample, spr;
     unsigned skip_mask;
     int pos_L, pos_id, pos_nkb, dir_L, dir_id, dir_nkb, use_dir;
+    int total_slabs;   // split-bf16 kernel: slabs of the transposed stream (persistent workgroups wrap around)
+    int64_t n_tiles;   // split-bf16 kernel: 128-sample tiles
 };
 
 // Backward of the positional encoding (utils.py:127-131) for the slots this lane holds: dpe[kb][2u], [2u+1] are
