@@ -415,3 +415,24 @@ def test_packed_weight_cache_follows_fused_optimizer_updates(dev, prec):
     assert finals[True][0][3] < finals[True][0][0]                       # it does learn
     close(finals[True][0], finals[False][0], 1e-4, 1e-6)                 # like the unfused optimiser
     assert float(np.abs(finals[True][1] - finals[False][1]).max()) <= 5e-4   # and inference sees the trained weights
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gradient_additivity_over_a_full_frame(dev, prec):
+    """Training at the bench size (a whole 128 x 128 frame = 16 384 rays, 4.2 M MLP evaluations per step) through a
+    size-independent property: the loss is a mean over rays, so the gradient of the frame equals the ray-weighted mean
+    of the gradients of any partition of it (what data-parallel training relies on)."""
+    data = syn.frame_batch(128, 128, seed=7)
+    full = [T(a, dev) for a in data]
+    R = full[0].shape[0]
+    cut = 6000                                                             # ragged split
+    grads = []
+    for lo, hi in ((0, R), (0, cut), (cut, R)):
+        pipe, mc, mf = _pipeline(dev, precision=prec)
+        out = pipe([t[lo:hi] for t in full])
+        loss = torch.nn.functional.mse_loss(out[0], full[-1][lo:hi]) + torch.nn.functional.mse_loss(out[1], full[-1][lo:hi])
+        loss.backward()
+        grads.append([p.grad.double() for m in (mc, mf) for p in m.parameters()])
+    for g, ga, gb in zip(*grads):
+        mix = (ga * cut + gb * (R - cut)) / R
+        assert float((g - mix).norm()) <= 1e-4 * float(g.norm()) + 1e-9
