@@ -30,10 +30,13 @@ def main(sq, fetch, write):
         launches = {}
         tot_f = tot_w = tot_n = 0
         for key, e in a.items():
-            n = int(key.split("grid=")[1]) // 512 * 128  # 512 threads per workgroup, 128 samples
+            n = int(key.split("grid=")[1]) // 512 * 128  # 512 threads per workgroup, 128 samples (non-persistent kernels)
             c = e["counters"]
             fk, wk = f[key]["counters"]["FETCH_SIZE"], w[key]["counters"]["WRITE_SIZE"]
-            launches[f"n={n}"] = {"duration_ms": e["avg_seconds"] * 1e3, "effective_clock_GHz": e["effective_clock_ghz"],
+            label = f"n={n}"
+            if n not in ALG_BYTES:   # persistent kernels: the grid is one workgroup per CU whatever n is
+                label = "coarse n=1048576 and fine n=3145728 launches averaged (persistent grid)"
+            launches[label] = {"duration_ms": e["avg_seconds"] * 1e3, "effective_clock_GHz": e["effective_clock_ghz"],
                                   "mfma_pipe_busy_frac": e["mfma_busy_frac"],
                                   "wave_cycles_parked_frac": e.get("sq_wait_any_per_wave_cycle"),
                                   "wave_cycles_issue_stall_frac": e.get("sq_wait_inst_any_per_wave_cycle"),
