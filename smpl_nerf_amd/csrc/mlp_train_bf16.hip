@@ -107,9 +107,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
-    // persistent workgroups over the sample tiles, like mlp_fwd_bf16_kernel: the weight ring rolls on from tile to tile
+    // persistent workgroups over the sample tiles, like mlp_fwd_bf16_kernel: the weight ring rolls on from tile to tile.
+    // The INPUT_GRAD variants sit at the 256-register limit; carrying the ring state and the prefetched tile pair
+    // across tiles makes them spill, so they run one tile per workgroup (the loop folds away).
+    constexpr bool PERSIST = !INPUT_GRAD;
     SlabPipe16<NT, NS> pipe;
-    for (int64_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    int64_t tile = blockIdx.x;
+    if (tile >= A.n_tiles) return;
+    do {
     const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
     const int64_t sc = valid ? sample : A.n - 1;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         store_tile(A.dy, A.dy_sig, A.n, sample, g, g == 0 ? f4{dr[3], 0.f, 0.f, 0.f} : zero);
     }
 
-    if (tile == blockIdx.x) pipe.prologue(A.packed_t, ring, tid, A.total_slabs);
+    if (!PERSIST || tile == blockIdx.x) pipe.prologue(A.packed_t, ring, tid, A.total_slabs);
 
     f4 accd[TD], acce[TD];
     {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
@@ -228,10 +233,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
             q[2] = gz;
         }
     }
-    }  // tiles
-    // the last k-block prefetched the first tile pair of the wrapped-around stream: retire those loads before their
+    tile += gridDim.x;
+    } while (PERSIST && tile < A.n_tiles);
+    // the last k-block prefetched the first tile pair of the (wrapped-around) stream: retire those loads before their
     // registers can be reused
-    if (blockIdx.x < A.n_tiles) wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
+    wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
 }
 
 static int plans_t(const snerf_mlp_desc *desc, Plan &P, const char *what) {
@@ -262,7 +268,7 @@ static int launch_dgrad_bf16(const BwdArgs &A, hipStream_t s) {
         n_cu = cus;
     }
     static const bool persistent = !(getenv("SNERF_BF16_PERSISTENT") && atoi(getenv("SNERF_BF16_PERSISTENT")) == 0);
-    const int64_t grid = (persistent && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
+    const int64_t grid = (persistent && !INPUT_GRAD && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: n too large");
     hipLaunchKernelGGL((mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_bwd_bf16(dgrad)");
