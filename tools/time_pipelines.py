@@ -54,3 +54,44 @@ pa = syn.make_scene_net_params(301, add_first=True, additional_input_dim=69)
 ma, mb = net(pa, add=69), net(pa, add=69)
 asp = AppendSmplParamsPipeline(ma, mb, PipelineArgs(human_pose_encoding=0), *enc, PositionalEncoder(10, 0))
 timed(asp, frame[:4] + [pose, frame[4]], (ma, mb), "append_smpl_params")
+
+# ---- training steps (4096 rays, fwd + bwd + Adam), bf16x6 forward/dgrad and all-fp32 ---------------------------
+from smpl_nerf_amd.trainer import DataParallelTrainer
+
+
+def timed_train(make, label):
+    for prec in ("fp32", "bf16x6"):
+        pipe, models, batch = make(prec)
+        tr = DataParallelTrainer(pipe, models, lr=5e-4)
+        for _ in range(2):
+            tr.step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.step(batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print(f"train {label:16s} {prec:7s} {dt * 1e3:7.2f} ms/step  {4096 * 256 / dt:.3e} ray-samples/s")
+
+
+sub = torch.arange(0, 16384, 4, device=dev)
+
+
+def make_nerf(prec):
+    a, b = net(pc), net(pf)
+    a.precision = b.precision = prec
+    return NerfPipeline(a, b, PipelineArgs(), *enc), [a, b], [t[sub] for t in frame]
+
+
+def make_smpl(prec):
+    a, b = net(pc), net(pf)
+    a.precision = b.precision = prec
+    w = WarpFieldNet(8, 256, 60, 40)
+    w.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_params(103, out_scale=0.3).items()})
+    w = w.to(dev)
+    p = SmplNerfPipeline(a, b, w, PipelineArgs(), *enc, PositionalEncoder(10, 0))
+    return p, [a, b, w], [t[sub] for t in frame[:4]] + [pose[sub], frame[4][sub]]
+
+
+timed_train(make_nerf, "nerf")
+timed_train(make_smpl, "smpl_nerf (warp)")
