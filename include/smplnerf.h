@@ -229,6 +229,15 @@ int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const f
                        const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
                        float *warp, float *warped, float *sdirs, snerf_stream_t stream);
 
+/* The same forward on the bf16 matrix cores (split-bf16, always three parts / six products: fp32-class accuracy - the warp
+ * moves the sample in front of the 2^9 band of the position encoding).  packed from snerf_warp_pack_bf16
+ * (snerf_warp_packed_bf16_bytes bytes).  Fused mode only (x given); width 256. */
+int64_t snerf_warp_packed_bf16_bytes(const snerf_warp_desc *desc);
+int snerf_warp_pack_bf16(const snerf_warp_desc *desc, const float *params_flat, void *packed, snerf_stream_t stream);
+int snerf_warp_fwd_bf16_f32(const snerf_warp_desc *desc, const void *packed, const float *x, const float *pose_enc,
+                            const float *o, int64_t n, int samples_per_ray, float *warp, float *warped, float *sdirs,
+                            snerf_stream_t stream);
+
 /* Training of the warp net: forward that saves [PE(x) | pose | h] tile-rows, the transposed head, and the
  * backward d_warp [n,3] (= d loss / d warp, the sum of what arrives through warp, warped and sdirs) ->
  * flat_grad (snerf_warp_param_floats floats, state_dict order, overwritten).  Sizes as snerf_mlp_train_sizes. */

@@ -65,6 +65,9 @@ SIGNATURES = {
     "snerf_warp_packed_floats": (c_int64, [POINTER(WarpDesc)]),
     "snerf_warp_pack_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P]),
     "snerf_warp_fwd_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
+    "snerf_warp_packed_bf16_bytes": (c_int64, [POINTER(WarpDesc)]),
+    "snerf_warp_pack_bf16": (c_int, [POINTER(WarpDesc), _P, _P, _P]),
+    "snerf_warp_fwd_bf16_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "snerf_warp_train_sizes": (c_int, [POINTER(WarpDesc), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
                                        POINTER(c_int64)]),
     "snerf_warp_fwd_train_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P]),

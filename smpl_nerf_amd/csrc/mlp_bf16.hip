@@ -67,36 +67,6 @@ __global__ __launch_bounds__(256) void mlp_pack_bf16_kernel(Plan P, int NS, cons
     for (int j = threadIdx.x; j < 256; j += 256) aux[j] = (sl == 0 && j < Ly.n_out) ? params[Ly.b_off + j] : 0.f;
 }
 
-// B operand of encoder k-block kb: 4 units (sin, cos pairs) per lane
-// `half[h]` = the fp32 values of 16-wide k-block 2kb + h in the fp32 kernel's layout (mlp_device.h pe_operand): what
-// the training forward stores for the backward kernels
-template <int NS>
-__device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, int L, int ident, int kb, bf8 (&b)[NS],
-                                             f4 (&half)[2]) {
-    const float x = is_dir ? c.dx : c.px, y = is_dir ? c.dy : c.py, z = is_dir ? c.dz : c.pz;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        float s0, c0;
-        pe_unit(x, y, z, L, ident, 4 * (4 * kb + u) + c.g, s0, c0);
-        half[u >> 1][2 * (u & 1)] = s0;
-        half[u >> 1][2 * (u & 1) + 1] = c0;
-        split_pair_into<NS>(s0, c0, b, u);
-    }
-}
-template <int NS>
-__device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, int kb, bf8 (&b)[NS], f4 (&half)[2]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float v[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int e = 2 * j + h, col = 32 * kb + 16 * (e >> 2) + 4 * c.g + (e & 3);
-            v[h] = col < add_dim ? c.add[col] : 0.f;
-            half[e >> 2][e & 3] = v[h];
-        }
-        split_pair_into<NS>(v[0], v[1], b, j);
-    }
-}
 // post-activation tiles -> the tile-row-major activation buffer
 template <bool RELU, int N>
 __device__ __forceinline__ void store_act(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&t)[N]) {
@@ -262,6 +232,13 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     if (blockIdx.x < A.n_tiles) wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
 }
 
+// any (kw = 32) Plan -> split-bf16 slab stream; shared with warp_bf16.hip
+int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what) {
+    hipLaunchKernelGGL(mlp_pack_bf16_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, s, P, ns, params_flat,
+                       reinterpret_cast<unsigned char *>(packed));
+    return check_launch(what);
+}
+
 static int plan16(const snerf_mlp_desc *desc, Plan &P, const char *what) {
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "%s: desc is null", what);
@@ -382,9 +359,7 @@ extern "C" int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *para
     if (rc) return rc;
     if (!params_flat || !packed) return fail(SNERF_E_BADARG, "mlp_pack_bf16: null pointer");
     if (!aligned(packed, 16)) return fail(SNERF_E_ALIGN, "mlp_pack_bf16: packed must be 16-byte aligned");
-    hipLaunchKernelGGL(mlp_pack_bf16_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, (hipStream_t)stream, P, nsplit,
-                       params_flat, reinterpret_cast<unsigned char *>(packed));
-    return check_launch("mlp_pack_bf16");
+    return launch_pack_bf16(P, nsplit, params_flat, packed, (hipStream_t)stream, "mlp_pack_bf16");
 }
 
 extern "C" int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,

@@ -12,6 +12,9 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 __host__ __device__ constexpr int slab16_bytes(int ns) { return ns * 16384 + 1024; }
 
+// mlp_bf16.hip: any kw = 32 Plan -> split-bf16 slab stream
+int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what);
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -373,4 +376,34 @@ struct LayerRun16 {
     }
 };
 
+// B operand of encoder k-block kb: 4 units (sin, cos pairs) per lane
+// `half[h]` = the fp32 values of 16-wide k-block 2kb + h in the fp32 kernel's layout (mlp_device.h pe_operand): what
+// the training forward stores for the backward kernels
+template <int NS>
+__device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, int L, int ident, int kb, bf8 (&b)[NS],
+                                             f4 (&half)[2]) {
+    const float x = is_dir ? c.dx : c.px, y = is_dir ? c.dy : c.py, z = is_dir ? c.dz : c.pz;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float s0, c0;
+        pe_unit(x, y, z, L, ident, 4 * (4 * kb + u) + c.g, s0, c0);
+        half[u >> 1][2 * (u & 1)] = s0;
+        half[u >> 1][2 * (u & 1) + 1] = c0;
+        split_pair_into<NS>(s0, c0, b, u);
+    }
+}
+template <int NS>
+__device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, int kb, bf8 (&b)[NS], f4 (&half)[2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = 2 * j + h, col = 32 * kb + 16 * (e >> 2) + 4 * c.g + (e & 3);
+            v[h] = col < add_dim ? c.add[col] : 0.f;
+            half[e >> 2][e & 3] = v[h];
+        }
+        split_pair_into<NS>(v[0], v[1], b, j);
+    }
+}
 }  // namespace snerf

@@ -452,6 +452,9 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
         self._pack_cache = {}
         self._weights_epoch = 0
         self._trained_since_pack = False
+        # "fp32" (v_mfma_f32_16x16x4_f32) or split-bf16: any of "bf16x6" / "bf16x3" runs the warp net with three parts
+        # (fp32-class accuracy: the warp moves the sample in front of the position encoding's 2^9 band)
+        self.precision = os.environ.get("SNERF_PRECISION", "fp32")
 
     def _params(self):
         return [self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias]
@@ -478,6 +481,29 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
         packed = torch.empty(n_pack, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             check(lib.snerf_warp_pack_f32(desc, ptr(flat), ptr(packed), current_stream()), "snerf_warp_pack_f32")
+        self._pack_cache = {key: (stamp, packed)}
+        return packed
+
+    def _packed_bf16(self, desc):
+        """Split-bf16 weight stream of the fused forward (snerf_warp_pack_bf16), cached like _packed."""
+        self._begin_inference()
+        params = self._params()
+        dev = params[0].device
+        if not params[0].is_cuda:
+            raise RuntimeError("WarpFieldNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
+        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + ("bf16",)
+        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = _lib.load()
+        nbytes = lib.snerf_warp_packed_bf16_bytes(desc)
+        if nbytes < 0:
+            check(int(nbytes), "snerf_warp_packed_bf16_bytes")
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            check(lib.snerf_warp_pack_bf16(desc, ptr(flat), ptr(packed), current_stream()), "snerf_warp_pack_bf16")
         self._pack_cache = {key: (stamp, packed)}
         return packed
 
@@ -516,9 +542,16 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
             raise RuntimeError("forward_fused: per-ray inputs do not match positions / samples_per_ray")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _WarpFn.apply(self, desc, x.detach(), pe.detach(), o.detach(), int(samples_per_ray), *self._params())
-        packed = self._packed(desc)
         warp, warped, sdirs = (torch.empty((n, 3), device=x.device, dtype=torch.float32) for _ in range(3))
         lib = _lib.load()
+        if self.precision in ("bf16x6", "bf16x3") and self.width == 256:
+            packed = self._packed_bf16(desc)
+            with torch.cuda.device(x.device), _lib.timed(f"warp_fwd[n={n}]"):
+                check(lib.snerf_warp_fwd_bf16_f32(desc, ptr(packed), ptr(x), ptr(pe), ptr(o), n, int(samples_per_ray),
+                                                  ptr(warp), ptr(warped), ptr(sdirs), current_stream()),
+                      "snerf_warp_fwd_bf16_f32")
+            return warp, warped, sdirs
+        packed = self._packed(desc)
         with torch.cuda.device(x.device), _lib.timed(f"warp_fwd[n={n}]"):
             check(lib.snerf_warp_fwd_f32(desc, ptr(packed), ptr(x), ptr(pe), ptr(o), n, int(samples_per_ray), ptr(warp),
                                          ptr(warped), ptr(sdirs), current_stream()), "snerf_warp_fwd_f32")

@@ -433,10 +433,14 @@ def test_warp_field_net(dev):
     assert maxabs(N(out), g["warp_out"]) <= 2e-6
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("wb", [0, 1])
-def test_smpl_nerf_pipeline_vs_reference(dev, wb):
+def test_smpl_nerf_pipeline_vs_reference(dev, wb, prec):
+    """a7 against the frames the reference rendered; bf16x6 = the warp net and both RenderRayNets on the bf16 matrix
+    cores (split-bf16, fp32-class), held to the same tolerances."""
     g = load_golden("g6_smpl_nerf_pipeline.npz")
     pipe, _ = _smpl_pipeline(dev, wb=wb)
+    pipe.model_coarse.precision = pipe.model_fine.precision = pipe.model_warp_field.precision = prec
     data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
     sub = g["sub"]
     d = [T(a[sub], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][sub], dev)]
@@ -876,3 +880,34 @@ def test_full_256_frame_properties(dev, prec):
     want = O.nerf_pipeline_forward(pc, pf, O.Args(u=N(uniform_u(128, dev))), O.PositionalEncoder(10, 0),
                                    O.PositionalEncoder(4, 0), [a[sub] for a in data])
     assert maxabs(rgb[sub], want[0]) <= 1e-4 and maxabs(rgb_fine[sub], want[1]) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_warp_field_net_split_bf16(dev):
+    """The fused warp stage (warp, x' = x + warp, sdir = x' - o) on the bf16 matrix cores against the fp32 kernel: six
+    products per MAC, so the warp agrees to fp32 round-off (it feeds the 2^9 band of the position encoding), for ragged
+    sizes and both precision spellings."""
+    from smpl_nerf_amd.nets import WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(17)
+    mw = WarpFieldNet(8, 256, 60, 40)
+    mw.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_params(103, out_scale=0.3).items()})
+    mw = mw.to(dev)
+    pos_enc, pose_enc = PositionalEncoder(10, 0), PositionalEncoder(10, 0)
+    for B, Ns in ((1, 1), (37, 5), (300, 64), (513, 192)):
+        pts = T(rng.uniform(-2.5, 2.5, (B, Ns, 3)).astype(F32), dev)
+        o = T(rng.uniform(-3, 3, (B, 3)).astype(F32), dev)
+        pose = pose_enc.encode(T(rng.uniform(0, 1, (B, 2)).astype(F32), dev))
+        outs = {}
+        with torch.no_grad():
+            for prec in ("fp32", "bf16x6", "bf16x3"):
+                mw.precision = prec
+                a = mw.forward_fused(pts, pose, o, Ns, pos_enc)
+                b = mw.forward_fused(pts, pose, o, Ns, pos_enc)
+                assert all(torch.equal(x, y) for x, y in zip(a, b))
+                outs[prec] = [N(t) for t in a]
+        assert all(np.array_equal(x, y) for x, y in zip(outs["bf16x6"], outs["bf16x3"]))      # always three parts
+        scale = float(np.abs(outs["fp32"][0]).max()) + 1e-6
+        assert maxabs(outs["bf16x6"][0], outs["fp32"][0]) <= 4e-6 * scale + 1e-7
+        assert maxabs(outs["bf16x6"][1], outs["fp32"][1]) <= 4e-6 * scale + 5e-7
+        assert maxabs(outs["bf16x6"][2], outs["fp32"][2]) <= 4e-6 * scale + 1e-6

@@ -48,7 +48,7 @@ mw.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_param
 mw = mw.to(dev)
 pose = torch.from_numpy(np.tile(syn.human_poses()[3][None], (16384, 1)).astype(np.float32)).to(dev)
 smpl = SmplNerfPipeline(mc, mf, mw, PipelineArgs(), *enc, PositionalEncoder(10, 0))
-timed(smpl, frame[:4] + [pose, frame[4]], (mc, mf), "smpl_nerf (warp)")
+timed(smpl, frame[:4] + [pose, frame[4]], (mc, mf, mw), "smpl_nerf (warp)")
 
 pa = syn.make_scene_net_params(301, add_first=True, additional_input_dim=69)
 ma, mb = net(pa, add=69), net(pa, add=69)
@@ -87,6 +87,7 @@ def make_smpl(prec):
     a, b = net(pc), net(pf)
     a.precision = b.precision = prec
     w = WarpFieldNet(8, 256, 60, 40)
+    w.precision = prec
     w.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_params(103, out_scale=0.3).items()})
     w = w.to(dev)
     p = SmplNerfPipeline(a, b, w, PipelineArgs(), *enc, PositionalEncoder(10, 0))
