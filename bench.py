@@ -183,7 +183,7 @@ def main():
             for prec in sorted(MODES):
                 if prec == a.precision:
                     continue
-                pipe.model_coarse.precision = pipe.model_fine.precision = prec
+                pipe.set_precision(prec)
                 pipe(data)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -202,7 +202,7 @@ def main():
                              "rgb_fine_max_abs_diff_vs_" + a.precision: float((o2[1] - out[1]).abs().max()),
                              "mlp_kernel": MODES[prec][0], "mlp_kernel_ms_per_step": mlp_s * 1e3,
                              "mfma_tflops": tf, "mfma_peak": pk, "mfma_frac": tf / pk}
-            pipe.model_coarse.precision = pipe.model_fine.precision = a.precision
+            pipe.set_precision(a.precision)
 
     train = None
     if a.train_rays > 0:

@@ -44,6 +44,16 @@ class NerfPipeline(nn.Module):
         self.position_encoder = position_encoder
         self.direction_encoder = direction_encoder
 
+    def set_precision(self, precision: str):
+        """Matrix-core arithmetic of every net of the pipeline: "fp32" (exact fp32 MFMA), "bf16x6" (split-bf16, fp32-class
+        accuracy - the parity mode on the bf16 matrix cores) or "bf16x3" (split-bf16, ~2^-16 relative)."""
+        if precision not in ("fp32", "bf16x6", "bf16x3"):
+            raise ValueError(f"unknown precision {precision!r}")
+        for m in self.modules():
+            if hasattr(m, "precision") and m is not self:
+                m.precision = precision
+        return self
+
     def _noise(self, shape, device):
         # utils.py:171-173: drawn whenever sigma_noise_std > 0, also in eval mode (quirk Q3)
         std = getattr(self.args, "sigma_noise_std", 0.)

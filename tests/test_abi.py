@@ -167,3 +167,17 @@ def test_split_bf16_and_render_entry_points_validate_on_the_host(lib):
     assert lib.snerf_render_rays_f32(*args) == -1 and b"null" in lib.snerf_last_error_string()
     args[4] = 1
     assert lib.snerf_render_rays_f32(*args) == -1 and b"precision" in lib.snerf_last_error_string()
+
+
+def test_pipeline_set_precision_reaches_every_net():
+    import torch
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import PipelineArgs, SmplNerfPipeline
+    enc = PositionalEncoder(10, 0)
+    pipe = SmplNerfPipeline(RenderRayNet(), RenderRayNet(), WarpFieldNet(8, 256, 60, 40), PipelineArgs(), enc,
+                            PositionalEncoder(4, 0), enc)
+    assert pipe.set_precision("bf16x6") is pipe
+    assert {pipe.model_coarse.precision, pipe.model_fine.precision, pipe.model_warp_field.precision} == {"bf16x6"}
+    with pytest.raises(ValueError):
+        pipe.set_precision("fp16")
