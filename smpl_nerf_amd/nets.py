@@ -605,9 +605,16 @@ class AppendVerticesNet(RenderRayNet):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _FusedMlpFn.apply(self, desc, dummy_x, d.detach(), 0, int(samples_per_ray), add.detach(),
                                      *self._ordered_params())
-        packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=add.device, dtype=torch.float32)
         lib = _lib.load()
+        if self.precision in ("bf16x6", "bf16x3") and self.width == 256:
+            ns = 3 if self.precision == "bf16x6" else 2
+            packed = self.packed_weights_bf16(desc, ns)
+            with torch.cuda.device(add.device), _lib.timed(f"mlp_fwd[n={n}]"):
+                check(lib.snerf_mlp_fwd_bf16_f32(desc, ptr(packed), ns, ptr(dummy_x), ptr(d), 0, ptr(add), n,
+                                                 int(samples_per_ray), ptr(raw), current_stream()), "snerf_mlp_fwd_bf16_f32")
+            return raw
+        packed = self.packed_weights(desc)
         with torch.cuda.device(add.device), _lib.timed(f"mlp_fwd[n={n}]"):
             check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(dummy_x), ptr(d), 0, ptr(add), n, int(samples_per_ray),
                                         ptr(raw), current_stream()), "snerf_mlp_fwd_f32")

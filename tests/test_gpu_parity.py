@@ -494,12 +494,14 @@ def _av_pipeline(dev, wb=0, run_fine=0):
                                   PositionalEncoder(10, 0), PositionalEncoder(4, 0)), nets
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("wb", [0, 1])
-def test_append_vertices_pipeline(dev, wb):
+def test_append_vertices_pipeline(dev, wb, prec):
     g = load_golden("g9_append_vertices.npz")
     data = syn.frame_batch(128, 128, phi=3.0, theta=-10.0, seed=11)
     d = [T(a[g["sub"]], dev) for a in data[:4]] + [torch.from_numpy(g["images"]).to(dev), T(data[4][g["sub"]], dev)]
     pipe, nets = _av_pipeline(dev, wb=wb)
+    pipe.set_precision(prec)
     with torch.no_grad():
         out = pipe(d)
         assert out[0] is out[1] and tuple(out[2].shape) == (24, 64, 3)
@@ -507,7 +509,7 @@ def test_append_vertices_pipeline(dev, wb):
         assert maxabs(N(out[3]), g[f"coarse_alpha_wb{wb}"]) <= 5e-5
         # the fine branch (which the reference cannot run, pipeline.py:71) against the oracle's restatement
         pipe, _ = _av_pipeline(dev, wb=wb, run_fine=1)
-        got = pipe(d)
+        got = pipe.set_precision(prec)(d)
     from smpl_nerf_amd.ops import uniform_u
     from smpl_nerf_amd.synthetic_smpl import LinearBodyModel
     verts = LinearBodyModel(seed=3)(body_pose=torch.from_numpy(syn.human_poses((41, 38), 0, 60, 10)[g["images"]])).vertices.numpy()
