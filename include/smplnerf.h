@@ -279,6 +279,24 @@ int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_
                           int Nf, int white_background, void *workspace, float *rgb, float *rgb_fine,
                           float *samples_fine, float *densities_fine, snerf_stream_t stream);
 
+/* ---- a7: the whole SmplNerfPipeline.forward for inference in one call (models/smpl_nerf_pipeline.py:16-100) ------
+ * snerf_render_rays_f32 with the warp stage in front of both nets: warp(samples) -> x' = x + warp, per-sample directions
+ * x' - o -> net -> composite (coarse: distances scaled by |x' - o| per sample, :63; fine: by the ray direction, :95-98);
+ * the hierarchical samples are drawn on the un-warped ray (:68).  pose_enc [B, pose_dim] = the encoded two joint angles
+ * (:28-30).  precision as in snerf_render_rays_f32 (the warp net runs fp32 for 0 and three-part split-bf16 otherwise;
+ * packed_warp from snerf_warp_pack_f32 / snerf_warp_pack_bf16 accordingly).  Nf >= 1.  workspace:
+ * snerf_render_rays_smpl_workspace_bytes bytes.  Outputs: rgb [B,3], rgb_fine [B,3], warp_fine / samples_fine /
+ * warped_fine [B,Nc+Nf,3], densities_fine [B,Nc+Nf]. */
+int64_t snerf_render_rays_smpl_workspace_bytes(int64_t B, int Nc, int Nf);
+int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+                               const snerf_mlp_desc *desc_fine, const void *packed_fine,
+                               const snerf_warp_desc *desc_warp, const void *packed_warp, int precision,
+                               const float *ray_samples, const float *rays_o, const float *rays_d, const float *z_vals,
+                               const float *pose_enc, const float *u, const float *noise_coarse,
+                               const float *noise_fine, int64_t B, int Nc, int Nf, int white_background,
+                               void *workspace, float *rgb, float *rgb_fine, float *warp_fine, float *samples_fine,
+                               float *warped_fine, float *densities_fine, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,9 @@ SIGNATURES = {
     "snerf_raygen_f64": (c_int, [_P, c_int64, c_int, c_int, c_double, _P, _P, c_int, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "snerf_mlp_fwd_encoded_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int64, c_int64, _P, _P]),
     "snerf_render_rays_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "snerf_render_rays_smpl_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "snerf_render_rays_smpl_f32": (c_int, [POINTER(MlpDesc), _P, POINTER(MlpDesc), _P, POINTER(WarpDesc), _P, c_int, _P, _P, _P, _P,
+                                           _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "snerf_render_rays_f32": (c_int, [POINTER(MlpDesc), _P, POINTER(MlpDesc), _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64,
                                       c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
 }

@@ -31,6 +31,36 @@ static int mlp(const snerf_mlp_desc *desc, const void *packed, int precision, co
     return snerf_mlp_fwd_bf16_f32(desc, packed, precision, x, dirs, 0, nullptr, n, spr, raw, stream);
 }
 
+static int mlp_per_sample_dirs(const snerf_mlp_desc *desc, const void *packed, int precision, const float *x,
+                               const float *sdirs, int64_t n, int spr, float *raw, snerf_stream_t stream) {
+    if (precision == 0)
+        return snerf_mlp_fwd_f32(desc, reinterpret_cast<const float *>(packed), x, sdirs, 1, nullptr, n, spr, raw, stream);
+    return snerf_mlp_fwd_bf16_f32(desc, packed, precision, x, sdirs, 1, nullptr, n, spr, raw, stream);
+}
+static int warp(const snerf_warp_desc *desc, const void *packed, int precision, const float *x, const float *pose_enc,
+                const float *o, int64_t n, int spr, float *w, float *warped, float *sdirs, snerf_stream_t stream) {
+    if (precision == 0)
+        return snerf_warp_fwd_f32(desc, reinterpret_cast<const float *>(packed), x, pose_enc, o, n, spr, w, warped, sdirs,
+                                  stream);
+    return snerf_warp_fwd_bf16_f32(desc, packed, x, pose_enc, o, n, spr, w, warped, sdirs, stream);
+}
+
+struct SmplWs {
+    int64_t base, warp_c, warped_c, sdirs_c, sdirs_f, total;
+};
+static SmplWs smpl_ws(int64_t B, int Nc, int Nf) {
+    SmplWs w{};
+    const int64_t N = Nc + Nf;
+    int64_t off = align16(render_ws(B, Nc, Nf).total);
+    w.base = 0;
+    w.warp_c = off, off += align16(B * Nc * 3 * 4);
+    w.warped_c = off, off += align16(B * Nc * 3 * 4);
+    w.sdirs_c = off, off += align16(B * Nc * 3 * 4);
+    w.sdirs_f = off, off += align16(B * N * 3 * 4);
+    w.total = off;
+    return w;
+}
+
 }  // namespace snerf
 
 extern "C" int64_t snerf_render_rays_workspace_bytes(int64_t B, int Nc, int Nf) {
@@ -86,6 +116,61 @@ extern "C" int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const vo
         return rc;
     const int N = Nc + Nf;
     if ((rc = mlp(desc_fine, packed_fine, precision, samples_fine, rays_d, B * N, N, raw_f, stream))) return rc;
+    return snerf_composite_fwd_f32(raw_f, z_fine, rays_d, 0, noise_fine, B, N, white_background, rgb_fine, nullptr,
+                                   densities_fine, stream);
+}
+
+extern "C" int64_t snerf_render_rays_smpl_workspace_bytes(int64_t B, int Nc, int Nf) {
+    using namespace snerf;
+    if (B < 0 || Nc < 1 || Nf < 1) return fail(SNERF_E_BADARG, "render_rays_smpl_workspace_bytes: bad B/Nc/Nf");
+    return smpl_ws(B, Nc, Nf).total;
+}
+
+extern "C" int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+                                          const snerf_mlp_desc *desc_fine, const void *packed_fine,
+                                          const snerf_warp_desc *desc_warp, const void *packed_warp, int precision,
+                                          const float *ray_samples, const float *rays_o, const float *rays_d,
+                                          const float *z_vals, const float *pose_enc, const float *u,
+                                          const float *noise_coarse, const float *noise_fine, int64_t B, int Nc, int Nf,
+                                          int white_background, void *workspace, float *rgb, float *rgb_fine,
+                                          float *warp_fine, float *samples_fine, float *warped_fine,
+                                          float *densities_fine, snerf_stream_t stream) {
+    using namespace snerf;
+    if (precision != 0 && precision != 2 && precision != 3)
+        return fail(SNERF_E_BADARG, "render_rays_smpl: precision must be 0 (fp32), 2 (bf16x3) or 3 (bf16x6)");
+    if (B < 0 || Nc < 1 || Nf < 1) return fail(SNERF_E_BADARG, "render_rays_smpl: bad B/Nc/Nf");
+    if (B == 0) return SNERF_OK;
+    if (!desc_coarse || !packed_coarse || !desc_fine || !packed_fine || !desc_warp || !packed_warp || !ray_samples ||
+        !rays_o || !rays_d || !z_vals || !pose_enc || !u || !workspace || !rgb || !rgb_fine || !warp_fine || !samples_fine ||
+        !warped_fine || !densities_fine)
+        return fail(SNERF_E_BADARG, "render_rays_smpl: null pointer");
+    if (desc_coarse->add_dim || desc_fine->add_dim)
+        return fail(SNERF_E_BADARG, "render_rays_smpl: nets with additional inputs go through snerf_mlp_fwd_* directly");
+    if (!aligned(workspace, 16)) return fail(SNERF_E_ALIGN, "render_rays_smpl: workspace must be 16-byte aligned");
+    const RenderWs w = render_ws(B, Nc, Nf);
+    const SmplWs sw = smpl_ws(B, Nc, Nf);
+    char *ws = reinterpret_cast<char *>(workspace);
+    auto f = [&](int64_t off) { return reinterpret_cast<float *>(ws + off); };
+    float *raw_c = f(w.raw_c), *weights_c = f(w.weights_c), *alpha_c = f(w.alpha_c), *z_samples = f(w.z_samples);
+    float *z_fine = f(w.z_fine), *raw_f = f(w.raw_f);
+    float *warp_c = f(sw.warp_c), *warped_c = f(sw.warped_c), *sdirs_c = f(sw.sdirs_c), *sdirs_f = f(sw.sdirs_f);
+    const int N = Nc + Nf;
+    int rc;
+    // coarse: warp the given samples, net on (x', x' - o), compositing scaled per sample (:38-63)
+    if ((rc = warp(desc_warp, packed_warp, precision, ray_samples, pose_enc, rays_o, B * Nc, Nc, warp_c, warped_c, sdirs_c, stream)))
+        return rc;
+    if ((rc = mlp_per_sample_dirs(desc_coarse, packed_coarse, precision, warped_c, sdirs_c, B * Nc, Nc, raw_c, stream))) return rc;
+    if ((rc = snerf_composite_fwd_f32(raw_c, z_vals, sdirs_c, 1, noise_coarse, B, Nc, white_background, rgb, weights_c, alpha_c,
+                                      stream)))
+        return rc;
+    // hierarchical samples on the un-warped ray (:68), then the fine stage (:71-98)
+    if ((rc = snerf_sample_pdf_f32(z_vals, weights_c, u, rays_o, rays_d, B, Nc, Nf, nullptr, z_samples, z_fine, samples_fine,
+                                   stream)))
+        return rc;
+    if ((rc = warp(desc_warp, packed_warp, precision, samples_fine, pose_enc, rays_o, B * N, N, warp_fine, warped_fine, sdirs_f,
+                   stream)))
+        return rc;
+    if ((rc = mlp_per_sample_dirs(desc_fine, packed_fine, precision, warped_fine, sdirs_f, B * N, N, raw_f, stream))) return rc;
     return snerf_composite_fwd_f32(raw_f, z_fine, rays_d, 0, noise_fine, B, N, white_background, rgb_fine, nullptr,
                                    densities_fine, stream);
 }

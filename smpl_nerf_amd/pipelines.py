@@ -167,6 +167,50 @@ class SmplNerfPipeline(NerfPipeline):
         return (rgb, rgb_fine, warp_f.view(B, N, 3), ray_samples_fine, warped_f.view(B, N, 3), densities_fine)  # :100
 
 
+    def render_rays(self, data):
+        """forward(data) for inference through the single C-ABI call snerf_render_rays_smpl_f32 (run_fine = 1 only)."""
+        from . import _lib
+        from ._lib import check, ptr, current_stream
+        ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
+        args = self.args
+        if not args.human_pose_encoding or not args.run_fine:
+            raise NotImplementedError("SmplNerfPipeline.render_rays: human_pose_encoding = 1 and run_fine = 1 only")
+        B, Nc = z_vals.shape
+        Nf = int(args.number_fine_samples)
+        N = Nc + Nf
+        dev = ray_samples.device
+        mc, mf, mw = self.model_coarse, self.model_fine, self.model_warp_field
+        if not (mc.precision == mf.precision == mw.precision):
+            raise RuntimeError("render_rays: all nets must use the same precision mode (set_precision)")
+        prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[mc.precision]
+        goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)
+        pose_enc = self.human_pose_encoder.encode(goal_pose.contiguous()).contiguous()
+        descs, packed = [], []
+        for m in (mc, mf):
+            d = m.desc_for_encoders(self.position_encoder, self.direction_encoder, False)
+            descs.append(d)
+            packed.append(m.packed_weights(d) if prec == 0 else m.packed_weights_bf16(d, prec))
+        pe = self.position_encoder
+        wdesc = _lib.WarpDesc(mw.width, pe.number_frequencies, 1 if pe.include_identity else 0, mw.direcions_dim)
+        wpacked = mw._packed(wdesc) if prec == 0 else mw._packed_bf16(wdesc)
+        lib = _lib.load()
+        f32 = dict(device=dev, dtype=torch.float32)
+        ws = torch.empty(int(lib.snerf_render_rays_smpl_workspace_bytes(B, Nc, Nf)), device=dev, dtype=torch.uint8)
+        rgb, rgb_fine = torch.empty((B, 3), **f32), torch.empty((B, 3), **f32)
+        warp_f, samples_f, warped_f = (torch.empty((B, N, 3), **f32) for _ in range(3))
+        dens = torch.empty((B, N), **f32)
+        u = ops.uniform_u(Nf, dev)
+        nc, nf = self._noise((B, Nc), dev), self._noise((B, N), dev)
+        x, o, d, z = (t.contiguous() for t in (ray_samples, ray_translation, ray_direction, z_vals))
+        with torch.cuda.device(dev), _lib.timed(f"render_rays_smpl[B={B}]"):
+            check(lib.snerf_render_rays_smpl_f32(descs[0], ptr(packed[0]), descs[1], ptr(packed[1]), wdesc, ptr(wpacked), prec,
+                                                 ptr(x), ptr(o), ptr(d), ptr(z), ptr(pose_enc), ptr(u), ptr(nc), ptr(nf), B, Nc,
+                                                 Nf, 1 if args.white_background else 0, ptr(ws), ptr(rgb), ptr(rgb_fine),
+                                                 ptr(warp_f), ptr(samples_f), ptr(warped_f), ptr(dens), current_stream()),
+                  "snerf_render_rays_smpl_f32")
+        return rgb, rgb_fine, warp_f, samples_f, warped_f, dens
+
+
 class AppendVerticesPipeline(NerfPipeline):
     """models/append_vertices_pipeline.py:7-94 drop-in.  data = [ray_samples, ray_translation, ray_direction,
     z_vals, images (estimator input, e.g. image indices), rgb_truth]; `smpl_estimator(images)` returns

@@ -913,3 +913,23 @@ def test_warp_field_net_split_bf16(dev):
         assert maxabs(outs["bf16x6"][0], outs["fp32"][0]) <= 4e-6 * scale + 1e-7
         assert maxabs(outs["bf16x6"][1], outs["fp32"][1]) <= 4e-6 * scale + 5e-7
         assert maxabs(outs["bf16x6"][2], outs["fp32"][2]) <= 4e-6 * scale + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("wb", [0, 1])
+def test_render_rays_smpl_single_call(dev, prec, wb):
+    """snerf_render_rays_smpl_f32 (SmplNerfPipeline.forward behind one C-ABI call) returns exactly what the separate entry
+    points return through SmplNerfPipeline.forward."""
+    g = load_golden("g6_smpl_nerf_pipeline.npz")
+    pipe, _ = _smpl_pipeline(dev, wb=wb)
+    pipe.set_precision(prec)
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    sub = g["sub"]
+    d = [T(a[sub], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][sub], dev)]
+    with torch.no_grad():
+        ref = pipe(d)
+        out = pipe.render_rays(d)
+    assert len(ref) == len(out) == 6
+    for a, b in zip(ref, out):
+        assert a.shape == b.shape and torch.equal(a.reshape(b.shape), b)
