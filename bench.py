@@ -42,11 +42,11 @@ except Exception:
     pass
 
 
-def build_pipeline(dev, precision="fp32"):
+def build_pipeline(dev, precision="fp32", workload="nerf"):
     from smpl_nerf_amd import synthetic as syn
     from smpl_nerf_amd.nets import RenderRayNet
     from smpl_nerf_amd.ops import PositionalEncoder
-    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs, SmplNerfPipeline
 
     params = list(syn.make_scene_nets(101))
     nets = []
@@ -56,6 +56,15 @@ def build_pipeline(dev, precision="fp32"):
         m.precision = precision
         nets.append(m.to(dev).eval())
     args = PipelineArgs(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0)
+    if workload == "smpl_nerf":   # BASELINE configs[2]: pose-conditioned warp field in front of both nets
+        from smpl_nerf_amd.nets import WarpFieldNet
+        pw = syn.make_warp_field_params(103, out_scale=0.3)
+        mw = WarpFieldNet(8, 256, 60, 40)
+        mw.load_state_dict({k: torch.from_numpy(v) for k, v in pw.items()})
+        params.append(pw)
+        pipe = SmplNerfPipeline(nets[0], nets[1], mw.to(dev).eval(), args, PositionalEncoder(10, 0), PositionalEncoder(4, 0),
+                                PositionalEncoder(10, 0))
+        return pipe.set_precision(precision), params
     pipe = NerfPipeline(nets[0], nets[1], args, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
     return pipe, params
 
@@ -67,9 +76,13 @@ def cpu_baseline(params, data_np, n_rays, u):
     args = O.Args(u=u)
     pe, de = O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0)
     sub = [a[:n_rays] for a in data_np]
-    O.nerf_pipeline_forward(params[0], params[1], args, pe, de, [a[:64] for a in data_np])   # warm-up
+    if len(params) == 3:   # smpl_nerf: data = [samples, o, d, z, goal_pose, rgb]
+        fwd = lambda d: O.smpl_nerf_pipeline_forward(params[0], params[1], params[2], args, pe, de, O.PositionalEncoder(10, 0), d)
+    else:
+        fwd = lambda d: O.nerf_pipeline_forward(params[0], params[1], args, pe, de, d)
+    fwd([a[:64] for a in data_np])   # warm-up
     t0 = time.perf_counter()
-    out = O.nerf_pipeline_forward(params[0], params[1], args, pe, de, sub)
+    out = fwd(sub)
     dt = time.perf_counter() - t0
     return n_rays * 256 / dt, dt, out
 
@@ -81,12 +94,12 @@ def train_section(pipe, data, rays, steps, world, rank, dev):
     from smpl_nerf_amd import _lib
     from smpl_nerf_amd.dist import barrier, max_over_ranks
     from smpl_nerf_amd.trainer import DataParallelTrainer
-    mc, mf = pipe.model_coarse, pipe.model_fine
-    for m in (mc, mf):
+    models = [pipe.model_coarse, pipe.model_fine] + ([pipe.model_warp_field] if hasattr(pipe, "model_warp_field") else [])
+    for m in models:
         m.train()
         for p in m.parameters():
             p.requires_grad_(True)
-    tr = DataParallelTrainer(pipe, [mc, mf], lr=5e-4)
+    tr = DataParallelTrainer(pipe, models, lr=5e-4)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     n_total = data[0].shape[0]
     batches = []
@@ -130,6 +143,9 @@ def main():
     ap.add_argument("--precision", choices=sorted(MODES), default="bf16x6",
                     help="matrix-core arithmetic of the render kernel: bf16x6 (split-bf16, fp32-class accuracy, default), "
                          "fp32 (v_mfma_f32_16x16x4_f32), bf16x3 (2-part split, ~1e-5 relative)")
+    ap.add_argument("--workload", choices=["nerf", "smpl_nerf"], default="nerf",
+                    help="nerf = BASELINE configs[1] (the metric's configuration); smpl_nerf = configs[2] (warp field + per-sample "
+                         "directions in front of the same nets), same frame size and sample counts")
     ap.add_argument("--train-rays", type=int, default=4096, help="rays per GPU per training step (0 = skip the train section)")
     ap.add_argument("--train-steps", type=int, default=10)
     a = ap.parse_args()
@@ -154,10 +170,13 @@ def main():
     from smpl_nerf_amd import _lib, synthetic as syn
     from smpl_nerf_amd.dist import barrier, max_over_ranks, shard_frames
 
-    pipe, params = build_pipeline(dev, a.precision)
+    pipe, params = build_pipeline(dev, a.precision, a.workload)
     # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
     frame_id = shard_frames(world, rank)
     data_np = syn.frame_batch(128, 128, phi=7.0 * frame_id, theta=25.0 * frame_id, seed=7 + frame_id)
+    if a.workload == "smpl_nerf":   # one of the 10 arm poses of configs[2] for the whole frame (render.py:190-220)
+        pose = np.tile(syn.human_poses()[3 + frame_id % 7][None], (data_np[0].shape[0], 1)).astype(np.float32)
+        data_np = list(data_np[:4]) + [pose, data_np[4]]
     data = [torch.from_numpy(x).to(dev) for x in data_np]
     rays = data[0].shape[0]
     evals_per_step = rays * 256
@@ -250,8 +269,11 @@ def main():
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "nerf 128x128 frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, "
-                                   "width 256, skips [4], forward render (BASELINE configs[1])",
+            "config": {"workload": ("nerf 128x128 frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, "
+                                    "width 256, skips [4], forward render (BASELINE configs[1])") if a.workload == "nerf" else
+                                   ("smpl_nerf 128x128 frame per GPU (one arm pose), coarse+fine 64+128 samples/ray, warp field + "
+                                    "netdepth 8 / width 256 nets, forward render (BASELINE configs[2]); roofline counts the "
+                                    "RenderRayNet kernel only"),
                        "rays_per_step_per_gpu": rays, "ray_samples_per_ray": 256, "parallelism": f"dp{world} (rays of "
                        "independent frames per rank, no data-path collective)"},
             "rays_per_s": world * a.steps * rays / elapsed,
