@@ -12,7 +12,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 struct TrainLayout;
 // defined in mlp_train.hip: split-K wgrad + fixed-order reduce for any (Plan, TrainLayout)
 int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
-                 float *flat_grad, hipStream_t s);
+                 float *flat_grad, hipStream_t s, int wide_nsplit = 0);
 // defined in mlp.hip: packs params_flat into the slab stream described by `P` (any plan)
 int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStream_t s, const char *what);
 

@@ -231,14 +231,6 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
 // ------------------------------------------------------------------------------------------------
 // wgrad
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float *act;
-    const float *dy;
-    float *part;  // [G][gp_floats]
-    int64_t n;
-    int64_t chunk;  // samples per K-split, multiple of 16
-};
-
 // One workgroup = 16 waves = one (layer, input segment, <=16 input k-blocks) job x one chunk of samples: the whole
 // <=256x256 block of dW.  Wave (bi, bj) owns the 64x64 sub-block of output tiles 4bi.. x input tiles 4bj.. (4x4
 // accumulator tiles, 64 VGPRs).  Operands reach the matrix cores through LDS: a stage is 16 samples of every
@@ -252,25 +244,6 @@ constexpr int WL_ROW_FLOATS = WL_STAGE * 16;      // one tile-row of a stage: 1 
 constexpr int WL_SLOT_FLOATS = 32 * WL_ROW_FLOATS;  // 16 dY rows + 16 X rows
 constexpr int WL_SLOTS = 4;                          // ring depth: up to WL_SLOTS - 2 stages in flight behind the one awaited
 constexpr int WL_LDS_BYTES = WL_SLOTS * WL_SLOT_FLOATS * 4;
-
-// A (layer, input segment) pair is "wide" when it fills the 16-wave workgroup of mlp_wgrad_kernel with real work
-// (the 256x256 layers and the 128x256 one); the narrow pairs - encoder columns, heads, the 128x128 layer: 15 % of
-// the FLOPs - go to mlp_wgrad_direct_kernel, whose independent single-wave workgroups have no per-stage barrier.
-__host__ __device__ inline bool wgrad_wide(const Layer &Ly, int s) { return Ly.t_out >= 8 && Ly.seg[s].nkb >= 16; }
-__host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups of <= 16 input k-blocks
-    int jobs = 0;
-    for (int l = 0; l < P.nlayers; ++l)
-        for (int s = 0; s < P.layer[l].nseg; ++s)
-            if (wgrad_wide(P.layer[l], s)) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
-    return jobs;
-}
-__host__ __device__ inline int wgrad_direct_jobs(const Plan &P) {  // narrow jobs: 4x4-tile blocks
-    int jobs = 0;
-    for (int l = 0; l < P.nlayers; ++l)
-        for (int s = 0; s < P.layer[l].nseg; ++s)
-            if (!wgrad_wide(P.layer[l], s)) jobs += ((P.layer[l].t_out + 3) / 4) * ((P.layer[l].seg[s].nkb + 3) / 4);
-    return jobs;
-}
 
 // the stage loop and the epilogue for one wave that owns TI x TJ accumulator tiles
 template <int TI, int TJ>
@@ -580,7 +553,7 @@ int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, flo
 
 // split-K wgrad + reduce for any (Plan, TrainLayout)
 int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
-                 float *flat_grad, hipStream_t s) {
+                 float *flat_grad, hipStream_t s, int wide_nsplit) {
     const int G = wgrad_chunks(n);
     WgradArgs W{};
     W.act = act;
@@ -597,8 +570,12 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     }
     int rc;
     if (const int jobs = wgrad_jobs(P)) {
-        hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(jobs, G), dim3(WL_THREADS), WL_LDS_BYTES, s, P, L, W);
-        if ((rc = check_launch("wgrad"))) return rc;
+        if (wide_nsplit) {   // the wide jobs on the bf16 matrix cores (mlp_train_bf16.hip)
+            if ((rc = launch_wgrad_wide_bf16(P, L, W, jobs, G, wide_nsplit, s))) return rc;
+        } else {
+            hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(jobs, G), dim3(WL_THREADS), WL_LDS_BYTES, s, P, L, W);
+            if ((rc = check_launch("wgrad"))) return rc;
+        }
     }
     if (const int jobs = wgrad_direct_jobs(P)) {
         hipLaunchKernelGGL(mlp_wgrad_direct_kernel, dim3(jobs, G), dim3(WG_THREADS), 0, s, P, L, W);

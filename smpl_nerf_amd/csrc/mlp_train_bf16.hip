@@ -240,6 +240,204 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
     wait_pair<NS, 0>(pipe.fa0, pipe.fa1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad of the wide jobs on the bf16 matrix cores
+// ------------------------------------------------------------------------------------------------
+// dW[i][j] = sum_s dY[s][i] X[s][j] with v_mfma_f32_16x16x32_bf16: the contraction index is the sample, so both
+// operands are "8 consecutive samples of one feature per lane" - the transpose of the tile-row layout
+// ([sample][16 features]).  One workgroup = 8 waves = one wide (layer, segment) job x one chunk of samples; wave
+// (bi, bj) owns output tiles 8bi.. x input tiles 4bj.. (8 x 4 accumulator tiles = 128 VGPRs).  A stage is 32 samples
+// of every tile-row of the job, brought into LDS by DMA as fp32 (two 1 KiB pieces per tile-row; 2 slots of 64 KiB);
+// each wave then gathers its operands with 8 ds_read_b32 per tile (feature i = lane & 15, samples 8 (lane >> 4) + e),
+// splits them into NS bf16 parts in registers (the same split as the forward) and runs NS(NS+1)/2 MFMAs per tile pair.
+// The DMA places sample s of a 16-sample piece at position s ^ ((s >> 3) & 1): the four lane groups of a gather then
+// hit disjoint banks.  Products are exact, accumulation fp32; partials and the reduce are those of the fp32 kernel.
+constexpr int WB_WAVES = 8, WB_THREADS = WB_WAVES * 64;
+constexpr int WB_STAGE = 32;                            // samples per stage = one MFMA k-block
+constexpr int WB_ROW_FLOATS = WB_STAGE * 16;            // one tile-row of a stage: 2 KiB
+constexpr int WB_SLOT_FLOATS = 32 * WB_ROW_FLOATS;      // 16 dY rows + 16 X rows: 64 KiB
+constexpr int WB_LDS_BYTES = 2 * WB_SLOT_FLOATS * 4;
+
+template <int NS>
+__global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, TrainLayout L, WgradArgs A) {
+    constexpr int TI = 8, TJ = 4;
+    using Tm = Terms<NS>;
+    extern __shared__ __attribute__((aligned(16))) float wring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- decode the job: (wide layer, segment, group of 16 input k-blocks), like mlp_wgrad_kernel ----
+    int job = blockIdx.x, l = 0, s = 0, kb0 = 0;
+    for (l = 0; l < P.nlayers; ++l) {
+        bool found = false;
+        kb0 = 0;
+        for (s = 0; s < P.layer[l].nseg; ++s) {
+            const int cnt = wgrad_wide(P.layer[l], s) ? (P.layer[l].seg[s].nkb + 15) / 16 : 0;
+            if (job < cnt) { found = true; break; }
+            job -= cnt;
+            kb0 += P.layer[l].seg[s].nkb;
+        }
+        if (found) break;
+    }
+    const Layer &Ly = P.layer[l];
+    const int jb = job;
+    const int n_rows_y = Ly.t_out, n_rows_x = min(16, Ly.seg[s].nkb - 16 * jb);
+    const int64_t n = A.n;
+    int first_seg = 0;
+    while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
+    const int bi = wave >> 2, bj = wave & 3;
+    const int n_ti = max(0, min(TI, n_rows_y - TI * bi)), n_tj = max(0, min(TJ, n_rows_x - TJ * bj));
+    const bool active = n_ti > 0 && n_tj > 0;
+    const bool want_bias = (s == first_seg && jb == 0 && bj == 0);
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+    const int nstages = begin < end ? (int)((end - begin + WB_STAGE - 1) / WB_STAGE) : 0;
+
+    // ---- stage loader: this wave brings LDS rows 4*wave .. 4*wave+3 (rows 0..15 = dY, 16..31 = X), two 16-sample
+    // pieces each; rows the job does not have re-load row 0 of dY so that every wave issues exactly 8 pieces per stage
+    const float *row_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wave + q;
+        int64_t grow = L.dy[l];
+        if (r < 16) {
+            if (r < n_rows_y) grow = L.dy[l] + r;
+            row_src[q] = A.dy + grow * n * 16;
+        } else if (r - 16 < n_rows_x) {
+            row_src[q] = A.act + (int64_t)(seg_act_row(P, L, l, s) + 16 * jb + (r - 16)) * n * 16;
+        } else {
+            row_src[q] = A.dy + grow * n * 16;
+        }
+    }
+    auto issue = [&](int stage, int slot) {
+        // lane covers 16 B of a piece: position q = lane >> 2 (of 16), feature quad lane & 3; position q holds sample
+        // q ^ ((q >> 3) & 1) of the piece (bank swizzle, see above)
+        const int q = lane >> 2, sp = q ^ ((q >> 3) & 1);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int64_t smp = min(begin + (int64_t)stage * WB_STAGE + 16 * sub + sp, n - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(row_src[r] + smp * 16 + (lane & 3) * 4),
+                    (__attribute__((address_space(3))) void *)(wring + slot * WB_SLOT_FLOATS + (4 * wave + r) * WB_ROW_FLOATS +
+                                                               sub * 256),
+                    16, 0, 0);
+        }
+    };
+
+    f4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
+
+    // operand of one tile: this lane's 8 samples (8 kq + e) of feature i16 -> NS packed-bf16 parts
+    auto gather = [&](const float *row, bool zero, bf8(&parts)[NS], float &sum) __attribute__((always_inline)) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int smp = 8 * kq + e;                               // sample within the stage
+            const int pos = (smp & 15) ^ (((smp & 15) >> 3) & 1);      // its position within its 16-sample piece
+            v[e] = row[(smp >> 4) * 256 + pos * 16 + i16];
+        }
+        if (zero) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair_into<NS>(v[2 * e], v[2 * e + 1], parts, e);
+    };
+
+    if (nstages > 0) {
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int st = 0; st < nstages; ++st) {
+        const int slot = st & 1;
+        if (st + 1 < nstages) issue(st + 1, slot ^ 1);  // the other slot was freed by the barrier that ended stage st-1
+        if (active) {
+            const float *base = wring + slot * WB_SLOT_FLOATS;
+            const int64_t s0 = begin + (int64_t)st * WB_STAGE;
+            // masked samples (past the chunk end) contribute a = 0; per lane the 8 samples 8 kq + e
+            const bool tail = s0 + WB_STAGE > end;
+            bf8 bpart[TJ][NS];
+            float dummy = 0.f;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) gather(base + (16 + TJ * bj + j) * WB_ROW_FLOATS, false, bpart[j], dummy);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                bf8 apart[NS];
+                if (!tail) {
+                    gather(base + (TI * bi + i) * WB_ROW_FLOATS, i >= n_ti, apart, bsum[i]);
+                } else {   // ragged end of the chunk: zero the samples past it one by one
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int smp = 8 * kq + e;
+                        const int pos = (smp & 15) ^ (((smp & 15) >> 3) & 1);
+                        const float x = base[(TI * bi + i) * WB_ROW_FLOATS + (smp >> 4) * 256 + pos * 16 + i16];
+                        v[e] = (i < n_ti && s0 + smp < end) ? x : 0.f;
+                        bsum[i] += v[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split_pair_into<NS>(v[2 * e], v[2 * e + 1], apart, e);
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int t = 0; t < Tm::N; ++t)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apart[Tm::A[t]], bpart[j][Tm::B[t]], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nstages) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage st+1 landed (this wave's pieces)
+            __builtin_amdgcn_s_barrier();                      // ... everyone's, and everyone is done reading `slot`
+        }
+    }
+    if (!active) return;
+    // ---- write the partial of this (block, chunk): same format as mlp_wgrad_kernel -----------------------
+    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        if (i >= n_ti) continue;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            if (j >= n_tj) continue;
+            const int ti = TI * bi + i, tj = kb0 + 16 * jb + TJ * bj + j;
+            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
+        }
+        if (want_bias) {   // lane (i16, kq) summed samples 8 kq .. of feature i16
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (TI * bi + i) * 16 + lane] = v;
+        }
+    }
+}
+
+int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, int nsplit, hipStream_t s) {
+    static bool attr = false;  // idempotent; a race only repeats the call
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_wgrad_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WB_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_wgrad_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WB_LDS_BYTES) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "wgrad_bf16: cannot raise the dynamic LDS limit to %d bytes", WB_LDS_BYTES);
+        attr = true;
+    }
+    if (nsplit == 3) hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<3>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
+    else hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<2>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
+    return check_launch("wgrad_bf16");
+}
+
 static int plans_t(const snerf_mlp_desc *desc, Plan &P, const char *what) {
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "%s: desc is null", what);
@@ -330,7 +528,9 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
     if (nsplit == 3) rc = input_grad ? launch_dgrad_bf16<3, true>(A, s) : launch_dgrad_bf16<3, false>(A, s);
     else rc = input_grad ? launch_dgrad_bf16<2, true>(A, s) : launch_dgrad_bf16<2, false>(A, s);
     if (rc) return rc;
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);  // fp32
+    // wide jobs on the bf16 matrix cores with the same number of parts, narrow jobs and the reduce in fp32
+    static const bool bf16_wgrad = !(getenv("SNERF_WGRAD_BF16") && atoi(getenv("SNERF_WGRAD_BF16")) == 0);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? nsplit : 0);
 }
 
 }  // namespace snerf

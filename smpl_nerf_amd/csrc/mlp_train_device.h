@@ -62,4 +62,35 @@ __device__ __forceinline__ float sum_over_g(float v) {  // the 4 lanes (g = 0..3
     return v;
 }
 
+struct WgradArgs {
+    const float *act;
+    const float *dy;
+    float *part;  // [G][gp_floats]
+    int64_t n;
+    int64_t chunk;  // samples per K-split, multiple of 16
+};
+
+
+// A (layer, input segment) pair is "wide" when it fills the 16-wave workgroup of mlp_wgrad_kernel with real work
+// (the 256x256 layers and the 128x256 one); the narrow pairs - encoder columns, heads, the 128x128 layer: 15 % of
+// the FLOPs - go to mlp_wgrad_direct_kernel, whose independent single-wave workgroups have no per-stage barrier.
+__host__ __device__ inline bool wgrad_wide(const Layer &Ly, int s) { return Ly.t_out >= 8 && Ly.seg[s].nkb >= 16; }
+__host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups of <= 16 input k-blocks
+    int jobs = 0;
+    for (int l = 0; l < P.nlayers; ++l)
+        for (int s = 0; s < P.layer[l].nseg; ++s)
+            if (wgrad_wide(P.layer[l], s)) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
+    return jobs;
+}
+__host__ __device__ inline int wgrad_direct_jobs(const Plan &P) {  // narrow jobs: 4x4-tile blocks
+    int jobs = 0;
+    for (int l = 0; l < P.nlayers; ++l)
+        for (int s = 0; s < P.layer[l].nseg; ++s)
+            if (!wgrad_wide(P.layer[l], s)) jobs += ((P.layer[l].t_out + 3) / 4) * ((P.layer[l].seg[s].nkb + 3) / 4);
+    return jobs;
+}
+
+// mlp_train_bf16.hip: the wide jobs with split-bf16 operands (nsplit parts each)
+int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, int nsplit, hipStream_t s);
+
 }  // namespace snerf
