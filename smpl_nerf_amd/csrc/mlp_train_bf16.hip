@@ -336,24 +336,27 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
 #pragma unroll
     for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
 
-    // operand of one tile: this lane's 8 samples (8 kq + e) of feature i16 -> NS packed-bf16 parts
-    auto gather = [&](const float *row, bool zero, bf8(&parts)[NS], float &sum) __attribute__((always_inline)) {
+    // operand of one tile: this lane's 8 samples (8 kq + e) of feature i16 -> NS packed-bf16 parts.  MASK: zero the
+    // samples at or past `limit` (ragged end of the chunk); SUM: also accumulate the values (bias gradient)
+    auto gather = [&](const float *row, auto mask, auto want_sum, int limit, bf8(&parts)[NS], float &sum)
+                      __attribute__((always_inline)) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int smp = 8 * kq + e;                               // sample within the stage
             const int pos = (smp & 15) ^ (((smp & 15) >> 3) & 1);      // its position within its 16-sample piece
             v[e] = row[(smp >> 4) * 256 + pos * 16 + i16];
+            if constexpr (decltype(mask)::value) v[e] = smp < limit ? v[e] : 0.f;
         }
-        if (zero) {
+        if constexpr (decltype(want_sum)::value) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int e = 0; e < 8; ++e) sum += v[e];
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sum += v[e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split_pair_into<NS>(v[2 * e], v[2 * e + 1], parts, e);
     };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
 
     if (nstages > 0) {
         issue(0, 0);
@@ -366,35 +369,28 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
         if (active) {
             const float *base = wring + slot * WB_SLOT_FLOATS;
             const int64_t s0 = begin + (int64_t)st * WB_STAGE;
-            // masked samples (past the chunk end) contribute a = 0; per lane the 8 samples 8 kq + e
-            const bool tail = s0 + WB_STAGE > end;
+            // samples past the chunk end contribute a = 0 (b is finite data); tiles past the edge of the job (the
+            // 128-row layer has no second row block... ) are skipped - wave-uniform branches
+            const int limit = (int)min((int64_t)WB_STAGE, end - s0);
+            const bool tail = limit < WB_STAGE;
             bf8 bpart[TJ][NS];
             float dummy = 0.f;
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) gather(base + (16 + TJ * bj + j) * WB_ROW_FLOATS, false, bpart[j], dummy);
+            for (int j = 0; j < TJ; ++j) gather(base + (16 + TJ * bj + j) * WB_ROW_FLOATS, No{}, No{}, 0, bpart[j], dummy);
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                bf8 apart[NS];
-                if (!tail) {
-                    gather(base + (TI * bi + i) * WB_ROW_FLOATS, i >= n_ti, apart, bsum[i]);
-                } else {   // ragged end of the chunk: zero the samples past it one by one
-                    float v[8];
+                if (i < n_ti) {
+                    bf8 apart[NS];
+                    const float *row = base + (TI * bi + i) * WB_ROW_FLOATS;
+                    if (tail) gather(row, Yes{}, Yes{}, limit, apart, bsum[i]);
+                    else if (want_bias) gather(row, No{}, Yes{}, 0, apart, bsum[i]);
+                    else gather(row, No{}, No{}, 0, apart, dummy);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int smp = 8 * kq + e;
-                        const int pos = (smp & 15) ^ (((smp & 15) >> 3) & 1);
-                        const float x = base[(TI * bi + i) * WB_ROW_FLOATS + (smp >> 4) * 256 + pos * 16 + i16];
-                        v[e] = (i < n_ti && s0 + smp < end) ? x : 0.f;
-                        bsum[i] += v[e];
-                    }
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split_pair_into<NS>(v[2 * e], v[2 * e + 1], apart, e);
+                        for (int t = 0; t < Tm::N; ++t)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apart[Tm::A[t]], bpart[j][Tm::B[t]], acc[i][j], 0, 0, 0);
                 }
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                    for (int t = 0; t < Tm::N; ++t)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apart[Tm::A[t]], bpart[j][Tm::B[t]], acc[i][j], 0, 0, 0);
             }
         }
         if (st + 1 < nstages) {
