@@ -149,13 +149,14 @@ int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int n
                            int samples_per_ray, float *raw, snerf_stream_t stream);
 /* The same forward for training: additionally saves every layer input into `act`, in exactly the layout
  * snerf_mlp_fwd_train_f32 writes (act_floats of snerf_mlp_train_sizes), so that snerf_mlp_bwd_f32 /
- * snerf_mlp_bwd_inputs_f32 run on it unchanged (the backward stays exact fp32). */
+ * snerf_mlp_bwd_inputs_f32 run on it unchanged (any mix of fp32 / split-bf16 forward and backward works: the buffers are fp32). */
 int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
                                  const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                                  int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
 
 /* The backward on the bf16 matrix cores: dgrad (the transposed network) with split-bf16 operands, fp32 accumulate
- * and fp32 stored d Y; the wgrad GEMMs stay exact fp32.  Same buffers as snerf_mlp_bwd_f32 / _bwd_inputs_f32
+ * and fp32 stored d Y, and the wide wgrad GEMMs (the 256x256 and 128x256 layers) with both operands split the same
+ * way; the narrow wgrad jobs and the reduction are exact fp32 (SNERF_WGRAD_BF16=0: all of wgrad in fp32).  Same buffers as snerf_mlp_bwd_f32 / _bwd_inputs_f32
  * (sizes from snerf_mlp_train_sizes) except the transposed weight stream, which comes from snerf_mlp_pack_t_bf16. */
 int64_t snerf_mlp_packed_t_bf16_bytes(const snerf_mlp_desc *desc, int nsplit, int input_grad);
 int snerf_mlp_pack_t_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed_t, int nsplit,

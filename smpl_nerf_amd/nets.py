@@ -52,7 +52,7 @@ class _FusedMlpFn(torch.autograd.Function):
             if per_sample == _ENCODED_ROWS:      # x holds already-encoded rows (RenderRayNet.forward(x))
                 check(lib.snerf_mlp_fwd_encoded_train_f32(desc, ptr(packed), ptr(x), n, x.shape[1], ptr(raw), ptr(act),
                                                           current_stream()), "snerf_mlp_fwd_encoded_train_f32")
-            elif ns:                             # forward on the bf16 matrix cores; the backward stays exact fp32
+            elif ns:                             # forward on the bf16 matrix cores, saving fp32 activations
                 check(lib.snerf_mlp_fwd_train_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n,
                                                        int(spr), ptr(raw), ptr(act), current_stream()),
                       "snerf_mlp_fwd_train_bf16_f32")
@@ -73,7 +73,7 @@ class _FusedMlpFn(torch.autograd.Function):
         net, desc, n = ctx.net, ctx.desc, ctx.n
         dev = d_raw.device
         d_raw = d_raw.contiguous().float()
-        ns = ctx.ns      # split-bf16 dgrad (the wgrad GEMMs are fp32 either way) when the forward ran in that mode
+        ns = ctx.ns      # split-bf16 dgrad and wide wgrad jobs when the forward ran in that mode
         packed_t = net.packed_weights_t_bf16(desc, ns, ctx.input_grad) if ns else net.packed_weights_t(desc, ctx.input_grad)
         dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
         gpart = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
@@ -170,9 +170,9 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         self._pack_t_cache = {}
         self._weights_epoch = 0            # see mark_weights_changed()
         self._trained_since_pack = False
-        # matrix-core arithmetic of the forward pass (inference and training): "fp32" (v_mfma_f32_16x16x4_f32) or
-        # split-bf16 "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5 relative); the backward
-        # kernels are always exact fp32
+        # matrix-core arithmetic of inference and of a training step's forward, dgrad and wide wgrad jobs: "fp32"
+        # (v_mfma_f32_16x16x4_f32) or split-bf16 "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5
+        # relative); activations, gradients, the narrow wgrad jobs and the reductions are fp32 in every mode
         self.precision = os.environ.get("SNERF_PRECISION", "fp32")
 
     # ------------------------------------------------------------------ parameter plumbing

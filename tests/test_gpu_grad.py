@@ -42,8 +42,8 @@ def make_net(dev, params, **kw):
     return net.to(dev)
 
 
-# forward arithmetic of the training step: exact fp32 MFMA, or split-bf16 with fp32-class accuracy (the backward
-# kernels are fp32 in both); both are held to the same tolerances
+# matrix-core arithmetic of the training step: exact fp32 MFMA everywhere, or split-bf16 with fp32-class accuracy for the
+# forward, the dgrad and the wide wgrad jobs; both are held to the same tolerances
 PRECISIONS = ["fp32", "bf16x6"]
 
 
