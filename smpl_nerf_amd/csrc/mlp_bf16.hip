@@ -1,4 +1,5 @@
-// Split-bf16 variant of the fused positional-encoding + RenderRayNet forward (inference path).
+// Split-bf16 variant of the fused positional-encoding + RenderRayNet forward (inference, and the training forward that
+// also saves the layer inputs).
 //
 // fp32-input MFMA runs at 1/16 of the bf16 MFMA rate on CDNA4.  This kernel keeps fp32-class accuracy on the
 // bf16 matrix cores by splitting every fp32 operand into NS bf16 parts (x = p0 + p1 [+ p2], p_k = bf16(x -
@@ -12,8 +13,10 @@
 // Everything else is the fp32 kernel's design (mlp.hip, mlp_plan.h) with 32-wide k-blocks: one wave owns 16
 // samples, the accumulator layout of a layer is the B-operand layout of the next (k-block b = accumulators
 // of tiles 2b, 2b+1), activations stay in registers as NS packed-bf16 B operands (96 VGPRs for 256 features
-// at NS = 3), weights are pre-split and stream L2 -> registers -> 3-slot LDS ring (one 48 KiB slab = one
-// k-block x 16 output tiles x 3 parts), positional encodings are evaluated in registers.
+// at NS = 3), weights are pre-split and stream L2 -> LDS by DMA through a 3-slot ring (one 48 KiB slab = one
+// k-block x 16 output tiles x 3 parts), positional encodings are evaluated in registers.  One persistent workgroup
+// per CU walks the 128-sample tiles with the ring rolling on from tile to tile.  The device machinery (operand
+// split, ring, hand-laid k-block stream, layer runner) is in mlp_bf16_device.h.
 #include <stdlib.h>
 
 #include "mlp_bf16_device.h"
