@@ -97,6 +97,24 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // blockIdx.x, blockIdx.x + gridDim.x, ...  The weight ring keeps rolling from one tile into the next (the stream
     // wraps around), so only the first tile of a workgroup pays the pipeline fill.
     SlabPipe16<NT, NS> pipe;
+    // the raw inputs of a tile are fetched while the previous tile's last two layers run (load_raw at the end of the
+    // directional_input layer), so that a tile never starts by waiting on HBM
+    float raw[6];
+    auto load_raw = [&](int64_t t, float(&r)[6]) __attribute__((always_inline)) {
+        const int64_t s0 = (t * NWAVES + wave) * 16 + (lane & 15);
+        const int64_t s1 = s0 < A.n ? s0 : A.n - 1;
+        // read-once / write-once streams bypass L2 retention: the 2.4 - 3.6 MB weight stream that every workgroup
+        // re-reads is what each XCD's 4 MB L2 should keep
+        r[0] = __builtin_nontemporal_load(A.x + s1 * 3 + 0);
+        r[1] = __builtin_nontemporal_load(A.x + s1 * 3 + 1);
+        r[2] = __builtin_nontemporal_load(A.x + s1 * 3 + 2);
+        r[3] = r[4] = r[5] = 0.f;
+        if (A.use_dir) {
+            const float *dp = A.dirs + (A.dirs_per_sample ? s1 : s1 / A.spr) * 3;
+            r[3] = dp[0], r[4] = dp[1], r[5] = dp[2];
+        }
+    };
+    if (blockIdx.x < A.n_tiles) load_raw(blockIdx.x, raw);
     for (int64_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
     const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
@@ -105,16 +123,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     c.g = lane >> 4;
     c.enc = nullptr;
     c.add = nullptr;
-    // read-once / write-once streams bypass L2 retention: the 2.4 - 3.6 MB weight stream that every workgroup
-    // re-reads is what each XCD's 4 MB L2 should keep
-    c.px = __builtin_nontemporal_load(A.x + sc * 3 + 0);
-    c.py = __builtin_nontemporal_load(A.x + sc * 3 + 1);
-    c.pz = __builtin_nontemporal_load(A.x + sc * 3 + 2);
+    c.px = raw[0], c.py = raw[1], c.pz = raw[2];
     c.dx = c.dy = c.dz = 0.f;
     const int64_t ray = sc / A.spr;
     if (A.use_dir) {
-        const float *dp = A.dirs + (A.dirs_per_sample ? sc : ray) * 3;
-        const float ux = dp[0], uy = dp[1], uz = dp[2];
+        const float ux = raw[3], uy = raw[4], uz = raw[5];
         const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ux, ux), __fmul_rn(uy, uy)), __fmul_rn(uz, uz)));
         c.dx = __fdiv_rn(ux, nrm);
         c.dy = __fdiv_rn(uy, nrm);
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
             }, accd);
         run.finish();
         if (TRAIN && valid) store_act<false>(A.act, A.act_h1, A.n, sample, c.g, accd);
+        if (tile + gridDim.x < A.n_tiles) load_raw(tile + gridDim.x, raw);
     }
     {  // directional_net[0] (its relu is applied when the rgb head splits acce)
         LayerRun16<TD, NT, NS> run(pipe, lane);
