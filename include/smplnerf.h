@@ -174,7 +174,8 @@ int snerf_mlp_bwd_inputs_bf16_f32(const snerf_mlp_desc *desc, const void *packed
  * transposed weight stream, the split-K partial gradients (gpart_count chunks). */
 int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
                           int64_t *packed_t_floats, int64_t *gpart_floats, int32_t *gpart_count);
-/* snerf_mlp_fwd_f32 that also saves every layer input into `act` (act_floats). */
+/* snerf_mlp_fwd_f32 that also saves every layer input into `act` (act_floats): fp32 tile-rows, followed by one
+ * sign bit per ReLU output (the masks the split-bf16 dgrad reads instead of the activation rows). */
 int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                             const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                             int samples_per_ray, float *raw, float *act, snerf_stream_t stream);

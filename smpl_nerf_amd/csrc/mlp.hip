@@ -150,7 +150,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         pos_segments(run, true);
         run.finish();
         relu_into(in, acc);
-        if (TRAIN && valid) store_tiles(A.act, A.act_x1, A.n, sample, c.g, in);
+        if (TRAIN && valid) {
+            store_tiles(A.act, A.act_x1, A.n, sample, c.g, in);
+            store_mask(A.act, A.act_mask, 0, A.n, sample, c.g, in);
+        }
     }
     for (int i = 0; i < A.n_hidden; ++i) {  // positional_net[i] + relu (:46-50)
         LayerRun<T, NT> run(pipe, lane);
@@ -160,7 +163,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         if ((A.skip_mask >> i) & 1u) pos_segments(run, false);
         run.finish();
         relu_into(in, acc);
-        if (TRAIN && valid) store_tiles(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, in);
+        if (TRAIN && valid) {
+            store_tiles(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, in);
+            store_mask(A.act, A.act_mask, i + 1, A.n, sample, c.g, in);
+        }
     }
     {  // additional_linear_layer, no activation (:51)
         LayerRun<T, NT> run(pipe, lane);
@@ -201,7 +207,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], accd);
         run.finish();
         relu_into(ind, accd);
-        if (TRAIN && valid) store_tiles(A.act, A.act_h2, A.n, sample, c.g, ind);
+        if (TRAIN && valid) {
+            store_tiles(A.act, A.act_h2, A.n, sample, c.g, ind);
+            store_mask(A.act, A.act_mask, A.n_hidden + 1, A.n, sample, c.g, ind);
+        }
     }
     f4 rgb[1];
     {  // rgb_out_layer (:60): rows 0..2
@@ -378,6 +387,7 @@ extern "C" int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *
     A.act_o = L.o;
     A.act_h1 = L.h1;
     A.act_h2 = L.h2;
+    A.act_mask = L.mask;
     return launch_fwd<false, true>(P, A, (hipStream_t)stream);
 }
 
@@ -412,6 +422,7 @@ extern "C" int snerf_mlp_fwd_encoded_train_f32(const snerf_mlp_desc *desc, const
     A.act_o = L.o;
     A.act_h1 = L.h1;
     A.act_h2 = L.h2;
+    A.act_mask = L.mask;
     return launch_fwd<true, true>(P, A, (hipStream_t)stream);
 }
 

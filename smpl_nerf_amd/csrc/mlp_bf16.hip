@@ -114,8 +114,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
             r[3] = dp[0], r[4] = dp[1], r[5] = dp[2];
         }
     };
-    if (blockIdx.x < A.n_tiles) load_raw(blockIdx.x, raw);
+    // (not in the TRAIN variants: they sit at the register limit)
+    if (!TRAIN && blockIdx.x < A.n_tiles) load_raw(blockIdx.x, raw);
     for (int64_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    if (TRAIN) load_raw(tile, raw);
     const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
     const int64_t sc = valid ? sample : A.n - 1;
@@ -177,14 +179,22 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         run.template run_hidden<true>(src, dst);
         if ((A.skip_mask >> i) & 1u) pos_segments(run, dst, false);
         run.finish();
-        if (TRAIN && valid) store_act<true>(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, dst);
+        if (TRAIN && valid) {
+            store_mask(A.act, A.act_mask, i + 1, A.n, sample, c.g, dst);
+            asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
+            store_act<true>(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, dst);
+        }
     };
     {  // positions_pose_input (its relu is applied when the next layer splits accA)
         LayerRun16<T, NT, NS> run(pipe, lane);
         run.init(accA);
         pos_segments(run, accA, true);
         run.finish();
-        if (TRAIN && valid) store_act<true>(A.act, A.act_x1, A.n, sample, c.g, accA);
+        if (TRAIN && valid) {
+            store_mask(A.act, A.act_mask, 0, A.n, sample, c.g, accA);
+            asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
+            store_act<true>(A.act, A.act_x1, A.n, sample, c.g, accA);
+        }
     }
     for (int i = 0; i < A.n_hidden; i += 2) {
         hidden(i, accA, accB);
@@ -225,14 +235,18 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
             }, accd);
         run.finish();
         if (TRAIN && valid) store_act<false>(A.act, A.act_h1, A.n, sample, c.g, accd);
-        if (tile + gridDim.x < A.n_tiles) load_raw(tile + gridDim.x, raw);
+        if (!TRAIN && tile + gridDim.x < A.n_tiles) load_raw(tile + gridDim.x, raw);
     }
     {  // directional_net[0] (its relu is applied when the rgb head splits acce)
         LayerRun16<TD, NT, NS> run(pipe, lane);
         run.init(acce);
         run.template run_hidden<false>(accd, acce);
         run.finish();
-        if (TRAIN && valid) store_act<true>(A.act, A.act_h2, A.n, sample, c.g, acce);
+        if (TRAIN && valid) {
+            store_mask(A.act, A.act_mask, A.n_hidden + 1, A.n, sample, c.g, acce);
+            asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
+            store_act<true>(A.act, A.act_h2, A.n, sample, c.g, acce);
+        }
     }
     f4 rgb[1];
     {
@@ -346,6 +360,7 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
         A.act_o = L.o;
         A.act_h1 = L.h1;
         A.act_h2 = L.h2;
+        A.act_mask = L.mask;
         A.pos_nkb16 = Q.pos_nkb;
         A.add_nkb16 = Q.add_nkb;
         A.dir_nkb16 = Q.dir_nkb;

@@ -37,7 +37,7 @@ struct FwdArgs {
     int enc_stride;
     // training only: activation buffer in tile-row-major layout (mlp_plan.h TrainLayout)
     float *act;
-    int act_pe, act_add, act_dpe, act_x1, act_o, act_h1, act_h2;
+    int act_pe, act_add, act_dpe, act_x1, act_o, act_h1, act_h2, act_mask;
     // split-bf16 training forward only: encoder / additional k-block counts of the 16-wide (fp32) plan, which
     // defines the activation layout the backward kernels read
     int pos_nkb16, add_nkb16, dir_nkb16;
@@ -47,7 +47,7 @@ struct FwdArgs {
 
 // one tile (16 features of this lane's sample) <-> the tile-row-major activation buffer
 __device__ __forceinline__ void store_tile(float *buf, int row, int64_t n, int64_t sample, int g, f4 v) {
-    *reinterpret_cast<f4 *>(buf + ((int64_t)row * n + sample) * 16 + 4 * g) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(buf + ((int64_t)row * n + sample) * 16 + 4 * g));
 }
 template <int N>
 __device__ __forceinline__ void store_tiles(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&tiles)[N]) {
@@ -56,6 +56,30 @@ __device__ __forceinline__ void store_tiles(float *buf, int row0, int64_t n, int
 }
 __device__ __forceinline__ f4 load_tile(const float *buf, int row, int64_t n, int64_t sample, int g) {
     return *reinterpret_cast<const f4 *>(buf + ((int64_t)row * n + sample) * 16 + 4 * g);
+}
+
+// ReLU sign mask of one layer output for the split-bf16 dgrad kernel: bit 4 t + r of this lane's 64-bit word is
+// (tiles[t][r] > 0).  Mask `idx` lives in tile-row mask_row + idx / 2, floats (idx & 1) * 8 + 2 g of the sample.
+__device__ __forceinline__ uint2 *mask_ptr(const float *buf, int mask_row, int idx, int64_t n, int64_t sample, int g) {
+    return reinterpret_cast<uint2 *>(const_cast<float *>(buf) + ((int64_t)(mask_row + (idx >> 1)) * n + sample) * 16 +
+                                     (idx & 1) * 8 + 2 * g);
+}
+template <int N>
+__device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, int64_t n, int64_t sample, int g,
+                                           const f4 (&tiles)[N]) {
+    static_assert(N <= 16, "one or two mask words");
+    unsigned w[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // x > 0 <=> its bit pattern, read as a signed integer, is > 0: clamp to {0, 1} and shift into place
+            const int bit = min(max(__float_as_int(tiles[t][r]), 0), 1);
+            w[t >> 3] |= static_cast<unsigned>(bit) << (((t & 7) << 2) | r);
+        }
+    // the address is formed here, not hoisted to the top of the tile (where it would cost two registers per layer)
+    asm volatile("" : "+v"(sample));
+    *mask_ptr(buf, mask_row, idx, n, sample, g) = uint2{w[0], w[1]};
 }
 
 // Streams the slab sequence global -> registers -> LDS ring (3 slots).

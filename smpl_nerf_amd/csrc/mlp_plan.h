@@ -227,6 +227,7 @@ struct TrainLayout {
     int pe, add, dpe;    // encoder inputs in slot order (pos_nkb / add_nkb / dir_nkb tile-rows)
     int x[18];           // x[i], i = 1..nh+1: input of positional_net[i-1] / additional (post-ReLU), T rows each
     int o, h1, h2;       // additional out (T), directional_input out (TD), directional_net[0] out post-ReLU (TD)
+    int mask;            // ReLU sign masks, 8 bytes per (sample, lane group): x[1..nh+1] then h2, two per tile-row
     int act_rows;
     int dy[MAX_LAYERS];  // dY of forward layer l (plan order): t_out tile-rows
     int dy_rows;
@@ -247,6 +248,7 @@ inline void make_train_layout(const Plan &P, TrainLayout &L) {
     L.o = r; r += L.T;
     L.h1 = r; r += L.TD;
     L.h2 = r; r += L.TD;
+    L.mask = r; r += (L.nh + 2 + 1) / 2;
     L.act_rows = r;
     int d = 0, g = 0;
     for (int l = 0; l < P.nlayers; ++l) {

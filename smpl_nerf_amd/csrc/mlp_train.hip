@@ -636,6 +636,7 @@ static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const f
     A.n_hidden = nh;
     A.act_x1 = L.x[1];
     A.act_h2 = L.h2;
+    A.act_mask = L.mask;
     A.dy_sig = L.dy[nh + 2];
     A.dy_din = L.dy[nh + 3];
     A.dy_dn0 = L.dy[nh + 4];

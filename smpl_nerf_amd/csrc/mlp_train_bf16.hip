@@ -80,22 +80,20 @@ __global__ __launch_bounds__(256) void mlp_pack_t_bf16_kernel(Plan P, BwdPlan B,
     }
 }
 
-// t[i] = m > 0 ? t[i] : 0 with m = the saved activation tile, four tiles at a time; then store t as d Y tile-rows
+// t[i] = (ReLU output > 0) ? t[i] : 0 from the forward kernel's sign mask (store_mask, mlp_device.h: 8 bytes per lane
+// instead of the 256-byte activation row), then store t as d Y tile-rows
 template <int N>
-__device__ __forceinline__ void mask_store(f4 (&t)[N], const float *act, int act_row0, float *dy, int dy_row0, int64_t n,
-                                           int64_t sc, int64_t sample, bool valid, int g) {
-    constexpr int CH = N < 4 ? N : 4;
+__device__ __forceinline__ void mask_store(f4 (&t)[N], uint2 m, float *dy, int dy_row0, int64_t n, int64_t sample,
+                                           bool valid, int g) {
 #pragma unroll
-    for (int c0 = 0; c0 < N; c0 += CH) {
-        f4 m[CH];
+    for (int i = 0; i < N; ++i) {
+        const unsigned w = i < 8 ? m.x : m.y;
 #pragma unroll
-        for (int q = 0; q < CH; ++q) m[q] = load_tile(act, act_row0 + c0 + q, n, sc, g);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[c0 + q][r] = m[q][r] > 0.f ? t[c0 + q][r] : 0.f;
-            if (valid) store_tile(dy, dy_row0 + c0 + q, n, sample, g, t[c0 + q]);
+        for (int r = 0; r < 4; ++r) {
+            const int keep = static_cast<int>(w << (31 - (((i & 7) << 2) | r))) >> 31;  // 0 or ~0
+            t[i][r] = __int_as_float(__float_as_int(t[i][r]) & keep);
         }
+        if (valid) store_tile(dy, dy_row0 + i, n, sample, g, t[i]);
     }
 }
 
@@ -121,7 +119,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
     const int nh = A.n_hidden;
 
     f4 dr = *reinterpret_cast<const f4 *>(A.d_raw + sc * 4);
-    asm volatile("" : "+v"(dr));  // retire the load here, before the weight DMA starts (cf. mlp_fwd_bf16_kernel)
+    // the sign mask of the next masked layer is fetched one layer ahead (2 registers)
+    uint2 mk = *mask_ptr(A.act, A.act_mask, nh + 1, A.n, sc, g);
+    asm volatile("" : "+v"(dr), "+v"(mk.x), "+v"(mk.y));  // retire the loads here, before the weight DMA starts (cf. mlp_fwd_bf16_kernel)
     const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
     // head gradients as tile-rows for the wgrad kernel (rows 0..2 = rgb, row 0 = sigma)
     if (valid) {
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         const f4 src[2] = {g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, zero};
         run.template run_hidden<false>(src, accd);
         run.finish();
-        mask_store(accd, A.act, A.act_h2, A.dy, A.dy_dn0, A.n, sc, sample, valid, g);
+        mask_store(accd, mk, A.dy, A.dy_dn0, A.n, sample, valid, g);
+        mk = *mask_ptr(A.act, A.act_mask, nh, A.n, sc, g);
     }
     {  // directional_net[0]^T; directional_input has no activation (:54-57)
         LayerRun16<TD, NT, NS> run(pipe, lane);
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         run.init(dst);
         run.template run_hidden<false>(src, dst);
         run.finish();
-        mask_store(dst, A.act, A.act_x1 + l * T, A.dy, l * T, A.n, sc, sample, valid, g);
+        mask_store(dst, mk, A.dy, l * T, A.n, sample, valid, g);
+        if (l > 0) mk = *mask_ptr(A.act, A.act_mask, l - 1, A.n, sc, g);
         pe_columns(l, dst);
     };
     for (int l = nh; l >= 0; l -= 2) {
@@ -501,6 +503,7 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
     A.n_hidden = nh;
     A.act_x1 = L.x[1];
     A.act_h2 = L.h2;
+    A.act_mask = L.mask;
     A.dy_sig = L.dy[nh + 2];
     A.dy_din = L.dy[nh + 3];
     A.dy_dn0 = L.dy[nh + 4];

@@ -12,7 +12,7 @@ struct BwdArgs {
     float *dy;
     int64_t n;
     int n_hidden;
-    int act_x1, act_h2;
+    int act_x1, act_h2, act_mask;
     int dy_sig, dy_din, dy_dn0, dy_rgb;  // dy of forward layer l <= nh+1 is l*T
     // input gradients (INPUT_GRAD kernels only)
     const float *x, *dirs;  // forward inputs: positions [n,3], directions [n/spr,3] or [n,3]
@@ -74,6 +74,9 @@ struct WgradArgs {
 // A (layer, input segment) pair is "wide" when it fills the 16-wave workgroup of mlp_wgrad_kernel with real work
 // (the 256x256 layers and the 128x256 one); the narrow pairs - encoder columns, heads, the 128x128 layer: 15 % of
 // the FLOPs - go to mlp_wgrad_direct_kernel, whose independent single-wave workgroups have no per-stage barrier.
+// (Measured: sending the narrow pairs with >= 8 output tiles through mlp_wgrad_kernel's LDS stages instead, which
+// would read dY and X from HBM once per job rather than 2-4 times, is 0.3 ms per 10^6 samples SLOWER - the re-reads
+// of concurrently running blocks hit L2.)
 __host__ __device__ inline bool wgrad_wide(const Layer &Ly, int s) { return Ly.t_out >= 8 && Ly.seg[s].nkb >= 16; }
 __host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups of <= 16 input k-blocks
     int jobs = 0;

@@ -126,6 +126,44 @@ def test_mlp_backward_full_net(dev, tag, prec):
         close(p.grad.cpu().numpy(), ref, 5e-4, 5e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("prec,kw", [("fp32", dict()), ("bf16x6", dict()), ("bf16x3", dict()),
+                                     ("fp32", dict(n_layers=4, width=128, skips=(1,)))])
+def test_training_forward_relu_sign_masks(dev, prec, kw):
+    """The training forward also leaves one bit per ReLU output, (output > 0), in the last tile-rows of the activation
+    buffer (store_mask, csrc/mlp_device.h; the split-bf16 dgrad reads these 8 bytes per lane instead of the saved
+    activation row): bit 4 (t & 7) + r of word t >> 3 of lane group g <-> feature 16 t + 4 g + r."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(5)
+    n_layers, width = kw.get("n_layers", 8), kw.get("width", 256)
+    params = syn.make_render_ray_net_params(21, 30.0, 10.0, **kw) if kw else syn.make_scene_nets(101)[0]
+    n = 1000                                                               # ragged against the 128-sample tile
+    pts, dirs = rng.uniform(-2, 2, (n, 1, 3)).astype(F32), rng.normal(size=(n, 3)).astype(F32)
+    net = make_net(dev, params, precision=prec, **kw)
+    raw = net.forward_fused(T(pts, dev), T(dirs, dev), 1, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    act = raw.grad_fn.act.cpu().numpy()
+    rows = act.size // (n * 16)
+    act = act.reshape(rows, n, 16)
+    t_w, t_d, nh = width // 16, width // 32, n_layers - 1
+    x1 = 4 + 2                                                             # encoder rows: 63 -> 4 tiles, 27 -> 2
+    h2 = x1 + (nh + 2) * t_w + t_d                                         # x[1..nh+1], additional out, h1, then h2
+    mask_row = h2 + t_d
+    assert rows == mask_row + (nh + 3) // 2
+    words = act.view(np.uint32)
+    for idx in range(nh + 2):
+        r0, nt = (x1 + idx * t_w, t_w) if idx <= nh else (h2, t_d)
+        tiles = act[r0:r0 + nt].reshape(nt, n, 4, 4)                       # [t][sample][g][r]
+        w = words[mask_row + idx // 2, :, (idx & 1) * 8:(idx & 1) * 8 + 8].reshape(n, 4, 2)   # [sample][g][word]
+        assert (tiles >= 0).all()                                          # saved post-ReLU
+        for t in range(nt):
+            for r in range(4):
+                got = (w[:, :, t >> 3] >> (4 * (t & 7) + r)) & 1
+                np.testing.assert_array_equal(got, (tiles[t, :, :, r] > 0).astype(np.uint32))
+        if nt <= 8:
+            assert (w[:, :, 1] == 0).all()
+        if nt < 8:
+            assert (w[:, :, 0] >> (4 * nt) == 0).all()
+
+
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_mlp_backward_many_samples_ragged(dev, prec):
     """n = 5003 samples (ragged vs the 64-sample tile, several split-K chunks), per-ray directions."""
