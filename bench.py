@@ -99,7 +99,10 @@ def train_section(pipe, data, rays, steps, world, rank, dev):
         m.train()
         for p in m.parameters():
             p.requires_grad_(True)
-    tr = DataParallelTrainer(pipe, models, lr=5e-4)
+    # lr: small enough that both nets stay alive on this synthetic scene (at 1e-4 and above Adam's first steps push the
+    # fine net's densities below zero everywhere: the rendered colour and every gradient become exactly 0, and the
+    # backward kernels would be timed on all-zero operands)
+    tr = DataParallelTrainer(pipe, models, lr=3e-5)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     n_total = data[0].shape[0]
     batches = []
@@ -120,6 +123,8 @@ def train_section(pipe, data, rays, steps, world, rank, dev):
         dt = time.perf_counter() - t0
     kern = prof.summary()
     dt = max_over_ranks(dt, dev)
+    with torch.no_grad():   # the trained nets still render something (not collapsed to zero density)
+        fine_std = float(pipe(batches[0])[1].std())
     losses = [float(l) for l in losses]
     evals = world * steps * rays * 256
     bwd = {k: v for k, v in kern.items() if k.startswith("mlp_bwd")}
@@ -128,7 +133,7 @@ def train_section(pipe, data, rays, steps, world, rank, dev):
     mlp_ms = (sum(v[1] for v in bwd.values()) + sum(v[1] for v in fwd.values())) / steps
     return {"metric": "ray-samples/s, training step (fwd+bwd+all-reduce+Adam)", "value": evals / dt,
             "rays_per_step_per_gpu": rays, "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "loss_first": losses[0], "loss_last": losses[-1],
+            "loss_first": losses[0], "loss_last": losses[-1], "rgb_fine_std_last_step": fine_std,
             "mlp_kernels_ms_per_step": mlp_ms, "mlp_tflops": flop_step / (mlp_ms * 1e-3) / 1e12,
             "kernels_ms_per_step": {k: v[1] / steps for k, v in sorted(kern.items())},
             "collective": "one all-reduce of 1 220 872 fp32 gradients per step" if world > 1 else "none (1 GPU)"}
