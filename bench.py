@@ -263,6 +263,8 @@ def main():
             flop_per_unit = FLOP_PER_EVAL * products
             roof_extra = {"fp32_equivalent_tflops": alg_tflops,
                           "fp32_equivalent_vs_fp32_mfma_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
+                          "fp32_equivalent_vs_bf16_mfma_peak": alg_tflops / PEAK_BF16_MFMA_TFLOPS,
+                          "algorithmic_flop_per_unit": FLOP_PER_EVAL,
                           "bf16_products_per_fp32_mac": products,
                           "peak_note": f"dense bf16 MFMA peak 2500 TFLOP/s (v_mfma_f32_16x16x32_bf16); operands split into "
                                        f"bf16 parts, {products} bf16 products per fp32 MAC, fp32 accumulate; padded tiles "
