@@ -140,7 +140,12 @@ int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const flo
  * Every fp32 operand is split into nsplit bf16 parts and the cross terms are accumulated in fp32:
  * nsplit = 3 (6 products, ~2^-24 relative: same parity class as the fp32 kernel, 2.7x less matrix-pipe time),
  * nsplit = 2 (3 products, ~2^-16 relative: RGB within ~8e-5, 5.3x less).  Same inputs/outputs as
- * snerf_mlp_fwd_f32; `packed` comes from snerf_mlp_pack_bf16 with the same nsplit.  Width 256 only. */
+ * snerf_mlp_fwd_f32; `packed` comes from snerf_mlp_pack_bf16 with the same nsplit.  Width 256 only.
+ * nsplit = SNERF_SPLIT_F16X3 selects two fp16 parts instead (3 products, ~2^-22 relative: raw outputs within the fp32
+ * kernel's own tolerance, at the speed of nsplit = 2): operands are scaled by exact powers of two - weights per layer at
+ * pack time, activations per sample in the kernel - so that fp16's range is never left.  Inference only
+ * (snerf_mlp_fwd_bf16_f32, snerf_render_rays*), nets without additional inputs. */
+#define SNERF_SPLIT_F16X3 16
 int64_t snerf_mlp_packed_bf16_bytes(const snerf_mlp_desc *desc, int nsplit);
 int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed, int nsplit,
                         snerf_stream_t stream);
@@ -266,8 +271,8 @@ int snerf_raygen_f64(const double *poses, int64_t n_frames, int H, int W, double
 
 /* ---- a3: the whole NerfPipeline.forward for inference in one call (models/nerf_pipeline.py:14-67) -------------
  * Five launches on `stream`: fused encode+MLP (coarse) -> composite -> inverse-CDF sampler + merge + points ->
- * fused encode+MLP (fine) -> composite.  precision: 0 = fp32 kernel (packed_* from snerf_mlp_pack_f32), 2 / 3 =
- * split-bf16 with that nsplit (packed_* from snerf_mlp_pack_bf16).  Inputs as the Solver hands them over
+ * fused encode+MLP (fine) -> composite.  precision: 0 = fp32 kernel (packed_* from snerf_mlp_pack_f32), 2 / 3 / 16 =
+ * split-bf16 / split-fp16 with that nsplit (packed_* from snerf_mlp_pack_bf16).  Inputs as the Solver hands them over
  * (solver/nerf_solver.py:77-81): ray_samples [B,Nc,3], rays_o [B,3], rays_d [B,3], z_vals [B,Nc]; u [Nf] =
  * linspace(0,1,Nf) (utils.py:204-205); noise_coarse [B,Nc] / noise_fine [B,Nc+Nf] nullable (sigma noise,
  * utils.py:171-173).  Nf == 0 is run_fine = 0: the fine outputs are copies of the coarse ones (:43-44).

@@ -11,6 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsmplnerf_hip.so")
+SPLIT_F16X3 = 16   # include/smplnerf.h SNERF_SPLIT_F16X3: nsplit / precision code of the two-part fp16 kernel
 
 SNERF_OK = 0
 

@@ -27,18 +27,43 @@ namespace snerf {
 // weight packing: params_flat -> split-bf16 slab stream
 // slab = [k-block in slab][output tile][part][lane][8 bf16] then 256 fp32 of bias
 // ------------------------------------------------------------------------------------------------
+// f16x3 (fmt = FMT_F16): exponent that brings the largest |weight| of layer li to [2^14, 2^15) - block-wide
+__device__ int layer_weight_exp(const Plan &P, int li, const float *__restrict__ params) {
+    __shared__ float red[256];
+    const Layer &Ly = P.layer[li];
+    float m = 0.f;
+    for (int64_t e = threadIdx.x; e < (int64_t)Ly.n_out * Ly.n_in; e += 256) m = fmaxf(m, fabsf(params[Ly.w_off + e]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    const int e = ((__float_as_int(m) >> 23) & 0xff) - 127;
+    return m > 0.f ? min(14 - e, 50) : 0;
+}
+
 __global__ __launch_bounds__(256) void mlp_pack_bf16_kernel(Plan P, int NS, const float *__restrict__ params,
-                                                            unsigned char *__restrict__ packed) {
+                                                            unsigned char *__restrict__ packed, int fmt) {
     const int slab = blockIdx.x;
     const int SB = slab16_bytes(NS);
     unsigned char *dst = packed + (int64_t)slab * SB;
     if (slab >= P.total_slabs) {
         for (int e = threadIdx.x; e < SB / 4; e += 256) reinterpret_cast<float *>(dst)[e] = 0.f;
+        if (fmt == FMT_F16 && slab == P.total_slabs) {   // the table of weight exponents the f16x3 kernel reads
+            for (int l = 0; l < P.nlayers; ++l) {
+                const int we = layer_weight_exp(P, l, params);
+                if (threadIdx.x == 0) reinterpret_cast<int *>(dst)[l] = we;
+            }
+        }
         return;
     }
     int li = 0;
     while (li + 1 < P.nlayers && slab >= P.layer[li + 1].first_slab) ++li;
     const Layer &Ly = P.layer[li];
+    const int we = fmt == FMT_F16 ? layer_weight_exp(P, li, params) : 0;
     const int sl = slab - Ly.first_slab;
     const int kps = 16 / Ly.t_out;
     const float *Wm = params + Ly.w_off;
@@ -58,6 +83,13 @@ __global__ __launch_bounds__(256) void mlp_pack_bf16_kernel(Plan P, int NS, cons
         if (kb < Ly.nkb && row < Ly.n_out) {
             const int col = slot_to_col32(Ly, kb, g, e);
             if (col >= 0) w = Wm[(int64_t)row * Ly.n_in + col];
+        }
+        if (fmt == FMT_F16) {   // fp16 parts (RNE) of the scaled weight
+            w = ldexpf(w, we);
+            _Float16 h = (_Float16)w;
+            if (s == 1) h = (_Float16)(w - (float)h);
+            reinterpret_cast<_Float16 *>(a)[q] = h;
+            continue;
         }
         __bf16 h = (__bf16)w;
         for (int t = 0; t < s; ++t) {
@@ -86,11 +118,48 @@ __device__ __forceinline__ void store_act(float *buf, int row0, int64_t n, int64
 
 // TRAIN additionally stores every layer input (post-activation, fp32, the fp32 kernel's layout) for the backward
 // kernels of mlp_train.hip.
-template <int WIDTH, int NWAVES, int NS, bool TRAIN>
+//
+// FMT_F16 ("f16x3", inference only): two fp16 parts per operand and three products per MAC on
+// v_mfma_f32_16x16x32_f16.  fp16 keeps 11 mantissa bits per part (2^-22 relative for the pair, against 2^-16 for two
+// bf16 parts) but only 5 exponent bits, so every operand is scaled by a power of two first - exactly, and undone
+// exactly: the weights of layer l by 2^wexp[l] (largest |w| of the layer at 2^14; the pack kernel leaves the table in
+// the first pad slab of the stream), the B operands of a layer per SAMPLE by 2^kx, kx from the largest activation of
+// the sample that enters the layer (all of a sample's values sit in the four lanes that share its column), capped at
+// 14 when encoder columns (|sin|, |cos| <= 1) enter too.  An accumulator column then carries 2^(wexp + kx): the bias is
+// loaded with that scale, the next layer's split rescales by the difference of the two exponents (one v_ldexp per
+// value), the heads are scaled back before the store.  Nothing can overflow: scaled operands are < 2^15, a sum of 320
+// products < 2^39.
+template <int WIDTH, int NWAVES, int NS, bool TRAIN, int FMT = FMT_BF16>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16, TD = WIDTH / 32;
+    constexpr bool F16 = FMT == FMT_F16;
+    static_assert(!(F16 && (TRAIN || NS != 2)), "f16x3: two parts, inference only");
     extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int *wexp_tab = reinterpret_cast<const int *>(reinterpret_cast<const char *>(A.packed) + (int64_t)A.total_slabs * slab16_bytes(NS));
+    auto wexp = [&](int l) __attribute__((always_inline)) -> int {
+        if constexpr (F16) return wexp_tab[l];
+        else return 0;
+    };
+    // operand scale when encoder columns take part / upper limit (activations below 2^-50: with a weight exponent <= 50 a
+    // bias of up to 2^13 still fits the scaled accumulator)
+    constexpr int KX_PE = 14, KX_MAX = 64;
+    // unbiased exponent of the largest |value| (after the ReLU, if any) that this lane's sample has in `src`
+    auto sample_exp = [&](const auto &src, bool relu) __attribute__((always_inline)) -> int {
+        constexpr int N = sizeof(src) / sizeof(f4);
+        float m = 0.f;
+#pragma unroll
+        for (int t = 0; t < N; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, relu ? src[t][r] : fabsf(src[t][r]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        return ((__float_as_int(m) >> 23) & 0xff) - 127;
+    };
+    // operand scale of a layer whose input has exponent e_src at accumulator scale es
+    auto operand_scale = [&](int e_src, int es, int cap) __attribute__((always_inline)) -> int {
+        return min(14 - (e_src - es), cap);
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Persistent workgroups: one per CU (the LDS ring allows no more), each walking the sample tiles
@@ -145,12 +214,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // two accumulator sets ping-pong between consecutive layers: the finished set feeds the next layer's B
     // operands (split just in time, k-block by k-block) while the other set accumulates
     f4 accA[T], accB[T];
-    auto pos_segments = [&](LayerRun16<T, NT, NS> &run, f4(&acc)[T], bool first) __attribute__((always_inline)) {
+    auto pos_segments = [&](LayerRun16<T, NT, NS, FMT> &run, f4(&acc)[T], bool first, int kx) __attribute__((always_inline)) {
         auto pe_segment = [&]() __attribute__((always_inline)) {
             for (int kb = 0; kb < A.pos_nkb; ++kb)
                 run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) {
                     f4 half[2];
-                    pe_operand16<NS>(c, false, A.pos_L, A.pos_id, kb, b, half);
+                    pe_operand16<NS, FMT>(c, false, A.pos_L, A.pos_id, kb, b, half, kx);
                     if (TRAIN && first && valid) {
                         store_tile(A.act, A.act_pe + 2 * kb, A.n, sample, c.g, half[0]);
                         if (2 * kb + 1 < A.pos_nkb16) store_tile(A.act, A.act_pe + 2 * kb + 1, A.n, sample, c.g, half[1]);
@@ -173,12 +242,17 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         if (!A.add_first) add_segment();
     };
     // positional_net[i] + relu: src (pre-activation of the previous layer) -> dst
+    int es = 0;   // f16x3: the accumulators of the layer just finished hold (true value) x 2^es
     auto hidden = [&](int i, const f4(&src)[T], f4(&dst)[T]) __attribute__((always_inline)) {
-        LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(dst);
-        run.template run_hidden<true>(src, dst);
-        if ((A.skip_mask >> i) & 1u) pos_segments(run, dst, false);
+        const bool skip = (A.skip_mask >> i) & 1u;
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale(sample_exp(src, true), es, skip ? KX_PE : KX_MAX);
+        LayerRun16<T, NT, NS, FMT> run(pipe, lane);
+        run.init(dst, wexp(i + 1) + kx);
+        run.template run_hidden<true>(src, dst, kx - es);
+        if (skip) pos_segments(run, dst, false, kx);
         run.finish();
+        if constexpr (F16) es = wexp(i + 1) + kx;
         if (TRAIN && valid) {
             store_mask(A.act, A.act_mask, i + 1, A.n, sample, c.g, dst);
             asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
@@ -186,9 +260,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         }
     };
     {  // positions_pose_input (its relu is applied when the next layer splits accA)
-        LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(accA);
-        pos_segments(run, accA, true);
+        LayerRun16<T, NT, NS, FMT> run(pipe, lane);
+        if constexpr (F16) es = wexp(0) + KX_PE;
+        run.init(accA, es);
+        pos_segments(run, accA, true, KX_PE);
         run.finish();
         if (TRAIN && valid) {
             store_mask(A.act, A.act_mask, 0, A.n, sample, c.g, accA);
@@ -205,43 +280,56 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
             for (int t = 0; t < T; ++t) accA[t] = accB[t];
         }
     }
+    const int nh = A.n_hidden;
     {  // additional_linear_layer: relu(accA) -> accB (no activation on its output)
-        LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(accB);
-        run.template run_hidden<true>(accA, accB);
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale(sample_exp(accA, true), es, KX_MAX);
+        LayerRun16<T, NT, NS, FMT> run(pipe, lane);
+        run.init(accB, wexp(nh + 1) + kx);
+        run.template run_hidden<true>(accA, accB, kx - es);
         run.finish();
+        if constexpr (F16) es = wexp(nh + 1) + kx;
         if (TRAIN && valid) store_act<false>(A.act, A.act_o, A.n, sample, c.g, accB);
     }
+    int e_o = 0;   // f16x3: exponent of the largest |additional output| of the sample (feeds two layers)
+    if constexpr (F16) e_o = sample_exp(accB, false);
     f4 sig[1];
     {
-        LayerRun16<1, NT, NS> run(pipe, lane);
-        run.init(sig);
-        run.template run_hidden<false>(accB, sig);
+        const int kx = F16 ? operand_scale(e_o, es, KX_MAX) : 0;
+        LayerRun16<1, NT, NS, FMT> run(pipe, lane);
+        run.init(sig, wexp(nh + 2) + kx);
+        run.template run_hidden<false>(accB, sig, kx - es);
         run.finish();
+        if constexpr (F16) sig[0][0] = __builtin_ldexpf(sig[0][0], -(wexp(nh + 2) + kx));
     }
     f4 accd[TD], acce[TD];
     {  // directional_input (no activation)
-        LayerRun16<TD, NT, NS> run(pipe, lane);
-        run.init(accd);
-        run.template run_hidden<false>(accB, accd);
+        const int kx = F16 ? operand_scale(e_o, es, A.dir_nkb > 0 ? KX_PE : KX_MAX) : 0;
+        LayerRun16<TD, NT, NS, FMT> run(pipe, lane);
+        run.init(accd, wexp(nh + 3) + kx);
+        run.template run_hidden<false>(accB, accd, kx - es);
         for (int kb = 0; kb < A.dir_nkb; ++kb)
             run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) {
                 f4 half[2];
-                pe_operand16<NS>(c, true, A.dir_L, A.dir_id, kb, b, half);
+                pe_operand16<NS, FMT>(c, true, A.dir_L, A.dir_id, kb, b, half, kx);
                 if (TRAIN && valid) {
                     store_tile(A.act, A.act_dpe + 2 * kb, A.n, sample, c.g, half[0]);
                     if (2 * kb + 1 < A.dir_nkb16) store_tile(A.act, A.act_dpe + 2 * kb + 1, A.n, sample, c.g, half[1]);
                 }
             }, accd);
         run.finish();
+        if constexpr (F16) es = wexp(nh + 3) + kx;
         if (TRAIN && valid) store_act<false>(A.act, A.act_h1, A.n, sample, c.g, accd);
         if (!TRAIN && tile + gridDim.x < A.n_tiles) load_raw(tile + gridDim.x, raw);
     }
     {  // directional_net[0] (its relu is applied when the rgb head splits acce)
-        LayerRun16<TD, NT, NS> run(pipe, lane);
-        run.init(acce);
-        run.template run_hidden<false>(accd, acce);
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale(sample_exp(accd, false), es, KX_MAX);
+        LayerRun16<TD, NT, NS, FMT> run(pipe, lane);
+        run.init(acce, wexp(nh + 4) + kx);
+        run.template run_hidden<false>(accd, acce, kx - es);
         run.finish();
+        if constexpr (F16) es = wexp(nh + 4) + kx;
         if (TRAIN && valid) {
             store_mask(A.act, A.act_mask, A.n_hidden + 1, A.n, sample, c.g, acce);
             asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
@@ -250,10 +338,16 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     }
     f4 rgb[1];
     {
-        LayerRun16<1, NT, NS> run(pipe, lane);
-        run.init(rgb);
-        run.template run_hidden<true>(acce, rgb);
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale(sample_exp(acce, true), es, KX_MAX);
+        LayerRun16<1, NT, NS, FMT> run(pipe, lane);
+        run.init(rgb, wexp(nh + 5) + kx);
+        run.template run_hidden<true>(acce, rgb, kx - es);
         run.finish();
+        if constexpr (F16) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) rgb[0][r] = __builtin_ldexpf(rgb[0][r], -(wexp(nh + 5) + kx));
+        }
     }
     if (valid && c.g == 0)
         __builtin_nontemporal_store(f4{rgb[0][0], rgb[0][1], rgb[0][2], sig[0][0]}, reinterpret_cast<f4 *>(A.raw) + sample);
@@ -264,9 +358,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
 }
 
 // any (kw = 32) Plan -> split-bf16 slab stream; shared with warp_bf16.hip
-int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what) {
+int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what, int fmt) {
     hipLaunchKernelGGL(mlp_pack_bf16_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, s, P, ns, params_flat,
-                       reinterpret_cast<unsigned char *>(packed));
+                       reinterpret_cast<unsigned char *>(packed), fmt);
     return check_launch(what);
 }
 
@@ -278,13 +372,13 @@ static int plan16(const snerf_mlp_desc *desc, Plan &P, const char *what) {
     return SNERF_OK;
 }
 
-template <int NS, bool TRAIN>
+template <int NS, bool TRAIN, int FMT = FMT_BF16>
 static int launch_bf16(const FwdArgs &A, hipStream_t s) {
     constexpr int NW = 8;
     const int lds = 3 * slab16_bytes(NS);
     static bool attr = false;  // idempotent; a race only repeats the call
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_bf16_kernel<256, NW, NS, TRAIN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_bf16_kernel<256, NW, NS, TRAIN, FMT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return fail(SNERF_E_LAUNCH, "mlp_fwd_bf16: cannot raise the dynamic LDS limit to %d bytes", lds);
         attr = true;
@@ -301,7 +395,7 @@ static int launch_bf16(const FwdArgs &A, hipStream_t s) {
     static const bool persistent = !(getenv("SNERF_BF16_PERSISTENT") && atoi(getenv("SNERF_BF16_PERSISTENT")) == 0);
     const int64_t grid = (persistent && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: n too large");
-    hipLaunchKernelGGL((mlp_fwd_bf16_kernel<256, NW, NS, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
+    hipLaunchKernelGGL((mlp_fwd_bf16_kernel<256, NW, NS, TRAIN, FMT>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_fwd_bf16");
 }
 
@@ -310,9 +404,12 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
                     int dirs_per_sample, const float *add, int64_t n, int samples_per_ray, float *raw, float *act,
                     bool train, snerf_stream_t stream, const char *what) {
     Plan P;
-    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "%s: nsplit must be 2 or 3", what);
+    if (nsplit != 2 && nsplit != 3 && nsplit != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "%s: nsplit must be 2, 3 or %d (f16x3)", what, SNERF_SPLIT_F16X3);
     int rc = plan16(desc, P, what);
     if (rc) return rc;
+    if (nsplit == SNERF_SPLIT_F16X3 && (train || P.add_dim))
+        return fail(SNERF_E_BADARG, "%s: f16x3 is the inference kernel of nets without additional inputs", what);
     if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "%s: bad n/samples_per_ray", what);
     if (n == 0) return SNERF_OK;
     if (!packed || !x || !raw || (train && !act)) return fail(SNERF_E_BADARG, "%s: null pointer", what);
@@ -367,6 +464,7 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
         if (nsplit == 3) return launch_bf16<3, true>(A, (hipStream_t)stream);
         return launch_bf16<2, true>(A, (hipStream_t)stream);
     }
+    if (nsplit == SNERF_SPLIT_F16X3) return launch_bf16<2, false, FMT_F16>(A, (hipStream_t)stream);
     if (nsplit == 3) return launch_bf16<3, false>(A, (hipStream_t)stream);
     return launch_bf16<2, false>(A, (hipStream_t)stream);
 }
@@ -376,21 +474,24 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
 extern "C" int64_t snerf_mlp_packed_bf16_bytes(const snerf_mlp_desc *desc, int nsplit) {
     using namespace snerf;
     Plan P;
-    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_packed_bf16_bytes: nsplit must be 2 or 3");
+    if (nsplit != 2 && nsplit != 3 && nsplit != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "mlp_packed_bf16_bytes: nsplit must be 2, 3 or %d (f16x3)", SNERF_SPLIT_F16X3);
     int rc = plan16(desc, P, "mlp_packed_bf16_bytes");
     if (rc) return rc;
-    return (int64_t)(P.total_slabs + SLAB_PAD) * slab16_bytes(nsplit);
+    return (int64_t)(P.total_slabs + SLAB_PAD) * slab16_bytes(nsplit == SNERF_SPLIT_F16X3 ? 2 : nsplit);
 }
 
 extern "C" int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed, int nsplit,
                                    snerf_stream_t stream) {
     using namespace snerf;
     Plan P;
-    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_pack_bf16: nsplit must be 2 or 3");
+    if (nsplit != 2 && nsplit != 3 && nsplit != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "mlp_pack_bf16: nsplit must be 2, 3 or %d (f16x3)", SNERF_SPLIT_F16X3);
     int rc = plan16(desc, P, "mlp_pack_bf16");
     if (rc) return rc;
     if (!params_flat || !packed) return fail(SNERF_E_BADARG, "mlp_pack_bf16: null pointer");
     if (!aligned(packed, 16)) return fail(SNERF_E_ALIGN, "mlp_pack_bf16: packed must be 16-byte aligned");
+    if (nsplit == SNERF_SPLIT_F16X3) return launch_pack_bf16(P, 2, params_flat, packed, (hipStream_t)stream, "mlp_pack_bf16", FMT_F16);
     return launch_pack_bf16(P, nsplit, params_flat, packed, (hipStream_t)stream, "mlp_pack_bf16");
 }
 

@@ -13,7 +13,7 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 __host__ __device__ constexpr int slab16_bytes(int ns) { return ns * 16384 + 1024; }
 
 // mlp_bf16.hip: any kw = 32 Plan -> split-bf16 slab stream
-int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what);
+int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what, int fmt = 0);
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
 template <int I, int N, class F>
@@ -191,7 +191,20 @@ struct SlabPipe16 {
 //     B operand (splitting fp32 accumulators into bf16 parts); the pieces are spread over the pairs and float
 //     between that pair's MFMAs instead of forming a serial phase between k-blocks.
 // `b` holds this k-block's B operand parts (ready on entry).
-template <int T_OUT, int NS, class MakePiece, class Boundary>
+// operand formats of the split kernels: FMT_BF16 - bf16 parts on v_mfma_f32_16x16x32_bf16; FMT_F16 - two fp16 parts of
+// operands pre-scaled by powers of two (per layer for the weights, per sample for the activations) on
+// v_mfma_f32_16x16x32_f16 (mlp_bf16.hip, "f16x3").  Both take eight 16-bit values per lane: `bf8` is the container.
+enum { FMT_BF16 = 0, FMT_F16 = 1 };
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+template <int FMT>
+__device__ __forceinline__ f4 mfma16(const bf8 &a, const bf8 &b, const f4 &c) {
+    if constexpr (FMT == FMT_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int T_OUT, int NS, int FMT, class MakePiece, class Boundary>
 __device__ __forceinline__ void kblock16(uint32_t addr, bf8 (&fa0)[NS], bf8 (&fa1)[NS], const bf8 (&b)[NS],
                                          MakePiece make_piece, f4 (&acc)[T_OUT], Boundary boundary) {
     using Tm = Terms<NS>;
@@ -206,7 +219,7 @@ __device__ __forceinline__ void kblock16(uint32_t addr, bf8 (&fa0)[NS], bf8 (&fa
 #pragma unroll
         for (int i = 0; i < 4; ++i) make_piece.make(i);
 #pragma unroll
-        for (int t = 0; t < Tm::N; ++t) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[Tm::A[t]], b[Tm::B[t]], acc[0], 0, 0, 0);
+        for (int t = 0; t < Tm::N; ++t) acc[0] = mfma16<FMT>(a[Tm::A[t]], b[Tm::B[t]], acc[0]);
         make_piece.touch();
         __builtin_amdgcn_sched_barrier(0);
     } else {
@@ -237,13 +250,13 @@ __device__ __forceinline__ void kblock16(uint32_t addr, bf8 (&fa0)[NS], bf8 (&fa
                 if constexpr (t < NS) {
                     constexpr int s = Tm::FIRST[t];
                     wait_two<2 * NS - 2>(a0[s], a1[s]);
-                    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[Tm::A[t]], b[Tm::B[t]], acc[to], 0, 0, 0);
+                    acc[to] = mfma16<FMT>(a0[Tm::A[t]], b[Tm::B[t]], acc[to]);
                     lds_load_between<(NEXT_TILE * NS + s) * 1024>(n0[s], src, acc[to], acc[to + 1]);
-                    acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1], 0, 0, 0);
+                    acc[to + 1] = mfma16<FMT>(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1]);
                     lds_load_between<((NEXT_TILE + 1) * NS + s) * 1024>(n1[s], src, acc[to + 1], acc[to]);
                 } else {
-                    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[Tm::A[t]], b[Tm::B[t]], acc[to], 0, 0, 0);
-                    acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1], 0, 0, 0);
+                    acc[to] = mfma16<FMT>(a0[Tm::A[t]], b[Tm::B[t]], acc[to]);
+                    acc[to + 1] = mfma16<FMT>(a1[Tm::A[t]], b[Tm::B[t]], acc[to + 1]);
                 }
             });
             if constexpr (has_piece) make_piece.touch();
@@ -269,8 +282,26 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // (v0, v1) -> dword `i` (elements 2i, 2i+1) of the NS packed-bf16 parts.  Per part: one v_cvt_pk_bf16_f32 for both
 // values, a shift and a mask to widen the two halves back to fp32, and two scalar subtractions (kept scalar on
 // purpose: packed-fp32 VALU beside MFMAs costs matrix-pipe issue slots - MI355X_MICROARCH.md).
-template <int NS>
+typedef __fp16 h2v __attribute__((ext_vector_type(2)));
+template <int NS, int FMT = FMT_BF16>
 __device__ __forceinline__ void split_pair_into(float v0, float v1, bf8 (&dst)[NS], int i) {
+    if constexpr (FMT == FMT_F16) {
+        // two fp16 parts, rounded toward zero (v_cvt_pkrtz_f16_f32: the one packed conversion there is); the caller
+        // has scaled the values into fp16's range
+        static_assert(NS == 2, "f16x3 = two parts");
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const h2v h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+            u4v t = __builtin_bit_cast(u4v, dst[s]);
+            t[i] = __builtin_bit_cast(uint32_t, h);
+            dst[s] = __builtin_bit_cast(bf8, t);
+            if (s == 0) {
+                v0 = v0 - (float)h[0];
+                v1 = v1 - (float)h[1];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{v0, v1}, bf2v));
@@ -289,27 +320,33 @@ __device__ __forceinline__ float relu1(float v) {
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
 }
-template <bool RELU, bool PIN, int T_SRC, int NS>
-__device__ __forceinline__ void split_piece(const f4 (&src)[T_SRC], int kb, int i, bf8 (&b)[NS]) {
+// `delta` (FMT_F16 only): power-of-two rescaling of the source accumulators into this layer's operand scale
+template <bool RELU, bool PIN, int T_SRC, int NS, int FMT = FMT_BF16>
+__device__ __forceinline__ void split_piece(const f4 (&src)[T_SRC], int kb, int i, bf8 (&b)[NS], int delta = 0) {
     float v0 = src[2 * kb + (i >> 1)][(2 * i) & 3], v1 = src[2 * kb + (i >> 1)][((2 * i) & 3) + 1];
     if constexpr (PIN) asm volatile("" : "+v"(v0), "+v"(v1));
     if constexpr (RELU) {
         v0 = relu1(v0);
         v1 = relu1(v1);
     }
-    split_pair_into<NS>(v0, v1, b, i);
+    if constexpr (FMT == FMT_F16) {
+        v0 = __builtin_ldexpf(v0, delta);
+        v1 = __builtin_ldexpf(v1, delta);
+    }
+    split_pair_into<NS, FMT>(v0, v1, b, i);
 }
 struct NoPiece {
     __device__ __forceinline__ void make(int) const {}
     __device__ __forceinline__ void touch() const {}
 };
-template <bool RELU, int T_SRC, int NS>
+template <bool RELU, int T_SRC, int NS, int FMT = FMT_BF16>
 struct NextPieceT {
     const f4 (&src)[T_SRC];
     bf8 (&bn)[NS];
     int kb;  // the k-block being prepared (nothing to do past the last one)
+    int delta = 0;
     __device__ __forceinline__ void make(int i) const {
-        if (kb < T_SRC / 2) split_piece<RELU, true>(src, kb, i, bn);
+        if (kb < T_SRC / 2) split_piece<RELU, true, T_SRC, NS, FMT>(src, kb, i, bn, delta);
     }
     // keeps the piece's results inside the tile-pair region they were issued in
     __device__ __forceinline__ void touch() const {
@@ -320,22 +357,29 @@ struct NextPieceT {
     }
 };
 
-template <int T_OUT, int NT, int NS>
+template <int T_OUT, int NT, int NS, int FMT = FMT_BF16>
 struct LayerRun16 {
     static constexpr int KPS = 16 / T_OUT;
     SlabPipe16<NT, NS> &pipe;
     const char *slab;
     int kbl, lane;
     __device__ __forceinline__ LayerRun16(SlabPipe16<NT, NS> &p, int lane_) : pipe(p), slab(p.acquire()), kbl(0), lane(lane_) {}
-    __device__ __forceinline__ void init(f4 (&acc)[T_OUT]) {
+    // bias_exp (FMT_F16): the accumulators of the layer carry the scale 2^bias_exp (weights x operands), so does the bias
+    __device__ __forceinline__ void init(f4 (&acc)[T_OUT], int bias_exp = 0) {
         const f4 *aux = reinterpret_cast<const f4 *>(slab + NS * 16384) + (lane >> 4);
 #pragma unroll
-        for (int to = 0; to < T_OUT; ++to) acc[to] = aux[to * 4];
+        for (int to = 0; to < T_OUT; ++to) {
+            acc[to] = aux[to * 4];
+            if constexpr (FMT == FMT_F16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[to][r] = __builtin_ldexpf(acc[to][r], bias_exp);
+            }
+        }
     }
     static constexpr int KB_BYTES = T_OUT * NS * 1024;
     template <class MakePiece>
     __device__ __forceinline__ void step(const bf8 (&b)[NS], MakePiece make_piece, f4 (&acc)[T_OUT]) {
-        kblock16<T_OUT, NS>(lds_addr(slab + kbl * KB_BYTES) + pipe.lane16, pipe.fa0, pipe.fa1, b, make_piece, acc,
+        kblock16<T_OUT, NS, FMT>(lds_addr(slab + kbl * KB_BYTES) + pipe.lane16, pipe.fa0, pipe.fa1, b, make_piece, acc,
                             [&]() __attribute__((always_inline)) -> uint32_t {
                                 if (++kbl == KPS) {  // this k-block was the last of its slab
                                     pipe.release();
@@ -354,13 +398,13 @@ struct LayerRun16 {
     }
     // k-blocks fed by the accumulators of a previous layer: tiles 2kb, 2kb+1 are split just in time
     template <bool RELU, int T_SRC>
-    __device__ __forceinline__ void run_hidden(const f4 (&src)[T_SRC], f4 (&acc)[T_OUT]) {
+    __device__ __forceinline__ void run_hidden(const f4 (&src)[T_SRC], f4 (&acc)[T_OUT], int delta = 0) {
         bf8 bc[NS], bn[NS];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split_piece<RELU, false>(src, 0, i, bc);  // the only split of the layer not hidden behind MFMAs
+        for (int i = 0; i < 4; ++i) split_piece<RELU, false, T_SRC, NS, FMT>(src, 0, i, bc, delta);  // the only split of the layer not hidden behind MFMAs
 #pragma unroll
         for (int kb = 0; kb < T_SRC / 2; ++kb) {
-            step(bc, NextPieceT<RELU, T_SRC, NS>{src, bn, kb + 1}, acc);
+            step(bc, NextPieceT<RELU, T_SRC, NS, FMT>{src, bn, kb + 1, delta}, acc);
 #pragma unroll
             for (int s = 0; s < NS; ++s) bc[s] = bn[s];
         }
@@ -379,9 +423,9 @@ struct LayerRun16 {
 // B operand of encoder k-block kb: 4 units (sin, cos pairs) per lane
 // `half[h]` = the fp32 values of 16-wide k-block 2kb + h in the fp32 kernel's layout (mlp_device.h pe_operand): what
 // the training forward stores for the backward kernels
-template <int NS>
+template <int NS, int FMT = FMT_BF16>
 __device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, int L, int ident, int kb, bf8 (&b)[NS],
-                                             f4 (&half)[2]) {
+                                             f4 (&half)[2], int scale_exp = 0) {
     const float x = is_dir ? c.dx : c.px, y = is_dir ? c.dy : c.py, z = is_dir ? c.dz : c.pz;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -389,7 +433,11 @@ __device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, in
         pe_unit(x, y, z, L, ident, 4 * (4 * kb + u) + c.g, s0, c0);
         half[u >> 1][2 * (u & 1)] = s0;
         half[u >> 1][2 * (u & 1) + 1] = c0;
-        split_pair_into<NS>(s0, c0, b, u);
+        if constexpr (FMT == FMT_F16) {
+            s0 = __builtin_ldexpf(s0, scale_exp);
+            c0 = __builtin_ldexpf(c0, scale_exp);
+        }
+        split_pair_into<NS, FMT>(s0, c0, b, u);
     }
 }
 template <int NS>

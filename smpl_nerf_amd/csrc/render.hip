@@ -77,8 +77,8 @@ extern "C" int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const vo
                                      void *workspace, float *rgb, float *rgb_fine, float *samples_fine,
                                      float *densities_fine, snerf_stream_t stream) {
     using namespace snerf;
-    if (precision != 0 && precision != 2 && precision != 3)
-        return fail(SNERF_E_BADARG, "render_rays: precision must be 0 (fp32), 2 (bf16x3) or 3 (bf16x6)");
+    if (precision != 0 && precision != 2 && precision != 3 && precision != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "render_rays: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
     if (B < 0 || Nc < 1 || Nf < 0) return fail(SNERF_E_BADARG, "render_rays: bad B/Nc/Nf");
     if (B == 0) return SNERF_OK;
     if (!desc_coarse || !packed_coarse || !ray_samples || !rays_d || !z_vals || !workspace || !rgb || !rgb_fine ||
@@ -136,8 +136,8 @@ extern "C" int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, con
                                           float *warp_fine, float *samples_fine, float *warped_fine,
                                           float *densities_fine, snerf_stream_t stream) {
     using namespace snerf;
-    if (precision != 0 && precision != 2 && precision != 3)
-        return fail(SNERF_E_BADARG, "render_rays_smpl: precision must be 0 (fp32), 2 (bf16x3) or 3 (bf16x6)");
+    if (precision != 0 && precision != 2 && precision != 3 && precision != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "render_rays_smpl: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
     if (B < 0 || Nc < 1 || Nf < 1) return fail(SNERF_E_BADARG, "render_rays_smpl: bad B/Nc/Nf");
     if (B == 0) return SNERF_OK;
     if (!desc_coarse || !packed_coarse || !desc_fine || !packed_fine || !desc_warp || !packed_warp || !ray_samples ||

@@ -40,7 +40,7 @@ class _FusedMlpFn(torch.autograd.Function):
         n = x.shape[0]
         dev = x.device
         net._begin_training_forward()
-        ns = {"bf16x6": 3, "bf16x3": 2}.get(net.precision, 0) if (net.width == 256 and per_sample != _ENCODED_ROWS) else 0
+        ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": 3}.get(net.precision, 0) if (net.width == 256 and per_sample != _ENCODED_ROWS) else 0
         packed = net.packed_weights_bf16(desc, ns, training=True) if ns else net.packed_weights(desc, training=True)
         sizes = [ctypes.c_int64() for _ in range(4)]
         cnt = ctypes.c_int32()
@@ -360,8 +360,9 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
                                      None if add is None else add.detach(), *self._ordered_params())
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
         lib = _lib.load()
-        if self.precision in ("bf16x6", "bf16x3") and self.width == 256:
-            ns = 3 if self.precision == "bf16x6" else 2
+        if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:
+            # "f16x3": two fp16 parts (inference, nets without additional inputs; otherwise its accuracy class, bf16x6)
+            ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3 if add is None else 3}[self.precision]
             packed = self.packed_weights_bf16(desc, ns)
             with torch.cuda.device(x.device), _lib.timed(f"mlp_fwd[n={n}]"):
                 check(lib.snerf_mlp_fwd_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n,
@@ -544,7 +545,7 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
             return _WarpFn.apply(self, desc, x.detach(), pe.detach(), o.detach(), int(samples_per_ray), *self._params())
         warp, warped, sdirs = (torch.empty((n, 3), device=x.device, dtype=torch.float32) for _ in range(3))
         lib = _lib.load()
-        if self.precision in ("bf16x6", "bf16x3") and self.width == 256:
+        if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:
             packed = self._packed_bf16(desc)
             with torch.cuda.device(x.device), _lib.timed(f"warp_fwd[n={n}]"):
                 check(lib.snerf_warp_fwd_bf16_f32(desc, ptr(packed), ptr(x), ptr(pe), ptr(o), n, int(samples_per_ray),
@@ -607,8 +608,8 @@ class AppendVerticesNet(RenderRayNet):
                                      *self._ordered_params())
         raw = torch.empty((n, 4), device=add.device, dtype=torch.float32)
         lib = _lib.load()
-        if self.precision in ("bf16x6", "bf16x3") and self.width == 256:
-            ns = 3 if self.precision == "bf16x6" else 2
+        if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:
+            ns = 2 if self.precision == "bf16x3" else 3   # ("f16x3" has no additional-input kernel: its accuracy class)
             packed = self.packed_weights_bf16(desc, ns)
             with torch.cuda.device(add.device), _lib.timed(f"mlp_fwd[n={n}]"):
                 check(lib.snerf_mlp_fwd_bf16_f32(desc, ptr(packed), ns, ptr(dummy_x), ptr(d), 0, ptr(add), n,

@@ -47,7 +47,7 @@ class NerfPipeline(nn.Module):
     def set_precision(self, precision: str):
         """Matrix-core arithmetic of every net of the pipeline: "fp32" (exact fp32 MFMA), "bf16x6" (split-bf16, fp32-class
         accuracy - the parity mode on the bf16 matrix cores) or "bf16x3" (split-bf16, ~2^-16 relative)."""
-        if precision not in ("fp32", "bf16x6", "bf16x3"):
+        if precision not in ("fp32", "bf16x6", "bf16x3", "f16x3"):
             raise ValueError(f"unknown precision {precision!r}")
         for m in self.modules():
             if hasattr(m, "precision") and m is not self:
@@ -97,7 +97,7 @@ class NerfPipeline(nn.Module):
         mc, mf = self.model_coarse, self.model_fine
         if mc.precision != mf.precision:
             raise RuntimeError("render_rays: both nets must use the same precision mode")
-        prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[mc.precision]
+        prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": _lib.SPLIT_F16X3}[mc.precision]
         descs, packed = [], []
         for m in (mc, mf):
             d = m.desc_for_encoders(self.position_encoder, self.direction_encoder, False)
@@ -182,7 +182,7 @@ class SmplNerfPipeline(NerfPipeline):
         mc, mf, mw = self.model_coarse, self.model_fine, self.model_warp_field
         if not (mc.precision == mf.precision == mw.precision):
             raise RuntimeError("render_rays: all nets must use the same precision mode (set_precision)")
-        prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[mc.precision]
+        prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": _lib.SPLIT_F16X3}[mc.precision]
         goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)
         pose_enc = self.human_pose_encoder.encode(goal_pose.contiguous()).contiguous()
         descs, packed = [], []

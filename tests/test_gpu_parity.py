@@ -637,10 +637,11 @@ def test_raygen_frame_and_random_batches(dev):
 
 
 # ------------------------------------------------------------------------------------------ split-bf16 MFMA modes
-@pytest.mark.parametrize("prec,tol_raw,tol_rgb", [("bf16x6", 1e-5, 1e-4), ("bf16x3", 2e-3, 2e-4)])
+@pytest.mark.parametrize("prec,tol_raw,tol_rgb", [("bf16x6", 1e-5, 1e-4), ("f16x3", 1e-5, 1e-4), ("bf16x3", 2e-3, 2e-4)])
 def test_split_bf16_modes(dev, prec, tol_raw, tol_rgb):
-    """The bf16-matrix-core modes of the inference kernel: bf16x6 is in the fp32 kernel's parity class (RGB <= 1e-4
-    vs the reference's frame, raw <= 1e-5 * head scale), bf16x3 trades ~2^-16 relative error for speed."""
+    """The 16-bit-matrix-core modes of the inference kernel: bf16x6 (three bf16 parts, six products) and f16x3 (two fp16
+    parts of power-of-two-scaled operands, three products) are in the fp32 kernel's parity class (RGB <= 1e-4 vs the
+    reference's frame, raw <= 1e-5 * head scale), bf16x3 trades ~2^-16 relative error for speed."""
     from smpl_nerf_amd.ops import PositionalEncoder
     g = load_golden("g2_mlp.npz")
     net = _net(dev, syn.make_scene_nets(101)[1])
@@ -766,7 +767,7 @@ def test_split_bf16_stress_against_fp32_kernel(dev):
             tdirs = T(dirs.reshape(-1, 3), dev)
             outs = {}
             with torch.no_grad():
-                for prec in ("fp32", "bf16x6", "bf16x3"):
+                for prec in ("fp32", "bf16x6", "bf16x3", "f16x3"):   # (f16x3 with additional inputs runs bf16x6)
                     net.precision = prec
                     a = net.forward_fused(T(pts, dev), tdirs, Ns, *enc, **kwf)
                     b = net.forward_fused(T(pts, dev), tdirs, Ns, *enc, **kwf)
@@ -775,10 +776,41 @@ def test_split_bf16_stress_against_fp32_kernel(dev):
             ref = _mlp_ref64(params, pts, np.broadcast_to(dirs, (B, Ns, 3)),
                              None if add is None else np.broadcast_to(add, (B, Ns, add_dim)), add_first, **kw)
             scale = float(np.abs(ref).max()) + 1e-6
-            e32, e6, e3 = (float(np.abs(outs[k] - ref).max()) for k in ("fp32", "bf16x6", "bf16x3"))
-            assert np.isfinite(outs["bf16x6"]).all() and np.isfinite(outs["bf16x3"]).all()
+            e32, e6, e3, ef = (float(np.abs(outs[k] - ref).max()) for k in ("fp32", "bf16x6", "bf16x3", "f16x3"))
+            assert np.isfinite(outs["bf16x6"]).all() and np.isfinite(outs["bf16x3"]).all() and np.isfinite(outs["f16x3"]).all()
             assert e6 <= 2.0 * e32 + 1e-5 * scale, (kw, B, Ns, e32, e6)
+            assert ef <= 8.0 * e32 + 1e-5 * scale, (kw, B, Ns, e32, ef)   # 2^-22 products, parts rounded toward zero
             assert e3 <= 300.0 * e32 + 2e-3 * scale, (kw, B, Ns, e32, e3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (1e-3, 1.0), (300.0, 1.0), (1.0, 1e-4), (3e-3, 40.0), (1e3, 1e3)])
+def test_f16x3_operand_ranges(dev, wscale, xscale):
+    """f16x3 scales every operand into fp16's range by exact powers of two (weights per layer, activations per sample):
+    hidden weights scaled by `wscale` (activations then grow or shrink by wscale^depth: 1e-21 .. 1e21 relative to the
+    inputs) and sample positions by `xscale` must neither overflow nor lose the result - error against float64 bounded
+    like the fp32 kernel's own."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(int(wscale * 1000) % 97 + 3)
+    params = syn.make_render_ray_net_params(77, 30.0, 10.0)
+    for k in list(params):
+        if k.startswith("positional_net.") and k.endswith(".weight"):
+            params[k] = (params[k] * np.float32(wscale)).astype(F32)
+    net = _net(dev, params)
+    B, Ns = 64, 16
+    pts = (rng.uniform(-2.5, 2.5, (B, Ns, 3)) * xscale).astype(F32)
+    dirs = rng.normal(size=(B, 1, 3)).astype(F32)
+    enc = (PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    outs = {}
+    with torch.no_grad():
+        for prec in ("fp32", "f16x3"):
+            net.precision = prec
+            outs[prec] = N(net.forward_fused(T(pts, dev), T(dirs.reshape(-1, 3), dev), Ns, *enc)).reshape(B, Ns, 4).astype(np.float64)
+    ref = _mlp_ref64(params, pts, np.broadcast_to(dirs, (B, Ns, 3)), None, False)
+    scale = float(np.abs(ref).max()) + 1e-30
+    assert np.isfinite(ref).all() and np.isfinite(outs["f16x3"]).all()
+    e32, ef = (float(np.abs(outs[k] - ref).max()) for k in ("fp32", "f16x3"))
+    assert ef <= 8.0 * e32 + 1e-5 * scale, (wscale, xscale, e32, ef, scale)
 
 
 @pytest.mark.gpu

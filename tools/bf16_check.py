@@ -16,7 +16,7 @@ data = [torch.from_numpy(a).to(dev) for a in syn.frame_batch(128, 128, seed=7)]
 g = dict(np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "g5_nerf_pipeline.npz")))
 res = {}
 with torch.no_grad():
-    for prec in ("fp32", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "bf16x3", "f16x3"):
         mc.precision = mf.precision = prec
         out = pipe(data); torch.cuda.synchronize()
         t0 = time.perf_counter()
