@@ -30,8 +30,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X fp32 matrix peak (MI355X_MICROARCH
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md)
 # precision modes of the inference kernel: (kernel name for rocprof, products per fp32-accurate MAC)
 MODES = {"fp32": ("snerf::mlp_fwd_kernel<256, 8, false, false>", 1),
-         "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3, false>", 6),
-         "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false>", 3)}
+         "f16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false, 1>", 3),
+         "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3, false, 0>", 6),
+         "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false, 0>", 3)}
 # HBM bytes per average launch of the MLP kernel, per precision mode, from the rocprofv3 PMC passes committed under
 # profiles/ (FETCH_SIZE as reported plus WRITE_SIZE); the kernels are MFMA-bound, this is informational.
 TRAFFIC_PER_LAUNCH = {}
@@ -145,9 +146,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the frame the CPU baseline renders (0 = skip)")
-    ap.add_argument("--precision", choices=sorted(MODES), default="bf16x6",
-                    help="matrix-core arithmetic of the render kernel: bf16x6 (split-bf16, fp32-class accuracy, default), "
-                         "fp32 (v_mfma_f32_16x16x4_f32), bf16x3 (2-part split, ~1e-5 relative)")
+    ap.add_argument("--precision", choices=sorted(MODES), default="f16x3",
+                    help="matrix-core arithmetic of the render kernel: f16x3 (two fp16 parts of power-of-two-scaled "
+                         "operands, 3 products per MAC, fp32-class accuracy, default), bf16x6 (three bf16 parts, 6 products, "
+                         "fp32-class accuracy), fp32 (v_mfma_f32_16x16x4_f32), bf16x3 (two bf16 parts, ~1e-5 relative)")
     ap.add_argument("--workload", choices=["nerf", "smpl_nerf"], default="nerf",
                     help="nerf = BASELINE configs[1] (the metric's configuration); smpl_nerf = configs[2] (warp field + per-sample "
                          "directions in front of the same nets), same frame size and sample counts")
@@ -254,9 +256,9 @@ def main():
             roof_extra = {"peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32, 157.3 TFLOP/s"}
             dtype = "f32"
         else:
-            # split-bf16: every fp32 MAC of the network is `products` exact bf16 products on the bf16 matrix cores,
-            # accumulated in fp32 - that is the algorithm of this kernel, so its flop count per ray-sample is
-            # products x 1 215 744 and its roofline is the dense bf16 MFMA peak.  The fp32-equivalent rate
+            # split operands: every fp32 MAC of the network is `products` exact 16-bit products on the bf16 / fp16 matrix
+            # cores (same dense peak), accumulated in fp32 - that is the algorithm of this kernel, so its flop count per
+            # ray-sample is products x 1 215 744 and its roofline is the dense 16-bit MFMA peak.  The fp32-equivalent rate
             # (`fp32_equivalent_tflops`, what the network needs) is reported beside it.
             peak = PEAK_BF16_MFMA_TFLOPS
             achieved = alg_tflops * products
@@ -265,12 +267,15 @@ def main():
                           "fp32_equivalent_vs_fp32_mfma_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
                           "fp32_equivalent_vs_bf16_mfma_peak": alg_tflops / PEAK_BF16_MFMA_TFLOPS,
                           "algorithmic_flop_per_unit": FLOP_PER_EVAL,
-                          "bf16_products_per_fp32_mac": products,
-                          "peak_note": f"dense bf16 MFMA peak 2500 TFLOP/s (v_mfma_f32_16x16x32_bf16); operands split into "
-                                       f"bf16 parts, {products} bf16 products per fp32 MAC, fp32 accumulate; padded tiles "
+                          "products_per_fp32_mac": products,
+                          "peak_note": f"dense {'fp16' if a.precision == 'f16x3' else 'bf16'} MFMA peak 2500 TFLOP/s "
+                                       f"(v_mfma_f32_16x16x32_{'f16' if a.precision == 'f16x3' else 'bf16'}); operands split into "
+                                       f"{'two fp16' if a.precision == 'f16x3' else 'bf16'} parts, {products} products per fp32 MAC, fp32 accumulate; padded tiles "
                                        f"(84->96, 280->288 inputs, 4-wide heads) are not counted"}
-            dtype = f"f32 via {a.precision} (split-bf16 operands, fp32 accumulate; RGB parity class of the fp32 kernel)" \
-                if a.precision == "bf16x6" else f"f32 via {a.precision} (split-bf16, ~2^-16 relative)"
+            dtype = {"f16x3": "f32 via f16x3 (operands scaled by exact powers of two and split into two fp16 parts, three "
+                              "products per MAC, fp32 accumulate; RGB parity class of the fp32 kernel)",
+                     "bf16x6": "f32 via bf16x6 (split-bf16 operands, fp32 accumulate; RGB parity class of the fp32 kernel)",
+                     "bf16x3": "f32 via bf16x3 (split-bf16, ~2^-16 relative)"}[a.precision]
         line = {
             "metric": "ray-samples/sec (coarse+fine) at 128^2 / 64+128 samples",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -23,7 +23,7 @@ def net(p, **kw):
 
 
 def timed(pipe, data, nets, label):
-    for prec in ("fp32", "bf16x6", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "f16x3", "bf16x3"):
         for m in nets:
             m.precision = prec
         with torch.no_grad():
