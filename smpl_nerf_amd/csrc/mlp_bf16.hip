@@ -144,17 +144,30 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // operand scale when encoder columns take part / upper limit (activations below 2^-50: with a weight exponent <= 50 a
     // bias of up to 2^13 still fits the scaled accumulator)
     constexpr int KX_PE = 14, KX_MAX = 64;
-    // unbiased exponent of the largest |value| (after the ReLU, if any) that this lane's sample has in `src`
+    // unbiased exponent of the largest |value| (after the ReLU, if any) that this lane's sample has in `src`.  On the bit
+    // patterns: as signed integers the largest positive float wins (ReLU: negatives lose against 0); as unsigned ones a
+    // negative float, if there is one, wins with the largest magnitude (v_max3_i32 / v_max3_u32: no canonicalising
+    // extra instruction as with fmaxf).  The four lanes of a sample are 16 and 32 lanes apart: two row swaps.
     auto sample_exp = [&](const auto &src, bool relu) __attribute__((always_inline)) -> int {
         constexpr int N = sizeof(src) / sizeof(f4);
-        float m = 0.f;
+        int mp = 0;
+        unsigned mu = 0u;
 #pragma unroll
         for (int t = 0; t < N; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, relu ? src[t][r] : fabsf(src[t][r]));
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        return ((__float_as_int(m) >> 23) & 0xff) - 127;
+            for (int r = 0; r < 4; r += 2) {
+                const int b0 = __float_as_int(src[t][r]), b1 = __float_as_int(src[t][r + 1]);
+                mp = max(mp, max(b0, b1));
+                if (!relu) mu = max(mu, max((unsigned)b0, (unsigned)b1));
+            }
+        unsigned m = (unsigned)mp;
+        if (!relu) m = max(m, mu & 0x7fffffffu);   // (mu is a positive float <= mp when no value is negative)
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        u2v w = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+        m = max(w[0], w[1]);
+        w = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+        m = max(w[0], w[1]);
+        return (int)((m >> 23) & 0xffu) - 127;
     };
     // operand scale of a layer whose input has exponent e_src at accumulator scale es
     auto operand_scale = [&](int e_src, int es, int cap) __attribute__((always_inline)) -> int {

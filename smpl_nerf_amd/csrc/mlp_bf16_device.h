@@ -370,9 +370,10 @@ struct LayerRun16 {
 #pragma unroll
         for (int to = 0; to < T_OUT; ++to) {
             acc[to] = aux[to * 4];
-            if constexpr (FMT == FMT_F16) {
+            if constexpr (FMT == FMT_F16) {   // x 2^bias_exp as a multiplication (|bias_exp| stays far below 126)
+                const float sc = __int_as_float((min(max(bias_exp, -126), 127) + 127) << 23);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[to][r] = __builtin_ldexpf(acc[to][r], bias_exp);
+                for (int r = 0; r < 4; ++r) acc[to][r] *= sc;
             }
         }
     }
