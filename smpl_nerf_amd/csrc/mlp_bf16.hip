@@ -125,7 +125,7 @@ __device__ __forceinline__ void store_act(float *buf, int row0, int64_t n, int64
 // exactly: the weights of layer l by 2^wexp[l] (largest |w| of the layer at 2^14; the pack kernel leaves the table in
 // the first pad slab of the stream), the B operands of a layer per SAMPLE by 2^kx, kx from the largest activation of
 // the sample that enters the layer (all of a sample's values sit in the four lanes that share its column), capped at
-// 14 when encoder columns (|sin|, |cos| <= 1) enter too.  An accumulator column then carries 2^(wexp + kx): the bias is
+// 14 when encoder columns (|sin|, |cos| <= 1) enter too (lower if identity columns or additional inputs exceed 1).  An accumulator column then carries 2^(wexp + kx): the bias is
 // loaded with that scale, the next layer's split rescales by the difference of the two exponents (one v_ldexp per
 // value), the heads are scaled back before the store.  Nothing can overflow: scaled operands are < 2^15, a sum of 320
 // products < 2^39.
@@ -224,6 +224,29 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
 
     if (tile == blockIdx.x) pipe.prologue(A.packed, ring, tid, A.total_slabs);
 
+    // f16x3: operand scale limit of the layers that take position-encoder / additional columns: sin and cos are <= 1,
+    // identity columns and additional inputs are whatever the caller passes - the sample's largest one decides
+    int kx_pos = KX_PE;
+    if constexpr (F16) {
+        unsigned m = __float_as_uint(1.0f);
+        if (A.pos_id) m = max(m, max(__float_as_uint(fabsf(c.px)), max(__float_as_uint(fabsf(c.py)), __float_as_uint(fabsf(c.pz)))));
+        if (A.add_dim) {
+            unsigned ma = 0u;
+            for (int kb = 0; kb < A.add_nkb; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int col = 32 * kb + 16 * (e >> 2) + 4 * c.g + (e & 3);
+                    if (col < A.add_dim) ma = max(ma, __float_as_uint(fabsf(c.add[col])));
+                }
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            u2v w = __builtin_amdgcn_permlane16_swap(ma, ma, false, false);
+            ma = max(w[0], w[1]);
+            w = __builtin_amdgcn_permlane32_swap(ma, ma, false, false);
+            m = max(m, max(w[0], w[1]));
+        }
+        kx_pos = 14 - ((int)((m >> 23) & 0xffu) - 127);
+    }
+
     // two accumulator sets ping-pong between consecutive layers: the finished set feeds the next layer's B
     // operands (split just in time, k-block by k-block) while the other set accumulates
     f4 accA[T], accB[T];
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
             for (int kb = 0; kb < A.add_nkb; ++kb)
                 run.step_make([&](bf8(&b)[NS]) __attribute__((always_inline)) {
                     f4 half[2];
-                    add_operand16<NS>(c, A.add_dim, kb, b, half);
+                    add_operand16<NS, FMT>(c, A.add_dim, kb, b, half, kx);
                     if (TRAIN && first && valid) {
                         store_tile(A.act, A.act_add + 2 * kb, A.n, sample, c.g, half[0]);
                         if (2 * kb + 1 < A.add_nkb16) store_tile(A.act, A.act_add + 2 * kb + 1, A.n, sample, c.g, half[1]);
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     auto hidden = [&](int i, const f4(&src)[T], f4(&dst)[T]) __attribute__((always_inline)) {
         const bool skip = (A.skip_mask >> i) & 1u;
         int kx = 0;
-        if constexpr (F16) kx = operand_scale(sample_exp(src, true), es, skip ? KX_PE : KX_MAX);
+        if constexpr (F16) kx = operand_scale(sample_exp(src, true), es, skip ? kx_pos : KX_MAX);
         LayerRun16<T, NT, NS, FMT> run(pipe, lane);
         run.init(dst, wexp(i + 1) + kx);
         run.template run_hidden<true>(src, dst, kx - es);
@@ -274,9 +297,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     };
     {  // positions_pose_input (its relu is applied when the next layer splits accA)
         LayerRun16<T, NT, NS, FMT> run(pipe, lane);
-        if constexpr (F16) es = wexp(0) + KX_PE;
+        if constexpr (F16) es = wexp(0) + kx_pos;
         run.init(accA, es);
-        pos_segments(run, accA, true, KX_PE);
+        pos_segments(run, accA, true, kx_pos);
         run.finish();
         if (TRAIN && valid) {
             store_mask(A.act, A.act_mask, 0, A.n, sample, c.g, accA);
@@ -421,8 +444,7 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
         return fail(SNERF_E_BADARG, "%s: nsplit must be 2, 3 or %d (f16x3)", what, SNERF_SPLIT_F16X3);
     int rc = plan16(desc, P, what);
     if (rc) return rc;
-    if (nsplit == SNERF_SPLIT_F16X3 && (train || P.add_dim))
-        return fail(SNERF_E_BADARG, "%s: f16x3 is the inference kernel of nets without additional inputs", what);
+    if (nsplit == SNERF_SPLIT_F16X3 && train) return fail(SNERF_E_BADARG, "%s: f16x3 is an inference kernel", what);
     if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "%s: bad n/samples_per_ray", what);
     if (n == 0) return SNERF_OK;
     if (!packed || !x || !raw || (train && !act)) return fail(SNERF_E_BADARG, "%s: null pointer", what);

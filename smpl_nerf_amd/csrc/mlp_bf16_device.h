@@ -441,8 +441,9 @@ __device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, in
         split_pair_into<NS, FMT>(s0, c0, b, u);
     }
 }
-template <int NS>
-__device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, int kb, bf8 (&b)[NS], f4 (&half)[2]) {
+template <int NS, int FMT = FMT_BF16>
+__device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, int kb, bf8 (&b)[NS], f4 (&half)[2],
+                                              int scale_exp = 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v[2];
@@ -451,8 +452,9 @@ __device__ __forceinline__ void add_operand16(const SampleCtx &c, int add_dim, i
             const int e = 2 * j + h, col = 32 * kb + 16 * (e >> 2) + 4 * c.g + (e & 3);
             v[h] = col < add_dim ? c.add[col] : 0.f;
             half[e >> 2][e & 3] = v[h];
+            if constexpr (FMT == FMT_F16) v[h] = __builtin_ldexpf(v[h], scale_exp);
         }
-        split_pair_into<NS>(v[0], v[1], b, j);
+        split_pair_into<NS, FMT>(v[0], v[1], b, j);
     }
 }
 }  // namespace snerf

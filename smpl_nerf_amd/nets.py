@@ -361,8 +361,8 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
         lib = _lib.load()
         if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:
-            # "f16x3": two fp16 parts (inference, nets without additional inputs; otherwise its accuracy class, bf16x6)
-            ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3 if add is None else 3}[self.precision]
+            # "f16x3": two fp16 parts (inference kernel only)
+            ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}[self.precision]
             packed = self.packed_weights_bf16(desc, ns)
             with torch.cuda.device(x.device), _lib.timed(f"mlp_fwd[n={n}]"):
                 check(lib.snerf_mlp_fwd_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n,
@@ -609,7 +609,7 @@ class AppendVerticesNet(RenderRayNet):
         raw = torch.empty((n, 4), device=add.device, dtype=torch.float32)
         lib = _lib.load()
         if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:
-            ns = 2 if self.precision == "bf16x3" else 3   # ("f16x3" has no additional-input kernel: its accuracy class)
+            ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}[self.precision]
             packed = self.packed_weights_bf16(desc, ns)
             with torch.cuda.device(add.device), _lib.timed(f"mlp_fwd[n={n}]"):
                 check(lib.snerf_mlp_fwd_bf16_f32(desc, ptr(packed), ns, ptr(dummy_x), ptr(d), 0, ptr(add), n,

@@ -767,7 +767,7 @@ def test_split_bf16_stress_against_fp32_kernel(dev):
             tdirs = T(dirs.reshape(-1, 3), dev)
             outs = {}
             with torch.no_grad():
-                for prec in ("fp32", "bf16x6", "bf16x3", "f16x3"):   # (f16x3 with additional inputs runs bf16x6)
+                for prec in ("fp32", "bf16x6", "bf16x3", "f16x3"):
                     net.precision = prec
                     a = net.forward_fused(T(pts, dev), tdirs, Ns, *enc, **kwf)
                     b = net.forward_fused(T(pts, dev), tdirs, Ns, *enc, **kwf)
@@ -811,6 +811,48 @@ def test_f16x3_operand_ranges(dev, wscale, xscale):
     assert np.isfinite(ref).all() and np.isfinite(outs["f16x3"]).all()
     e32, ef = (float(np.abs(outs[k] - ref).max()) for k in ("fp32", "f16x3"))
     assert ef <= 8.0 * e32 + 1e-5 * scale, (wscale, xscale, e32, ef, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xscale", [1.0, 300.0])
+def test_f16x3_identity_encoder_columns(dev, xscale):
+    """Encoders with include_identity=1 put the raw coordinates beside the sin / cos columns (utils.py:114-131): f16x3
+    must take the operand scale of those layers from the sample's largest coordinate (|x| up to 750 here; 2^14 |x| would
+    overflow fp16 from |x| = 4 on)."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(17)
+    params = syn.make_render_ray_net_params(79, 30.0, 10.0, positions_dim=63, directions_dim=27)
+    net = RenderRayNet(8, 256, 63, 27, skips=[4])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.to(dev)
+    B, Ns = 48, 9
+    pts = (rng.uniform(-2.5, 2.5, (B, Ns, 3)) * xscale).astype(F32)
+    dirs = rng.normal(size=(B, 1, 3)).astype(F32)
+    enc = (PositionalEncoder(10, 1), PositionalEncoder(4, 1))
+    outs = {}
+    with torch.no_grad():
+        for prec in ("fp32", "f16x3"):
+            net.precision = prec
+            outs[prec] = N(net.forward_fused(T(pts, dev), T(dirs.reshape(-1, 3), dev), Ns, *enc)).astype(np.float64)
+    P = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    d = np.broadcast_to(dirs, (B, Ns, 3)).reshape(-1, 3).astype(np.float64)
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    pe = lambda x, L: np.concatenate([x] + [f(x * 2.0 ** k) for k in range(L) for f in (np.sin, np.cos)], -1)
+    xin, dpe = pe(pts.reshape(-1, 3).astype(np.float64), 10), pe(d, 4)
+    lin = lambda x, n: x @ P[n + ".weight"].T + P[n + ".bias"]
+    o = np.maximum(lin(xin, "positions_pose_input"), 0)
+    for i in range(7):
+        o = np.maximum(lin(np.concatenate([o, xin], -1) if i == 4 else o, f"positional_net.{i}"), 0)
+    o = lin(o, "additional_linear_layer")
+    sigma = lin(o, "sigma_out_layer")
+    o = np.maximum(lin(lin(np.concatenate([o, dpe], -1), "directional_input"), "directional_net.0"), 0)
+    ref = np.concatenate([lin(o, "rgb_out_layer"), sigma], -1)
+    scale = float(np.abs(ref).max())
+    e32, ef = (float(np.abs(outs[k] - ref).max()) for k in ("fp32", "f16x3"))
+    assert np.isfinite(outs["f16x3"]).all()
+    assert e32 <= 1e-4 * scale                      # (the layout of the identity columns is what the fp32 kernel uses)
+    assert ef <= 8.0 * e32 + 1e-5 * scale, (xscale, e32, ef, scale)
 
 
 @pytest.mark.gpu
