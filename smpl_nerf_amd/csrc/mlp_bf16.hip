@@ -103,11 +103,17 @@ __global__ __launch_bounds__(256) void mlp_pack_bf16_kernel(Plan P, int NS, cons
 }
 
 // post-activation tiles -> the tile-row-major activation buffer
+// `unscale` (f16x3): the accumulators hold (value) x 2^unscale
 template <bool RELU, int N>
-__device__ __forceinline__ void store_act(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&t)[N]) {
+__device__ __forceinline__ void store_act(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&t)[N],
+                                          int unscale = 0) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         f4 v = t[i];
+        if (unscale != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_ldexpf(v[r], -unscale);
+        }
         if (RELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -119,7 +125,7 @@ __device__ __forceinline__ void store_act(float *buf, int row0, int64_t n, int64
 // TRAIN additionally stores every layer input (post-activation, fp32, the fp32 kernel's layout) for the backward
 // kernels of mlp_train.hip.
 //
-// FMT_F16 ("f16x3", inference only): two fp16 parts per operand and three products per MAC on
+// FMT_F16 ("f16x3"): two fp16 parts per operand and three products per MAC on
 // v_mfma_f32_16x16x32_f16.  fp16 keeps 11 mantissa bits per part (2^-22 relative for the pair, against 2^-16 for two
 // bf16 parts) but only 5 exponent bits, so every operand is scaled by a power of two first - exactly, and undone
 // exactly: the weights of layer l by 2^wexp[l] (largest |w| of the layer at 2^14; the pack kernel leaves the table in
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16, TD = WIDTH / 32;
     constexpr bool F16 = FMT == FMT_F16;
-    static_assert(!(F16 && (TRAIN || NS != 2)), "f16x3: two parts, inference only");
+    static_assert(!(F16 && NS != 2), "f16x3: two parts");
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int *wexp_tab = reinterpret_cast<const int *>(reinterpret_cast<const char *>(A.packed) + (int64_t)A.total_slabs * slab16_bytes(NS));
     auto wexp = [&](int l) __attribute__((always_inline)) -> int {
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         if (TRAIN && valid) {
             store_mask(A.act, A.act_mask, i + 1, A.n, sample, c.g, dst);
             asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
-            store_act<true>(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, dst);
+            store_act<true>(A.act, A.act_x1 + (i + 1) * T, A.n, sample, c.g, dst, es);
         }
     };
     {  // positions_pose_input (its relu is applied when the next layer splits accA)
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         if (TRAIN && valid) {
             store_mask(A.act, A.act_mask, 0, A.n, sample, c.g, accA);
             asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
-            store_act<true>(A.act, A.act_x1, A.n, sample, c.g, accA);
+            store_act<true>(A.act, A.act_x1, A.n, sample, c.g, accA, es);
         }
     }
     for (int i = 0; i < A.n_hidden; i += 2) {
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         run.template run_hidden<true>(accA, accB, kx - es);
         run.finish();
         if constexpr (F16) es = wexp(nh + 1) + kx;
-        if (TRAIN && valid) store_act<false>(A.act, A.act_o, A.n, sample, c.g, accB);
+        if (TRAIN && valid) store_act<false>(A.act, A.act_o, A.n, sample, c.g, accB, es);
     }
     int e_o = 0;   // f16x3: exponent of the largest |additional output| of the sample (feeds two layers)
     if constexpr (F16) e_o = sample_exp(accB, false);
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
             }, accd);
         run.finish();
         if constexpr (F16) es = wexp(nh + 3) + kx;
-        if (TRAIN && valid) store_act<false>(A.act, A.act_h1, A.n, sample, c.g, accd);
+        if (TRAIN && valid) store_act<false>(A.act, A.act_h1, A.n, sample, c.g, accd, es);
         if (!TRAIN && tile + gridDim.x < A.n_tiles) load_raw(tile + gridDim.x, raw);
     }
     {  // directional_net[0] (its relu is applied when the rgb head splits acce)
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         if (TRAIN && valid) {
             store_mask(A.act, A.act_mask, A.n_hidden + 1, A.n, sample, c.g, acce);
             asm volatile("" ::: "memory");  // mask first, then the tiles: interleaved, the two run out of registers
-            store_act<true>(A.act, A.act_h2, A.n, sample, c.g, acce);
+            store_act<true>(A.act, A.act_h2, A.n, sample, c.g, acce, es);
         }
     }
     f4 rgb[1];
@@ -444,7 +450,6 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
         return fail(SNERF_E_BADARG, "%s: nsplit must be 2, 3 or %d (f16x3)", what, SNERF_SPLIT_F16X3);
     int rc = plan16(desc, P, what);
     if (rc) return rc;
-    if (nsplit == SNERF_SPLIT_F16X3 && train) return fail(SNERF_E_BADARG, "%s: f16x3 is an inference kernel", what);
     if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "%s: bad n/samples_per_ray", what);
     if (n == 0) return SNERF_OK;
     if (!packed || !x || !raw || (train && !act)) return fail(SNERF_E_BADARG, "%s: null pointer", what);
@@ -496,6 +501,7 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
         A.pos_nkb16 = Q.pos_nkb;
         A.add_nkb16 = Q.add_nkb;
         A.dir_nkb16 = Q.dir_nkb;
+        if (nsplit == SNERF_SPLIT_F16X3) return launch_bf16<2, true, FMT_F16>(A, (hipStream_t)stream);
         if (nsplit == 3) return launch_bf16<3, true>(A, (hipStream_t)stream);
         return launch_bf16<2, true>(A, (hipStream_t)stream);
     }

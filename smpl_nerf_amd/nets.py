@@ -40,8 +40,11 @@ class _FusedMlpFn(torch.autograd.Function):
         n = x.shape[0]
         dev = x.device
         net._begin_training_forward()
-        ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": 3}.get(net.precision, 0) if (net.width == 256 and per_sample != _ENCODED_ROWS) else 0
-        packed = net.packed_weights_bf16(desc, ns, training=True) if ns else net.packed_weights(desc, training=True)
+        split = net.width == 256 and per_sample != _ENCODED_ROWS
+        # forward / backward kernels of the mode: "f16x3" has a forward (two fp16 parts); its backward is the bf16x6 one
+        ns_fwd = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}.get(net.precision, 0) if split else 0
+        ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": 3}.get(net.precision, 0) if split else 0
+        packed = net.packed_weights_bf16(desc, ns_fwd, training=True) if ns else net.packed_weights(desc, training=True)
         sizes = [ctypes.c_int64() for _ in range(4)]
         cnt = ctypes.c_int32()
         check(lib.snerf_mlp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes], ctypes.byref(cnt)),
@@ -53,7 +56,7 @@ class _FusedMlpFn(torch.autograd.Function):
                 check(lib.snerf_mlp_fwd_encoded_train_f32(desc, ptr(packed), ptr(x), n, x.shape[1], ptr(raw), ptr(act),
                                                           current_stream()), "snerf_mlp_fwd_encoded_train_f32")
             elif ns:                             # forward on the bf16 matrix cores, saving fp32 activations
-                check(lib.snerf_mlp_fwd_train_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n,
+                check(lib.snerf_mlp_fwd_train_bf16_f32(desc, ptr(packed), ns_fwd, ptr(x), ptr(d), per_sample, ptr(add), n,
                                                        int(spr), ptr(raw), ptr(act), current_stream()),
                       "snerf_mlp_fwd_train_bf16_f32")
             else:

@@ -44,7 +44,7 @@ def make_net(dev, params, **kw):
 
 # matrix-core arithmetic of the training step: exact fp32 MFMA everywhere, or split-bf16 with fp32-class accuracy for the
 # forward, the dgrad and the wide wgrad jobs; both are held to the same tolerances
-PRECISIONS = ["fp32", "bf16x6"]
+PRECISIONS = ["fp32", "bf16x6", "f16x3"]   # (f16x3: two-fp16-part forward, bf16x6 backward)
 
 
 # ------------------------------------------------------------------------------------------ a4 backward
