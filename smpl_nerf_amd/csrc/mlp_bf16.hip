@@ -45,25 +45,30 @@ __device__ int layer_weight_exp(const Plan &P, int li, const float *__restrict__
     return m > 0.f ? min(14 - e, 50) : 0;
 }
 
+// f16x3: the table of weight exponents (one block per layer), left in the first pad slab of the stream - where the
+// forward kernel reads it - before the pack kernel runs
+__global__ __launch_bounds__(256) void mlp_wexp_kernel(Plan P, int NS, const float *__restrict__ params,
+                                                       unsigned char *__restrict__ packed) {
+    const int we = layer_weight_exp(P, blockIdx.x, params);
+    if (threadIdx.x == 0) reinterpret_cast<int *>(packed + (int64_t)P.total_slabs * slab16_bytes(NS))[blockIdx.x] = we;
+}
+
 __global__ __launch_bounds__(256) void mlp_pack_bf16_kernel(Plan P, int NS, const float *__restrict__ params,
                                                             unsigned char *__restrict__ packed, int fmt) {
     const int slab = blockIdx.x;
     const int SB = slab16_bytes(NS);
     unsigned char *dst = packed + (int64_t)slab * SB;
+    const int *wexp_tab = reinterpret_cast<const int *>(packed + (int64_t)P.total_slabs * SB);
     if (slab >= P.total_slabs) {
-        for (int e = threadIdx.x; e < SB / 4; e += 256) reinterpret_cast<float *>(dst)[e] = 0.f;
-        if (fmt == FMT_F16 && slab == P.total_slabs) {   // the table of weight exponents the f16x3 kernel reads
-            for (int l = 0; l < P.nlayers; ++l) {
-                const int we = layer_weight_exp(P, l, params);
-                if (threadIdx.x == 0) reinterpret_cast<int *>(dst)[l] = we;
-            }
-        }
+        const int keep = (fmt == FMT_F16 && slab == P.total_slabs) ? MAX_LAYERS : 0;   // (the table of weight exponents)
+        for (int e = threadIdx.x; e < SB / 4; e += 256)
+            if (e >= keep) reinterpret_cast<float *>(dst)[e] = 0.f;
         return;
     }
     int li = 0;
     while (li + 1 < P.nlayers && slab >= P.layer[li + 1].first_slab) ++li;
     const Layer &Ly = P.layer[li];
-    const int we = fmt == FMT_F16 ? layer_weight_exp(P, li, params) : 0;
+    const int we = fmt == FMT_F16 ? wexp_tab[li] : 0;
     const int sl = slab - Ly.first_slab;
     const int kps = 16 / Ly.t_out;
     const float *Wm = params + Ly.w_off;
@@ -401,6 +406,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
 
 // any (kw = 32) Plan -> split-bf16 slab stream; shared with warp_bf16.hip
 int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what, int fmt) {
+    if (fmt == FMT_F16) {
+        hipLaunchKernelGGL(mlp_wexp_kernel, dim3(P.nlayers), dim3(256), 0, s, P, ns, params_flat, reinterpret_cast<unsigned char *>(packed));
+        if (int rc = check_launch(what)) return rc;
+    }
     hipLaunchKernelGGL(mlp_pack_bf16_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, s, P, ns, params_flat,
                        reinterpret_cast<unsigned char *>(packed), fmt);
     return check_launch(what);
