@@ -48,9 +48,14 @@ __device__ int layer_weight_exp(const Plan &P, int li, const float *__restrict__
 // f16x3: the table of weight exponents (one block per layer), left in the first pad slab of the stream - where the
 // forward kernel reads it - before the pack kernel runs
 __global__ __launch_bounds__(256) void mlp_wexp_kernel(Plan P, int NS, const float *__restrict__ params,
-                                                       unsigned char *__restrict__ packed) {
+                                                       unsigned char *__restrict__ packed, int table_slab) {
     const int we = layer_weight_exp(P, blockIdx.x, params);
-    if (threadIdx.x == 0) reinterpret_cast<int *>(packed + (int64_t)P.total_slabs * slab16_bytes(NS))[blockIdx.x] = we;
+    if (threadIdx.x == 0) reinterpret_cast<int *>(packed + (int64_t)table_slab * slab16_bytes(NS))[blockIdx.x] = we;
+}
+int launch_wexp(const Plan &P, int ns, const float *params_flat, void *packed, int table_slab, hipStream_t s, const char *what) {
+    hipLaunchKernelGGL(mlp_wexp_kernel, dim3(P.nlayers), dim3(256), 0, s, P, ns, params_flat, reinterpret_cast<unsigned char *>(packed),
+                       table_slab);
+    return check_launch(what);
 }
 
 __global__ __launch_bounds__(256) void mlp_pack_bf16_kernel(Plan P, int NS, const float *__restrict__ params,
@@ -155,35 +160,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // operand scale when encoder columns take part / upper limit (activations below 2^-50: with a weight exponent <= 50 a
     // bias of up to 2^13 still fits the scaled accumulator)
     constexpr int KX_PE = 14, KX_MAX = 64;
-    // unbiased exponent of the largest |value| (after the ReLU, if any) that this lane's sample has in `src`.  On the bit
-    // patterns: as signed integers the largest positive float wins (ReLU: negatives lose against 0); as unsigned ones a
-    // negative float, if there is one, wins with the largest magnitude (v_max3_i32 / v_max3_u32: no canonicalising
-    // extra instruction as with fmaxf).  The four lanes of a sample are 16 and 32 lanes apart: two row swaps.
-    auto sample_exp = [&](const auto &src, bool relu) __attribute__((always_inline)) -> int {
-        constexpr int N = sizeof(src) / sizeof(f4);
-        int mp = 0;
-        unsigned mu = 0u;
-#pragma unroll
-        for (int t = 0; t < N; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const int b0 = __float_as_int(src[t][r]), b1 = __float_as_int(src[t][r + 1]);
-                mp = max(mp, max(b0, b1));
-                if (!relu) mu = max(mu, max((unsigned)b0, (unsigned)b1));
-            }
-        unsigned m = (unsigned)mp;
-        if (!relu) m = max(m, mu & 0x7fffffffu);   // (mu is a positive float <= mp when no value is negative)
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        u2v w = __builtin_amdgcn_permlane16_swap(m, m, false, false);
-        m = max(w[0], w[1]);
-        w = __builtin_amdgcn_permlane32_swap(m, m, false, false);
-        m = max(w[0], w[1]);
-        return (int)((m >> 23) & 0xffu) - 127;
-    };
-    // operand scale of a layer whose input has exponent e_src at accumulator scale es
-    auto operand_scale = [&](int e_src, int es, int cap) __attribute__((always_inline)) -> int {
-        return min(14 - (e_src - es), cap);
-    };
+    auto sample_exp = [&](const auto &src, bool relu) __attribute__((always_inline)) -> int { return sample_exp16(src, relu); };
+    auto operand_scale = [&](int e_src, int es_, int cap) __attribute__((always_inline)) -> int { return operand_scale16(e_src, es_, cap); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Persistent workgroups: one per CU (the LDS ring allows no more), each walking the sample tiles
@@ -406,10 +384,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
 
 // any (kw = 32) Plan -> split-bf16 slab stream; shared with warp_bf16.hip
 int launch_pack_bf16(const Plan &P, int ns, const float *params_flat, void *packed, hipStream_t s, const char *what, int fmt) {
-    if (fmt == FMT_F16) {
-        hipLaunchKernelGGL(mlp_wexp_kernel, dim3(P.nlayers), dim3(256), 0, s, P, ns, params_flat, reinterpret_cast<unsigned char *>(packed));
-        if (int rc = check_launch(what)) return rc;
-    }
+    if (fmt == FMT_F16)
+        if (int rc = launch_wexp(P, ns, params_flat, packed, P.total_slabs, s, what)) return rc;
     hipLaunchKernelGGL(mlp_pack_bf16_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, s, P, ns, params_flat,
                        reinterpret_cast<unsigned char *>(packed), fmt);
     return check_launch(what);

@@ -364,6 +364,12 @@ struct LayerRun16 {
     const char *slab;
     int kbl, lane;
     __device__ __forceinline__ LayerRun16(SlabPipe16<NT, NS> &p, int lane_) : pipe(p), slab(p.acquire()), kbl(0), lane(lane_) {}
+    // as stored (bf16 modes; f16x3 dgrad: zeros, or fp32 values the caller scales itself)
+    __device__ __forceinline__ void init_plain(f4 (&acc)[T_OUT]) {
+        const f4 *aux = reinterpret_cast<const f4 *>(slab + NS * 16384) + (lane >> 4);
+#pragma unroll
+        for (int to = 0; to < T_OUT; ++to) acc[to] = aux[to * 4];
+    }
     // bias_exp (FMT_F16): the accumulators of the layer carry the scale 2^bias_exp (weights x operands), so does the bias
     __device__ __forceinline__ void init(f4 (&acc)[T_OUT], int bias_exp = 0) {
         const f4 *aux = reinterpret_cast<const f4 *>(slab + NS * 16384) + (lane >> 4);
@@ -424,6 +430,37 @@ struct LayerRun16 {
 // B operand of encoder k-block kb: 4 units (sin, cos pairs) per lane
 // `half[h]` = the fp32 values of 16-wide k-block 2kb + h in the fp32 kernel's layout (mlp_device.h pe_operand): what
 // the training forward stores for the backward kernels
+// ---- f16x3 scaling helpers (shared by the forward and the dgrad kernel) --------------------------------------------
+// Unbiased exponent of the largest |value| (after the ReLU, if any) that this lane's sample has in `src`.  On the bit
+// patterns: as signed integers the largest positive float wins (ReLU: negatives lose against 0); as unsigned ones a
+// negative float, if there is one, wins with the largest magnitude (v_max3_i32 / v_max3_u32: no canonicalising extra
+// instruction as with fmaxf).  The four lanes of a sample are 16 and 32 lanes apart: two row swaps.
+template <int N>
+__device__ __forceinline__ int sample_exp16(const f4 (&src)[N], bool relu) {
+    int mp = 0;
+    unsigned mu = 0u;
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const int b0 = __float_as_int(src[t][r]), b1 = __float_as_int(src[t][r + 1]);
+            mp = max(mp, max(b0, b1));
+            if (!relu) mu = max(mu, max((unsigned)b0, (unsigned)b1));
+        }
+    unsigned m = (unsigned)mp;
+    if (!relu) m = max(m, mu & 0x7fffffffu);   // (mu is a positive float <= mp when no value is negative)
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v w = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+    m = max(w[0], w[1]);
+    w = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    m = max(w[0], w[1]);
+    return (int)((m >> 23) & 0xffu) - 127;
+}
+// operand scale exponent of a layer whose input has exponent e_src at accumulator scale es: largest input to [2^14, 2^15)
+__device__ __forceinline__ int operand_scale16(int e_src, int es, int cap) { return min(14 - (e_src - es), cap); }
+// the table of weight exponents (f16x3) sits in pad slab `table_slab` of a packed stream
+int launch_wexp(const Plan &P, int ns, const float *params_flat, void *packed, int table_slab, hipStream_t s, const char *what);
+
 template <int NS, int FMT = FMT_BF16>
 __device__ __forceinline__ void pe_operand16(const SampleCtx &c, bool is_dir, int L, int ident, int kb, bf8 (&b)[NS],
                                              f4 (&half)[2], int scale_exp = 0) {

@@ -21,13 +21,17 @@ namespace snerf {
 // transposed weight stream, split-bf16:  slab = [k-block in slab][output tile][part][lane][8 bf16] then 256 fp32 aux
 //   A[(kb, to, s, lane (i,g), e)] = part_s(W_fwd[32*kb + 16*(e>>2) + 4*g + (e&3)][col(to, i)])
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mlp_pack_t_bf16_kernel(Plan P, BwdPlan B, int NS, const float *__restrict__ params,
+__global__ __launch_bounds__(256) void mlp_pack_t_bf16_kernel(Plan P, BwdPlan B, int NS, int fmt, const float *__restrict__ params,
                                                               unsigned char *__restrict__ packed) {
     const int slab = blockIdx.x;
     const int SB = slab16_bytes(NS);
     unsigned char *dst = packed + (int64_t)slab * SB;
+    // f16x3: the table of weight exponents (launch_wexp, indexed by forward layer) sits in the first pad slab
+    const int *wexp_tab = reinterpret_cast<const int *>(packed + (int64_t)B.total_slabs * SB);
     if (slab >= B.total_slabs) {
-        for (int e = threadIdx.x; e < SB / 4; e += 256) reinterpret_cast<float *>(dst)[e] = 0.f;
+        const int keep = (fmt == FMT_F16 && slab == B.total_slabs) ? MAX_LAYERS : 0;
+        for (int e = threadIdx.x; e < SB / 4; e += 256)
+            if (e >= keep) reinterpret_cast<float *>(dst)[e] = 0.f;
         return;
     }
     int bi = 0;
@@ -62,6 +66,13 @@ __global__ __launch_bounds__(256) void mlp_pack_t_bf16_kernel(Plan P, BwdPlan B,
         }
         float w = 0.f;
         if (kb < Bl.nkb && row < Ly.n_out && col >= 0) w = Wm[(int64_t)row * Ly.n_in + col];
+        if (fmt == FMT_F16) {   // fp16 parts (RNE) of the scaled weight
+            w = ldexpf(w, wexp_tab[Bl.fwd]);
+            _Float16 hh = (_Float16)w;
+            if (s == 1) hh = (_Float16)(w - (float)hh);
+            reinterpret_cast<_Float16 *>(a)[q] = hh;
+            continue;
+        }
         __bf16 h = (__bf16)w;
         for (int t = 0; t < s; ++t) {
             w = w - (float)h;
@@ -82,9 +93,10 @@ __global__ __launch_bounds__(256) void mlp_pack_t_bf16_kernel(Plan P, BwdPlan B,
 
 // t[i] = (ReLU output > 0) ? t[i] : 0 from the forward kernel's sign mask (store_mask, mlp_device.h: 8 bytes per lane
 // instead of the 256-byte activation row), then store t as d Y tile-rows
+// `unscale` (f16x3): t holds (value) x 2^unscale - stays so for the next layer, is stored unscaled
 template <int N>
 __device__ __forceinline__ void mask_store(f4 (&t)[N], uint2 m, float *dy, int dy_row0, int64_t n, int64_t sample,
-                                           bool valid, int g) {
+                                           bool valid, int g, int unscale = 0) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const unsigned w = i < 8 ? m.x : m.y;
@@ -93,15 +105,47 @@ __device__ __forceinline__ void mask_store(f4 (&t)[N], uint2 m, float *dy, int d
             const int keep = static_cast<int>(w << (31 - (((i & 7) << 2) | r))) >> 31;  // 0 or ~0
             t[i][r] = __int_as_float(__float_as_int(t[i][r]) & keep);
         }
-        if (valid) store_tile(dy, dy_row0 + i, n, sample, g, t[i]);
+        if (valid) {
+            f4 v = t[i];
+            if (unscale != 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = __builtin_ldexpf(v[r], -unscale);
+            }
+            store_tile(dy, dy_row0 + i, n, sample, g, v);
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_tiles_unscaled(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&t)[N],
+                                                     int unscale) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        f4 v = t[i];
+        if (unscale != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_ldexpf(v[r], -unscale);
+        }
+        store_tile(buf, row0 + i, n, sample, g, v);
     }
 }
 
-template <int WIDTH, int NWAVES, int NS, bool INPUT_GRAD>
+// FMT_F16: the f16x3 scheme of mlp_fwd_bf16_kernel on the transposed network - weights scaled per (forward) layer, the
+// gradient operands per sample; the masked accumulators keep their scale for the next layer and are stored unscaled.
+// No bias here; the fp32 sigma-head term of d o is brought to the scale of its accumulator.
+template <int WIDTH, int NWAVES, int NS, bool INPUT_GRAD, int FMT = FMT_BF16>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16, TD = WIDTH / 32;
     constexpr int TPP = 4, TPD = 2;
+    constexpr bool F16 = FMT == FMT_F16;
+    static_assert(!(F16 && NS != 2), "f16x3: two parts");
+    constexpr int KX_MAX = 40;   // gradients below 2^-26 keep fewer bits; bounds the fp32 sigma-head term of d o
+    const int *wexp_tab = reinterpret_cast<const int *>(reinterpret_cast<const char *>(A.packed_t) + (int64_t)A.total_slabs * slab16_bytes(NS));
+    auto wexp = [&](int l) __attribute__((always_inline)) -> int {
+        if constexpr (F16) return wexp_tab[l];
+        else return 0;
+    };
+    int es = 0;   // f16x3: scale exponent of the accumulators of the layer just finished
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
@@ -133,28 +177,43 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
 
     f4 accd[TD], acce[TD];
     {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
-        LayerRun16<TD, NT, NS> run(pipe, lane);
-        run.init(accd);
+        LayerRun16<TD, NT, NS, FMT> run(pipe, lane);
+        run.init_plain(accd);
         const f4 src[2] = {g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, zero};
-        run.template run_hidden<false>(src, accd);
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale16(sample_exp16(src, false), 0, KX_MAX);
+        run.template run_hidden<false>(src, accd, kx);
         run.finish();
-        mask_store(accd, mk, A.dy, A.dy_dn0, A.n, sample, valid, g);
+        if constexpr (F16) es = wexp(nh + 5) + kx;
+        mask_store(accd, mk, A.dy, A.dy_dn0, A.n, sample, valid, g, es);
         mk = *mask_ptr(A.act, A.act_mask, nh, A.n, sc, g);
     }
     {  // directional_net[0]^T; directional_input has no activation (:54-57)
-        LayerRun16<TD, NT, NS> run(pipe, lane);
-        run.init(acce);
-        run.template run_hidden<false>(accd, acce);
+        LayerRun16<TD, NT, NS, FMT> run(pipe, lane);
+        run.init_plain(acce);
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale16(sample_exp16(accd, false), es, KX_MAX);
+        run.template run_hidden<false>(accd, acce, kx - es);
         run.finish();
-        if (valid) store_tiles(A.dy, A.dy_din, A.n, sample, g, acce);
+        if constexpr (F16) es = wexp(nh + 4) + kx;
+        if (valid) store_tiles_unscaled(A.dy, A.dy_din, A.n, sample, g, acce, es);
     }
+    // d h1 (acce, scale es) feeds the two transposes of directional_input: one operand scale for both
+    int kx_din = 0;
+    if constexpr (F16) kx_din = operand_scale16(sample_exp16(acce, false), es, KX_MAX);
     if (INPUT_GRAD && A.use_dir && A.dir_nkb > 0) {
         // d (direction encoding) = directional_input[:, W:]^T d h1, then encoder and normalisation backward
         f4 ddpe[TPD];
-        LayerRun16<TPD, NT, NS> run(pipe, lane);
-        run.init(ddpe);
-        run.template run_hidden<false>(acce, ddpe);
+        LayerRun16<TPD, NT, NS, FMT> run(pipe, lane);
+        run.init_plain(ddpe);
+        run.template run_hidden<false>(acce, ddpe, kx_din - es);
         run.finish();
+        if constexpr (F16) {
+#pragma unroll
+            for (int q = 0; q < TPD; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ddpe[q][r] = __builtin_ldexpf(ddpe[q][r], -(wexp(nh + 3) + kx_din));
+        }
         const float *dp = A.dirs + (A.dirs_per_sample ? sc : sc / A.spr) * 3;
         const float ux = dp[0], uy = dp[1], uz = dp[2];
         const float nrm = sqrtf(ux * ux + uy * uy + uz * uz);
@@ -181,35 +240,49 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         if (!INPUT_GRAD || A.pos_nkb <= 0) return;
         if (!(l == 0 || ((A.skip_mask >> (l - 1)) & 1u))) return;
         f4 t[TPP];
-        LayerRun16<TPP, NT, NS> run(pipe, lane);
-        run.init(t);
-        run.template run_hidden<false>(cur, t);
+        LayerRun16<TPP, NT, NS, FMT> run(pipe, lane);
+        run.init_plain(t);
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale16(sample_exp16(cur, false), es, KX_MAX);
+        run.template run_hidden<false>(cur, t, kx - es);
         run.finish();
 #pragma unroll
-        for (int q = 0; q < TPP; ++q) dpe[q] += t[q];
+        for (int q = 0; q < TPP; ++q) {
+            if constexpr (F16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[q][r] = __builtin_ldexpf(t[q][r], -(wexp(l) + kx));
+            }
+            dpe[q] += t[q];
+        }
     };
     {  // d o = directional_input[:, :W]^T d h1 + sigma_out_layer^T d sigma; additional layer has no activation (:51-52)
-        LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(accA);  // aux block = sigma head weights (fp32)
+        LayerRun16<T, NT, NS, FMT> run(pipe, lane);
+        run.init_plain(accA);  // aux block = sigma head weights (fp32)
+        const int es_o = wexp(nh + 3) + kx_din;
+        const float dsig = F16 ? __builtin_ldexpf(dr[3], es_o) : dr[3];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            accA[t][0] *= dr[3];
-            accA[t][1] *= dr[3];
-            accA[t][2] *= dr[3];
-            accA[t][3] *= dr[3];
+            accA[t][0] *= dsig;
+            accA[t][1] *= dsig;
+            accA[t][2] *= dsig;
+            accA[t][3] *= dsig;
         }
-        run.template run_hidden<false>(acce, accA);
+        run.template run_hidden<false>(acce, accA, kx_din - es);
         run.finish();
-        if (valid) store_tiles(A.dy, (nh + 1) * T, A.n, sample, g, accA);
+        if constexpr (F16) es = es_o;
+        if (valid) store_tiles_unscaled(A.dy, (nh + 1) * T, A.n, sample, g, accA, es);
     }
     // additional^T, positional_net[nh-1]^T ... positional_net[0]^T: forward layer l+1 transposed yields
     // d X_{l+1}; masking with X_{l+1} > 0 gives d Y of forward layer l (:46-50).  Two accumulator sets ping-pong.
     auto layer = [&](int l, const f4(&src)[T], f4(&dst)[T]) __attribute__((always_inline)) {
-        LayerRun16<T, NT, NS> run(pipe, lane);
-        run.init(dst);
-        run.template run_hidden<false>(src, dst);
+        LayerRun16<T, NT, NS, FMT> run(pipe, lane);
+        run.init_plain(dst);
+        int kx = 0;
+        if constexpr (F16) kx = operand_scale16(sample_exp16(src, false), es, KX_MAX);
+        run.template run_hidden<false>(src, dst, kx - es);
         run.finish();
-        mask_store(dst, mk, A.dy, l * T, A.n, sample, valid, g);
+        if constexpr (F16) es = wexp(l + 1) + kx;
+        mask_store(dst, mk, A.dy, l * T, A.n, sample, valid, g, es);
         if (l > 0) mk = *mask_ptr(A.act, A.act_mask, l - 1, A.n, sc, g);
         pe_columns(l, dst);
     };
@@ -444,13 +517,13 @@ static int plans_t(const snerf_mlp_desc *desc, Plan &P, const char *what) {
     return SNERF_OK;
 }
 
-template <int NS, bool INPUT_GRAD>
+template <int NS, bool INPUT_GRAD, int FMT = FMT_BF16>
 static int launch_dgrad_bf16(const BwdArgs &A, hipStream_t s) {
     constexpr int NW = 8;
     const int lds = 3 * slab16_bytes(NS);
     static bool attr = false;  // idempotent; a race only repeats the call
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD, FMT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return fail(SNERF_E_LAUNCH, "mlp_bwd_bf16: cannot raise the dynamic LDS limit to %d bytes", lds);
         attr = true;
@@ -466,7 +539,7 @@ static int launch_dgrad_bf16(const BwdArgs &A, hipStream_t s) {
     static const bool persistent = !(getenv("SNERF_BF16_PERSISTENT") && atoi(getenv("SNERF_BF16_PERSISTENT")) == 0);
     const int64_t grid = (persistent && !INPUT_GRAD && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: n too large");
-    hipLaunchKernelGGL((mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
+    hipLaunchKernelGGL((mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD, FMT>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_bwd_bf16(dgrad)");
 }
 
@@ -475,7 +548,8 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
                            const float *dirs, int dirs_per_sample, int spr, float *d_x, float *d_dirs,
                            snerf_stream_t stream) {
     Plan P;
-    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: nsplit must be 2 or 3");
+    if (nsplit != 2 && nsplit != 3 && nsplit != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "mlp_bwd_bf16: nsplit must be 2, 3 or %d (f16x3)", SNERF_SPLIT_F16X3);
     int rc = plans_t(desc, P, "mlp_bwd_bf16");
     if (rc) return rc;
     if (n < 0) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: negative n");
@@ -524,12 +598,14 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
     A.use_dir = desc->use_dir ? 1 : 0;
     A.total_slabs = bwd_total_slabs(P, input_grad, 32);
     A.n_tiles = (n + 8 * 16 - 1) / (8 * 16);
-    if (nsplit == 3) rc = input_grad ? launch_dgrad_bf16<3, true>(A, s) : launch_dgrad_bf16<3, false>(A, s);
+    if (nsplit == SNERF_SPLIT_F16X3) rc = input_grad ? launch_dgrad_bf16<2, true, FMT_F16>(A, s) : launch_dgrad_bf16<2, false, FMT_F16>(A, s);
+    else if (nsplit == 3) rc = input_grad ? launch_dgrad_bf16<3, true>(A, s) : launch_dgrad_bf16<3, false>(A, s);
     else rc = input_grad ? launch_dgrad_bf16<2, true>(A, s) : launch_dgrad_bf16<2, false>(A, s);
     if (rc) return rc;
-    // wide jobs on the bf16 matrix cores with the same number of parts, narrow jobs and the reduce in fp32
+    // wide jobs on the bf16 matrix cores with the same number of parts (f16x3: three bf16 parts - the per-sample scaling of
+    // the other kernels does not carry over to a contraction over samples), narrow jobs and the reduce in fp32
     static const bool bf16_wgrad = !(getenv("SNERF_WGRAD_BF16") && atoi(getenv("SNERF_WGRAD_BF16")) == 0);
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? nsplit : 0);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? (nsplit == SNERF_SPLIT_F16X3 ? 3 : nsplit) : 0);
 }
 
 }  // namespace snerf
@@ -537,24 +613,29 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
 extern "C" int64_t snerf_mlp_packed_t_bf16_bytes(const snerf_mlp_desc *desc, int nsplit, int input_grad) {
     using namespace snerf;
     Plan P;
-    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_packed_t_bf16_bytes: nsplit must be 2 or 3");
+    if (nsplit != 2 && nsplit != 3 && nsplit != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "mlp_packed_t_bf16_bytes: nsplit must be 2, 3 or %d (f16x3)", SNERF_SPLIT_F16X3);
     int rc = plans_t(desc, P, "mlp_packed_t_bf16_bytes");
     if (rc) return rc;
-    return (int64_t)(bwd_total_slabs(P, input_grad != 0, 32) + SLAB_PAD) * slab16_bytes(nsplit);
+    return (int64_t)(bwd_total_slabs(P, input_grad != 0, 32) + SLAB_PAD) * slab16_bytes(nsplit == SNERF_SPLIT_F16X3 ? 2 : nsplit);
 }
 
 extern "C" int snerf_mlp_pack_t_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed_t, int nsplit,
                                      int input_grad, snerf_stream_t stream) {
     using namespace snerf;
     Plan P;
-    if (nsplit != 2 && nsplit != 3) return fail(SNERF_E_BADARG, "mlp_pack_t_bf16: nsplit must be 2 or 3");
+    if (nsplit != 2 && nsplit != 3 && nsplit != SNERF_SPLIT_F16X3)
+        return fail(SNERF_E_BADARG, "mlp_pack_t_bf16: nsplit must be 2, 3 or %d (f16x3)", SNERF_SPLIT_F16X3);
     int rc = plans_t(desc, P, "mlp_pack_t_bf16");
     if (rc) return rc;
     if (!params_flat || !packed_t) return fail(SNERF_E_BADARG, "mlp_pack_t_bf16: null pointer");
     if (!aligned(packed_t, 16)) return fail(SNERF_E_ALIGN, "mlp_pack_t_bf16: packed_t must be 16-byte aligned");
     BwdPlan B;
     make_bwd_plan(P, B, input_grad != 0, 32);
-    hipLaunchKernelGGL(mlp_pack_t_bf16_kernel, dim3(B.total_slabs + SLAB_PAD), dim3(256), 0, (hipStream_t)stream, P, B, nsplit,
+    const int fmt = nsplit == SNERF_SPLIT_F16X3 ? FMT_F16 : FMT_BF16, ns = fmt == FMT_F16 ? 2 : nsplit;
+    if (fmt == FMT_F16)
+        if ((rc = launch_wexp(P, ns, params_flat, packed_t, B.total_slabs, (hipStream_t)stream, "mlp_pack_t_bf16"))) return rc;
+    hipLaunchKernelGGL(mlp_pack_t_bf16_kernel, dim3(B.total_slabs + SLAB_PAD), dim3(256), 0, (hipStream_t)stream, P, B, ns, fmt,
                        params_flat, reinterpret_cast<unsigned char *>(packed_t));
     return check_launch("mlp_pack_t_bf16");
 }

@@ -41,9 +41,8 @@ class _FusedMlpFn(torch.autograd.Function):
         dev = x.device
         net._begin_training_forward()
         split = net.width == 256 and per_sample != _ENCODED_ROWS
-        # forward / backward kernels of the mode: "f16x3" has a forward (two fp16 parts); its backward is the bf16x6 one
         ns_fwd = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}.get(net.precision, 0) if split else 0
-        ns = {"bf16x6": 3, "bf16x3": 2, "f16x3": 3}.get(net.precision, 0) if split else 0
+        ns = ns_fwd   # (the f16x3 backward: dgrad with two fp16 parts, wide wgrad with three bf16 parts)
         packed = net.packed_weights_bf16(desc, ns_fwd, training=True) if ns else net.packed_weights(desc, training=True)
         sizes = [ctypes.c_int64() for _ in range(4)]
         cnt = ctypes.c_int32()
