@@ -143,8 +143,9 @@ int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const flo
  * snerf_mlp_fwd_f32; `packed` comes from snerf_mlp_pack_bf16 with the same nsplit.  Width 256 only.
  * nsplit = SNERF_SPLIT_F16X3 selects two fp16 parts instead (3 products, ~2^-22 relative: raw outputs within the fp32
  * kernel's own tolerance, at the speed of nsplit = 2): operands are scaled by exact powers of two - weights per layer at
- * pack time, activations per sample in the kernel - so that fp16's range is never left.  Forward kernels only
- * (snerf_mlp_fwd_bf16_f32, snerf_mlp_fwd_train_bf16_f32, snerf_render_rays*); the backward entry points take 2 / 3. */
+ * pack time, activations (and, in the backward, gradients) per sample in the kernel - so that fp16's range is never
+ * left.  Accepted wherever an nsplit / precision is: forward, training forward, snerf_render_rays*, and the backward
+ * entry points (dgrad with two fp16 parts; the wide wgrad GEMMs, which contract over samples, keep three bf16 parts). */
 #define SNERF_SPLIT_F16X3 16
 int64_t snerf_mlp_packed_bf16_bytes(const snerf_mlp_desc *desc, int nsplit);
 int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed, int nsplit,

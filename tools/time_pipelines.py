@@ -60,7 +60,7 @@ from smpl_nerf_amd.trainer import DataParallelTrainer
 
 
 def timed_train(make, label):
-    for prec in ("fp32", "bf16x6"):
+    for prec in ("fp32", "bf16x6", "f16x3"):
         pipe, models, batch = make(prec)
         tr = DataParallelTrainer(pipe, models, lr=3e-5)  # cf. bench.py: larger steps kill the fine net (all gradients 0)
         for _ in range(2):
