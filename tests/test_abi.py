@@ -143,6 +143,12 @@ def test_split_bf16_and_render_entry_points_validate_on_the_host(lib):
     assert b3 % (3 * 16384 + 1024) == 0 and b2 % (2 * 16384 + 1024) == 0
     assert b3 // (3 * 16384 + 1024) == b2 // (2 * 16384 + 1024) > 3
     assert lib.snerf_mlp_packed_bf16_bytes(d, 4) == -1 and b"nsplit" in lib.snerf_last_error_string()
+    # nsplit = SNERF_SPLIT_F16X3 (16): two fp16 parts - the layout of nsplit = 2, accepted by every split entry point
+    assert _lib.SPLIT_F16X3 == 16
+    assert lib.snerf_mlp_packed_bf16_bytes(d, _lib.SPLIT_F16X3) == b2
+    assert lib.snerf_mlp_packed_t_bf16_bytes(d, _lib.SPLIT_F16X3, 1) == lib.snerf_mlp_packed_t_bf16_bytes(d, 2, 1)
+    assert lib.snerf_mlp_fwd_bf16_f32(d, None, _lib.SPLIT_F16X3, None, None, 0, None, 0, 64, None, None) == 0
+    assert lib.snerf_mlp_bwd_bf16_f32(d, None, _lib.SPLIT_F16X3, None, None, 0, None, None, None, None) == 0
     narrow = _lib.MlpDesc(4, 128, 10, 0, 4, 0, 0, 2, 1)
     assert lib.snerf_mlp_packed_bf16_bytes(narrow, 3) == -1 and b"256" in lib.snerf_last_error_string()
     assert lib.snerf_mlp_packed_t_bf16_bytes(d, 3, 0) > 0
