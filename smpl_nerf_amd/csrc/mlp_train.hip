@@ -554,7 +554,23 @@ int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, flo
 // split-K wgrad + reduce for any (Plan, TrainLayout)
 int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
                  float *flat_grad, hipStream_t s, int wide_nsplit) {
-    const int G = wgrad_chunks(n);
+    // chunks: at most the wgrad_chunks(n) the partial buffer is sized for; with more wide workgroups than CUs, as many as
+    // fill whole rounds of the chip (9 wide jobs x 128 chunks on 256 CUs = 4.5 rounds, the last one half empty: 113
+    // chunks = 3.97 rounds of 13 % longer workgroups)
+    int G = wgrad_chunks(n);
+    {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0, cus = 0;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                    cus > 0) ? cus : 256;
+        }
+        const int jobs = wgrad_jobs(P);
+        if (jobs > 0 && (int64_t)jobs * G > n_cu) {
+            const int rounds = (int)((int64_t)jobs * G / n_cu);
+            G = min(G, max(1, rounds * n_cu / jobs));
+        }
+    }
     WgradArgs W{};
     W.act = act;
     W.dy = dy;
