@@ -27,33 +27,34 @@ namespace snerf {
 // weight packing: params_flat -> split-bf16 slab stream
 // slab = [k-block in slab][output tile][part][lane][8 bf16] then 256 fp32 of bias
 // ------------------------------------------------------------------------------------------------
-// f16x3 (fmt = FMT_F16): exponent that brings the largest |weight| of layer li to [2^14, 2^15) - block-wide
+// f16x3 (fmt = FMT_F16): exponent that brings the largest |weight| of layer li to [2^14, 2^15) - block-wide (1024 threads)
 __device__ int layer_weight_exp(const Plan &P, int li, const float *__restrict__ params) {
-    __shared__ float red[256];
+    __shared__ float red[1024];
     const Layer &Ly = P.layer[li];
+    const float *w = params + Ly.w_off;
+    const int64_t count = (int64_t)Ly.n_out * Ly.n_in;
     float m = 0.f;
-    for (int64_t e = threadIdx.x; e < (int64_t)Ly.n_out * Ly.n_in; e += 256) m = fmaxf(m, fabsf(params[Ly.w_off + e]));
+    for (int64_t e = threadIdx.x; e < count; e += 1024) m = fmaxf(m, fabsf(w[e]));
     red[threadIdx.x] = m;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = 512; st > 0; st >>= 1) {
         if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
         __syncthreads();
     }
     m = red[0];
-    __syncthreads();
     const int e = ((__float_as_int(m) >> 23) & 0xff) - 127;
     return m > 0.f ? min(14 - e, 50) : 0;
 }
 
 // f16x3: the table of weight exponents (one block per layer), left in the first pad slab of the stream - where the
 // forward kernel reads it - before the pack kernel runs
-__global__ __launch_bounds__(256) void mlp_wexp_kernel(Plan P, int NS, const float *__restrict__ params,
+__global__ __launch_bounds__(1024) void mlp_wexp_kernel(Plan P, int NS, const float *__restrict__ params,
                                                        unsigned char *__restrict__ packed, int table_slab) {
     const int we = layer_weight_exp(P, blockIdx.x, params);
     if (threadIdx.x == 0) reinterpret_cast<int *>(packed + (int64_t)table_slab * slab16_bytes(NS))[blockIdx.x] = we;
 }
 int launch_wexp(const Plan &P, int ns, const float *params_flat, void *packed, int table_slab, hipStream_t s, const char *what) {
-    hipLaunchKernelGGL(mlp_wexp_kernel, dim3(P.nlayers), dim3(256), 0, s, P, ns, params_flat, reinterpret_cast<unsigned char *>(packed),
+    hipLaunchKernelGGL(mlp_wexp_kernel, dim3(P.nlayers), dim3(1024), 0, s, P, ns, params_flat, reinterpret_cast<unsigned char *>(packed),
                        table_slab);
     return check_launch(what);
 }
