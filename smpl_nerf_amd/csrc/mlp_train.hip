@@ -519,8 +519,9 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_direct_kernel(Plan P, Tr
 }
 
 // sum over the G partials and scatter slot order -> state_dict order
+// G_wide / G_narrow: number of sample chunks (partials) the wide and the narrow jobs were split into
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayout L, const float *__restrict__ part,
-                                                               int G, float *__restrict__ flat_grad) {
+                                                               int G_wide, int G_narrow, float *__restrict__ flat_grad) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= L.gp_floats) return;
     int l = 0;
@@ -529,9 +530,13 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
     int rel = e - L.gp[l];
     int64_t dst = -1;
     const int nw = Ly.t_out * Ly.nkb * 256;
+    int seg = 0;   // the input segment whose job wrote this element (the bias sums ride with the first non-empty one)
+    while (seg < Ly.nseg && Ly.seg[seg].nkb == 0) ++seg;
     if (rel < nw) {
         const int r = rel & 3, lane = (rel >> 2) & 63, tile = rel >> 8;
         const int ti = tile / Ly.nkb, tj = tile - ti * Ly.nkb;
+        int kb0 = 0;
+        for (seg = 0; seg + 1 < Ly.nseg && tj >= kb0 + Ly.seg[seg].nkb; ++seg) kb0 += Ly.seg[seg].nkb;
         const int row = 16 * ti + 4 * (lane >> 4) + r;  // MFMA D layout: row = 4*(lane>>4)+r, col = lane&15
         const int jj = lane & 15;
         const int col = slot_to_col(Ly, tj, jj >> 2, jj & 3);
@@ -541,6 +546,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
         if (row < Ly.n_out) dst = Ly.b_off + row;
     }
     if (dst < 0) return;
+    const int G = (seg < Ly.nseg && wgrad_wide(Ly, seg)) ? G_wide : G_narrow;
     float sum = 0.f;
     for (int c = 0; c < G; ++c) sum += part[(int64_t)c * L.gp_floats + e];
     flat_grad[dst] = sum;
@@ -557,7 +563,8 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     // chunks: at most the wgrad_chunks(n) the partial buffer is sized for; with more wide workgroups than CUs, as many as
     // fill whole rounds of the chip (9 wide jobs x 128 chunks on 256 CUs = 4.5 rounds, the last one half empty: 113
     // chunks = 3.97 rounds of 13 % longer workgroups)
-    int G = wgrad_chunks(n);
+    const int G_narrow = wgrad_chunks(n);   // (the single-wave narrow jobs gain nothing from longer chunks)
+    int G = G_narrow;
     {
         static int n_cu = 0;
         if (!n_cu) {
@@ -594,10 +601,11 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
         }
     }
     if (const int jobs = wgrad_direct_jobs(P)) {
-        hipLaunchKernelGGL(mlp_wgrad_direct_kernel, dim3(jobs, G), dim3(WG_THREADS), 0, s, P, L, W);
+        W.chunk = (((n + G_narrow - 1) / G_narrow) + 15) / 16 * 16;
+        hipLaunchKernelGGL(mlp_wgrad_direct_kernel, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, P, L, W);
         if ((rc = check_launch("wgrad_direct"))) return rc;
     }
-    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, flat_grad);
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, G_narrow, flat_grad);
     return check_launch("wgrad_reduce");
 }
 
