@@ -2,7 +2,7 @@
  * NerfPipeline.forward, models/nerf_pipeline.py:14-67) using nothing but the C-ABI of include/smplnerf.h and the
  * HIP runtime for device memory.  Plain C99.
  *
- *   render_rays <in.bin> <out.bin> <precision: 0 | 2 | 3>
+ *   render_rays <in.bin> <out.bin> <precision: 0 | 2 | 3 | 16 (SNERF_SPLIT_F16X3)>
  *
  * in.bin  (little endian): int32 magic 0x534e5246, int32 B, Nc, Nf, white_background, then two snerf_mlp_desc
  *          (coarse, fine; 10 x int32 each), then float32 arrays: params_coarse, params_fine (state_dict order,
@@ -48,7 +48,7 @@ static float *to_device(FILE *f, size_t count, int *ok) {
 
 int main(int argc, char **argv) {
     if (argc != 4) {
-        fprintf(stderr, "usage: %s in.bin out.bin precision(0|2|3)\n", argv[0]);
+        fprintf(stderr, "usage: %s in.bin out.bin precision(0|2|3|16)\n", argv[0]);
         return 1;
     }
     const int precision = atoi(argv[3]);

@@ -879,7 +879,7 @@ def test_torchsearchsorted_shim_on_gpu(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", [0, 3])
+@pytest.mark.parametrize("precision", [0, 3, 16])
 def test_c_host_example(dev, tmp_path, precision):
     """examples/c_host/render_rays.c - plain C99, the C-ABI of include/smplnerf.h plus the HIP runtime, no Python in
     the process - renders the same rays as NerfPipeline.forward, bit for bit."""
@@ -895,7 +895,7 @@ def test_c_host_example(dev, tmp_path, precision):
                     os.path.join(root, "examples", "c_host", "render_rays.c"), lib, "-L/opt/rocm/lib", "-lamdhip64",
                     "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True)
     pipe = _pipeline(dev)
-    prec = {0: "fp32", 3: "bf16x6"}[precision]
+    prec = {0: "fp32", 3: "bf16x6", 16: "f16x3"}[precision]
     pipe.model_coarse.precision = pipe.model_fine.precision = prec
     data = syn.frame_batch(128, 128, phi=10.0, theta=5.0, seed=11, near=1.0, far=4.0)
     sub = np.arange(0, 16384, 29)
