@@ -145,7 +145,9 @@ int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const flo
  * kernel's own tolerance, at the speed of nsplit = 2): operands are scaled by exact powers of two - weights per layer at
  * pack time, activations (and, in the backward, gradients) per sample in the kernel - so that fp16's range is never
  * left.  Accepted wherever an nsplit / precision is: forward, training forward, snerf_render_rays*, and the backward
- * entry points (dgrad with two fp16 parts; the wide wgrad GEMMs, which contract over samples, keep three bf16 parts). */
+ * entry points (dgrad with per-sample scales; the wide wgrad GEMMs, which contract over samples, with per-layer scales
+ * taken from the exponents the f16x3 training forward leaves behind the rows of `act` and the f16x3 dgrad behind those
+ * of `dy`: an f16x3 backward therefore needs the `act` of an f16x3 training forward). */
 #define SNERF_SPLIT_F16X3 16
 int64_t snerf_mlp_packed_bf16_bytes(const snerf_mlp_desc *desc, int nsplit);
 int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed, int nsplit,
@@ -155,7 +157,8 @@ int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int n
                            int samples_per_ray, float *raw, snerf_stream_t stream);
 /* The same forward for training: additionally saves every layer input into `act`, in exactly the layout
  * snerf_mlp_fwd_train_f32 writes (act_floats of snerf_mlp_train_sizes), so that snerf_mlp_bwd_f32 /
- * snerf_mlp_bwd_inputs_f32 run on it unchanged (any mix of fp32 / split-bf16 forward and backward works: the buffers are fp32). */
+ * snerf_mlp_bwd_inputs_f32 run on it unchanged (any mix of fp32 / split-bf16 forward and backward works: the buffers are
+ * fp32 - except that the f16x3 backward needs the f16x3 forward, see SNERF_SPLIT_F16X3). */
 int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
                                  const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                                  int samples_per_ray, float *raw, float *act, snerf_stream_t stream);

@@ -345,8 +345,10 @@ extern "C" int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int6
     if (n < 0) return fail(SNERF_E_BADARG, "mlp_train_sizes: negative n");
     TrainLayout L;
     make_train_layout(P, L);
-    if (act_floats) *act_floats = (int64_t)L.act_rows * n * 16;
-    if (dy_floats) *dy_floats = (int64_t)L.dy_rows * n * 16;
+    // (+ STAT_INTS ints behind the rows of each: per-layer exponents of the largest |X| / |dY|, left by the f16x3 forward /
+    // dgrad for the f16x3 wgrad)
+    if (act_floats) *act_floats = (int64_t)L.act_rows * n * 16 + STAT_INTS;
+    if (dy_floats) *dy_floats = (int64_t)L.dy_rows * n * 16 + STAT_INTS;
     if (packed_t_floats) *packed_t_floats = (int64_t)(bwd_total_slabs(P, true) + SLAB_PAD) * SLAB_FLOATS;  // covers both streams
     const int G = wgrad_chunks(n);
     if (gpart_count) *gpart_count = G;

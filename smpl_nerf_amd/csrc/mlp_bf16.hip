@@ -162,6 +162,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     // bias of up to 2^13 still fits the scaled accumulator)
     constexpr int KX_PE = 14, KX_MAX = 64;
     auto sample_exp = [&](const auto &src, bool relu) __attribute__((always_inline)) -> int { return sample_exp16(src, relu); };
+    // f16x3 training: exponent of the largest |X| that enters forward layer l, for the f16x3 wgrad (behind the rows of act)
+    int *xstat = nullptr;
+    if constexpr (F16 && TRAIN) xstat = reinterpret_cast<int *>(A.act + (int64_t)A.act_rows * A.n * 16);
+    auto note_x = [&](int l, int e_true) __attribute__((always_inline)) {
+        if constexpr (F16 && TRAIN) stat_max16(xstat, l, e_true);
+    };
     auto operand_scale = [&](int e_src, int es_, int cap) __attribute__((always_inline)) -> int { return operand_scale16(e_src, es_, cap); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -272,7 +278,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     auto hidden = [&](int i, const f4(&src)[T], f4(&dst)[T]) __attribute__((always_inline)) {
         const bool skip = (A.skip_mask >> i) & 1u;
         int kx = 0;
-        if constexpr (F16) kx = operand_scale(sample_exp(src, true), es, skip ? kx_pos : KX_MAX);
+        if constexpr (F16) {
+            const int e = sample_exp(src, true);
+            note_x(i + 1, e - es);
+            kx = operand_scale(e, es, skip ? kx_pos : KX_MAX);
+        }
         LayerRun16<T, NT, NS, FMT> run(pipe, lane);
         run.init(dst, wexp(i + 1) + kx);
         run.template run_hidden<true>(src, dst, kx - es);
@@ -309,7 +319,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     const int nh = A.n_hidden;
     {  // additional_linear_layer: relu(accA) -> accB (no activation on its output)
         int kx = 0;
-        if constexpr (F16) kx = operand_scale(sample_exp(accA, true), es, KX_MAX);
+        if constexpr (F16) {
+            const int e = sample_exp(accA, true);
+            note_x(nh + 1, e - es);
+            kx = operand_scale(e, es, KX_MAX);
+        }
         LayerRun16<T, NT, NS, FMT> run(pipe, lane);
         run.init(accB, wexp(nh + 1) + kx);
         run.template run_hidden<true>(accA, accB, kx - es);
@@ -318,7 +332,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
         if (TRAIN && valid) store_act<false>(A.act, A.act_o, A.n, sample, c.g, accB, es);
     }
     int e_o = 0;   // f16x3: exponent of the largest |additional output| of the sample (feeds two layers)
-    if constexpr (F16) e_o = sample_exp(accB, false);
+    if constexpr (F16) {
+        e_o = sample_exp(accB, false);
+        note_x(nh + 3, e_o - es);
+    }
     f4 sig[1];
     {
         const int kx = F16 ? operand_scale(e_o, es, KX_MAX) : 0;
@@ -484,6 +501,10 @@ static int fwd_bf16(const snerf_mlp_desc *desc, const void *packed, int nsplit, 
         A.act_h1 = L.h1;
         A.act_h2 = L.h2;
         A.act_mask = L.mask;
+        A.act_rows = L.act_rows;
+        if (nsplit == SNERF_SPLIT_F16X3 &&
+            hipMemsetAsync(act + (int64_t)L.act_rows * n * 16, 0x80, STAT_INTS * sizeof(int), (hipStream_t)stream) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "%s: cannot reset the layer statistics", what);
         A.pos_nkb16 = Q.pos_nkb;
         A.add_nkb16 = Q.add_nkb;
         A.dir_nkb16 = Q.dir_nkb;

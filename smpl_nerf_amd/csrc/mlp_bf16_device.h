@@ -456,6 +456,12 @@ __device__ __forceinline__ int sample_exp16(const f4 (&src)[N], bool relu) {
     m = max(w[0], w[1]);
     return (int)((m >> 23) & 0xffu) - 127;
 }
+// raise stat[idx] to the largest exponent in this wave (one atomic per wave, and only when it would change the entry)
+__device__ __forceinline__ void stat_max16(int *stat, int idx, int e) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) e = max(e, __shfl_xor(e, d, 64));
+    if ((threadIdx.x & 63) == 0 && e > stat[idx]) atomicMax(stat + idx, e);
+}
 // operand scale exponent of a layer whose input has exponent e_src at accumulator scale es: largest input to [2^14, 2^15)
 __device__ __forceinline__ int operand_scale16(int e_src, int es, int cap) { return min(14 - (e_src - es), cap); }
 // the table of weight exponents (f16x3) sits in pad slab `table_slab` of a packed stream

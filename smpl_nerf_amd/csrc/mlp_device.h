@@ -38,6 +38,7 @@ struct FwdArgs {
     // training only: activation buffer in tile-row-major layout (mlp_plan.h TrainLayout)
     float *act;
     int act_pe, act_add, act_dpe, act_x1, act_o, act_h1, act_h2, act_mask;
+    int act_rows;      // f16x3 training forward: the per-layer |X| exponents go behind this many tile-rows of `act`
     // split-bf16 training forward only: encoder / additional k-block counts of the 16-wide (fp32) plan, which
     // defines the activation layout the backward kernels read
     int pos_nkb16, add_nkb16, dir_nkb16;

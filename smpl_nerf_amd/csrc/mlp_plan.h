@@ -31,6 +31,7 @@ constexpr int SLAB_AUX_FLOATS = 256;
 constexpr int SLAB_FLOATS = SLAB_A_FLOATS + SLAB_AUX_FLOATS;  // 4352 floats = 17 KiB
 constexpr int SLAB_PAD = 3;                                    // zero slabs after the stream (prefetch overrun)
 constexpr int MAX_LAYERS = 21;  // n_layers <= 16, + 5 fixed layers
+constexpr int STAT_INTS = 32;    // per-layer statistics behind the activation / dY rows of a training step (f16x3)
 
 enum SegType : int { SEG_HIDDEN = 0, SEG_PE = 1, SEG_ADD = 2 };
 

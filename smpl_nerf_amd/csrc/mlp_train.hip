@@ -583,6 +583,8 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     W.dy = dy;
     W.part = gpart;
     W.n = n;
+    W.xstat = reinterpret_cast<const int *>(act + (int64_t)L.act_rows * n * 16);   // (f16x3 wide jobs only)
+    W.ystat = reinterpret_cast<const int *>(dy + (int64_t)L.dy_rows * n * 16);
     W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
     static bool attr = false;  // idempotent; a race only repeats the call
     if (!attr) {

@@ -146,6 +146,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         else return 0;
     };
     int es = 0;   // f16x3: scale exponent of the accumulators of the layer just finished
+    // f16x3: exponent of the largest |dY| of forward layer l, for the f16x3 wgrad (behind the rows of dy)
+    int *ystat = nullptr;
+    if constexpr (F16) ystat = reinterpret_cast<int *>(A.dy + (int64_t)A.dy_rows * A.n * 16);
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
@@ -200,7 +203,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
     }
     // d h1 (acce, scale es) feeds the two transposes of directional_input: one operand scale for both
     int kx_din = 0;
-    if constexpr (F16) kx_din = operand_scale16(sample_exp16(acce, false), es, KX_MAX);
+    if constexpr (F16) {
+        const int e = sample_exp16(acce, false);
+        stat_max16(ystat, nh + 3, e - es);
+        kx_din = operand_scale16(e, es, KX_MAX);
+    }
     if (INPUT_GRAD && A.use_dir && A.dir_nkb > 0) {
         // d (direction encoding) = directional_input[:, W:]^T d h1, then encoder and normalisation backward
         f4 ddpe[TPD];
@@ -278,7 +285,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         LayerRun16<T, NT, NS, FMT> run(pipe, lane);
         run.init_plain(dst);
         int kx = 0;
-        if constexpr (F16) kx = operand_scale16(sample_exp16(src, false), es, KX_MAX);
+        if constexpr (F16) {
+            const int e = sample_exp16(src, false);
+            stat_max16(ystat, l + 1, e - es);
+            kx = operand_scale16(e, es, KX_MAX);
+        }
         run.template run_hidden<false>(src, dst, kx - es);
         run.finish();
         if constexpr (F16) es = wexp(l + 1) + kx;
@@ -333,10 +344,15 @@ constexpr int WB_ROW_FLOATS = WB_STAGE * 16;            // one tile-row of a sta
 constexpr int WB_SLOT_FLOATS = 32 * WB_ROW_FLOATS;      // 16 dY rows + 16 X rows: 64 KiB
 constexpr int WB_LDS_BYTES = 2 * WB_SLOT_FLOATS * 4;
 
-template <int NS>
+// FMT_F16 (f16x3 training): two fp16 parts and three products.  The contraction runs over samples, so the operand
+// scales must not depend on the sample: X and dY of the job are scaled by 2^(14 - exponent of their largest value over
+// ALL samples), which the f16x3 forward and dgrad kernels leave behind the activation / dY rows (stat_max16).  Samples
+// with small gradients then lose bits of their own, but not relative to the sum they are added to.
+template <int NS, int FMT = FMT_BF16>
 __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, TrainLayout L, WgradArgs A) {
     constexpr int TI = 8, TJ = 4;
     using Tm = Terms<NS>;
+    constexpr bool F16 = FMT == FMT_F16;
     extern __shared__ __attribute__((aligned(16))) float wring[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -368,6 +384,13 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
     const int64_t begin = (int64_t)blockIdx.y * A.chunk;
     const int64_t end = min(n, begin + A.chunk);
     const int nstages = begin < end ? (int)((end - begin + WB_STAGE - 1) / WB_STAGE) : 0;
+    float sx = 1.f, sy = 1.f, unscale = 1.f;   // f16x3: operand scales of the job and the scale of its result
+    if constexpr (F16) {
+        const int ex = 14 - min(max(A.xstat[l], -100), 100), ey = 14 - min(max(A.ystat[l], -100), 100);
+        sx = __builtin_ldexpf(1.f, ex);
+        sy = __builtin_ldexpf(1.f, ey);
+        unscale = __builtin_ldexpf(1.f, -(ex + ey));
+    }
 
     // ---- stage loader: this wave brings LDS rows 4*wave .. 4*wave+3 (rows 0..15 = dY, 16..31 = X), two 16-sample
     // pieces each; rows the job does not have re-load row 0 of dY so that every wave issues exactly 8 pieces per stage
@@ -413,7 +436,7 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
 
     // operand of one tile: this lane's 8 samples (8 kq + e) of feature i16 -> NS packed-bf16 parts.  MASK: zero the
     // samples at or past `limit` (ragged end of the chunk); SUM: also accumulate the values (bias gradient)
-    auto gather = [&](const float *row, auto mask, auto want_sum, int limit, bf8(&parts)[NS], float &sum)
+    auto gather = [&](const float *row, auto mask, auto want_sum, int limit, bf8(&parts)[NS], float &sum, float scale)
                       __attribute__((always_inline)) {
         float v[8];
 #pragma unroll
@@ -427,8 +450,12 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += v[e];
         }
+        if constexpr (F16) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split_pair_into<NS>(v[2 * e], v[2 * e + 1], parts, e);
+            for (int e = 0; e < 8; ++e) v[e] *= scale;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair_into<NS, FMT>(v[2 * e], v[2 * e + 1], parts, e);
     };
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
@@ -451,20 +478,20 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
             bf8 bpart[TJ][NS];
             float dummy = 0.f;
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) gather(base + (16 + TJ * bj + j) * WB_ROW_FLOATS, No{}, No{}, 0, bpart[j], dummy);
+            for (int j = 0; j < TJ; ++j) gather(base + (16 + TJ * bj + j) * WB_ROW_FLOATS, No{}, No{}, 0, bpart[j], dummy, sx);
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 if (i < n_ti) {
                     bf8 apart[NS];
                     const float *row = base + (TI * bi + i) * WB_ROW_FLOATS;
-                    if (tail) gather(row, Yes{}, Yes{}, limit, apart, bsum[i]);
-                    else if (want_bias) gather(row, No{}, Yes{}, 0, apart, bsum[i]);
-                    else gather(row, No{}, No{}, 0, apart, dummy);
+                    if (tail) gather(row, Yes{}, Yes{}, limit, apart, bsum[i], sy);
+                    else if (want_bias) gather(row, No{}, Yes{}, 0, apart, bsum[i], sy);
+                    else gather(row, No{}, No{}, 0, apart, dummy, sy);
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int t = 0; t < Tm::N; ++t)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apart[Tm::A[t]], bpart[j][Tm::B[t]], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma16<FMT>(apart[Tm::A[t]], bpart[j][Tm::B[t]], acc[i][j]);
                 }
             }
         }
@@ -483,6 +510,7 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
         for (int j = 0; j < TJ; ++j) {
             if (j >= n_tj) continue;
             const int ti = TI * bi + i, tj = kb0 + 16 * jb + TJ * bj + j;
+            if constexpr (F16) acc[i][j] *= unscale;
             *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
         }
         if (want_bias) {   // lane (i16, kq) summed samples 8 kq .. of feature i16
@@ -504,7 +532,16 @@ int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs 
             return fail(SNERF_E_LAUNCH, "wgrad_bf16: cannot raise the dynamic LDS limit to %d bytes", WB_LDS_BYTES);
         attr = true;
     }
-    if (nsplit == 3) hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<3>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
+    if (nsplit == SNERF_SPLIT_F16X3) {
+        static bool attr16 = false;
+        if (!attr16) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_wgrad_bf16_kernel<2, FMT_F16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WB_LDS_BYTES) != hipSuccess)
+                return fail(SNERF_E_LAUNCH, "wgrad_bf16: cannot raise the dynamic LDS limit to %d bytes", WB_LDS_BYTES);
+            attr16 = true;
+        }
+        hipLaunchKernelGGL((mlp_wgrad_bf16_kernel<2, FMT_F16>), dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
+    } else if (nsplit == 3) hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<3>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
     else hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<2>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
     return check_launch("wgrad_bf16");
 }
@@ -598,14 +635,20 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
     A.use_dir = desc->use_dir ? 1 : 0;
     A.total_slabs = bwd_total_slabs(P, input_grad, 32);
     A.n_tiles = (n + 8 * 16 - 1) / (8 * 16);
+    A.dy_rows = L.dy_rows;
+    const bool f16 = nsplit == SNERF_SPLIT_F16X3;
+    if (f16 && hipMemsetAsync(dy + (int64_t)L.dy_rows * n * 16, 0x80, STAT_INTS * sizeof(int), s) != hipSuccess)
+        return fail(SNERF_E_LAUNCH, "mlp_bwd_bf16: cannot reset the layer statistics");
     if (nsplit == SNERF_SPLIT_F16X3) rc = input_grad ? launch_dgrad_bf16<2, true, FMT_F16>(A, s) : launch_dgrad_bf16<2, false, FMT_F16>(A, s);
     else if (nsplit == 3) rc = input_grad ? launch_dgrad_bf16<3, true>(A, s) : launch_dgrad_bf16<3, false>(A, s);
     else rc = input_grad ? launch_dgrad_bf16<2, true>(A, s) : launch_dgrad_bf16<2, false>(A, s);
     if (rc) return rc;
-    // wide jobs on the bf16 matrix cores with the same number of parts (f16x3: three bf16 parts - the per-sample scaling of
-    // the other kernels does not carry over to a contraction over samples), narrow jobs and the reduce in fp32
+    // wide jobs on the 16-bit matrix cores in the same format (f16x3: with per-layer scales - a per-sample scale cannot be
+    // factored out of a contraction over samples), narrow jobs and the reduce in fp32
     static const bool bf16_wgrad = !(getenv("SNERF_WGRAD_BF16") && atoi(getenv("SNERF_WGRAD_BF16")) == 0);
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? (nsplit == SNERF_SPLIT_F16X3 ? 3 : nsplit) : 0);
+    // SNERF_WGRAD_F16=0: three bf16 parts for the wide jobs of an f16x3 step (A/B knob)
+    static const bool f16_wgrad = !(getenv("SNERF_WGRAD_F16") && atoi(getenv("SNERF_WGRAD_F16")) == 0);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? ((f16 && !f16_wgrad) ? 3 : nsplit) : 0);
 }
 
 }  // namespace snerf

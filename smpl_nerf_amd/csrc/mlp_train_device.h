@@ -13,6 +13,7 @@ struct BwdArgs {
     int64_t n;
     int n_hidden;
     int act_x1, act_h2, act_mask;
+    int dy_rows;       // f16x3 dgrad: the per-layer |dY| exponents go behind this many tile-rows of `dy`
     int dy_sig, dy_din, dy_dn0, dy_rgb;  // dy of forward layer l <= nh+1 is l*T
     // input gradients (INPUT_GRAD kernels only)
     const float *x, *dirs;  // forward inputs: positions [n,3], directions [n/spr,3] or [n,3]
@@ -68,6 +69,7 @@ struct WgradArgs {
     float *part;  // [G][gp_floats]
     int64_t n;
     int64_t chunk;  // samples per K-split, multiple of 16
+    const int *xstat, *ystat;  // f16x3 wide wgrad: exponents of the largest |X| entering / |dY| leaving forward layer l
 };
 
 
