@@ -165,6 +165,30 @@ def test_training_forward_relu_sign_masks(dev, prec, kw):
             assert (w[:, :, 0] >> (4 * nt) == 0).all()
 
 
+@pytest.mark.parametrize("c", [2.0 ** -24, 2.0 ** -8, 2.0 ** 12])
+def test_f16x3_backward_is_homogeneous(dev, c):
+    """The f16x3 backward scales its operands by powers of two - per sample in the dgrad, per layer (from the recorded
+    maxima) in the wide wgrad: gradients of c x loss must be c x the gradients of the loss, to fp32 accuracy, for
+    upstream gradients far smaller and far larger than those of the MSE loss (no overflow, no precision loss)."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(91)
+    params = syn.make_scene_nets(101)[0]
+    B, Ns = 300, 7
+    pts = rng.uniform(-2, 2, (B, Ns, 3)).astype(F32)
+    dray = rng.normal(size=(B, 3)).astype(F32)
+    gout = rng.normal(size=(B * Ns, 4)).astype(F32)
+    grads = []
+    for scale in (1.0, c):
+        net = make_net(dev, params, precision="f16x3")
+        raw = net.forward_fused(T(pts, dev), T(dray, dev), Ns, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        (raw * T(gout * F32(scale), dev)).sum().backward()
+        grads.append({k: p.grad.cpu().numpy().astype(np.float64) for k, p in net.named_parameters()})
+    for k in grads[0]:
+        ref = grads[0][k] * c
+        assert np.isfinite(grads[1][k]).all()
+        assert np.abs(grads[1][k] - ref).max() <= 2e-5 * np.abs(ref).max(), (k, c)
+
+
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_mlp_backward_many_samples_ragged(dev, prec):
     """n = 5003 samples (ragged vs the 64-sample tile, several split-K chunks), per-ray directions."""
