@@ -241,6 +241,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
             m = max(m, max(w[0], w[1]));
         }
         kx_pos = 14 - ((int)((m >> 23) & 0xffu) - 127);
+        if constexpr (TRAIN) stat_max16(reinterpret_cast<int *>(A.act + (int64_t)A.act_rows * A.n * 16), STAT_INTS - 1, 14 - kx_pos);
     }
 
     // two accumulator sets ping-pong between consecutive layers: the finished set feeds the next layer's B
@@ -367,7 +368,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     }
     {  // directional_net[0] (its relu is applied when the rgb head splits acce)
         int kx = 0;
-        if constexpr (F16) kx = operand_scale(sample_exp(accd, false), es, KX_MAX);
+        if constexpr (F16) {
+            const int e = sample_exp(accd, false);
+            note_x(nh + 4, e - es);
+            kx = operand_scale(e, es, KX_MAX);
+        }
         LayerRun16<TD, NT, NS, FMT> run(pipe, lane);
         run.init(acce, wexp(nh + 4) + kx);
         run.template run_hidden<false>(accd, acce, kx - es);
@@ -382,7 +387,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_bf16_kernel(FwdArgs A) {
     f4 rgb[1];
     {
         int kx = 0;
-        if constexpr (F16) kx = operand_scale(sample_exp(acce, true), es, KX_MAX);
+        if constexpr (F16) {
+            const int e = sample_exp(acce, true);
+            note_x(nh + 5, e - es);
+            kx = operand_scale(e, es, KX_MAX);
+        }
         LayerRun16<1, NT, NS, FMT> run(pipe, lane);
         run.init(rgb, wexp(nh + 5) + kx);
         run.template run_hidden<true>(acce, rgb, kx - es);

@@ -604,8 +604,14 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     }
     if (const int jobs = wgrad_direct_jobs(P)) {
         W.chunk = (((n + G_narrow - 1) / G_narrow) + 15) / 16 * 16;
-        hipLaunchKernelGGL(mlp_wgrad_direct_kernel, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, P, L, W);
-        if ((rc = check_launch("wgrad_direct"))) return rc;
+        // f16x3 step: the narrow jobs with two fp16 parts as well (SNERF_WGRAD_NARROW_F16=0: fp32 MFMA)
+        static const bool narrow_f16 = !(getenv("SNERF_WGRAD_NARROW_F16") && atoi(getenv("SNERF_WGRAD_NARROW_F16")) == 0);
+        if (wide_nsplit == SNERF_SPLIT_F16X3 && narrow_f16) {
+            if ((rc = launch_wgrad_direct_f16(P, L, W, jobs, G_narrow, s))) return rc;
+        } else {
+            hipLaunchKernelGGL(mlp_wgrad_direct_kernel, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, P, L, W);
+            if ((rc = check_launch("wgrad_direct"))) return rc;
+        }
     }
     hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, G_narrow, flat_grad);
     return check_launch("wgrad_reduce");

@@ -184,7 +184,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         run.init_plain(accd);
         const f4 src[2] = {g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, zero};
         int kx = 0;
-        if constexpr (F16) kx = operand_scale16(sample_exp16(src, false), 0, KX_MAX);
+        if constexpr (F16) {
+            const int e = sample_exp16(src, false);
+            stat_max16(ystat, nh + 5, e);                                            // d rgb
+            stat_max16(ystat, nh + 2, (int)((__float_as_uint(dr[3]) >> 23) & 0xffu) - 127);  // d sigma
+            kx = operand_scale16(e, 0, KX_MAX);
+        }
         run.template run_hidden<false>(src, accd, kx);
         run.finish();
         if constexpr (F16) es = wexp(nh + 5) + kx;
@@ -195,7 +200,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         LayerRun16<TD, NT, NS, FMT> run(pipe, lane);
         run.init_plain(acce);
         int kx = 0;
-        if constexpr (F16) kx = operand_scale16(sample_exp16(accd, false), es, KX_MAX);
+        if constexpr (F16) {
+            const int e = sample_exp16(accd, false);
+            stat_max16(ystat, nh + 4, e - es);
+            kx = operand_scale16(e, es, KX_MAX);
+        }
         run.template run_hidden<false>(accd, acce, kx - es);
         run.finish();
         if constexpr (F16) es = wexp(nh + 4) + kx;
@@ -294,6 +303,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_bf16_kernel(BwdArgs A) {
         run.finish();
         if constexpr (F16) es = wexp(l + 1) + kx;
         mask_store(dst, mk, A.dy, l * T, A.n, sample, valid, g, es);
+        if constexpr (F16) {
+            if (l == 0) stat_max16(ystat, 0, sample_exp16(dst, false) - es);   // (the other layers' |dY| are noted where they are consumed)
+        }
         if (l > 0) mk = *mask_ptr(A.act, A.act_mask, l - 1, A.n, sc, g);
         pe_columns(l, dst);
     };
@@ -520,6 +532,119 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
             if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (TI * bi + i) * 16 + lane] = v;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the narrow wgrad jobs of an f16x3 step
+// ------------------------------------------------------------------------------------------------
+// mlp_wgrad_direct_kernel (mlp_train.hip) with two fp16 parts instead of fp32 MFMA: one wave per <= 4x4-tile block of dW
+// and one chunk of samples, operands straight from L2/HBM - 8 strided dwords per lane and tile-row for a 32-sample
+// k-step (feature lane & 15, samples 8 (lane >> 4) + e: the operand layout of v_mfma_f32_16x16x32_f16) - scaled by the
+// per-layer powers of two of the wide kernel (xstat_index), split, 3 MFMAs of 16 cycles per tile pair and 32 samples
+// where the fp32 kernel spends 8 of 32 cycles.
+__global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainLayout L, WgradArgs A) {
+    using Tm = Terms<2>;
+    const int lane = threadIdx.x;
+    // ---- decode the job: (narrow layer, segment, 4x4-tile block), like mlp_wgrad_direct_kernel ----
+    int job = blockIdx.x, l = 0, s = 0, kb0 = 0, nbj = 1;
+    for (l = 0; l < P.nlayers; ++l) {
+        bool found = false;
+        kb0 = 0;
+        for (s = 0; s < P.layer[l].nseg; ++s) {
+            nbj = (P.layer[l].seg[s].nkb + 3) / 4;
+            const int cnt = wgrad_wide(P.layer[l], s) ? 0 : ((P.layer[l].t_out + 3) / 4) * nbj;
+            if (job < cnt) { found = true; break; }
+            job -= cnt;
+            kb0 += P.layer[l].seg[s].nkb;
+        }
+        if (found) break;
+    }
+    const Layer &Ly = P.layer[l];
+    const int bi = job / nbj, bj = job - bi * nbj;
+    const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
+    const int64_t n = A.n;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + i16;
+    const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + i16;
+    int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
+    while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
+    const bool want_bias = (s == first_seg && bj == 0);
+    const int xi = xstat_index(P, l, s);
+    const int ex = 14 - (xi < 0 ? 0 : min(max(A.xstat[xi], -100), 100)), ey = 14 - min(max(A.ystat[l], -100), 100);
+    const float sx = __builtin_ldexpf(1.f, ex), sy = __builtin_ldexpf(1.f, ey), unscale = __builtin_ldexpf(1.f, -(ex + ey));
+
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    float ra[4][8], rb[4][8];   // the k-step in flight: 8 samples of this lane's feature per tile-row
+    auto load_ab = [&](int64_t s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t smp = s0 + 8 * kq + e;
+            const bool ok = smp < end;
+            const int64_t off = (ok ? smp : end - 1) * 16;   // masked lanes read a valid sample: finite data, a = 0
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ra[t][e] = (t < n_ti && ok) ? dyp[(int64_t)t * n * 16 + off] : 0.f;
+                rb[t][e] = (t < n_tj) ? xp[(int64_t)t * n * 16 + off] : 0.f;
+            }
+        }
+    };
+    if (begin < end) load_ab(begin);
+    for (int64_t s0 = begin; s0 < end; s0 += 32) {
+        bf8 ap[4][2], bp[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[t] += ra[t][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split_pair_into<2, FMT_F16>(ra[t][2 * e] * sy, ra[t][2 * e + 1] * sy, ap[t], e);
+                split_pair_into<2, FMT_F16>(rb[t][2 * e] * sx, rb[t][2 * e + 1] * sx, bp[t], e);
+            }
+        }
+        if (s0 + 32 < end) load_ab(s0 + 32);   // in flight behind the MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < n_ti) {
+#pragma unroll
+                for (int t = 0; t < Tm::N; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < n_tj) acc[i][j] = mfma16<FMT_F16>(ap[i][Tm::A[t]], bp[j][Tm::B[t]], acc[i][j]);
+            }
+        }
+    }
+    // ---- write the partial of this (block, chunk): the format of mlp_wgrad_direct_kernel ----------------
+    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i >= n_ti) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= n_tj) continue;
+            const int ti = 4 * bi + i, tj = kb0 + 4 * bj + j;
+            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j] * unscale;
+        }
+        if (want_bias) {   // lane (i16, kq) summed samples 8 kq .. of feature i16
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
+        }
+    }
+}
+
+int launch_wgrad_direct_f16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, hipStream_t s) {
+    hipLaunchKernelGGL(mlp_wgrad_direct_f16_kernel, dim3(jobs, G), dim3(64), 0, s, P, L, W);
+    return check_launch("wgrad_direct_f16");
 }
 
 int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, int nsplit, hipStream_t s) {

@@ -95,6 +95,18 @@ __host__ __device__ inline int wgrad_direct_jobs(const Plan &P) {  // narrow job
     return jobs;
 }
 
+// f16x3 statistics (STAT_INTS ints behind the rows of act / dy): exponent of the largest |X| entering forward layer l
+// through its hidden segment at [l], of the largest encoder / additional-input column at [STAT_ENC]; of the largest |dY|
+// of forward layer l at [l].  Encoded directions are <= 1.
+constexpr int STAT_ENC = STAT_INTS - 1;
+__host__ __device__ inline int xstat_index(const Plan &P, int l, int s) {   // -1: exponent 0 (direction encoding)
+    const Seg &sg = P.layer[l].seg[s];
+    if (sg.type == SEG_HIDDEN) return l == P.n_hidden + 2 ? P.n_hidden + 3 : l;   // the sigma head reads what directional_input reads
+    if (sg.type == SEG_PE && l == P.n_hidden + 3) return -1;
+    return STAT_ENC;
+}
+// mlp_train_bf16.hip: the narrow jobs with two fp16 parts (f16x3 training)
+int launch_wgrad_direct_f16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, hipStream_t s);
 // mlp_train_bf16.hip: the wide jobs with split-bf16 operands (nsplit parts each)
 int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, int nsplit, hipStream_t s);
 
