@@ -135,7 +135,7 @@ def train_section(pipe, data, rays, steps, world, rank, dev):
     return {"metric": "ray-samples/s, training step (fwd+bwd+all-reduce+Adam)", "value": evals / dt,
             "rays_per_step_per_gpu": rays, "ms_per_step": dt / steps * 1e3, "steps": steps,
             "loss_first": losses[0], "loss_last": losses[-1], "rgb_fine_std_last_step": fine_std,
-            "kernels": {"f16x3": "f16x3 forward (activations saved in fp32), dgrad and wide wgrad; fp32 narrow wgrad",
+            "kernels": {"f16x3": "f16x3 forward (activations saved in fp32), dgrad and wgrad (fp32 reduce)",
                         "bf16x6": "bf16x6 forward, dgrad and wide wgrad, fp32 narrow wgrad", "bf16x3": "bf16x3 forward, dgrad "
                         "and wide wgrad, fp32 narrow wgrad", "fp32": "fp32"}.get(getattr(pipe.model_coarse, "precision", ""), ""),
             "mlp_kernels_ms_per_step": mlp_ms, "mlp_tflops": flop_step / (mlp_ms * 1e-3) / 1e12,
