@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the frame the CPU baseline renders (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the frame the CPU baseline renders (0 = skip)")
     ap.add_argument("--precision", choices=sorted(MODES), default="f16x3",
                     help="matrix-core arithmetic of the render kernel: f16x3 (two fp16 parts of power-of-two-scaled "
                          "operands, 3 products per MAC, fp32-class accuracy, default), bf16x6 (three bf16 parts, 6 products, "
