@@ -538,10 +538,10 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
 // the narrow wgrad jobs of an f16x3 step
 // ------------------------------------------------------------------------------------------------
 // mlp_wgrad_direct_kernel (mlp_train.hip) with two fp16 parts instead of fp32 MFMA: one wave per <= 4x4-tile block of dW
-// and one chunk of samples, operands straight from L2/HBM - 8 strided dwords per lane and tile-row for a 32-sample
-// k-step (feature lane & 15, samples 8 (lane >> 4) + e: the operand layout of v_mfma_f32_16x16x32_f16) - scaled by the
-// per-layer powers of two of the wide kernel (xstat_index), split, 3 MFMAs of 16 cycles per tile pair and 32 samples
-// where the fp32 kernel spends 8 of 32 cycles.
+// and one chunk of samples; 32-sample stages of its 8 tile-rows arrive in LDS by DMA (32 KiB per workgroup: five waves
+// per SIMD keep loads in flight), are gathered into the operand layout of v_mfma_f32_16x16x32_f16 (feature lane & 15,
+// samples 8 (lane >> 4) + e), scaled by the per-layer powers of two of the wide kernel (xstat_index) and split; 3 MFMAs
+// of 16 cycles per tile pair and 32 samples where the fp32 kernel spends 8 of 32 cycles.
 __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainLayout L, WgradArgs A) {
     using Tm = Terms<2>;
     const int lane = threadIdx.x;
@@ -564,8 +564,6 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
     const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
     const int64_t n = A.n;
     const int i16 = lane & 15, kq = lane >> 4;
-    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + i16;
-    const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + i16;
     int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
     while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
     const bool want_bias = (s == first_seg && bj == 0);
@@ -576,6 +574,38 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
     const int64_t begin = (int64_t)blockIdx.y * A.chunk;
     const int64_t end = min(n, begin + A.chunk);
 
+    // ---- stage loader: 32 samples of the block's 4 dY and 4 X tile-rows per stage, by DMA into LDS (two 1 KiB pieces per
+    // row, sample s of a piece at position s ^ ((s >> 3) & 1) like the wide kernel; 2 slots of 16 KiB); rows the block does
+    // not have re-load its first dY row, so that every stage is 16 pieces and one counted vmcnt serves
+    extern __shared__ __attribute__((aligned(16))) float dring[];
+    constexpr int ROW = 32 * 16, SLOT = 8 * ROW;
+    const float *row_src[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int64_t grow = (int64_t)(L.dy[l] + 4 * bi) * n * 16;
+        const float *base = A.dy;
+        if (r < 4) {
+            if (r < n_ti) grow += (int64_t)r * n * 16;
+        } else if (r - 4 < n_tj) {
+            base = A.act;
+            grow = (int64_t)(seg_act_row(P, L, l, s) + 4 * bj + (r - 4)) * n * 16;
+        }
+        row_src[r] = base + grow;
+    }
+    const int nstages = begin < end ? (int)((end - begin + 31) / 32) : 0;
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const int q = lane >> 2, sp = q ^ ((q >> 3) & 1);
+        float *slot = dring + (stage & 1) * SLOT;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int64_t smp = min(begin + (int64_t)stage * 32 + 16 * sub + sp, n - 1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(row_src[r] + smp * 16 + (lane & 3) * 4),
+                                                 (__attribute__((address_space(3))) void *)(slot + r * ROW + sub * 256), 16, 0, 0);
+        }
+    };
+
     f4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -583,34 +613,39 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    float ra[4][8], rb[4][8];   // the k-step in flight: 8 samples of this lane's feature per tile-row
-    auto load_ab = [&](int64_t s0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t smp = s0 + 8 * kq + e;
-            const bool ok = smp < end;
-            const int64_t off = (ok ? smp : end - 1) * 16;   // masked lanes read a valid sample: finite data, a = 0
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                ra[t][e] = (t < n_ti && ok) ? dyp[(int64_t)t * n * 16 + off] : 0.f;
-                rb[t][e] = (t < n_tj) ? xp[(int64_t)t * n * 16 + off] : 0.f;
-            }
+    if (nstages > 0) issue(0);
+    for (int st = 0; st < nstages; ++st) {
+        if (st + 1 < nstages) {
+            issue(st + 1);   // the other slot: read by the previous iteration, whose values are consumed
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-    };
-    if (begin < end) load_ab(begin);
-    for (int64_t s0 = begin; s0 < end; s0 += 32) {
+        const float *slot = dring + (st & 1) * SLOT;
+        const int limit = (int)min((int64_t)32, end - (begin + (int64_t)st * 32));   // dY samples past the chunk end count as zero
         bf8 ap[4][2], bp[4][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int r = 0; r < 8; ++r) {
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bsum[t] += ra[t][e];
+            for (int e = 0; e < 8; ++e) {
+                const int smp = 8 * kq + e;
+                const int pos = (smp & 15) ^ (((smp & 15) >> 3) & 1);
+                v[e] = slot[r * ROW + (smp >> 4) * 256 + pos * 16 + i16];
+            }
+            if (r < 4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                split_pair_into<2, FMT_F16>(ra[t][2 * e] * sy, ra[t][2 * e + 1] * sy, ap[t], e);
-                split_pair_into<2, FMT_F16>(rb[t][2 * e] * sx, rb[t][2 * e + 1] * sx, bp[t], e);
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = (r < n_ti && 8 * kq + e < limit) ? v[e] : 0.f;
+                    bsum[r] += v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_pair_into<2, FMT_F16>(v[2 * e] * sy, v[2 * e + 1] * sy, ap[r], e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_pair_into<2, FMT_F16>(v[2 * e] * sx, v[2 * e + 1] * sx, bp[r - 4], e);
             }
         }
-        if (s0 + 32 < end) load_ab(s0 + 32);   // in flight behind the MFMAs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < n_ti) {
@@ -643,7 +678,7 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
 }
 
 int launch_wgrad_direct_f16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, hipStream_t s) {
-    hipLaunchKernelGGL(mlp_wgrad_direct_f16_kernel, dim3(jobs, G), dim3(64), 0, s, P, L, W);
+    hipLaunchKernelGGL(mlp_wgrad_direct_f16_kernel, dim3(jobs, G), dim3(64), 2 * 8 * 32 * 16 * 4, s, P, L, W);
     return check_launch("wgrad_direct_f16");
 }
 
