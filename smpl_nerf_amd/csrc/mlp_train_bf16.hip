@@ -538,8 +538,7 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
 // the narrow wgrad jobs of an f16x3 step
 // ------------------------------------------------------------------------------------------------
 // mlp_wgrad_direct_kernel (mlp_train.hip) with two fp16 parts instead of fp32 MFMA: one wave per <= 4x4-tile block of dW
-// and one chunk of samples; 32-sample stages of its 8 tile-rows arrive in LDS by DMA (32 KiB per workgroup: five waves
-// per SIMD keep loads in flight), are gathered into the operand layout of v_mfma_f32_16x16x32_f16 (feature lane & 15,
+// and one chunk of samples; 32-sample stages of its 8 tile-rows arrive in LDS by DMA (16 KiB per workgroup), are gathered into the operand layout of v_mfma_f32_16x16x32_f16 (feature lane & 15,
 // samples 8 (lane >> 4) + e), scaled by the per-layer powers of two of the wide kernel (xstat_index) and split; 3 MFMAs
 // of 16 cycles per tile pair and 32 samples where the fp32 kernel spends 8 of 32 cycles.
 __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainLayout L, WgradArgs A) {
@@ -575,8 +574,9 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
     const int64_t end = min(n, begin + A.chunk);
 
     // ---- stage loader: 32 samples of the block's 4 dY and 4 X tile-rows per stage, by DMA into LDS (two 1 KiB pieces per
-    // row, sample s of a piece at position s ^ ((s >> 3) & 1) like the wide kernel; 2 slots of 16 KiB); rows the block does
-    // not have re-load its first dY row, so that every stage is 16 pieces and one counted vmcnt serves
+    // row, sample s of a piece at position s ^ ((s >> 3) & 1) like the wide kernel; ONE slot of 16 KiB, refilled behind the
+    // MFMAs: ten workgroups per CU hide each other's loads better than a second slot would); rows the block does not have
+    // re-load its first dY row
     extern __shared__ __attribute__((aligned(16))) float dring[];
     constexpr int ROW = 32 * 16, SLOT = 8 * ROW;
     const float *row_src[8];
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
     const int nstages = begin < end ? (int)((end - begin + 31) / 32) : 0;
     auto issue = [&](int stage) __attribute__((always_inline)) {
         const int q = lane >> 2, sp = q ^ ((q >> 3) & 1);
-        float *slot = dring + (stage & 1) * SLOT;
+        float *slot = dring;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int64_t smp = min(begin + (int64_t)stage * 32 + 16 * sub + sp, n - 1);
@@ -615,13 +615,8 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
 
     if (nstages > 0) issue(0);
     for (int st = 0; st < nstages; ++st) {
-        if (st + 1 < nstages) {
-            issue(st + 1);   // the other slot: read by the previous iteration, whose values are consumed
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const float *slot = dring + (st & 1) * SLOT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float *slot = dring;
         const int limit = (int)min((int64_t)32, end - (begin + (int64_t)st * 32));   // dY samples past the chunk end count as zero
         bf8 ap[4][2], bp[4][2];
 #pragma unroll
@@ -646,6 +641,8 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
                 for (int e = 0; e < 4; ++e) split_pair_into<2, FMT_F16>(v[2 * e] * sx, v[2 * e + 1] * sx, bp[r - 4], e);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is in registers: refill the slot behind the MFMAs
+        if (st + 1 < nstages) issue(st + 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < n_ti) {
@@ -678,7 +675,7 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
 }
 
 int launch_wgrad_direct_f16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, hipStream_t s) {
-    hipLaunchKernelGGL(mlp_wgrad_direct_f16_kernel, dim3(jobs, G), dim3(64), 2 * 8 * 32 * 16 * 4, s, P, L, W);
+    hipLaunchKernelGGL(mlp_wgrad_direct_f16_kernel, dim3(jobs, G), dim3(64), 8 * 32 * 16 * 4, s, P, L, W);
     return check_launch("wgrad_direct_f16");
 }
 
