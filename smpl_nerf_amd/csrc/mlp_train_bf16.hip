@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void mlp_wgrad_direct_f16_kernel(Plan P, TrainL
     // MFMAs: ten workgroups per CU hide each other's loads better than a second slot would); rows the block does not have
     // re-load its first dY row
     extern __shared__ __attribute__((aligned(16))) float dring[];
-    constexpr int ROW = 32 * 16, SLOT = 8 * ROW;
+    constexpr int ROW = 32 * 16;
     const float *row_src[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
