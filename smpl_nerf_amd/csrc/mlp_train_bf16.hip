@@ -679,6 +679,210 @@ int launch_wgrad_direct_f16(const Plan &P, const TrainLayout &L, const WgradArgs
     return check_launch("wgrad_direct_f16");
 }
 
+// ------------------------------------------------------------------------------------------------
+// the wide wgrad jobs of an f16x3 step, operands converted once per workgroup
+// ------------------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_f16, 16-sample stages: wave w brings tile-rows 4w .. 4w+3 of the job into LDS by DMA two stages
+// ahead and turns these same rows - two 32-feature operand tiles - into scaled fp16 parts ONCE for the workgroup
+// (mlp_wgrad_bf16_kernel splits in every wave: each dY tile four times and each X tile twice, and with three products per
+// MAC that VALU work outweighs the MFMAs); every wave then reads its 4 + 2 operand tiles and runs 3 MFMAs per tile pair.
+// Landing and operand areas are both double-buffered (2 x 32 KiB + 2 x 32 KiB): one barrier per stage.  The same kernel
+// with three bf16 parts needs all 160 KiB and ran exactly as fast as mlp_wgrad_bf16_kernel<3> (energy-bound).
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int WC_THREADS = 8 * 64;
+constexpr int WC_STAGE = 16;                            // samples per stage = one MFMA k-block
+constexpr int WC_ROW_FLOATS = WC_STAGE * 16;            // one tile-row of a stage: 1 KiB
+constexpr int WC_LAND_FLOATS = 32 * WC_ROW_FLOATS;      // 16 dY rows + 16 X rows: 32 KiB
+constexpr int WC_LDS_BYTES = 2 * WC_LAND_FLOATS * 4 + 2 * 16 * 2 * 1024;
+
+__global__ __launch_bounds__(WC_THREADS) void mlp_wgrad_f16_kernel(Plan P, TrainLayout L, WgradArgs A) {
+    constexpr int NS = 2;
+    constexpr int TI = 4, TJ = 2;   // accumulator tiles (32 x 32) per wave
+    using Tm = Terms<NS>;
+    extern __shared__ __attribute__((aligned(16))) float wring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- decode the job: (wide layer, segment, group of 16 input k-blocks), like mlp_wgrad_kernel ----
+    int job = blockIdx.x, l = 0, s = 0, kb0 = 0;
+    for (l = 0; l < P.nlayers; ++l) {
+        bool found = false;
+        kb0 = 0;
+        for (s = 0; s < P.layer[l].nseg; ++s) {
+            const int cnt = wgrad_wide(P.layer[l], s) ? (P.layer[l].seg[s].nkb + 15) / 16 : 0;
+            if (job < cnt) { found = true; break; }
+            job -= cnt;
+            kb0 += P.layer[l].seg[s].nkb;
+        }
+        if (found) break;
+    }
+    const Layer &Ly = P.layer[l];
+    const int jb = job;
+    const int n_rows_y = Ly.t_out, n_rows_x = min(16, Ly.seg[s].nkb - 16 * jb);   // 16-feature tile-rows of the job
+    const int64_t n = A.n;
+    int first_seg = 0;
+    while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
+    const int bi = wave >> 2, bj = wave & 3;
+    const bool active = 2 * TI * bi < n_rows_y && 2 * TJ * bj < n_rows_x;
+    const int m32 = lane & 31, kg = lane >> 5;
+
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+    const int nstages = begin < end ? (int)((end - begin + WC_STAGE - 1) / WC_STAGE) : 0;
+    // operand scales of the job (per layer, over all samples) and the scale of its result
+    const int ex = 14 - min(max(A.xstat[l], -100), 100), ey = 14 - min(max(A.ystat[l], -100), 100);
+    const float sx = __builtin_ldexpf(1.f, ex), sy = __builtin_ldexpf(1.f, ey), unscale = __builtin_ldexpf(1.f, -(ex + ey));
+
+    // ---- stage loader: this wave brings (and later converts) tile-rows 4*wave .. 4*wave+3 (rows 0..15 = dY, 16..31 =
+    // X); rows the job does not have re-load row 0 of dY (finite filler), so that every wave issues exactly 4 pieces per
+    // stage and one counted vmcnt serves all waves
+    const float *row_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wave + q;
+        int64_t grow = L.dy[l];
+        if (r < 16) {
+            if (r < n_rows_y) grow = L.dy[l] + r;
+            row_src[q] = A.dy + grow * n * 16;
+        } else if (r - 16 < n_rows_x) {
+            row_src[q] = A.act + (int64_t)(seg_act_row(P, L, l, s) + 16 * jb + (r - 16)) * n * 16;
+        } else {
+            row_src[q] = A.dy + grow * n * 16;
+        }
+    }
+    auto issue = [&](int stage) {
+        // lane covers 16 B of a piece: position q = lane >> 2 (of 16), feature quad lane & 3; position q of row r holds
+        // sample q ^ ((((q >> 3) & 1) << 1) | (r & 1)) (bank swizzle, see above; 4*wave + rr has the parity of rr)
+        float *slot = wring + (stage & 1) * WC_LAND_FLOATS;
+        const int q = lane >> 2;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int sp = q ^ ((((q >> 3) & 1) << 1) | (rr & 1));
+            const int64_t smp = min(begin + (int64_t)stage * WC_STAGE + sp, n - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(row_src[rr] + smp * 16 + (lane & 3) * 4),
+                (__attribute__((address_space(3))) void *)(slot + (4 * wave + rr) * WC_ROW_FLOATS), 16, 0, 0);
+        }
+    };
+
+    f16v acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum[2] = {0.f, 0.f};   // bias sums of the two dY operand tiles this wave converts (waves 0-3)
+    // operand area: [2 slots][16 operand tiles: 8 of dY, 8 of X][NS parts][64 lanes] x 16 B
+    bf8 *const ops = reinterpret_cast<bf8 *>(wring + 2 * WC_LAND_FLOATS);
+    constexpr int OPS_SLOT = 16 * NS * 64;
+
+    // operand tiles 2*wave, 2*wave+1 of `stage`: lane (m32, kg) takes samples 8 kg .. 8 kg + 7 of feature m32 of the tile
+    auto convert = [&](int stage) __attribute__((always_inline)) {
+        const float *slot = wring + (stage & 1) * WC_LAND_FLOATS;
+        bf8 *dst = ops + (stage & 1) * OPS_SLOT;
+        const int limit = (int)min((int64_t)WC_STAGE, end - (begin + (int64_t)stage * WC_STAGE));  // dY: ragged chunk end
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = 4 * wave + 2 * t + (m32 >> 4);   // parity of r = m32 >> 4
+            const float *row = slot + r * WC_ROW_FLOATS + (m32 & 15);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int smp = 8 * kg + e;
+                v[e] = row[(smp ^ ((kg << 1) | (m32 >> 4))) * 16];
+            }
+            if (wave < 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = 8 * kg + e < limit ? v[e] : 0.f;
+                    bsum[t] += v[e];
+                }
+            }
+            const float sc = wave < 4 ? sy : sx;
+            bf8 parts[NS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_pair_into<NS, FMT_F16>(v[2 * e] * sc, v[2 * e + 1] * sc, parts, e);
+#pragma unroll
+            for (int p = 0; p < NS; ++p) dst[((2 * wave + t) * NS + p) * 64 + lane] = parts[p];
+        }
+    };
+    auto multiply = [&](int stage) __attribute__((always_inline)) {
+        const bf8 *src = ops + (stage & 1) * OPS_SLOT;
+        bf8 bpart[TJ][NS];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) bpart[j][p] = src[((8 + TJ * bj + j) * NS + p) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            bf8 apart[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) apart[p] = src[((TI * bi + i) * NS + p) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < Tm::N; ++t)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, apart[Tm::A[t]]), __builtin_bit_cast(h8v, bpart[j][Tm::B[t]]), acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // (not __syncthreads(): its fence would also wait for the DMA in flight)
+    auto ops_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // every wave issues 4 pieces per stage, in stage order: vmcnt(4k) leaves the k newest stages in flight
+    if (nstages > 0) {
+        issue(0);
+        if (nstages > 1) issue(1);
+        if (nstages > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        convert(0);
+        if (nstages > 2) issue(2);   // into the rows just converted
+        ops_barrier();
+    }
+    for (int st = 0; st < nstages; ++st) {
+        if (st + 1 < nstages) {
+            // this wave's rows of stage st+1 have landed (stage st+2 may still be in flight)
+            if (st + 2 < nstages) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            convert(st + 1);
+            if (st + 3 < nstages) issue(st + 3);   // into the rows just converted
+        }
+        if (active) multiply(st);
+        ops_barrier();     // operands of stage st+1 complete; those of stage st free for stage st+2
+    }
+    // ---- write the partial of this (block, chunk): the [ti][tj][64 lanes][4] format of mlp_wgrad_kernel ----
+    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
+    if (s == first_seg && jb == 0 && wave < 4) {   // bias sums: lane (m32, kg) summed samples 8 kg .. of feature m32
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = bsum[t];
+            v += __shfl_xor(v, 32, 64);
+            const int feat = 32 * (2 * wave + t) + m32;
+            if (feat < n_rows_y * 16 && lane < 32) part[(int64_t)Ly.t_out * Ly.nkb * 256 + feat] = v;
+        }
+    }
+    if (!active) return;
+    // 32x32 accumulator: register 4 g + r of lane (m32, kg) is element (row 8 g + 4 kg + r, column m32) -> 16x16 tile
+    // (row >> 4, column >> 4), lane (column & 15) + 16 ((row & 15) >> 2), register r
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ti = 2 * (TI * bi + i) + (g >> 1), tjl = 2 * (TJ * bj + j) + (m32 >> 4);
+                if (ti >= n_rows_y || tjl >= n_rows_x) continue;
+                const int tj = kb0 + 16 * jb + tjl;
+                const int lane16 = (m32 & 15) + 16 * (2 * (g & 1) + kg);
+                *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane16) * 4) =
+                    f4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} * unscale;
+            }
+        }
+}
+
 int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, int nsplit, hipStream_t s) {
     static bool attr = false;  // idempotent; a race only repeats the call
     if (!attr) {
@@ -697,7 +901,17 @@ int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs 
                 return fail(SNERF_E_LAUNCH, "wgrad_bf16: cannot raise the dynamic LDS limit to %d bytes", WB_LDS_BYTES);
             attr16 = true;
         }
-        hipLaunchKernelGGL((mlp_wgrad_bf16_kernel<2, FMT_F16>), dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
+        // SNERF_WGRAD_F16_SPLIT_PER_WAVE=1: mlp_wgrad_bf16_kernel<2, FMT_F16> (every wave converts its own operands)
+        static const bool per_wave = getenv("SNERF_WGRAD_F16_SPLIT_PER_WAVE") && atoi(getenv("SNERF_WGRAD_F16_SPLIT_PER_WAVE")) != 0;
+        static bool attr_c = false;
+        if (!per_wave && !attr_c) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_wgrad_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    WC_LDS_BYTES) != hipSuccess)
+                return fail(SNERF_E_LAUNCH, "wgrad_f16: cannot raise the dynamic LDS limit to %d bytes", WC_LDS_BYTES);
+            attr_c = true;
+        }
+        if (per_wave) hipLaunchKernelGGL((mlp_wgrad_bf16_kernel<2, FMT_F16>), dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
+        else hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(jobs, G), dim3(WC_THREADS), WC_LDS_BYTES, s, P, L, W);
     } else if (nsplit == 3) hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<3>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
     else hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<2>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
     return check_launch("wgrad_bf16");
