@@ -6,96 +6,234 @@ batch of synthetic input: a whole 128x128 frame (16 384 rays) with 64 coarse + 1
 through two 8-layer / 256-wide RenderRayNets (BASELINE configs[1]).  One ray-sample = one MLP
 evaluation of one sample point: 64 (coarse) + 192 (fine) = 256 per ray, 4 194 304 per step.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`); when a
+launcher already set RANK / WORLD_SIZE it joins that group.  One rank per GPU over RCCL ("nccl"); when fewer
+GPUs than ranks are visible (dry runs of the multi-rank path on a 1-GPU box) the ranks share devices and the
+group runs on gloo.
+
+The headline `value` is measured in the reference's own arithmetic: exact fp32 (`--precision fp32`,
+v_mfma_f32_16x16x4_f32).  The operand-split modes on the 16-bit matrix cores are timed in the same run and
+reported under `other_precisions_1gpu`, each with its algorithmic roofline fraction.
 
 Inputs are resident in HBM before the timed region.  Rays of independent frames shard across ranks
 (each rank renders its own camera pose); rendering has no exchange step, so there is no data-path
-collective - RCCL is used only for the barrier and the max-over-ranks of the elapsed time.
+collective - the process group is used only for the barrier and the max-over-ranks of the elapsed time
+(and, in the `train` section, for the one gradient all-reduce per step).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
-FLOP_PER_EVAL = 2 * 607872           # RenderRayNet 8x256, pos 60, dir 24, skips=[4] (BASELINE.md section 3)
+FLOP_PER_EVAL = 2 * 607872           # RenderRayNet 8x256, pos 60, dir 24, skips=[4] (SURVEY.md 8d / BASELINE.md 3)
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
-PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md)
-# precision modes of the inference kernel: (kernel name for rocprof, products per fp32-accurate MAC)
-MODES = {"fp32": ("snerf::mlp_fwd_kernel<256, 8, false, false>", 1),
-         "f16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false, 1>", 3),
-         "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3, false, 0>", 6),
-         "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false, 0>", 3)}
-# HBM bytes per average launch of the MLP kernel, per precision mode, from the rocprofv3 PMC passes committed under
-# profiles/ (FETCH_SIZE as reported plus WRITE_SIZE); the kernels are MFMA-bound, this is informational.
-TRAFFIC_PER_LAUNCH = {}
-try:
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as _f:
-        TRAFFIC_PER_LAUNCH = {k: v["avg_launch"]["hbm_bytes"] for k, v in json.load(_f)["kernels"].items()}
-except Exception:
-    pass
+PEAK_16BIT_MFMA_TFLOPS = 2500.0      # MI355X dense bf16 / fp16 matrix peak (MI355X_MICROARCH.md)
+# precision modes of the render kernel: (kernel name as rocprofv3 prints it, 16-bit products per fp32 MAC, dtype text)
+MODES = {
+    "fp32": ("snerf::mlp_fwd_kernel<256, 8, false, false>", 1, "f32"),
+    "bf16x6": ("snerf::mlp_fwd_bf16_kernel<256, 8, 3, false, 0>", 6,
+               "f32 via bf16x6 (operands split into three bf16 parts, six products per MAC, fp32 accumulate)"),
+    "f16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false, 1>", 3,
+              "f32 via f16x3 (power-of-two-scaled operands split into two fp16 parts: 22 significand bits, three products "
+              "per MAC, fp32 accumulate) - narrower than fp32"),
+    "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false, 0>", 3,
+               "f32 via bf16x3 (two bf16 parts: 16 significand bits) - narrower than fp32"),
+}
+WORKLOADS = {
+    "nerf": "nerf {r}x{r} frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, width 256, skips [4], "
+            "forward render (BASELINE configs[1])",
+    "smpl_nerf": "smpl_nerf {r}x{r} frame per GPU (one arm pose), coarse+fine 64+128 samples/ray, warp field + netdepth 8 / "
+                 "width 256 nets, forward render (BASELINE configs[2] at 128, configs[3] at 256); roofline counts the "
+                 "RenderRayNet kernel only",
+    "append_vertices": "append_vertices {r}x{r} frame per GPU, SMPL-vertex-conditioned nets (per-ray constant inputs, quirk "
+                       "Q7), coarse+fine 64+128 samples/ray (BASELINE configs[4]); synthetic linear body model",
+    "append_smpl_params": "append_smpl_params {r}x{r} frame per GPU, 69 pose columns in front of the encoding, coarse+fine "
+                          "64+128 samples/ray (SURVEY 8f-4, the paper's headline model)",
+}
 
 
+# ---------------------------------------------------------------------------------------------------- launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------- workload
 def build_pipeline(dev, precision="fp32", workload="nerf"):
+    """(pipeline, parameter dicts, trainable models) of `workload` with seeded synthetic-scene weights."""
+    import torch
     from smpl_nerf_amd import synthetic as syn
-    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.nets import AppendVerticesNet, RenderRayNet, WarpFieldNet
     from smpl_nerf_amd.ops import PositionalEncoder
-    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs, SmplNerfPipeline
+    from smpl_nerf_amd.pipelines import (AppendSmplParamsPipeline, AppendVerticesPipeline, NerfPipeline, PipelineArgs,
+                                         SmplNerfPipeline)
 
-    params = list(syn.make_scene_nets(101))
-    nets = []
-    for p in params:
-        m = RenderRayNet(8, 256, 60, 24, skips=[4])
+    def load(m, p):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
-        m.precision = precision
-        nets.append(m.to(dev).eval())
-    args = PipelineArgs(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0)
-    if workload == "smpl_nerf":   # BASELINE configs[2]: pose-conditioned warp field in front of both nets
-        from smpl_nerf_amd.nets import WarpFieldNet
+        return m.to(dev).eval()
+
+    args = PipelineArgs(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0, human_pose_encoding=1)
+    enc = (PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    if workload == "append_vertices":
+        from smpl_nerf_amd.synthetic_smpl import IndexPoseEstimator, LinearBodyModel
+        params = [syn.make_append_vertices_params(s) for s in (201, 202)]
+        nets = [load(AppendVerticesNet(8, 256, 60, 24, 6890, additional_input_layers=1, skips=[4]), p) for p in params]
+        est = IndexPoseEstimator(torch.from_numpy(syn.human_poses((41, 38), 0, 60, 60)), torch.zeros(1, 10)).to(dev)
+        pipe = AppendVerticesPipeline(nets[0], nets[1], est, LinearBodyModel(seed=3).to(dev), args, *enc)
+        return pipe.set_precision(precision), params, nets
+    if workload == "append_smpl_params":
+        args.human_pose_encoding = 0
+        params = [syn.make_scene_net_params(s, add_first=True, additional_input_dim=69) for s in (301, 303)]
+        nets = [load(RenderRayNet(8, 256, 60, 24, 69, skips=[4]), p) for p in params]
+        pipe = AppendSmplParamsPipeline(nets[0], nets[1], args, *enc, PositionalEncoder(10, 0))
+        return pipe.set_precision(precision), params, nets
+    params = list(syn.make_scene_nets(101))
+    nets = [load(RenderRayNet(8, 256, 60, 24, skips=[4]), p) for p in params]
+    if workload == "smpl_nerf":   # pose-conditioned warp field in front of both nets
         pw = syn.make_warp_field_params(103, out_scale=0.3)
-        mw = WarpFieldNet(8, 256, 60, 40)
-        mw.load_state_dict({k: torch.from_numpy(v) for k, v in pw.items()})
+        mw = load(WarpFieldNet(8, 256, 60, 40), pw)
         params.append(pw)
-        pipe = SmplNerfPipeline(nets[0], nets[1], mw.to(dev).eval(), args, PositionalEncoder(10, 0), PositionalEncoder(4, 0),
-                                PositionalEncoder(10, 0))
-        return pipe.set_precision(precision), params
-    pipe = NerfPipeline(nets[0], nets[1], args, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
-    return pipe, params
+        pipe = SmplNerfPipeline(nets[0], nets[1], mw, args, *enc, PositionalEncoder(10, 0))
+        return pipe.set_precision(precision), params, nets + [mw]
+    pipe = NerfPipeline(nets[0], nets[1], args, *enc)
+    return pipe.set_precision(precision), params, nets
 
 
-def cpu_baseline(params, data_np, n_rays, u):
-    """The numpy oracle (a port of the reference's CPU path) timed on the host cores on a bounded
-    sample of the same workload: the first n_rays rays of the same frame, same weights."""
-    from oracle import nerf_oracle as O
-    args = O.Args(u=u)
-    pe, de = O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0)
-    sub = [a[:n_rays] for a in data_np]
-    if len(params) == 3:   # smpl_nerf: data = [samples, o, d, z, goal_pose, rgb]
-        fwd = lambda d: O.smpl_nerf_pipeline_forward(params[0], params[1], params[2], args, pe, de, O.PositionalEncoder(10, 0), d)
+def frame_inputs(workload, res, frame_id):
+    """Numpy pipeline input list of the frame rank `frame_id` renders (camera on the sphere, per-ray jitter)."""
+    import numpy as np
+    from smpl_nerf_amd import synthetic as syn
+    data = syn.frame_batch(res, res, phi=7.0 * frame_id, theta=25.0 * frame_id, seed=7 + frame_id)
+    n = data[0].shape[0]
+    if workload in ("smpl_nerf", "append_smpl_params"):   # one of the arm poses (render.py:190-220) for the whole frame
+        pose = np.tile(syn.human_poses()[(3 + frame_id) % 10][None], (n, 1)).astype(np.float32)
+        data = list(data[:4]) + [pose, data[4]]
+    elif workload == "append_vertices":                    # image index -> estimator -> body model (dummy_dynamic_dataset.py:93)
+        data = list(data[:4]) + [np.full((n,), (7 + frame_id) % 60, np.int64), data[4]]
+    return data
+
+
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, params, data_np, n_rays):
+    """The reference's CPU path, as restated op for op in PyTorch-CPU fp32 by oracle/torch_cpu_path.py (calibrated against
+    the reference itself in the build container: oracle/cpu_baseline_calibration.json), timed on this host on a bounded
+    sample of the same workload: the first n_rays rays of the same frame, same weights; warm-up 1, median of 5."""
+    import numpy as np
+    import torch
+    from oracle import torch_cpu_path as T
+    threads = torch.get_num_threads()
+    P = [T.tparams(p) for p in params]
+    data = [torch.from_numpy(np.ascontiguousarray(a[:n_rays])) for a in data_np]
+    pe, de = T.PositionalEncoder(10, False), T.PositionalEncoder(4, False)
+    if workload == "smpl_nerf":
+        fwd = lambda: T.smpl_nerf_pipeline_forward(P[0], P[1], P[2], T.Args(), pe, de, T.PositionalEncoder(10, False), data)
     else:
-        fwd = lambda d: O.nerf_pipeline_forward(params[0], params[1], args, pe, de, d)
-    fwd([a[:64] for a in data_np])   # warm-up
-    t0 = time.perf_counter()
-    out = fwd(sub)
-    dt = time.perf_counter() - t0
-    return n_rays * 256 / dt, dt, out
+        fwd = lambda: T.nerf_pipeline_forward(P[0], P[1], T.Args(), pe, de, data)
+    with torch.no_grad():
+        fwd()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            out = fwd()
+            ts.append(time.perf_counter() - t0)
+    dt = statistics.median(ts)
+    cal = None
+    try:
+        with open(os.path.join(ROOT, "oracle", "cpu_baseline_calibration.json")) as f:
+            c = json.load(f)
+        cal = {k: c[k] for k in ("host_cpu", "threads", "reference_ray_samples_per_s", "port_ray_samples_per_s",
+                                 "port_over_reference_speed", "outputs_bit_identical")}
+    except Exception:
+        pass
+    info = {"value": n_rays * 256 / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+            "host_cpu": _cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"first {n_rays} rays of the same frame, same weights ({n_rays * 256} ray-samples per pass; warm-up 1, "
+                      f"median of 5 passes, {dt:.2f} s each): oracle/torch_cpu_path.py = the reference's NerfPipeline.forward "
+                      f"restated op for op on PyTorch-CPU fp32, torch.set_num_threads({threads}) (torch's default here)",
+            "calibration_vs_reference_in_build_container": cal}
+    return info, [o.numpy() for o in out]
 
 
-def train_section(pipe, data, rays, steps, world, rank, dev):
-    """Secondary measurement (not `value`): data-parallel training steps - forward with saved
-    activations, MSE coarse+fine, HIP backward, one flat RCCL all-reduce of the gradients, Adam - on
-    `rays` rays per GPU drawn from this rank's frame (solver/nerf_solver.py:76-87)."""
+# ---------------------------------------------------------------------------------------------------- HBM traffic
+def pmc_traffic(argv_child, kernel_substr, timeout_s=240):
+    """HBM bytes per average launch of the dominant kernel from two separate rocprofv3 --pmc passes over a short run of
+    this same script (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots').  Units:
+    KB as rocprofv3 reports them.  gfx950 correction: the guide's 2x under-count applies to wide (16 B/lane) streaming
+    reads; this kernel's HBM reads are 4 B/lane position loads, and its FETCH_SIZE + WRITE_SIZE equals the known byte
+    count of the exact-fp32 kernel, so the figure is used as reported."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="snerf_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__)] + argv_child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no {ctr} rows for the kernel (rc {r.returncode}): {r.stderr[-200:]}"
+            out[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals))
+        except Exception as e:
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out, None
+
+
+# ---------------------------------------------------------------------------------------------------- training
+def train_section(precision, workload, data, rays, steps, world, rank, dev):
+    """Secondary measurement (not `value`): data-parallel training steps - forward with saved activations, MSE
+    coarse+fine, HIP backward, one flat all-reduce of the gradients, Adam - on `rays` rays per GPU drawn from this rank's
+    frame (solver/nerf_solver.py:76-87).  Fresh nets per call (the step updates them)."""
+    import torch
     from smpl_nerf_amd import _lib
     from smpl_nerf_amd.dist import barrier, max_over_ranks
     from smpl_nerf_amd.trainer import DataParallelTrainer
-    models = [pipe.model_coarse, pipe.model_fine] + ([pipe.model_warp_field] if hasattr(pipe, "model_warp_field") else [])
+    pipe, _, models = build_pipeline(dev, precision, workload)
     for m in models:
         m.train()
         for p in m.parameters():
@@ -128,65 +266,73 @@ def train_section(pipe, data, rays, steps, world, rank, dev):
         fine_std = float(pipe(batches[0])[1].std())
     losses = [float(l) for l in losses]
     evals = world * steps * rays * 256
-    bwd = {k: v for k, v in kern.items() if k.startswith("mlp_bwd")}
-    fwd = {k: v for k, v in kern.items() if k.startswith("mlp_fwd_train")}
-    flop_step = 3 * FLOP_PER_EVAL * rays * 256          # fwd + dgrad + wgrad
-    mlp_ms = (sum(v[1] for v in bwd.values()) + sum(v[1] for v in fwd.values())) / steps
-    return {"metric": "ray-samples/s, training step (fwd+bwd+all-reduce+Adam)", "value": evals / dt,
+    mlp_ms = sum(v[1] for k, v in kern.items() if k.startswith(("mlp_bwd", "mlp_fwd_train"))) / steps
+    flop_step = 3 * FLOP_PER_EVAL * rays * 256          # fwd + dgrad + wgrad of the two RenderRayNets
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
+    tf = flop_step / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None
+    return {"metric": "ray-samples/s, training step (fwd+bwd+all-reduce+Adam)", "value": evals / dt, "precision": precision,
             "rays_per_step_per_gpu": rays, "ms_per_step": dt / steps * 1e3, "steps": steps,
             "loss_first": losses[0], "loss_last": losses[-1], "rgb_fine_std_last_step": fine_std,
-            "kernels": {"f16x3": "f16x3 forward (activations saved in fp32), dgrad and wgrad (fp32 reduce)",
-                        "bf16x6": "bf16x6 forward, dgrad and wide wgrad, fp32 narrow wgrad", "bf16x3": "bf16x3 forward, dgrad "
-                        "and wide wgrad, fp32 narrow wgrad", "fp32": "fp32"}.get(getattr(pipe.model_coarse, "precision", ""), ""),
-            "mlp_kernels_ms_per_step": mlp_ms, "mlp_tflops": flop_step / (mlp_ms * 1e-3) / 1e12,
+            "mlp_kernels_ms_per_step": mlp_ms, "mlp_algorithmic_tflops": tf, "mlp_peak_tflops": peak,
+            "mlp_roofline_frac": tf / peak if tf else None,
             "kernels_ms_per_step": {k: v[1] / steps for k, v in sorted(kern.items())},
-            "collective": "one all-reduce of 1 220 872 fp32 gradients per step" if world > 1 else "none (1 GPU)"}
+            "collective": (f"one all-reduce of {sum(p.numel() for p in tr.params)} fp32 gradients per step"
+                           if world > 1 else "none (1 GPU)")}
 
 
+# ---------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the frame the CPU baseline renders (0 = skip)")
-    ap.add_argument("--precision", choices=sorted(MODES), default="f16x3",
-                    help="matrix-core arithmetic of the render kernel: f16x3 (two fp16 parts of power-of-two-scaled "
-                         "operands, 3 products per MAC, fp32-class accuracy, default), bf16x6 (three bf16 parts, 6 products, "
-                         "fp32-class accuracy), fp32 (v_mfma_f32_16x16x4_f32), bf16x3 (two bf16 parts, ~1e-5 relative)")
-    ap.add_argument("--workload", choices=["nerf", "smpl_nerf"], default="nerf",
-                    help="nerf = BASELINE configs[1] (the metric's configuration); smpl_nerf = configs[2] (warp field + per-sample "
-                         "directions in front of the same nets), same frame size and sample counts")
+    ap.add_argument("--cpu-rays", type=int, default=2048,
+                    help="rays of the frame the CPU baseline renders per pass (2048 = the reference's default batch; 0 = skip)")
+    ap.add_argument("--precision", choices=sorted(MODES), default="fp32",
+                    help="matrix-core arithmetic of the headline measurement: fp32 (v_mfma_f32_16x16x4_f32, the reference's "
+                         "arithmetic, default), bf16x6 (three bf16 parts, 6 products per MAC), f16x3 (two fp16 parts of "
+                         "power-of-two-scaled operands, 3 products), bf16x3 (two bf16 parts)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="nerf")
+    ap.add_argument("--res", type=int, default=128, help="frame edge in pixels (BASELINE configs[3]/[4] use 256)")
     ap.add_argument("--train-rays", type=int, default=4096, help="rays per GPU per training step (0 = skip the train section)")
     ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--no-alt", action="store_true", help="skip the other precision modes")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     ndev = torch.cuda.device_count()
-    dev = torch.device("cuda", local_rank % max(ndev, 1))   # one rank per GPU; the modulo only matters for
-    torch.cuda.set_device(dev)                               # single-GPU dry runs of the multi-rank path
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X (no CUDA/HIP device visible; there is no CPU path)")
+    dev = torch.device("cuda", local_rank % ndev)   # one rank per GPU; the modulo only matters for dry runs of the
+    torch.cuda.set_device(dev)                       # multi-rank path on fewer GPUs than ranks
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SNERF_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("SNERF_DIST_BACKEND", "nccl" if ndev >= world else "gloo")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from smpl_nerf_amd import _lib, synthetic as syn
+    from smpl_nerf_amd import _lib
     from smpl_nerf_amd.dist import barrier, max_over_ranks, shard_frames
 
-    pipe, params = build_pipeline(dev, a.precision, a.workload)
+    pipe, params, _ = build_pipeline(dev, a.precision, a.workload)
     # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
     frame_id = shard_frames(world, rank)
-    data_np = syn.frame_batch(128, 128, phi=7.0 * frame_id, theta=25.0 * frame_id, seed=7 + frame_id)
-    if a.workload == "smpl_nerf":   # one of the 10 arm poses of configs[2] for the whole frame (render.py:190-220)
-        pose = np.tile(syn.human_poses()[3 + frame_id % 7][None], (data_np[0].shape[0], 1)).astype(np.float32)
-        data_np = list(data_np[:4]) + [pose, data_np[4]]
+    data_np = frame_inputs(a.workload, a.res, frame_id)
     data = [torch.from_numpy(x).to(dev) for x in data_np]
     rays = data[0].shape[0]
     evals_per_step = rays * 256
@@ -206,115 +352,116 @@ def main():
         kern = prof.summary()
     elapsed = max_over_ranks(elapsed, dev)
 
+    def mlp_launch_stats(k, steps):
+        mlp = {n: v for n, v in k.items() if n.startswith("mlp_fwd")}
+        calls = sum(v[0] for v in mlp.values())
+        ms = sum(v[1] for v in mlp.values())
+        return calls, ms / calls, steps * evals_per_step / calls
+
+    def roofline_of(prec, calls, avg_ms, units_per_launch):
+        kname, products, _ = MODES[prec]
+        alg = FLOP_PER_EVAL * units_per_launch / (avg_ms * 1e-3) / 1e12     # 1 215 744 FLOP per ray-sample
+        peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_16BIT_MFMA_TFLOPS
+        r = {"bound": "mfma", "kernel": kname + " (coarse + fine launches)", "achieved": alg, "peak": peak,
+             "unit": "TFLOP/s", "frac": alg / peak, "traffic": None, "avg_launch_ms": avg_ms, "launches": calls,
+             "flop_per_unit": FLOP_PER_EVAL, "units_per_launch": units_per_launch}
+        if prec == "fp32":
+            r["peak_note"] = "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32: 157.3 TFLOP/s"
+        else:
+            r["peak_note"] = ("dense 16-bit MFMA peak 2500 TFLOP/s; `achieved` counts the network's own fp32 MACs "
+                              "(algorithmic), not the split products")
+            r["products_per_fp32_mac"] = products
+            r["mfma_issue_frac"] = alg * products / peak        # executed 16-bit products against the same peak
+            r["achieved_vs_fp32_mfma_peak"] = alg / PEAK_F32_MFMA_TFLOPS
+        return r
+
     alt = {}
-    if rank == 0 or world > 1:
+    if not a.no_alt:
         with torch.no_grad():
             for prec in sorted(MODES):
                 if prec == a.precision:
                     continue
                 pipe.set_precision(prec)
-                pipe(data)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(2):
                     o2 = pipe(data)
                 torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / 3
                 with _lib.profile() as p2:
-                    pipe(data)
-                k2 = {k: v for k, v in p2.summary().items() if k.startswith("mlp_fwd")}
-                mlp_s = sum(v[1] for v in k2.values()) * 1e-3
-                prod = MODES[prec][1]
-                pk = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
-                tf = FLOP_PER_EVAL * prod * evals_per_step / mlp_s / 1e12
-                alt[prec] = {"ray_samples_per_s_per_gpu": evals_per_step / dt, "ms_per_step": dt * 1e3,
+                    t0 = time.perf_counter()
+                    for _ in range(a.steps):
+                        o2 = pipe(data)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / a.steps
+                calls, avg_ms, upl = mlp_launch_stats(p2.summary(), a.steps)
+                r = roofline_of(prec, calls, avg_ms, upl)
+                alt[prec] = {"ray_samples_per_s_per_gpu": evals_per_step / dt, "ms_per_step": dt * 1e3, "steps": a.steps,
+                             "dtype": MODES[prec][2],
                              "rgb_fine_max_abs_diff_vs_" + a.precision: float((o2[1] - out[1]).abs().max()),
-                             "mlp_kernel": MODES[prec][0], "mlp_kernel_ms_per_step": mlp_s * 1e3,
-                             "mfma_tflops": tf, "mfma_peak": pk, "mfma_frac": tf / pk}
+                             "roofline": r}
             pipe.set_precision(a.precision)
 
-    train = None
+    train = train_alt = None
     if a.train_rays > 0:
         try:
-            train = train_section(pipe, data, a.train_rays, a.train_steps, world, rank, dev)
+            train = train_section(a.precision, a.workload, data, a.train_rays, a.train_steps, world, rank, dev)
+            if not a.no_alt:
+                train_alt = {}
+                for prec in ("bf16x6", "f16x3", "fp32"):
+                    if prec != a.precision:
+                        t = train_section(prec, a.workload, data, a.train_rays, a.train_steps, world, rank, dev)
+                        train_alt[prec] = {k: t[k] for k in ("value", "ms_per_step", "loss_first", "loss_last",
+                                                             "mlp_kernels_ms_per_step", "mlp_algorithmic_tflops",
+                                                             "mlp_roofline_frac")}
         except Exception as e:  # the render metric above stays valid
             train = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         value = world * a.steps * evals_per_step / elapsed
-        # dominant kernel = the fused encode+MLP kernel; it is launched twice per step (coarse: 16384*64
-        # samples, fine: 16384*192).  Roofline over ALL its launches in the timed region, so that the
-        # average launch duration is the number rocprofv3 --stats reports for the kernel.
-        mlp = {k: v for k, v in kern.items() if k.startswith("mlp_fwd")}
-        calls = sum(v[0] for v in mlp.values())
-        ms = sum(v[1] for v in mlp.values())
-        avg_ms = ms / calls
-        units_per_launch = a.steps * evals_per_step / calls
-        kname, products = MODES[a.precision]
-        alg_tflops = FLOP_PER_EVAL * units_per_launch / (avg_ms * 1e-3) / 1e12    # fp32 MACs of the network
-        if a.precision == "fp32":
-            peak = PEAK_F32_MFMA_TFLOPS
-            achieved = alg_tflops
-            flop_per_unit = FLOP_PER_EVAL
-            roof_extra = {"peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32, 157.3 TFLOP/s"}
-            dtype = "f32"
-        else:
-            # split operands: every fp32 MAC of the network is `products` exact 16-bit products on the bf16 / fp16 matrix
-            # cores (same dense peak), accumulated in fp32 - that is the algorithm of this kernel, so its flop count per
-            # ray-sample is products x 1 215 744 and its roofline is the dense 16-bit MFMA peak.  The fp32-equivalent rate
-            # (`fp32_equivalent_tflops`, what the network needs) is reported beside it.
-            peak = PEAK_BF16_MFMA_TFLOPS
-            achieved = alg_tflops * products
-            flop_per_unit = FLOP_PER_EVAL * products
-            roof_extra = {"fp32_equivalent_tflops": alg_tflops,
-                          "fp32_equivalent_vs_fp32_mfma_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
-                          "fp32_equivalent_vs_bf16_mfma_peak": alg_tflops / PEAK_BF16_MFMA_TFLOPS,
-                          "algorithmic_flop_per_unit": FLOP_PER_EVAL,
-                          "products_per_fp32_mac": products,
-                          "peak_note": f"dense {'fp16' if a.precision == 'f16x3' else 'bf16'} MFMA peak 2500 TFLOP/s "
-                                       f"(v_mfma_f32_16x16x32_{'f16' if a.precision == 'f16x3' else 'bf16'}); operands split into "
-                                       f"{'two fp16' if a.precision == 'f16x3' else 'bf16'} parts, {products} products per fp32 MAC, fp32 accumulate; padded tiles "
-                                       f"(84->96, 280->288 inputs, 4-wide heads) are not counted"}
-            dtype = {"f16x3": "f32 via f16x3 (operands scaled by exact powers of two and split into two fp16 parts, three "
-                              "products per MAC, fp32 accumulate; RGB parity class of the fp32 kernel)",
-                     "bf16x6": "f32 via bf16x6 (split-bf16 operands, fp32 accumulate; RGB parity class of the fp32 kernel)",
-                     "bf16x3": "f32 via bf16x3 (split-bf16, ~2^-16 relative)"}[a.precision]
+        # dominant kernel = the fused encode+MLP kernel; it is launched twice per step (coarse: rays*64 samples, fine:
+        # rays*192).  Roofline over ALL its launches in the timed region, so that the average launch duration is the
+        # number rocprofv3 --stats reports for the kernel.
+        calls, avg_ms, upl = mlp_launch_stats(kern, a.steps)
+        roof = roofline_of(a.precision, calls, avg_ms, upl)
+        alg_bytes = upl * (12 + 16) + rays * 12       # positions in, raw out, one direction per ray
+        roof["algorithmic_hbm_bytes_per_launch"] = alg_bytes
+        if world == 1 and not a.no_pmc:
+            child = ["--steps", "3", "--warmup", "1", "--cpu-rays", "0", "--train-rays", "0", "--no-alt", "--no-pmc",
+                     "--precision", a.precision, "--workload", a.workload, "--res", str(a.res)]
+            t, err = pmc_traffic(child, MODES[a.precision][0].replace("snerf::", ""))
+            if t:
+                roof["traffic"] = t["FETCH_SIZE"][0] + t["WRITE_SIZE"][0]
+                roof["traffic_detail"] = {"fetch_bytes": t["FETCH_SIZE"][0], "write_bytes": t["WRITE_SIZE"][0],
+                                          "launches_sampled": t["FETCH_SIZE"][1],
+                                          "source": "live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over "
+                                                    "`bench.py " + " ".join(child) + "`, per average launch"}
+            else:
+                roof["traffic_detail"] = {"error": err}
         line = {
-            "metric": "ray-samples/sec (coarse+fine) at 128^2 / 64+128 samples",
+            "metric": "ray-samples/sec (coarse+fine) at 128^2 / 64+128 samples" if a.res == 128 else
+                      f"ray-samples/sec (coarse+fine) at {a.res}^2 / 64+128 samples",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": ("nerf 128x128 frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, "
-                                    "width 256, skips [4], forward render (BASELINE configs[1])") if a.workload == "nerf" else
-                                   ("smpl_nerf 128x128 frame per GPU (one arm pose), coarse+fine 64+128 samples/ray, warp field + "
-                                    "netdepth 8 / width 256 nets, forward render (BASELINE configs[2]); roofline counts the "
-                                    "RenderRayNet kernel only"),
-                       "rays_per_step_per_gpu": rays, "ray_samples_per_ray": 256, "parallelism": f"dp{world} (rays of "
-                       "independent frames per rank, no data-path collective)"},
+            "vs_baseline": None, "dtype": MODES[a.precision][2], "data": "synthetic",
+            "config": {"workload": WORKLOADS[a.workload].format(r=a.res), "rays_per_step_per_gpu": rays,
+                       "ray_samples_per_ray": 256,
+                       "parallelism": f"dp{world} (rays of independent frames per rank, no data-path collective"
+                                      + (f"; process group on {backend}" if backend else "") + ")"},
             "rays_per_s": world * a.steps * rays / elapsed,
-            "roofline": dict({"bound": "mfma", "kernel": kname + " (coarse + fine launches)",
-                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                              "frac": achieved / peak, "traffic": TRAFFIC_PER_LAUNCH.get(a.precision),
-                              "avg_launch_ms": avg_ms, "launches": calls, "flop_per_unit": flop_per_unit,
-                              "units_per_launch": units_per_launch,
-                              "traffic_note": "(FETCH_SIZE + WRITE_SIZE) per average launch from the PMC passes under "
-                                              "profiles/, not measured live"}, **roof_extra),
+            "roofline": roof,
             "precision": a.precision,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(kern.items())},
         }
-        line["other_precisions_1gpu"] = alt
+        if alt:
+            line["other_precisions_1gpu"] = alt
         if train is not None:
             line["train"] = train
-        if world == 1 and a.cpu_rays > 0:
-            from smpl_nerf_amd.ops import uniform_u
-            u = uniform_u(128, dev).cpu().numpy()
-            cpu_val, cpu_dt, ref = cpu_baseline(params, data_np, min(a.cpu_rays, rays), u)
+        if train_alt:
+            line["train_other_precisions"] = train_alt
+        if world == 1 and a.cpu_rays > 0 and a.workload in ("nerf", "smpl_nerf"):
             n = min(a.cpu_rays, rays)
-            err = float(np.max(np.abs(out[1][:n].cpu().numpy() - ref[1])))
-            line["cpu_baseline"] = {"value": cpu_val, "unit": "ray-samples/s", "cores": os.cpu_count(),
-                                    "kind": "port", "sample": f"first {n} rays of the same frame, same weights "
-                                    f"({n * 256} ray-samples, {cpu_dt:.1f} s): numpy oracle, BLAS threads = host cores"}
-            line["rgb_fine_max_abs_diff_vs_oracle"] = err
+            info, ref = cpu_baseline(a.workload, params, data_np, n)
+            line["cpu_baseline"] = info
+            line["rgb_fine_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[1][:n].cpu().numpy() - ref[1])))
+            line["rgb_coarse_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[0][:n].cpu().numpy() - ref[0])))
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -56,6 +56,7 @@ SIGNATURES = {
                                               _P, _P, _P]),
     "snerf_mlp_train_sizes": (c_int, [POINTER(MlpDesc), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
                                       POINTER(c_int64), POINTER(c_int32)]),
+    "snerf_mlp_dy_layout": (c_int, [POINTER(MlpDesc), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "snerf_mlp_fwd_train_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P, _P]),
     "snerf_mlp_fwd_encoded_train_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int64, c_int64, _P, _P, _P]),
     "snerf_mlp_pack_t_f32": (c_int, [POINTER(MlpDesc), _P, _P, c_int, _P]),

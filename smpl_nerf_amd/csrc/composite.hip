@@ -107,7 +107,7 @@ __global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
 // One wave per ray: a forward sweep records the transmittance carried into every 64-sample chunk, a
 // reverse sweep recomputes each chunk and runs the suffix sum as a reverse wavefront scan (fp64).
 // HBM: raw and z are read twice (40 B/sample), d raw written once (16 B/sample).
-constexpr int CP_MAX_CHUNKS = 16;  // N <= 1024
+constexpr int CP_MAX_CHUNKS = 64;  // N <= 4096 (forward and backward accept the same range)
 
 __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
     const float4 *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs, int dirs_per_sample,
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
             d_raw[base + i] = make_float4(w * gr * cr * (1.f - cr), w * gg * cg * (1.f - cg), w * gb * cb * (1.f - cb), dsig);
             if (d_dirs) {  // per-sample directions: dist = delta * |dir|  =>  d dir = d dist * delta * dir / |dir|
                 const float ddist = sig > 0.f ? da * sig * ex : 0.f;
-                const float s = ddist * delta / nrm;
+                const float s = nrm > 0.f ? ddist * delta / nrm : 0.f;  // torch.norm's subgradient at 0 is 0
                 const float *dp = dirs + (base + i) * 3;
                 float *q = d_dirs + (base + i) * 3;
                 q[0] = s * dp[0];
@@ -214,7 +214,7 @@ extern "C" int snerf_composite_fwd_f32(const float *raw, const float *z, const f
                                        const float *noise, int64_t B, int N, int white_background, float *rgb,
                                        float *weights, float *alpha, snerf_stream_t stream) {
     using namespace snerf;
-    if (B < 0 || N < 1) return fail(SNERF_E_BADARG, "composite: bad B/N");
+    if (B < 0 || N < 1 || N > WAVE * CP_MAX_CHUNKS) return fail(SNERF_E_BADARG, "composite: need B >= 0 and 1 <= N <= 4096");
     if (B == 0) return SNERF_OK;
     if (!raw || !z) return fail(SNERF_E_BADARG, "composite: raw/z is null");
     if (N > 1 && !dirs) return fail(SNERF_E_BADARG, "composite: dirs is null");
@@ -232,7 +232,7 @@ extern "C" int snerf_composite_bwd_f32(const float *raw, const float *z, const f
                                        const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
                                        float *d_raw, float *d_dirs, snerf_stream_t stream) {
     using namespace snerf;
-    if (B < 0 || N < 1 || N > WAVE * CP_MAX_CHUNKS) return fail(SNERF_E_BADARG, "composite_bwd: need 1 <= N <= 1024");
+    if (B < 0 || N < 1 || N > WAVE * CP_MAX_CHUNKS) return fail(SNERF_E_BADARG, "composite_bwd: need 1 <= N <= 4096");
     if (B == 0) return SNERF_OK;
     if (!raw || !z || !d_rgb || !d_raw) return fail(SNERF_E_BADARG, "composite_bwd: null pointer");
     if (N > 1 && !dirs) return fail(SNERF_E_BADARG, "composite_bwd: dirs is null");

@@ -356,6 +356,24 @@ extern "C" int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int6
     return SNERF_OK;
 }
 
+extern "C" int snerf_mlp_dy_layout(const snerf_mlp_desc *desc, int32_t *n_layers, int32_t *first_row, int32_t *n_out,
+                                   int32_t *n_in) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "mlp_dy_layout: desc is null");
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_dy_layout: %s", why);
+    TrainLayout L;
+    make_train_layout(P, L);
+    if (n_layers) *n_layers = P.nlayers;
+    for (int l = 0; l < P.nlayers; ++l) {
+        if (first_row) first_row[l] = L.dy[l];
+        if (n_out) n_out[l] = P.layer[l].n_out;
+        if (n_in) n_in[l] = P.layer[l].n_in;
+    }
+    return SNERF_OK;
+}
+
 extern "C" int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                                        const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                                        int samples_per_ray, float *raw, float *act, snerf_stream_t stream) {

@@ -26,6 +26,19 @@ __global__ __launch_bounds__(RG_THREADS) void raygen_kernel(const double *__rest
     if (ray >= B) return;
     const int64_t idx = ray_index[ray];
     const int64_t hw = (int64_t)H * W;
+    if (idx < 0 || idx >= P * hw) {  // out-of-range ray index: never read poses out of bounds; the ray comes back as NaN
+        const float qnan = __builtin_nanf("");
+        if (lane < 3) {
+            o_out[ray * 3 + lane] = qnan;
+            d_out[ray * 3 + lane] = qnan;
+        }
+        for (int k = lane; k < Nc; k += WAVE) {
+            z_out[ray * Nc + k] = qnan;
+            float *p = samples + (ray * Nc + k) * 3;
+            p[0] = p[1] = p[2] = qnan;
+        }
+        return;
+    }
     const int64_t frame = idx / hw;
     const int pix = (int)(idx - frame * hw);
     const int j = pix / W, i = pix - j * W;

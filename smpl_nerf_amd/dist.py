@@ -42,6 +42,24 @@ def shard_rays(tensors, world: int = None, rank: int = None):
     return [t[b:e] for t in tensors]
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo moves host memory: a CUDA tensor is staged through the host for the collective (the CPU test backend, and
+    the dry runs of the multi-rank path with several ranks sharing one GPU, where RCCL cannot form a group)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast of `t` from rank `src`."""
+    if is_dist():
+        if _host_staged(t):
+            h = t.detach().cpu()
+            dist.broadcast(h, src)
+            t.detach().copy_(h)
+        else:
+            dist.broadcast(t.detach(), src)
+    return t
+
+
 def barrier(device=None):
     if is_dist():
         if device is not None and device.type == "cuda" and dist.get_backend() == "nccl":
@@ -53,7 +71,8 @@ def barrier(device=None):
 def max_over_ranks(value: float, device=None) -> float:
     if not is_dist():
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    on_host = device is None or dist.get_backend() == "gloo"
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_host else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -68,9 +87,11 @@ def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     maxn = max(e - b for b, e in sizes)
     pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
+    if _host_staged(pad):
+        pad = pad.cpu()
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
-    return torch.cat([o[: e - b] for o, (b, e) in zip(outs, sizes)], 0)
+    return torch.cat([o[: e - b] for o, (b, e) in zip(outs, sizes)], 0).to(local.device)
 
 
 def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
@@ -78,6 +99,11 @@ def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
     one collective of a data-parallel training step.  A single bucket: at this size a ring over xGMI
     is latency-bound, so splitting it only adds launches."""
     if is_dist():
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        if _host_staged(flat_grad):
+            h = flat_grad.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat_grad.copy_(h)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         flat_grad.div_(dist.get_world_size())
     return flat_grad

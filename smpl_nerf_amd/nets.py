@@ -28,6 +28,82 @@ def _encoder_shape(dim: int):
 _ENCODED_ROWS = -1  # marker passed in the `per_sample` slot of _FusedMlpFn
 
 
+def _need_f32_cuda(what: str, *tensors):
+    """The kernels read raw device pointers as fp32: anything else must be rejected here, not reinterpreted."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(f"{what}: inputs must live on the GPU (got {t.device}); smpl_nerf_amd has no CPU path")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{what}: inputs must be float32 (got {t.dtype})")
+
+
+def flat_parameter_vector(params) -> torch.Tensor:
+    """The parameters as one contiguous fp32 vector in the given order (the C-ABI's params_flat).  Zero-copy when
+    they already are adjacent views of one buffer (trainer.flatten_parameters_ lays them out like that, so a training step
+    packs its weight streams without a torch.cat of 26 tensors); otherwise a torch.cat."""
+    p0 = params[0]
+    if all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+        base, addr = p0.untyped_storage().data_ptr(), p0.data_ptr()
+        for p in params:
+            if p.untyped_storage().data_ptr() != base or p.data_ptr() != addr:
+                break
+            addr += 4 * p.numel()
+        else:
+            return torch.as_strided(p0.detach(), (sum(p.numel() for p in params),), (1,))
+    return torch.cat([p.detach().reshape(-1).float() for p in params])
+
+
+def _layer_output_grads(desc, dy, n, layers):
+    """{l: d Y_l [n, n_out_l]} for the forward layers in `layers`, gathered from the tile-row-major `dy` buffer the
+    backward kernels leave behind (include/smplnerf.h: snerf_mlp_dy_layout)."""
+    lib = _lib.load()
+    cnt = ctypes.c_int32()
+    rows = (ctypes.c_int32 * 21)()
+    nout = (ctypes.c_int32 * 21)()
+    check(lib.snerf_mlp_dy_layout(desc, ctypes.byref(cnt), rows, nout, None), "snerf_mlp_dy_layout")
+    out = {}
+    for l in layers:
+        t = (nout[l] + 15) // 16
+        blk = dy[rows[l] * n * 16:(rows[l] + t) * n * 16].view(t, n, 16)
+        out[l] = blk.permute(1, 0, 2).reshape(n, t * 16)[:, :nout[l]]
+    return out
+
+
+def _extra_input_grads(net, desc, dy, n, want_pos, want_dir):
+    """Gradients w.r.t. the non-hidden input columns of the net, as contractions of the stored d Y_l with the weight
+    columns that read them (what autograd does in the reference, models/render_ray_net.py:43-56): layer 0 and the skip
+    layers read [positions | additional] (in the column order of the weight matrix), directional_input reads the
+    direction encoding.  Returns (d_posadd [n, pin] or None, d_direnc [n, dir_dim] or None)."""
+    nh = net.n_layers - 1
+    pin = net.positions_pose_input.weight.shape[1]       # positions (+ additional) columns
+    with torch.no_grad():
+        d_pa = d_dir = None
+        if want_pos:
+            readers = [(0, net.positions_pose_input.weight, 0)]
+            readers += [(i + 1, net.positional_net[i].weight, net.width) for i in range(nh) if i in net.skips]
+            g = _layer_output_grads(desc, dy, n, [l for l, _, _ in readers])
+            for l, w, c0 in readers:
+                term = g[l] @ w[:, c0:c0 + pin]
+                d_pa = term if d_pa is None else d_pa + term
+        if want_dir and net.use_directional_input:
+            g = _layer_output_grads(desc, dy, n, [nh + 3])
+            d_dir = g[nh + 3] @ net.directional_input.weight[:, net.width:]
+    return d_pa, d_dir
+
+
+def _grads_from_flat(flat, shapes):
+    grads, off = [], 0
+    for shp in shapes:
+        k = 1
+        for v in shp:
+            k *= v
+        grads.append(flat[off:off + k].view(shp))
+        off += k
+    return grads
+
+
 class _FusedMlpFn(torch.autograd.Function):
     """raw = RenderRayNet(encode(x), encode(normalise(d))) with gradients for every weight and bias.
     Forward saves the layer inputs in the tile-row-major activation buffer; backward = dgrad + split-K
@@ -67,6 +143,11 @@ class _FusedMlpFn(torch.autograd.Function):
         ctx.input_grad = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and per_sample != _ENCODED_ROWS
         if ctx.input_grad:       # SmplNerfPipeline: positions / per-sample directions depend on the warp net
             ctx.xd = (x, d, per_sample, int(spr))
+        # gradients w.r.t. already-encoded rows (RenderRayNet.forward(x) feeding an upstream module) and w.r.t. the per-ray
+        # additional inputs (AppendVerticesPipeline: vertices <- smpl_model <- smpl_estimator)
+        ctx.rows_grad = bool(ctx.needs_input_grad[2]) and per_sample == _ENCODED_ROWS
+        ctx.add_grad = bool(ctx.needs_input_grad[6]) and add is not None
+        ctx.spr, ctx.row_floats = int(spr), (x.shape[1] if per_sample == _ENCODED_ROWS else 0)
         return raw
 
     @staticmethod
@@ -79,7 +160,7 @@ class _FusedMlpFn(torch.autograd.Function):
         packed_t = net.packed_weights_t_bf16(desc, ns, ctx.input_grad) if ns else net.packed_weights_t(desc, ctx.input_grad)
         dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
         gpart = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
-        flat = torch.empty(lib.snerf_mlp_param_floats(desc), device=dev, dtype=torch.float32)
+        flat = net._take_grad_sink(lib.snerf_mlp_param_floats(desc), dev)
         d_x = d_d = None
         if ctx.input_grad:
             x, d, per_sample, spr = ctx.xd
@@ -106,14 +187,18 @@ class _FusedMlpFn(torch.autograd.Function):
                     check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), n, ptr(dy), ptr(gpart),
                                                 ptr(flat), current_stream()), "snerf_mlp_bwd_f32")
         ctx.act = None
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            k = 1
-            for v in shp:
-                k *= v
-            grads.append(flat[off:off + k].view(shp))
-            off += k
-        return (None, None, d_x, d_d, None, None, None) + tuple(grads)
+        d_add = None
+        if ctx.rows_grad:        # encoded rows = [positions (+ additional) | ... | directions]
+            d_pa, d_dir = _extra_input_grads(net, desc, dy, n, True, True)
+            d_x = torch.zeros((n, ctx.row_floats), device=dev, dtype=torch.float32)
+            d_x[:, :d_pa.shape[1]] = d_pa
+            if d_dir is not None:
+                d_x[:, ctx.row_floats - d_dir.shape[1]:] += d_dir
+        elif ctx.add_grad:       # per-ray constants: sum the per-sample contributions of the ray
+            d_pa, _ = _extra_input_grads(net, desc, dy, n, True, False)
+            a0 = 0 if desc.add_first else 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
+            d_add = d_pa[:, a0:a0 + desc.add_dim].reshape(-1, ctx.spr, desc.add_dim).sum(1)
+        return (None, None, d_x, d_d, None, None, d_add) + tuple(_grads_from_flat(flat, ctx.shapes))
 
 
 
@@ -125,6 +210,10 @@ class _PackedWeightsEpoch:
     mark_weights_changed() (DataParallelTrainer.step does after every optimiser step)."""
 
     def mark_weights_changed(self):
+        """Call after changing parameter values in a way autograd's version counters do not see: fused optimisers,
+        `p.data.copy_(...)` / `p.data[...] = ...` (`.data` has its own version counter), raw-pointer writes.  In-place ops
+        on the parameter itself (`p.copy_()` under no_grad, `load_state_dict`) and re-assigned parameters are detected
+        without it."""
         self._weights_epoch += 1
 
     def _begin_training_forward(self):
@@ -135,6 +224,41 @@ class _PackedWeightsEpoch:
         if self._trained_since_pack:
             self._weights_epoch += 1
             self._trained_since_pack = False
+
+    # -- gradient sink: DataParallelTrainer hands every net its segment of ONE flat gradient buffer; the backward kernels
+    #    write the parameter gradients straight into it (what is all-reduced is what snerf_mlp_bwd_* wrote - no copy-in /
+    #    copy-out).  A segment is handed out once per backward pass: a net that is evaluated twice per step (the warp
+    #    field: coarse and fine stage) gets a private buffer the second time and autograd accumulates into the first.
+    _grad_sink = None
+    _grad_sink_taken = False
+
+    def set_grad_sink(self, flat_segment):
+        self._grad_sink = flat_segment
+        self._grad_sink_taken = False
+
+    def _take_grad_sink(self, numel: int, dev):
+        sink = self._grad_sink
+        if sink is not None and not self._grad_sink_taken and sink.numel() == numel and sink.device == dev:
+            self._grad_sink_taken = True
+            return sink
+        return torch.empty(numel, device=dev, dtype=torch.float32)
+
+    def _cached_pack(self, cache, key, params, build, keep_others=False):
+        """Weight stream `key`, rebuilt by build(flat fp32 parameter vector) only when a parameter changed: the cache is
+        keyed on (data_ptr, autograd version) of every parameter and the weights epoch (mark_weights_changed)."""
+        dev = params[0].device
+        if not params[0].is_cuda:
+            raise RuntimeError(f"{type(self).__name__}: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
+        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.cuda.device(dev):
+            packed = build(flat_parameter_vector(params), dev)
+        if not keep_others:
+            cache.clear()
+        cache[key] = (stamp, packed)
+        return packed
 
 
 class RenderRayNet(_PackedWeightsEpoch, nn.Module):
@@ -221,97 +345,74 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
             return self.make_desc(0, 0, d[0], d[1], self.positions_dim + self.additional_input_dim)
         return self.make_desc(p[0], p[1], d[0], d[1], self.additional_input_dim)
 
+    @staticmethod
+    def _desc_key(desc):
+        return tuple(getattr(desc, f[0]) for f in desc._fields_)
+
     def packed_weights(self, desc: MlpDesc, training: bool = False) -> torch.Tensor:
-        """MFMA-ordered weight stream for `desc`, re-packed only when a parameter changed."""
+        """MFMA-ordered fp32 weight stream for `desc` (snerf_mlp_pack_f32), re-packed only when a parameter changed."""
         if not training:
             self._begin_inference()
-        params = self._ordered_params()
-        dev = params[0].device
-        if not params[0].is_cuda:
-            raise RuntimeError("RenderRayNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
-        key = tuple(getattr(desc, f[0]) for f in desc._fields_)
-        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
         lib = _lib.load()
-        n_param = lib.snerf_mlp_param_floats(desc)
-        n_pack = lib.snerf_mlp_packed_floats(desc)
-        if n_param < 0 or n_pack < 0:
-            check(int(min(n_param, n_pack)), "snerf_mlp_packed_floats")
-        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        if flat.numel() != n_param:
-            raise RuntimeError(f"RenderRayNet: {flat.numel()} parameters but the descriptor expects {n_param}")
-        packed = torch.empty(n_pack, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+
+        def build(flat, dev):
+            n_param, n_pack = lib.snerf_mlp_param_floats(desc), lib.snerf_mlp_packed_floats(desc)
+            if n_param < 0 or n_pack < 0:
+                check(int(min(n_param, n_pack)), "snerf_mlp_packed_floats")
+            if flat.numel() != n_param:
+                raise RuntimeError(f"RenderRayNet: {flat.numel()} parameters but the descriptor expects {n_param}")
+            packed = torch.empty(n_pack, device=dev, dtype=torch.float32)
             check(lib.snerf_mlp_pack_f32(desc, ptr(flat), ptr(packed), current_stream()), "snerf_mlp_pack_f32")
-        self._pack_cache = {key: (stamp, packed)}
-        return packed
+            return packed
+
+        return self._cached_pack(self._pack_cache, self._desc_key(desc), self._ordered_params(), build)
 
     def packed_weights_bf16(self, desc: MlpDesc, nsplit: int, training: bool = False) -> torch.Tensor:
-        """Split-bf16 weight stream (snerf_mlp_pack_bf16), cached like packed_weights."""
+        """Split-bf16 / two-part fp16 weight stream (snerf_mlp_pack_bf16), cached like packed_weights."""
         if not training:
             self._begin_inference()
-        params = self._ordered_params()
-        dev = params[0].device
-        if not params[0].is_cuda:
-            raise RuntimeError("RenderRayNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
-        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + ("bf16", nsplit)
-        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
         lib = _lib.load()
-        nbytes = lib.snerf_mlp_packed_bf16_bytes(desc, nsplit)
-        if nbytes < 0:
-            check(int(nbytes), "snerf_mlp_packed_bf16_bytes")
-        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        with torch.cuda.device(dev):
+
+        def build(flat, dev):
+            nbytes = lib.snerf_mlp_packed_bf16_bytes(desc, nsplit)
+            if nbytes < 0:
+                check(int(nbytes), "snerf_mlp_packed_bf16_bytes")
+            packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             check(lib.snerf_mlp_pack_bf16(desc, ptr(flat), ptr(packed), nsplit, current_stream()), "snerf_mlp_pack_bf16")
-        self._pack_cache = {key: (stamp, packed)}
-        return packed
+            return packed
+
+        return self._cached_pack(self._pack_cache, self._desc_key(desc) + ("bf16", nsplit), self._ordered_params(), build)
 
     def packed_weights_t(self, desc: MlpDesc, input_grad: bool = False) -> torch.Tensor:
-        """Transposed weight stream for the dgrad kernel (same caching rule as packed_weights)."""
-        params = self._ordered_params()
-        dev = params[0].device
-        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + (bool(input_grad),)
-        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
-        hit = self._pack_t_cache.get(key)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
+        """Transposed fp32 weight stream for the dgrad kernel (same caching rule as packed_weights)."""
         lib = _lib.load()
-        n_pack = ctypes.c_int64()
-        check(lib.snerf_mlp_train_sizes(desc, 0, None, None, ctypes.byref(n_pack), None, None), "snerf_mlp_train_sizes")
-        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        packed = torch.empty(n_pack.value, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+
+        def build(flat, dev):
+            n_pack = ctypes.c_int64()
+            check(lib.snerf_mlp_train_sizes(desc, 0, None, None, ctypes.byref(n_pack), None, None), "snerf_mlp_train_sizes")
+            packed = torch.empty(n_pack.value, device=dev, dtype=torch.float32)
             check(lib.snerf_mlp_pack_t_f32(desc, ptr(flat), ptr(packed), 1 if input_grad else 0, current_stream()),
                   "snerf_mlp_pack_t_f32")
-        self._pack_t_cache[key] = (stamp, packed)
-        return packed
+            return packed
+
+        return self._cached_pack(self._pack_t_cache, self._desc_key(desc) + (bool(input_grad),), self._ordered_params(),
+                                 build, keep_others=True)
 
     def packed_weights_t_bf16(self, desc: MlpDesc, nsplit: int, input_grad: bool = False) -> torch.Tensor:
         """Split-bf16 transposed weight stream for the bf16 dgrad kernel (snerf_mlp_pack_t_bf16)."""
-        params = self._ordered_params()
-        dev = params[0].device
-        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + (bool(input_grad), "bf16", nsplit)
-        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
-        hit = self._pack_t_cache.get(key)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
         lib = _lib.load()
-        nbytes = lib.snerf_mlp_packed_t_bf16_bytes(desc, nsplit, 1 if input_grad else 0)
-        if nbytes < 0:
-            check(int(nbytes), "snerf_mlp_packed_t_bf16_bytes")
-        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        with torch.cuda.device(dev):
+
+        def build(flat, dev):
+            nbytes = lib.snerf_mlp_packed_t_bf16_bytes(desc, nsplit, 1 if input_grad else 0)
+            if nbytes < 0:
+                check(int(nbytes), "snerf_mlp_packed_t_bf16_bytes")
+            packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             check(lib.snerf_mlp_pack_t_bf16(desc, ptr(flat), ptr(packed), nsplit, 1 if input_grad else 0, current_stream()),
                   "snerf_mlp_pack_t_bf16")
-        self._pack_t_cache[key] = (stamp, packed)
-        return packed
+            return packed
+
+        return self._cached_pack(self._pack_t_cache, self._desc_key(desc) + (bool(input_grad), "bf16", nsplit),
+                                 self._ordered_params(), build, keep_others=True)
 
     # ------------------------------------------------------------------ forward paths
     def forward(self, x):
@@ -322,10 +423,10 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         desc = self.desc_for_encoded()
         xf = x.reshape(-1, x.shape[-1]).contiguous().float()
         n = xf.shape[0]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # parameter gradients only: the encoded rows are treated as constants (the pipelines of this
-            # package differentiate through the fused path instead)
-            raw = _FusedMlpFn.apply(self, desc, xf.detach(), None, _ENCODED_ROWS, 1, None, *self._ordered_params())
+        if torch.is_grad_enabled() and (xf.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # gradients for the parameters and, like the reference's module, for the encoded rows themselves (the
+            # reference's smpl_nerf / dynamic / image-wise pipelines train upstream modules through model(inputs))
+            raw = _FusedMlpFn.apply(self, desc, xf, None, _ENCODED_ROWS, 1, None, *self._ordered_params())
             return raw.reshape(x.shape[:-1] + (4,))
         packed = self.packed_weights(desc)
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
@@ -342,6 +443,7 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         [n/samples_per_ray, additional_input_dim] per-ray constants whose weight columns sit after
         (add_first=False) or before (add_first=True) the position-encoding columns.  Returns raw [n, 4]."""
         desc = self.desc_for_encoders(position_encoder, direction_encoder, add_first)
+        _need_f32_cuda("RenderRayNet.forward_fused", positions, directions, additional)
         x = positions.reshape(-1, 3).contiguous()
         n = x.shape[0]
         d = directions.reshape(-1, 3).contiguous()
@@ -356,10 +458,9 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
             if additional is None:
                 raise RuntimeError("forward_fused: this net needs `additional` inputs")
             add = additional.reshape(-1, self.additional_input_dim).contiguous()
-        if torch.is_grad_enabled() and (x.requires_grad or d.requires_grad or
+        if torch.is_grad_enabled() and (x.requires_grad or d.requires_grad or (add is not None and add.requires_grad) or
                                         any(p.requires_grad for p in self.parameters())):
-            return _FusedMlpFn.apply(self, desc, x, d, per_sample, int(samples_per_ray),
-                                     None if add is None else add.detach(), *self._ordered_params())
+            return _FusedMlpFn.apply(self, desc, x, d, per_sample, int(samples_per_ray), add, *self._ordered_params())
         raw = torch.empty((n, 4), device=x.device, dtype=torch.float32)
         lib = _lib.load()
         if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:
@@ -419,24 +520,17 @@ class _WarpFn(torch.autograd.Function):
         total = total.contiguous().float()
         dev = total.device
         params = net._params()
-        flatp = torch.cat([p.detach().reshape(-1).float() for p in params])
+        flatp = flat_parameter_vector(params)
         packed_t = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
         dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
         gpart = torch.empty(ctx.sizes[2], device=dev, dtype=torch.float32)
-        flat = torch.empty(flatp.numel(), device=dev, dtype=torch.float32)
+        flat = net._take_grad_sink(flatp.numel(), dev)
         with torch.cuda.device(dev), _lib.timed(f"warp_bwd[n={n}]"):
             check(lib.snerf_warp_pack_t_f32(desc, ptr(flatp), ptr(packed_t), current_stream()), "snerf_warp_pack_t_f32")
             check(lib.snerf_warp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(total), n, ptr(dy), ptr(gpart), ptr(flat),
                                          current_stream()), "snerf_warp_bwd_f32")
         ctx.act = None
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            k = 1
-            for v in shp:
-                k *= v
-            grads.append(flat[off:off + k].view(shp))
-            off += k
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(_grads_from_flat(flat, ctx.shapes))
 
 
 class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
@@ -465,50 +559,35 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
     def _packed(self, desc, training: bool = False):
         if not training:
             self._begin_inference()
-        params = self._params()
-        dev = params[0].device
-        if not params[0].is_cuda:
-            raise RuntimeError("WarpFieldNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
-        key = tuple(getattr(desc, f[0]) for f in desc._fields_)
-        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
         lib = _lib.load()
-        n_param, n_pack = lib.snerf_warp_param_floats(desc), lib.snerf_warp_packed_floats(desc)
-        if n_param < 0 or n_pack < 0:
-            check(int(min(n_param, n_pack)), "snerf_warp_packed_floats")
-        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        if flat.numel() != n_param:
-            raise RuntimeError(f"WarpFieldNet: {flat.numel()} parameters but the descriptor expects {n_param}")
-        packed = torch.empty(n_pack, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+
+        def build(flat, dev):
+            n_param, n_pack = lib.snerf_warp_param_floats(desc), lib.snerf_warp_packed_floats(desc)
+            if n_param < 0 or n_pack < 0:
+                check(int(min(n_param, n_pack)), "snerf_warp_packed_floats")
+            if flat.numel() != n_param:
+                raise RuntimeError(f"WarpFieldNet: {flat.numel()} parameters but the descriptor expects {n_param}")
+            packed = torch.empty(n_pack, device=dev, dtype=torch.float32)
             check(lib.snerf_warp_pack_f32(desc, ptr(flat), ptr(packed), current_stream()), "snerf_warp_pack_f32")
-        self._pack_cache = {key: (stamp, packed)}
-        return packed
+            return packed
+
+        return self._cached_pack(self._pack_cache, tuple(getattr(desc, f[0]) for f in desc._fields_), self._params(), build)
 
     def _packed_bf16(self, desc):
         """Split-bf16 weight stream of the fused forward (snerf_warp_pack_bf16), cached like _packed."""
         self._begin_inference()
-        params = self._params()
-        dev = params[0].device
-        if not params[0].is_cuda:
-            raise RuntimeError("WarpFieldNet: parameters must be on the GPU (smpl_nerf_amd has no CPU path)")
-        key = tuple(getattr(desc, f[0]) for f in desc._fields_) + ("bf16",)
-        stamp = (str(dev), self._weights_epoch) + tuple((p.data_ptr(), p._version) for p in params)
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
         lib = _lib.load()
-        nbytes = lib.snerf_warp_packed_bf16_bytes(desc)
-        if nbytes < 0:
-            check(int(nbytes), "snerf_warp_packed_bf16_bytes")
-        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        with torch.cuda.device(dev):
+
+        def build(flat, dev):
+            nbytes = lib.snerf_warp_packed_bf16_bytes(desc)
+            if nbytes < 0:
+                check(int(nbytes), "snerf_warp_packed_bf16_bytes")
+            packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             check(lib.snerf_warp_pack_bf16(desc, ptr(flat), ptr(packed), current_stream()), "snerf_warp_pack_bf16")
-        self._pack_cache = {key: (stamp, packed)}
-        return packed
+            return packed
+
+        return self._cached_pack(self._pack_cache, tuple(getattr(desc, f[0]) for f in desc._fields_) + ("bf16",),
+                                 self._params(), build)
 
     def _no_grad(self):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -537,6 +616,7 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
         if 3 * (pos_id + 2 * pos_L) != self.positions_dim or pose_encoding.shape[-1] != self.direcions_dim:
             raise RuntimeError("WarpFieldNet: encoder output sizes do not match positions_dim/pose_dim")
         desc = _lib.WarpDesc(self.width, pos_L, pos_id, self.direcions_dim)
+        _need_f32_cuda("WarpFieldNet.forward_fused", positions, pose_encoding, ray_translation)
         x = positions.reshape(-1, 3).contiguous()
         n = x.shape[0]
         pe = pose_encoding.reshape(-1, self.direcions_dim).contiguous()
@@ -602,12 +682,14 @@ class AppendVerticesNet(RenderRayNet):
         """ray_inputs [B, positions_dim] (the first positions_dim columns of the reference's input rows, a
         per-ray constant), directions [B,3] -> raw [n = B*samples_per_ray, 4]."""
         desc = self.desc_for_rows()
-        add = ray_inputs.reshape(-1, self.positions_dim).contiguous().float()
+        _need_f32_cuda("AppendVerticesNet.forward_rays", ray_inputs, directions)
+        add = ray_inputs.reshape(-1, self.positions_dim).contiguous()
         d = directions.reshape(-1, 3).contiguous()
         dummy_x = torch.zeros((n, 3), device=add.device, dtype=torch.float32)   # no position encoder: never read for slots
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _FusedMlpFn.apply(self, desc, dummy_x, d.detach(), 0, int(samples_per_ray), add.detach(),
-                                     *self._ordered_params())
+        if torch.is_grad_enabled() and (add.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # `add` keeps its graph: the vertex floats come from smpl_model(smpl_estimator(images)), whose parameters
+            # AppendVerticesSolver optimises in their own group (solver/append_vertices_solver.py)
+            return _FusedMlpFn.apply(self, desc, dummy_x, d.detach(), 0, int(samples_per_ray), add, *self._ordered_params())
         raw = torch.empty((n, 4), device=add.device, dtype=torch.float32)
         lib = _lib.load()
         if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:

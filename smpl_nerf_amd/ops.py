@@ -147,6 +147,9 @@ class _CompositeFn(torch.autograd.Function):
 def composite(raw, z_vals, samples_directions, white_background: bool, noise=None,
               want_weights=True, want_alpha=True):
     B, N = z_vals.shape
+    for nm, t in (("raw", raw), ("z_vals", z_vals), ("samples_directions", samples_directions), ("noise", noise)):
+        if t is not None:
+            _need_cuda(nm, t)
     dirs, per_sample = _directions_arg(samples_directions, B, N)
     raw = raw.contiguous()
     z_vals = z_vals.contiguous()
@@ -211,6 +214,9 @@ def hierarchical_samples(ray_translation, ray_direction, z_vals, weights, number
     B, Nc = z_vals.shape
     Nf = int(number_fine_samples)
     dev = z_vals.device
+    for nm, t in (("ray_translation", ray_translation), ("ray_direction", ray_direction), ("z_vals", z_vals),
+                  ("weights", weights)):
+        _need_cuda(nm, t)
     z_vals, weights = z_vals.contiguous(), weights.contiguous()
     o, d = ray_translation.contiguous(), ray_direction.contiguous()
     u = uniform_u(Nf, dev)

@@ -49,7 +49,10 @@ class RayGenerator:
 
     def batch(self, ray_index: torch.Tensor, jitter: torch.Tensor):
         """ray_index int64 [B] (frame*H*W + row*W + col), jitter fp64 [B] in [0,1) ->
-        [ray_samples [B,Nc,3], ray_translation [B,3], ray_direction [B,3], z_vals [B,Nc], rgb_truth [B,3]]."""
+        [ray_samples [B,Nc,3], ray_translation [B,3], ray_direction [B,3], z_vals [B,Nc], rgb_truth [B,3]].
+        Without images the rgb_truth slot holds zeros, so the list always has the five entries the pipelines unpack.
+        Indices outside [0, n_rays) are not checked on the host (that would synchronise); the kernel never reads out
+        of bounds for them and returns NaN rays (and indexing the image table raises a device-side assert)."""
         if not ray_index.is_cuda or not jitter.is_cuda:
             raise RuntimeError("RayGenerator.batch: ray_index and jitter must be on the GPU (no CPU path)")
         idx = ray_index.to(torch.int64).contiguous()
@@ -65,10 +68,8 @@ class RayGenerator:
             check(lib.snerf_raygen_f64(ptr(self.poses), self.n_frames, self.h, self.w, self.focal, ptr(self.lower),
                                        ptr(self.span), self.n, ptr(idx), ptr(jit), B, ptr(samples), ptr(o), ptr(d),
                                        ptr(z), current_stream()), "snerf_raygen_f64")
-        out = [samples, o, d, z]
-        if self.images is not None:
-            out.append(self.images[idx])
-        return out
+        truth = self.images[idx] if self.images is not None else torch.zeros((B, 3), device=dev, dtype=torch.float32)
+        return [samples, o, d, z, truth]
 
     def random_batch(self, batch_size: int, generator=None):
         """A shuffled-DataLoader-like draw (train.py:100): uniform ray indices, one uniform jitter per ray."""

@@ -22,49 +22,113 @@ from . import dist as sdist
 from . import io as sio
 
 
+def flatten_parameters_(models):
+    """Moves every parameter of `models` into ONE contiguous fp32 buffer (values kept; `p.data` becomes a view of it)
+    and returns (flat_params, flat_grads, segments) with segments = [(model, offset, numel of its kernel-ordered
+    parameters)].  Per model the kernel-ordered parameters (`_ordered_params()` / `_params()`: the C-ABI's params_flat
+    order) come first, so a net packs its weight streams from its segment without a torch.cat
+    (nets.flat_parameter_vector) and the backward kernels can write its gradients into the matching segment of
+    `flat_grads` (set_grad_sink)."""
+    order, segments, seen = [], [], set()
+    for m in models:
+        first = m._ordered_params() if hasattr(m, "_ordered_params") else (m._params() if hasattr(m, "_params") else [])
+        off = sum(p.numel() for p in order)
+        own = [p for p in list(first) + list(m.parameters()) if not (id(p) in seen or seen.add(id(p)))]
+        order += own
+        if first and all(a is b for a, b in zip(first, own)):
+            segments.append((m, off, sum(p.numel() for p in first)))
+    if not order:
+        return None, None, []
+    dev = order[0].device
+    if any(p.device != dev or p.dtype != torch.float32 for p in order):
+        return None, None, []          # mixed devices / dtypes: keep the parameters where they are
+    flat = torch.empty(sum(p.numel() for p in order), dtype=torch.float32, device=dev)
+    off = 0
+    with torch.no_grad():
+        for p in order:
+            v = flat[off:off + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            off += p.numel()
+    return flat, torch.zeros_like(flat), segments
+
+
 class DataParallelTrainer:
     default_adam_args = {"lr": 1e-4, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0}  # nerf_solver.py:11-14
 
     def __init__(self, pipeline, models, lr: float = 5e-4, weight_decay: float = 0.0, loss_func=None, fused=None):
         self.pipeline = pipeline
         self.models = list(models)
-        self.params = [p for m in models for p in m.parameters()]
+        self.world, self.rank = sdist.world_rank()
+        # one flat parameter buffer and one flat gradient buffer for all nets (SURVEY 8e: what is all-reduced is the flat
+        # gradient the backward kernels wrote)
+        self._flat_p, self._flat_g, self._segments = flatten_parameters_(self.models)
+        seen = set()
+        self.params = [p for m in self.models for p in m.parameters() if not (id(p) in seen or seen.add(id(p)))]
+        self._views = None
+        if self._flat_g is not None:
+            off, self._views = 0, []
+            for p in self.params:       # same order as flatten_parameters_ laid them out
+                self._views.append(self._flat_g[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+        # every rank must start from the same replica (DDP broadcasts at construction; so does this)
+        if self.world > 1:
+            if self._flat_p is not None:
+                sdist.broadcast_(self._flat_p, 0)
+            else:
+                for p in self.params:
+                    sdist.broadcast_(p.data, 0)
+            for m in self.models:
+                for buf in m.buffers():
+                    sdist.broadcast_(buf, 0)
+                if hasattr(m, "mark_weights_changed"):
+                    m.mark_weights_changed()
         args = dict(self.default_adam_args)
         args.update({"lr": lr, "weight_decay": weight_decay})
         if fused is None:
             fused = all(p.is_cuda for p in self.params)
         self.optim = torch.optim.Adam(self.params, fused=fused, **args) if fused else torch.optim.Adam(self.params, **args)
         self.loss_func = loss_func or torch.nn.MSELoss()
-        self.world, self.rank = sdist.world_rank()
-        self._flat = None
 
     def loss(self, rgb, rgb_fine, rgb_truth):
         return self.loss_func(rgb, rgb_truth) + self.loss_func(rgb_fine, rgb_truth)  # nerf_solver.py:48-52
 
-    def sync_gradients(self):
-        """Mean over ranks of all parameter gradients through one flat fp32 buffer (one collective)."""
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if self.world == 1 or not grads:
+    def _arm_grad_sinks(self):
+        if self._flat_g is None:
             return
-        total = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != total or self._flat.device != grads[0].device:
-            self._flat = torch.empty(total, dtype=torch.float32, device=grads[0].device)
-        off = 0
-        views = []
-        for g in grads:
-            v = self._flat[off:off + g.numel()].view_as(g)
-            v.copy_(g)
-            views.append(v)
-            off += g.numel()
-        sdist.allreduce_mean_(self._flat)
-        for g, v in zip(grads, views):
-            g.copy_(v)
+        for m, off, n in self._segments:
+            if hasattr(m, "set_grad_sink"):
+                m.set_grad_sink(self._flat_g[off:off + n])
+
+    def sync_gradients(self):
+        """Mean over ranks of all parameter gradients through ONE flat fp32 buffer (one collective).  The buffer covers
+        every parameter on every rank - a parameter without a gradient on this rank contributes zeros - so the
+        collective has the same size everywhere.  Gradients the backward kernels already wrote into the buffer (the
+        grad sinks) are not copied; afterwards every p.grad is a view of the buffer."""
+        if self.world == 1:
+            return
+        if self._flat_g is None:       # parameters could not be flattened: per-tensor fallback, fixed list, zeros for None
+            for p in self.params:
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                sdist.allreduce_mean_(g)
+                p.grad = g
+            return
+        for p, v in zip(self.params, self._views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+        sdist.allreduce_mean_(self._flat_g)
+        for p, v in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
 
     def step(self, batch):
         """One optimisation step on this rank's batch (list of tensors, rgb_truth last). Returns the
         local loss tensor (not synchronised with the host)."""
-        out = self.pipeline(batch)
         self.optim.zero_grad(set_to_none=True)
+        self._arm_grad_sinks()
+        out = self.pipeline(batch)
         loss = self.loss(out[0], out[1], batch[-1])
         loss.backward()
         self.sync_gradients()

@@ -112,3 +112,64 @@ def test_data_parallel_steps_equal_single_process_on_the_concatenated_batch():
         tr.step([x, gt])
     for a, b in zip(got, net.parameters()):
         assert torch.allclose(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def _replica_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smpl_nerf_amd.trainer import DataParallelTrainer
+        torch.manual_seed(100 + rank)                      # ranks build DIFFERENT replicas ...
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+        dead = torch.nn.Linear(4, 4)                        # ... and only rank 1 ever produces a gradient for `dead`
+
+        class Pipe(torch.nn.Module):
+            def forward(self, data):
+                y = torch.sigmoid(net(data[0]))
+                if rank == 1:
+                    y = y + 0.0 * dead(data[0][:, :4]).sum()
+                return y, y * 0.5
+
+        tr = DataParallelTrainer(Pipe(), [net, dead], lr=1e-2, fused=False)
+        start = [p.detach().clone() for p in tr.params]    # after the constructor's broadcast
+        g = torch.Generator().manual_seed(1)
+        x, gt = torch.rand(64, 6, generator=g), torch.rand(64, 3, generator=g)
+        b, e = sd.shard_range(64, world, rank)
+        for _ in range(2):
+            tr.step([x[b:e], gt[b:e]])                     # must not hang although rank 0 has p.grad None for `dead`
+        q.put((rank, [s.numpy() for s in start], [p.detach().numpy().copy() for p in tr.params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_broadcasts_the_replica_and_survives_rank_dependent_missing_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (s, e)) for r, s, e in (q.get(), q.get()))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)                        # same replica after construction (rank 0's)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)                        # and still in lock-step after two steps
+
+
+def test_flat_parameter_vector_is_zero_copy_after_flattening():
+    from smpl_nerf_amd.nets import RenderRayNet, flat_parameter_vector
+    from smpl_nerf_amd.trainer import flatten_parameters_
+    net = RenderRayNet(4, 128, 60, 24, skips=[2])
+    before = [p.detach().clone() for p in net._ordered_params()]
+    v0 = flat_parameter_vector(net._ordered_params())
+    assert v0.data_ptr() != net._ordered_params()[0].data_ptr()          # separate tensors: a torch.cat copy
+    flat, gflat, segs = flatten_parameters_([net])
+    v1 = flat_parameter_vector(net._ordered_params())
+    assert v1.data_ptr() == flat.data_ptr() == net._ordered_params()[0].data_ptr() and torch.equal(v0, v1)
+    assert all(torch.equal(a, b) for a, b in zip(before, net._ordered_params()))
+    assert segs == [(net, 0, v1.numel())] and gflat.shape == flat.shape
+    assert list(net.state_dict().keys())[0] == "positions_pose_input.weight"   # the checkpoint contract is untouched

@@ -433,7 +433,7 @@ def test_warp_field_net(dev):
     assert maxabs(N(out), g["warp_out"]) <= 2e-6
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("wb", [0, 1])
 def test_smpl_nerf_pipeline_vs_reference(dev, wb, prec):
     """a7 against the frames the reference rendered; bf16x6 = the warp net and both RenderRayNets on the bf16 matrix
@@ -494,7 +494,7 @@ def _av_pipeline(dev, wb=0, run_fine=0):
                                   PositionalEncoder(10, 0), PositionalEncoder(4, 0)), nets
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("wb", [0, 1])
 def test_append_vertices_pipeline(dev, wb, prec):
     g = load_golden("g9_append_vertices.npz")
@@ -536,9 +536,10 @@ def test_append_vertices_net_forward_rows(dev):
 
 
 # ------------------------------------------------------------------------------------------ f-4
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("name,npose", [("smpl", 69), ("two", 2)])
 @pytest.mark.parametrize("enc", [0, 1])
-def test_append_pose_pipelines(dev, name, npose, enc):
+def test_append_pose_pipelines(dev, name, npose, enc, prec):
     from smpl_nerf_amd.nets import RenderRayNet
     from smpl_nerf_amd.ops import PositionalEncoder
     from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline
@@ -552,7 +553,7 @@ def test_append_pose_pipelines(dev, name, npose, enc):
         nets.append(m.to(dev))
     cls = AppendSmplParamsPipeline if name == "smpl" else AppendToNerfPipeline
     pipe = cls(nets[0], nets[1], O.Args(human_pose_encoding=enc), PositionalEncoder(10, 0), PositionalEncoder(4, 0),
-               PositionalEncoder(10, 0))
+               PositionalEncoder(10, 0)).set_precision(prec)
     data = syn.frame_batch(128, 128, phi=3.0, theta=-10.0, seed=11)
     d = [T(a[g["sub"]], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][g["sub"]], dev)]
     with torch.no_grad():
@@ -694,7 +695,7 @@ def test_split_bf16_additional_inputs_and_per_sample_dirs(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("run_fine,white", [(1, 0), (1, 1), (0, 0)])
 def test_render_rays_single_call(dev, prec, run_fine, white):
     """snerf_render_rays_f32 (the whole NerfPipeline.forward behind one C-ABI call) returns exactly what the five
@@ -922,7 +923,7 @@ def test_c_host_example(dev, tmp_path, precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
 def test_full_256_frame_properties(dev, prec):
     """BASELINE configs[3]/[4] frame size (256 x 256 = 65 536 rays, 64 + 128 samples = 16.8 M MLP evaluations) through
     size-independent properties: rays are independent, so (i) rendering the frame in one call, in 7 ragged chunks and in a

@@ -302,3 +302,56 @@ def test_rays_and_coarse_sampling():
     p2, _, _, z2 = O.coarse_sampling(o[rows], d[rows], 1.0, 4.0, 64, g["jitter"])
     np.testing.assert_array_equal(z2, g["z"])
     np.testing.assert_array_equal(p2, g["samples"])
+
+
+# ---------------------------------------------------------------- the torch-CPU restatement bench.py times as cpu_baseline
+@pytest.mark.parametrize("tag,near,far,wb", [("nf14", 1.0, 4.0, 0), ("nf1631wb", 1.6, 3.1, 1)])
+def test_torch_cpu_path_nerf_pipeline_is_the_reference_bit_for_bit(tag, near, far, wb):
+    """oracle/torch_cpu_path.py issues the reference's own ATen calls in the reference's order: on the host that produced
+    the fixtures it reproduces the reference's frames exactly (calibrate_cpu_baseline.py re-checks that against the live
+    reference); elsewhere (another torch build / SIMD width) within the fixtures' tolerance."""
+    import torch
+    from oracle import torch_cpu_path as TP
+    g = load_golden("g5_nerf_pipeline.npz")
+    pc, pf = _nerf_nets()
+    data = syn.frame_batch(128, 128, phi=0.0, theta=0.0, seed=7, near=near, far=far)
+    sub = g[f"sub_{tag}"]
+    with torch.no_grad():
+        out = TP.nerf_pipeline_forward(TP.tparams(pc), TP.tparams(pf), TP.Args(white_background=wb),
+                                       TP.PositionalEncoder(10, False), TP.PositionalEncoder(4, False),
+                                       [torch.from_numpy(np.ascontiguousarray(a[sub])) for a in data])
+    assert maxabs(out[0].numpy(), g[f"rgb_{tag}"][sub]) <= 1e-6
+    assert maxabs(out[1].numpy(), g[f"rgb_fine_{tag}"][sub]) <= 1e-5
+    assert np.mean(np.abs(out[2].numpy() - g[f"pts_fine_sub_{tag}"]) > 1e-4) <= 0.002
+
+
+@pytest.mark.parametrize("wb", [0, 1])
+def test_torch_cpu_path_smpl_nerf_pipeline(wb):
+    import torch
+    from oracle import torch_cpu_path as TP
+    g = load_golden("g6_smpl_nerf_pipeline.npz")
+    pc, pf = _nerf_nets()
+    pw = syn.make_warp_field_params(103, out_scale=0.3)
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    sub = g["sub"]
+    d = [torch.from_numpy(np.ascontiguousarray(a[sub])) for a in data[:4]] + [torch.from_numpy(g["goal_pose"]),
+                                                                              torch.from_numpy(data[4][sub])]
+    enc = TP.PositionalEncoder
+    with torch.no_grad():
+        out = TP.smpl_nerf_pipeline_forward(TP.tparams(pc), TP.tparams(pf), TP.tparams(pw), TP.Args(white_background=wb),
+                                            enc(10, False), enc(4, False), enc(10, False), d)
+    names = ("rgb", "rgb_fine", "warp_fine", "pts_fine", "warped_fine", "alpha_fine")
+    assert maxabs(out[0].numpy(), g[f"rgb_wb{wb}"]) <= 1e-6
+    assert maxabs(out[1].numpy(), g[f"rgb_fine_wb{wb}"]) <= 1e-5
+    for i in (2, 3, 4):
+        assert np.mean(np.abs(out[i].numpy() - g[f"{names[i]}_wb{wb}"]) > 1e-4) <= 0.002
+
+
+def test_cpu_baseline_calibration_record():
+    """The committed calibration of the CPU baseline against the live reference (oracle/calibrate_cpu_baseline.py)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "cpu_baseline_calibration.json")) as f:
+        c = json.load(f)
+    assert c["outputs_bit_identical"] is True
+    assert 0.9 <= c["port_over_reference_speed"] <= 1.1
