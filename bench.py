@@ -153,25 +153,40 @@ def _cpu_model():
 def cpu_baseline(workload, params, data_np, n_rays):
     """The reference's CPU path, as restated op for op in PyTorch-CPU fp32 by oracle/torch_cpu_path.py (calibrated against
     the reference itself in the build container: oracle/cpu_baseline_calibration.json), timed on this host on a bounded
-    sample of the same workload: the first n_rays rays of the same frame, same weights; warm-up 1, median of 5."""
+    sample of the same workload: the first n_rays rays of the same frame, same weights; warm-up 1, median of 5.
+    torch's default intra-op thread count (what the reference would get) oversubscribes a 128-core host on these small
+    GEMMs, so a short probe (256 rays per thread count) picks the fastest setting first and `cores` reports it."""
     import numpy as np
     import torch
     from oracle import torch_cpu_path as T
-    threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()
     P = [T.tparams(p) for p in params]
-    data = [torch.from_numpy(np.ascontiguousarray(a[:n_rays])) for a in data_np]
     pe, de = T.PositionalEncoder(10, False), T.PositionalEncoder(4, False)
-    if workload == "smpl_nerf":
-        fwd = lambda: T.smpl_nerf_pipeline_forward(P[0], P[1], P[2], T.Args(), pe, de, T.PositionalEncoder(10, False), data)
-    else:
-        fwd = lambda: T.nerf_pipeline_forward(P[0], P[1], T.Args(), pe, de, data)
+
+    def make_fwd(n):
+        data = [torch.from_numpy(np.ascontiguousarray(a[:n])) for a in data_np]
+        if workload == "smpl_nerf":
+            return lambda: T.smpl_nerf_pipeline_forward(P[0], P[1], P[2], T.Args(), pe, de, T.PositionalEncoder(10, False), data)
+        return lambda: T.nerf_pipeline_forward(P[0], P[1], T.Args(), pe, de, data)
+
+    probe, small = {}, make_fwd(min(256, n_rays))
     with torch.no_grad():
+        for t in sorted({default_threads, 64, 32, 16, 8} & set(range(1, (os.cpu_count() or 1) + 1)) | {default_threads}):
+            torch.set_num_threads(t)
+            small()
+            t0 = time.perf_counter()
+            small()
+            probe[t] = min(256, n_rays) * 256 / (time.perf_counter() - t0)
+        threads = max(probe, key=probe.get)
+        torch.set_num_threads(threads)
+        fwd = make_fwd(n_rays)
         fwd()
         ts = []
         for _ in range(5):
             t0 = time.perf_counter()
             out = fwd()
             ts.append(time.perf_counter() - t0)
+        torch.set_num_threads(default_threads)
     dt = statistics.median(ts)
     cal = None
     try:
@@ -182,10 +197,12 @@ def cpu_baseline(workload, params, data_np, n_rays):
     except Exception:
         pass
     info = {"value": n_rays * 256 / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
-            "host_cpu": _cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "host_cpu": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch_default_threads": default_threads,
+            "thread_probe_ray_samples_per_s": {str(k): v for k, v in sorted(probe.items())},
             "sample": f"first {n_rays} rays of the same frame, same weights ({n_rays * 256} ray-samples per pass; warm-up 1, "
                       f"median of 5 passes, {dt:.2f} s each): oracle/torch_cpu_path.py = the reference's NerfPipeline.forward "
-                      f"restated op for op on PyTorch-CPU fp32, torch.set_num_threads({threads}) (torch's default here)",
+                      f"restated op for op on PyTorch-CPU fp32, torch.set_num_threads({threads}) = the fastest of the probed "
+                      f"counts",
             "calibration_vs_reference_in_build_container": cal}
     return info, [o.numpy() for o in out]
 

@@ -94,6 +94,17 @@ int snerf_sample_pdf_f32(const float *z, const float *weights, const float *u,
                          int64_t *inds, float *z_samples, float *z_fine, float *pts,
                          snerf_stream_t stream);
 
+/* Strict variants (SURVEY 8b `strict_cumsum`): index parity with the reference FROM THE SAME WEIGHTS.  The reference's
+ * pdf is weights / torch.sum(weights) (utils.py:201); torch's CPU sum is a vectorised fp32 cascade whose bits depend on the
+ * host's SIMD width, and a 1-ulp difference in it moves ~0.15 % of the indices.  `tot` [B] = that sum as the reference's
+ * host evaluated it (e.g. (weights[:, 1:-1] + 1e-5).sum(-1) with torch on the CPU); every other step is independent of
+ * the evaluation order, so cdf, inds and the samples are then bit-identical to the reference's. */
+int snerf_sample_pdf_strict_f32(const float *z, const float *weights, const float *u, const float *o, const float *d,
+                                const float *tot, int64_t B, int Nc, int Nf, int64_t *inds, float *z_samples,
+                                float *z_fine, float *pts, snerf_stream_t stream);
+int snerf_sample_pdf_bins_strict_f32(const float *bins, const float *weights, const float *u, const float *tot, int64_t B,
+                                     int Nb, int Nf, int64_t *inds, float *z_samples, snerf_stream_t stream);
+
 /* The literal sample_pdf(bins, weights, args) convention (utils.py:194-228): bins [B, Nb] (coarse
  * midpoints), weights [B, Nb-1] (interior coarse weights) -> inds int64 [B, Nf] (nullable),
  * z_samples [B, Nf].  2 <= Nb <= 1023. */

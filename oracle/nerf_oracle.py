@@ -198,7 +198,7 @@ def linspace01(n: int) -> np.ndarray:
     return np.where(i < n // 2, lo, hi).astype(F32)
 
 
-def cdf_from_weights(weights):
+def cdf_from_weights(weights, tot=None):
     """utils.py:200-203: weights+1e-5 -> pdf -> cdf with a leading 0 ([..., len(weights)+1]).
 
     The normalising sum (utils.py:201) is evaluated in float64 and rounded once; the cumsum
@@ -206,9 +206,15 @@ def cdf_from_weights(weights):
     torch's CPU cumsum does (acc_type<float> = double - verified bit for bit in the build
     container); the former is within 1 ulp of torch's vectorised fp32 sum (whose bits depend on
     the host's SIMD width) and makes the result independent of summation order, which is what lets
-    the HIP kernel reproduce this oracle bit for bit."""
+    the HIP kernel reproduce this oracle bit for bit.
+
+    Strict mode: `tot` [..., 1] = the sums as torch.sum returned them on the reference's host (recorded in the golden
+    fixtures); with it the cdf - and everything downstream - equals the reference's bit for bit."""
     w = (np.asarray(weights, F32) + F32(1e-5)).astype(F32)                               # :200
-    tot = np.sum(w.astype(np.float64), -1, keepdims=True).astype(F32)
+    if tot is None:
+        tot = np.sum(w.astype(np.float64), -1, keepdims=True).astype(F32)
+    else:
+        tot = np.asarray(tot, F32).reshape(w.shape[:-1] + (1,))
     pdf = (w / tot).astype(F32)                                                          # :201
     cdf = np.cumsum(pdf.astype(np.float64), -1).astype(F32)                              # :202
     return np.concatenate([np.zeros(cdf[..., :1].shape, F32), cdf], -1)                  # :203
@@ -234,27 +240,27 @@ def invert_cdf(bins, cdf, u):
     return inds, samples
 
 
-def sample_pdf_detail(bins, weights, number_fine_samples, u=None):
+def sample_pdf_detail(bins, weights, number_fine_samples, u=None, tot=None):
     """utils.py:194-228 with every intermediate returned (cdf, u, inds, samples)."""
-    cdf = cdf_from_weights(weights)
+    cdf = cdf_from_weights(weights, tot)
     u1 = linspace01(number_fine_samples) if u is None else np.asarray(u, F32).reshape(-1)  # :206
     u = np.broadcast_to(u1, cdf.shape[:-1] + (number_fine_samples,)).copy()              # :207-210
     inds, samples = invert_cdf(bins, cdf, u)
     return dict(cdf=cdf, u=u, inds=inds, samples=samples)
 
 
-def sample_pdf(bins, weights, number_fine_samples, u=None):
-    return sample_pdf_detail(bins, weights, number_fine_samples, u)["samples"]
+def sample_pdf(bins, weights, number_fine_samples, u=None, tot=None):
+    return sample_pdf_detail(bins, weights, number_fine_samples, u, tot)["samples"]
 
 
-def fine_sampling(ray_translation, samples_directions, z_vals, weights, number_fine_samples, u=None):
+def fine_sampling(ray_translation, samples_directions, z_vals, weights, number_fine_samples, u=None, tot=None):
     """utils.py:231-264 -> (z_vals[B,Nc+Nf] sorted, ray_samples_fine[B,Nc+Nf,3])."""
     z_vals = np.asarray(z_vals, F32)
     weights = np.asarray(weights, F32)
     o = np.asarray(ray_translation, F32)
     d = np.asarray(samples_directions, F32)
     z_mid = (F32(0.5) * (z_vals[..., 1:] + z_vals[..., :-1])).astype(F32)                # :258
-    z_samples = sample_pdf(z_mid, weights[..., 1:-1], number_fine_samples, u)           # :259
+    z_samples = sample_pdf(z_mid, weights[..., 1:-1], number_fine_samples, u, tot)      # :259
     z_all = np.sort(np.concatenate([z_vals, z_samples], -1), -1)                        # :261
     pts = (o[..., None, :] + d[..., None, :] * z_all[..., :, None]).astype(F32)          # :262-263
     return z_all.astype(F32), pts

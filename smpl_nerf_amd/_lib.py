@@ -40,6 +40,8 @@ SIGNATURES = {
     "snerf_composite_fwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "snerf_composite_bwd_f32": (c_int, [_P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "snerf_sample_pdf_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "snerf_sample_pdf_strict_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "snerf_sample_pdf_bins_strict_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "snerf_sample_pdf_bins_f32": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "snerf_mlp_param_floats": (c_int64, [POINTER(MlpDesc)]),
     "snerf_mlp_packed_floats": (c_int64, [POINTER(MlpDesc)]),

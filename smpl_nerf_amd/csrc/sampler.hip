@@ -14,6 +14,8 @@
 // are evaluated in fp64 and rounded to fp32 once per element - identical to torch's CPU cumsum and
 // independent of the reduction order, which is what makes a wavefront scan legal here; every other
 // operation is a single correctly-rounded fp32 op in the reference's order (no FMA contraction).
+// The *_strict entry points take the normalising sums as an input (`tot` [B], what torch.sum returned on the
+// reference's host): the only step of the reference whose bits depend on the host.
 //
 // The merge exploits that both lists are ascending (rank = own index + cross-rank by bisection);
 // a wave-uniform check detects an out-of-order input and falls back to an O(n^2) stable rank sort,
@@ -51,7 +53,7 @@ __device__ __forceinline__ int count_lt(const float *__restrict__ row, int n, fl
 template <bool DIRECT>
 __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
     const float *__restrict__ z, const float *__restrict__ weights, const float *__restrict__ u,
-    const float *__restrict__ o, const float *__restrict__ d, int64_t B, int Nc, int Nf,
+    const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ tot_in, int64_t B, int Nc, int Nf,
     int64_t *__restrict__ inds_out, float *__restrict__ zs_out, float *__restrict__ zf_out,
     float *__restrict__ pts_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -90,7 +92,10 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
             if (i >= 1 && i <= M) part += (double)__fadd_rn(wr[i], 1e-5f);
         }
     }
-    const float tot = (float)wave_sum(part);
+    // strict mode: the caller supplies the normalising sum torch.sum produced on the reference's host (utils.py:201; a
+    // vectorised fp32 cascade whose bits depend on that host's SIMD width) - every later step is order-independent, so
+    // cdf, indices and samples then equal the reference's bit for bit
+    const float tot = tot_in ? tot_in[ray] : (float)wave_sum(part);
 
     // ---- cdf = [0, cumsum(pdf)] : fp64 wavefront scan with a carry between 64-element chunks ----
     if (lane == 0) s_cdf[0] = 0.f;
@@ -176,26 +181,42 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
 
 namespace snerf {
 static int launch_sample_pdf(bool direct, const float *z, const float *weights, const float *u, const float *o,
-                             const float *d, int64_t B, int Nc, int Nf, int64_t *inds, float *z_samples,
+                             const float *d, const float *tot, int64_t B, int Nc, int Nf, int64_t *inds, float *z_samples,
                              float *z_fine, float *pts, snerf_stream_t stream);
 }
 
 extern "C" int snerf_sample_pdf_f32(const float *z, const float *weights, const float *u, const float *o,
                                     const float *d, int64_t B, int Nc, int Nf, int64_t *inds, float *z_samples,
                                     float *z_fine, float *pts, snerf_stream_t stream) {
-    return snerf::launch_sample_pdf(false, z, weights, u, o, d, B, Nc, Nf, inds, z_samples, z_fine, pts, stream);
+    return snerf::launch_sample_pdf(false, z, weights, u, o, d, nullptr, B, Nc, Nf, inds, z_samples, z_fine, pts, stream);
+}
+
+extern "C" int snerf_sample_pdf_strict_f32(const float *z, const float *weights, const float *u, const float *o,
+                                           const float *d, const float *tot, int64_t B, int Nc, int Nf, int64_t *inds,
+                                           float *z_samples, float *z_fine, float *pts, snerf_stream_t stream) {
+    if (!tot) return snerf::fail(SNERF_E_BADARG, "sample_pdf_strict: tot is null");
+    return snerf::launch_sample_pdf(false, z, weights, u, o, d, tot, B, Nc, Nf, inds, z_samples, z_fine, pts, stream);
+}
+
+extern "C" int snerf_sample_pdf_bins_strict_f32(const float *bins, const float *weights, const float *u, const float *tot,
+                                                int64_t B, int Nb, int Nf, int64_t *inds, float *z_samples,
+                                                snerf_stream_t stream) {
+    if (Nb < 2) return snerf::fail(SNERF_E_BADARG, "sample_pdf_bins_strict: need Nb >= 2");
+    if (!tot) return snerf::fail(SNERF_E_BADARG, "sample_pdf_bins_strict: tot is null");
+    return snerf::launch_sample_pdf(true, bins, weights, u, nullptr, nullptr, tot, B, Nb + 1, Nf, inds, z_samples, nullptr,
+                                    nullptr, stream);
 }
 
 extern "C" int snerf_sample_pdf_bins_f32(const float *bins, const float *weights, const float *u, int64_t B, int Nb,
                                          int Nf, int64_t *inds, float *z_samples, snerf_stream_t stream) {
     if (Nb < 2) return snerf::fail(SNERF_E_BADARG, "sample_pdf_bins: need Nb >= 2");
-    return snerf::launch_sample_pdf(true, bins, weights, u, nullptr, nullptr, B, Nb + 1, Nf, inds, z_samples, nullptr,
-                                    nullptr, stream);
+    return snerf::launch_sample_pdf(true, bins, weights, u, nullptr, nullptr, nullptr, B, Nb + 1, Nf, inds, z_samples,
+                                    nullptr, nullptr, stream);
 }
 
 static int snerf::launch_sample_pdf(bool direct, const float *z, const float *weights, const float *u, const float *o,
-                                    const float *d, int64_t B, int Nc, int Nf, int64_t *inds, float *z_samples,
-                                    float *z_fine, float *pts, snerf_stream_t stream) {
+                                    const float *d, const float *tot, int64_t B, int Nc, int Nf, int64_t *inds,
+                                    float *z_samples, float *z_fine, float *pts, snerf_stream_t stream) {
     if (B < 0) return fail(SNERF_E_BADARG, "sample_pdf: negative B");
     if (Nc < 3 || Nc > 1024 || Nf < 1 || Nf > 1024)
         return fail(SNERF_E_BADARG, "sample_pdf: need 3 <= Nc <= 1024 and 1 <= Nf <= 1024 (got %d, %d)", Nc, Nf);
@@ -215,9 +236,9 @@ static int snerf::launch_sample_pdf(bool direct, const float *z, const float *we
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "sample_pdf: B too large");
     if (direct)
         hipLaunchKernelGGL(sample_pdf_kernel<true>, dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
-                           weights, u, o, d, B, Nc, Nf, inds, z_samples, z_fine, pts);
+                           weights, u, o, d, tot, B, Nc, Nf, inds, z_samples, z_fine, pts);
     else
         hipLaunchKernelGGL(sample_pdf_kernel<false>, dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
-                           weights, u, o, d, B, Nc, Nf, inds, z_samples, z_fine, pts);
+                           weights, u, o, d, tot, B, Nc, Nf, inds, z_samples, z_fine, pts);
     return check_launch("sample_pdf");
 }

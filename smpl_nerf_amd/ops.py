@@ -208,9 +208,20 @@ def uniform_u(n: int, device) -> torch.Tensor:
     return u
 
 
+def reference_normalising_sum(interior_weights: torch.Tensor) -> torch.Tensor:
+    """torch.sum(weights + 1e-5, -1) of utils.py:200-201 evaluated by torch's own CPU kernel on this host - exactly what
+    the reference's CPU path computes here (a vectorised fp32 cascade: its bits depend on the host's SIMD width, which
+    is why it cannot be restated portably) - returned on the weights' device.  Costs a device -> host -> device round
+    trip; used only in strict mode (args.strict_cumsum)."""
+    w = interior_weights.detach().to("cpu", torch.float32)
+    return torch.sum(w + 1e-5, -1).to(interior_weights.device).contiguous()
+
+
 def hierarchical_samples(ray_translation, ray_direction, z_vals, weights, number_fine_samples: int,
-                         want_inds=False, want_samples=False):
-    """One launch of snerf_sample_pdf_f32 -> dict(z_fine, pts, [inds], [z_samples])."""
+                         want_inds=False, want_samples=False, tot=None, strict=False):
+    """One launch of snerf_sample_pdf_f32 -> dict(z_fine, pts, [inds], [z_samples]).  strict (or an explicit `tot` [B]):
+    the normalising sums come from the reference's own host kernel, so the indices equal the reference's bit for bit
+    from the same weights (snerf_sample_pdf_strict_f32)."""
     B, Nc = z_vals.shape
     Nf = int(number_fine_samples)
     dev = z_vals.device
@@ -225,6 +236,18 @@ def hierarchical_samples(ray_translation, ray_direction, z_vals, weights, number
     inds = torch.empty((B, Nf), device=dev, dtype=torch.long) if want_inds else None
     zs = torch.empty((B, Nf), device=dev, dtype=torch.float32) if want_samples else None
     lib = _lib.load()
+    if tot is None and strict:
+        tot = reference_normalising_sum(weights[:, 1:-1])
+    if tot is not None:
+        _need_cuda("tot", tot)
+        tot = tot.reshape(-1).contiguous()
+        if tot.shape[0] != B:
+            raise RuntimeError(f"hierarchical_samples: tot must have one entry per ray ({B}), got {tot.shape[0]}")
+        with torch.cuda.device(dev), _lib.timed("sample_pdf"):
+            check(lib.snerf_sample_pdf_strict_f32(ptr(z_vals), ptr(weights), ptr(u), ptr(o), ptr(d), ptr(tot), B, Nc, Nf,
+                                                  ptr(inds), ptr(zs), ptr(z_fine), ptr(pts), current_stream()),
+                  "snerf_sample_pdf_strict_f32")
+        return dict(z_fine=z_fine, pts=pts, inds=inds, z_samples=zs)
     with torch.cuda.device(dev), _lib.timed("sample_pdf"):
         check(lib.snerf_sample_pdf_f32(ptr(z_vals), ptr(weights), ptr(u), ptr(o), ptr(d), B, Nc, Nf, ptr(inds),
                                        ptr(zs), ptr(z_fine), ptr(pts), current_stream()), "snerf_sample_pdf_f32")
@@ -245,8 +268,13 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, args) -> torch.Tensor:
     zs = torch.empty((B, Nf), device=bins.device, dtype=torch.float32)
     lib = _lib.load()
     with torch.cuda.device(bins.device):
-        check(lib.snerf_sample_pdf_bins_f32(ptr(bins), ptr(weights), ptr(u), B, Nb, Nf, None, ptr(zs),
-                                            current_stream()), "snerf_sample_pdf_bins_f32")
+        if getattr(args, "strict_cumsum", 0):
+            tot = reference_normalising_sum(weights)
+            check(lib.snerf_sample_pdf_bins_strict_f32(ptr(bins), ptr(weights), ptr(u), ptr(tot), B, Nb, Nf, None, ptr(zs),
+                                                       current_stream()), "snerf_sample_pdf_bins_strict_f32")
+        else:
+            check(lib.snerf_sample_pdf_bins_f32(ptr(bins), ptr(weights), ptr(u), B, Nb, Nf, None, ptr(zs),
+                                                current_stream()), "snerf_sample_pdf_bins_f32")
     return zs
 
 
@@ -258,5 +286,5 @@ def fine_sampling(ray_translation: torch.Tensor, samples_directions: torch.Tenso
                   ("z_vals", z_vals), ("weights", weights)):
         _need_cuda(nm, t)
     r = hierarchical_samples(ray_translation.detach(), samples_directions.detach(), z_vals.detach(),
-                             weights.detach(), args.number_fine_samples)
+                             weights.detach(), args.number_fine_samples, strict=bool(getattr(args, "strict_cumsum", 0)))
     return r["z_fine"], r["pts"]

@@ -20,8 +20,17 @@ from . import ops
 
 
 class PipelineArgs:
-    """The fields of the reference's argparse namespace (config_parser.py) that the pipelines read,
-    with the reference's defaults for them.  Any object with these attributes works as `args`."""
+    """The fields of the reference's argparse namespace (config_parser.py) that the pipelines read.  Any object with these
+    attributes works as `args` (the reference's own namespace included).
+
+    The defaults here are the deterministic, runnable settings - NOT the reference's parser defaults in two fields:
+    sigma_noise_std is 0 (config_parser.py:87 has 1: Gaussian noise on sigma, drawn even in eval mode, quirk Q3) and
+    human_pose_encoding is 1 (config_parser.py:72 has 0, with which the reference's own smpl_nerf fine branch crashes,
+    quirk Q5).  PipelineArgs.reference_defaults() returns the parser's values.
+
+    strict_cumsum (not a reference field): 1 = the hierarchical sampler takes its normalising sums from
+    torch's CPU kernel on this host, like the reference's CPU path, so that the sample indices equal the reference's bit
+    for bit from the same weights (ops.reference_normalising_sum; costs a host round trip per call)."""
 
     def __init__(self, **kw):
         self.sigma_noise_std = 0.0
@@ -29,8 +38,16 @@ class PipelineArgs:
         self.run_fine = 1
         self.number_fine_samples = 128
         self.human_pose_encoding = 1
+        self.strict_cumsum = 0
         self.u = None  # optional explicit linspace(0, 1, number_fine_samples) buffer (ops.uniform_u)
         self.__dict__.update(kw)
+
+    @classmethod
+    def reference_defaults(cls, **kw):
+        """config_parser.py:27,71,72,87,89."""
+        d = dict(sigma_noise_std=1.0, white_background=0, run_fine=1, number_fine_samples=128, human_pose_encoding=0)
+        d.update(kw)
+        return cls(**d)
 
 
 class NerfPipeline(nn.Module):
@@ -73,7 +90,8 @@ class NerfPipeline(nn.Module):
         if not args.run_fine:
             return rgb, rgb, ray_samples, densities                                               # :43-44
         # hierarchical samples (:47) and the fine net on them (:49-60)
-        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples)
+        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
+                                      strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]
         N = z_fine.shape[1]
         raw_fine = self.model_fine.forward_fused(ray_samples_fine, ray_direction, N, self.position_encoder,
@@ -158,7 +176,8 @@ class SmplNerfPipeline(NerfPipeline):
                                                 self._noise((B, Nc), dev))                        # :63
         if not args.run_fine:
             return rgb, rgb, warp.view(B, Nc, 3), ray_samples, warped.view(B, Nc, 3), densities   # :64-65
-        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples)
+        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
+                                      strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :68
         N = z_fine.shape[1]
         warp_f, warped_f, _, raw_f = self._stage(self.model_fine, ray_samples_fine, ray_translation, pose_enc, N)
@@ -247,7 +266,8 @@ class AppendVerticesPipeline(NerfPipeline):
                                                 self._noise((B, Nc), dev))                        # :65
         if not args.run_fine:
             return rgb, rgb, ray_samples, densities                                               # :66-67
-        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples)
+        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
+                                      strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :70
         N = z_fine.shape[1]
         raw_f = self.model_fine.forward_rays(ray_inputs, ray_direction, N, B * N)
@@ -284,7 +304,8 @@ class AppendSmplParamsPipeline(NerfPipeline):
                                                 self._noise((B, Nc), dev))                             # :55
         if not args.run_fine:
             return rgb, rgb, ray_samples, densities                                                    # :56-57
-        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples)
+        hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
+                                      strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                              # :60
         N = z_fine.shape[1]
         raw_f = self.model_fine.forward_fused(ray_samples_fine, ray_direction, N, self.position_encoder,

@@ -187,7 +187,10 @@ def main():
     cdf, u, inds = SS_LOG[-1]
     z_mid = .5 * (t(z)[..., 1:] + t(z)[..., :-1])
     z_samples = U.sample_pdf(z_mid, t(w)[..., 1:-1], args)
-    g4 = dict(o=o32, d=d32, z=z, w=w, cdf=cdf.numpy(), u=u.numpy(), inds=inds.numpy(),
+    # the one host-dependent intermediate of the path: the normalising sum of utils.py:200-201 as THIS torch build
+    # evaluates it on THIS host (same call, same operand as inside sample_pdf => same bits)
+    tot = torch.sum(t(w)[..., 1:-1] + 1e-5, -1, keepdim=True)
+    g4 = dict(o=o32, d=d32, z=z, w=w, cdf=cdf.numpy(), u=u.numpy(), inds=inds.numpy(), tot=tot.numpy(),
               z_samples=z_samples.numpy(), z_fine=z_f.numpy(), pts_fine=pts_f.numpy())
     # other (Nc, Nf) shapes
     for nc, nf in ((16, 8), (32, 64), (64, 64), (48, 200)):
@@ -197,6 +200,8 @@ def main():
         g4[f"z_{nc}_{nf}"], g4[f"w_{nc}_{nf}"] = zz, ww
         g4[f"zf_{nc}_{nf}"], g4[f"pf_{nc}_{nf}"] = zf.numpy(), pf.numpy()
         g4[f"o_{nc}_{nf}"], g4[f"d_{nc}_{nf}"] = oo, dd
+        g4[f"tot_{nc}_{nf}"] = torch.sum(t(ww)[..., 1:-1] + 1e-5, -1, keepdim=True).numpy()
+        g4[f"u_{nc}_{nf}"] = torch.linspace(0., 1., steps=nf).numpy()     # utils.py:206 on this host
     save("g4_sampler.npz", **g4)
 
     # ---- searchsorted known answers (torchsearchsorted semantics incl. ties / out of range) -----

@@ -179,18 +179,19 @@ def test_composite_frame_size_properties(dev):
 
 
 # ------------------------------------------------------------------------------------------ a5
-def _check_sampler(dev, o, d, z, w, nf, u=None):
+def _check_sampler(dev, o, d, z, w, nf, u=None, tot=None):
     from smpl_nerf_amd import ops
     if u is not None:
         ops._U_CACHE[(nf, str(dev))] = T(u, dev)
     try:
-        r = ops.hierarchical_samples(T(o, dev), T(d, dev), T(z, dev), T(w, dev), nf, want_inds=True, want_samples=True)
+        r = ops.hierarchical_samples(T(o, dev), T(d, dev), T(z, dev), T(w, dev), nf, want_inds=True, want_samples=True,
+                                     tot=None if tot is None else T(tot, dev))
     finally:
         ops._U_CACHE.pop((nf, str(dev)), None)
     uu = N(ops.uniform_u(nf, dev)) if u is None else u
     z_mid = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
-    det = O.sample_pdf_detail(z_mid, w[:, 1:-1], nf, u=uu)
-    zf, pts = O.fine_sampling(o, d, z, w, nf, u=uu)
+    det = O.sample_pdf_detail(z_mid, w[:, 1:-1], nf, u=uu, tot=tot)
+    zf, pts = O.fine_sampling(o, d, z, w, nf, u=uu, tot=tot)
     np.testing.assert_array_equal(N(r["inds"]), det["inds"])             # bit-exact indices
     np.testing.assert_array_equal(N(r["z_samples"]), det["samples"])     # bit-exact fp32
     np.testing.assert_array_equal(N(r["z_fine"]), zf)
@@ -205,6 +206,35 @@ def test_sampler_golden_inputs(dev):
     assert np.mean(N(r["inds"]) != g["inds"]) <= 5e-3
     assert np.mean(np.abs(N(r["z_fine"]) - g["z_fine"]) > 5e-6) <= 5e-3
     assert np.mean(np.abs(N(r["pts"]) - g["pts_fine"]) > 2e-5) <= 5e-3
+
+
+def test_sampler_strict_mode_is_the_reference_bit_for_bit_from_the_weights(dev):
+    """SURVEY 8b `strict_cumsum` / north_star "sample indices bit-exact": given the same weights and the normalising sums
+    as the reference's host evaluated them (the one host-dependent step, recorded in g4), the kernel's indices, samples,
+    merged depths and points ARE the reference's - including the adversarial rows (all-zero, all-equal, single spike,
+    mass at the ends, tiny, alternating zeros)."""
+    from smpl_nerf_amd import ops
+    g = load_golden("g4_sampler.npz")
+    r = _check_sampler(dev, g["o"], g["d"], g["z"], g["w"], 128, u=g["u"][0], tot=g["tot"])
+    np.testing.assert_array_equal(N(r["inds"]), g["inds"])
+    np.testing.assert_array_equal(N(r["z_samples"]), g["z_samples"])
+    np.testing.assert_array_equal(N(r["z_fine"]), g["z_fine"])
+    np.testing.assert_array_equal(N(r["pts"]), g["pts_fine"])
+    for nc, nf in ((16, 8), (32, 64), (64, 64), (48, 200)):
+        key = f"{nc}_{nf}"
+        ops._U_CACHE[(nf, str(dev))] = T(g["u_" + key], dev)          # the reference host's linspace bits
+        try:
+            r = ops.hierarchical_samples(T(g["o_" + key], dev), T(g["d_" + key], dev), T(g["z_" + key], dev),
+                                         T(g["w_" + key], dev), nf, tot=T(g["tot_" + key], dev))
+        finally:
+            ops._U_CACHE.pop((nf, str(dev)), None)
+        np.testing.assert_array_equal(N(r["z_fine"]), g["zf_" + key])
+        np.testing.assert_array_equal(N(r["pts"]), g["pf_" + key])
+    # the literal sample_pdf(bins, weights, args) convention with args.strict_cumsum: the host's own torch.sum supplies the
+    # sums, i.e. on the host that wrote the fixtures this is the reference bit for bit; elsewhere within the 1-ulp class
+    z_mid = (F32(0.5) * (g["z"][:, 1:] + g["z"][:, :-1])).astype(F32)
+    zs = ops.sample_pdf(T(z_mid, dev), T(np.ascontiguousarray(g["w"][:, 1:-1]), dev), O.Args(number_fine_samples=128, strict_cumsum=1))
+    assert np.mean(np.abs(N(zs) - g["z_samples"]) > 5e-6) <= 5e-3
 
 
 @pytest.mark.parametrize("nc,nf", [(16, 8), (32, 64), (64, 64), (48, 200), (3, 1), (200, 700)])
@@ -741,17 +771,25 @@ def _mlp_ref64(params, pts, dirs, add, add_first, n_layers=8, skips=(4,), use_di
 
 @pytest.mark.gpu
 def test_split_bf16_stress_against_fp32_kernel(dev):
-    """The split-bf16 kernels lay their instruction stream out by hand (asm loads with counted waits, DMA ring with
-    alternating issuers): sweep depths, skip positions, additional inputs, direction modes and ragged sizes.  Against a
-    float64 evaluation bf16x6 must be as accurate as the exact-fp32 kernel (the nets here are not all well conditioned,
-    so the bound is relative to the fp32 kernel's own error) and bf16x3 within 2^-16-class error; repeated launches
-    must be bit-identical (a timing-dependent hazard would show up as run-to-run noise)."""
+    """The split kernels lay their instruction stream out by hand (asm loads with counted waits, DMA ring with
+    alternating issuers): sweep depths, skip positions, additional inputs, direction modes and ragged sizes; repeated
+    launches must be bit-identical (a timing-dependent hazard would show up as run-to-run noise).
+
+    Accuracy is held against a float64 evaluation, RELATIVE TO THE EXACT-fp32 KERNEL'S OWN ERROR (the nets here are not
+    all well conditioned).  bf16x6 (three bf16 parts = 24 significand bits, the three dropped cross terms are below
+    2^-24) must be in the fp32 kernel's class in the strict sense: its RMS error over the whole sweep <= 1.0 x the fp32
+    kernel's (measured 0.89: the MFMA sums a 32-long block before rounding, the fp32 MFMA a 4-long one), and no case with
+    >= 1000 outputs worse than 1.25 x in RMS / 1.6 x in its maximum (the maximum of ~1e5 errors fluctuates by that much
+    between two equally accurate evaluations).  f16x3 (two fp16 parts of scaled operands, 22 bits) is held to the same
+    figures - measured 0.81 / 1.11 / 1.28 - and bf16x3 (16 bits) to 2^-16-class error."""
     from smpl_nerf_amd.ops import PositionalEncoder
     rng = np.random.default_rng(2024)
     enc = (PositionalEncoder(10, 0), PositionalEncoder(4, 0))
     cases = [dict(n_layers=8, skips=(4,)), dict(n_layers=8, skips=()), dict(n_layers=5, skips=(2,)), dict(n_layers=3, skips=(1,)),
              dict(n_layers=8, skips=(4,), additional_input_dim=69), dict(n_layers=8, skips=(3, 6), additional_input_dim=5),
              dict(n_layers=6, skips=(4,), use_directional_input=0)]
+    modes = ("fp32", "bf16x6", "bf16x3", "f16x3")
+    sq, cnt = {m: 0.0 for m in modes}, 0
     for ci, kw in enumerate(cases):
         add_dim = kw.get("additional_input_dim", 0)
         add_first = bool(add_dim and ci % 2)
@@ -768,20 +806,35 @@ def test_split_bf16_stress_against_fp32_kernel(dev):
             tdirs = T(dirs.reshape(-1, 3), dev)
             outs = {}
             with torch.no_grad():
-                for prec in ("fp32", "bf16x6", "bf16x3", "f16x3"):
+                for prec in modes:
                     net.precision = prec
                     a = net.forward_fused(T(pts, dev), tdirs, Ns, *enc, **kwf)
                     b = net.forward_fused(T(pts, dev), tdirs, Ns, *enc, **kwf)
                     assert torch.equal(a, b), (kw, B, Ns, prec)
                     outs[prec] = N(a).reshape(B, Ns, 4).astype(np.float64)
+                    assert np.isfinite(outs[prec]).all()
             ref = _mlp_ref64(params, pts, np.broadcast_to(dirs, (B, Ns, 3)),
                              None if add is None else np.broadcast_to(add, (B, Ns, add_dim)), add_first, **kw)
             scale = float(np.abs(ref).max()) + 1e-6
-            e32, e6, e3, ef = (float(np.abs(outs[k] - ref).max()) for k in ("fp32", "bf16x6", "bf16x3", "f16x3"))
-            assert np.isfinite(outs["bf16x6"]).all() and np.isfinite(outs["bf16x3"]).all() and np.isfinite(outs["f16x3"]).all()
-            assert e6 <= 2.0 * e32 + 1e-5 * scale, (kw, B, Ns, e32, e6)
-            assert ef <= 8.0 * e32 + 1e-5 * scale, (kw, B, Ns, e32, ef)   # 2^-22 products, parts rounded toward zero
-            assert e3 <= 300.0 * e32 + 2e-3 * scale, (kw, B, Ns, e32, e3)
+            err = {m: (outs[m] - ref) / scale for m in modes}
+            emax = {m: float(np.abs(err[m]).max()) for m in modes}
+            erms = {m: float(np.sqrt((err[m] ** 2).mean())) for m in modes}
+            for m in modes:
+                sq[m] += float((err[m] ** 2).sum())
+            cnt += ref.size
+            tag = (kw, B, Ns, emax, erms)
+            if ref.size >= 1000:
+                for m in ("bf16x6", "f16x3"):
+                    assert erms[m] <= 1.25 * erms["fp32"], (m,) + tag
+                    assert emax[m] <= 1.6 * emax["fp32"], (m,) + tag
+            else:       # a handful of outputs: no statistics, only "same class"
+                for m in ("bf16x6", "f16x3"):
+                    assert emax[m] <= 4.0 * emax["fp32"] + 2e-7, (m,) + tag
+            assert emax["bf16x3"] <= 300.0 * emax["fp32"] + 2e-3, tag
+    agg = {m: float(np.sqrt(sq[m] / cnt)) for m in modes}
+    print("aggregate RMS error vs float64, relative to the fp32 kernel:", {m: round(agg[m] / agg["fp32"], 4) for m in modes})
+    assert agg["bf16x6"] <= 1.0 * agg["fp32"], agg
+    assert agg["f16x3"] <= 1.0 * agg["fp32"], agg
 
 
 @pytest.mark.gpu

@@ -157,6 +157,26 @@ def test_sample_pdf_main_case():
     assert np.all(np.diff(zf, axis=-1) >= 0)
 
 
+def test_strict_sampler_is_the_reference_bit_for_bit_from_the_weights():
+    """With the recorded normalising sums (the one host-dependent intermediate, utils.py:201) the oracle's cdf, indices,
+    samples, merged depths and points equal the reference's exactly - all 48 rays x 128 samples of g4, the adversarial
+    rows included, and the four other (Nc, Nf) shapes."""
+    g = load_golden("g4_sampler.npz")
+    z_mid = (F32(0.5) * (g["z"][:, 1:] + g["z"][:, :-1])).astype(F32)
+    det = O.sample_pdf_detail(z_mid, g["w"][:, 1:-1], 128, u=g["u"][0], tot=g["tot"])
+    np.testing.assert_array_equal(det["cdf"], g["cdf"])
+    np.testing.assert_array_equal(det["inds"], g["inds"])
+    np.testing.assert_array_equal(det["samples"], g["z_samples"])
+    zf, pts = O.fine_sampling(g["o"], g["d"], g["z"], g["w"], 128, u=g["u"][0], tot=g["tot"])
+    np.testing.assert_array_equal(zf, g["z_fine"])
+    np.testing.assert_array_equal(pts, g["pts_fine"])
+    for nc, nf in ((16, 8), (32, 64), (64, 64), (48, 200)):
+        k = f"{nc}_{nf}"
+        zf, pts = O.fine_sampling(g["o_" + k], g["d_" + k], g["z_" + k], g["w_" + k], nf, u=g["u_" + k], tot=g["tot_" + k])
+        np.testing.assert_array_equal(zf, g["zf_" + k])
+        np.testing.assert_array_equal(pts, g["pf_" + k])
+
+
 @pytest.mark.parametrize("nc,nf", [(16, 8), (32, 64), (64, 64), (48, 200)])
 def test_fine_sampling_shapes(nc, nf):
     g = load_golden("g4_sampler.npz")
