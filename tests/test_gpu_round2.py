@@ -561,3 +561,22 @@ def test_bench_launches_its_own_ranks(dev):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["dtype"] == "f32"
     assert line["train"]["collective"].startswith("one all-reduce of 1220872 fp32")
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ f-3: the reference's files
+def test_reference_checkpoints_render_on_the_hip_path(dev):
+    """Weights the reference saved (utils.save_run -> tests/golden/io_fixture/model_*.pt) loaded through io.load_run give
+    the outputs the reference's own modules computed from them (expect.npz), on encoded rows."""
+    from smpl_nerf_amd import io as sio
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    fix = os.path.join(ROOT, "tests", "golden", "io_fixture")
+    e = dict(np.load(os.path.join(fix, "expect.npz")))
+    mc, mf = (RenderRayNet(n_layers=2, width=128, positions_dim=60, directions_dim=24, skips=[0]) for _ in range(2))
+    mw = WarpFieldNet(8, 128, 60, 40)
+    sio.load_run(fix, [mc, mf, mw], ["model_coarse.pt", "model_fine.pt", "model_warp_field.pt"])
+    with torch.no_grad():
+        oc = mc.to(dev)(T(e["rows"], dev))
+        of = mf.to(dev)(T(e["rows"], dev))
+        ow = mw.to(dev)(T(e["warp_rows"], dev))
+    assert maxabs(N(oc), e["out_coarse"]) <= 2e-6 and maxabs(N(of), e["out_fine"]) <= 2e-6
+    assert maxabs(N(ow), e["out_warp"]) <= 2e-6
