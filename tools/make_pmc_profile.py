@@ -1,7 +1,9 @@
-"""profiles/<round>_pmc_summary.json from the three rocprofv3 --pmc passes of bench.py (SQ/GRBM, FETCH_SIZE,
-WRITE_SIZE - separate runs, as MI355X_MICROARCH.md prescribes).
+"""profiles/<round>_pmc_summary.json from rocprofv3 --pmc passes of bench.py (SQ/GRBM, FETCH_SIZE, WRITE_SIZE - separate
+runs, as MI355X_MICROARCH.md prescribes).  The render rows come from passes WITHOUT the training section
+(`--train-rays 0`), so that every dispatch of a render kernel in them is one of the bench's frame launches; the training
+rows come from three more passes with it.
 
-    python tools/make_pmc_profile.py <sq_dir> <fetch_dir> <write_dir> > profiles/rNN_pmc_summary.json
+    python tools/make_pmc_profile.py <sq_dir> <fetch_dir> <write_dir> [<train_sq_dir> <train_fetch_dir> <train_write_dir>]
 """
 import json
 import sys
@@ -17,9 +19,11 @@ TRAIN_KERNELS = {"fwd_train_f16x3": "mlp_fwd_bf16_kernel<256, 8, 2, true, 1>", "
 ALG_BYTES = {1048576: 1048576 * (12 + 16) + 16384 * 12, 3145728: 3145728 * (12 + 16) + 16384 * 12}  # x, raw, dirs
 
 
-def main(sq, fetch, write):
-    out = {"command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --steps 3 --warmup 1 --cpu-rays 0 "
-                      "--train-rays 0 (three separate passes: SQ/GRBM, FETCH_SIZE, WRITE_SIZE)",
+def main(sq, fetch, write, tsq=None, tfetch=None, twrite=None):
+    out = {"command": "render rows: rocprofv3 --pmc <counters> --output-format csv -- python bench.py --steps 3 --warmup 1 "
+                      "--cpu-rays 0 --train-rays 0 --no-pmc (three separate passes: SQ/GRBM, FETCH_SIZE, WRITE_SIZE; every "
+                      "dispatch of a render kernel is a frame launch of the bench); training rows: the same three passes of "
+                      "python bench.py --steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc",
            "note": "FETCH_SIZE/WRITE_SIZE are KB; mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * "
                    "1024 SIMDs); effective clock = GRBM_GUI_ACTIVE / 8 / duration.  MI355X_MICROARCH.md: FETCH_SIZE "
                    "under-reports wide 16 B/lane streams by 2x; these kernels read 4 B/lane inputs and take their weights "
@@ -53,8 +57,11 @@ def main(sq, fetch, write):
                                                    "hbm_bytes": (tot_f + tot_w) / tot_n,
                                                    "algorithmic_bytes": sum(ALG_BYTES.values()) / 2}}
     out["training_kernels"] = {}
+    if tsq is None:
+        print(json.dumps(out, indent=1))
+        return
     for tag, name in TRAIN_KERNELS.items():
-        a, f, w = (summarise(name, [d]) for d in (sq, fetch, write))
+        a, f, w = (summarise(name, [d]) for d in (tsq, tfetch, twrite))
         for key, e in a.items():
             c = e["counters"]
             out["training_kernels"][f"{tag} grid={key.split('grid=')[1]}"] = {
@@ -66,4 +73,4 @@ def main(sq, fetch, write):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:7])

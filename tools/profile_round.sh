@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r02
+# -> gpurun_out/<tag>/ : kernel-trace stats of the default bench run, three PMC passes without the training section (clean
+#    render rows) and three with it; tools/make_pmc_profile.py reduces them to gpurun_out/<tag>/pmc_summary.json.
+set -u
+TAG=${1:-r02}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-pmc > $OUT/bench_under_rocprof.json.log 2> $OUT/trace.err
+RENDER="--steps 3 --warmup 1 --cpu-rays 0 --train-rays 0 --no-pmc"
+TRAIN="--steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc"
+timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py $RENDER > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py $RENDER > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py $RENDER > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmct_sq -- python $ROOT/bench.py $TRAIN > $OUT/pmct_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmct_fetch -- python $ROOT/bench.py $TRAIN > $OUT/pmct_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmct_write -- python $ROOT/bench.py $TRAIN > $OUT/pmct_write.log 2>&1
+cd $ROOT
+python tools/make_pmc_profile.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
+find $OUT/trace -name "*kernel_trace.csv" -exec cp {} $OUT/bench_kernel_trace.csv \;
+# keep what travels back small: the raw per-dispatch counter CSVs are reduced above
+rm -rf $OUT/trace $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write
+ls -la $OUT
