@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(Plan P, const float *__re
     while (li + 1 < P.nlayers && slab >= P.layer[li + 1].first_slab) ++li;
     const Layer &Ly = P.layer[li];
     const int sl = slab - Ly.first_slab;
-    const int kps = 16 / Ly.t_out;
+    const int kps = SLAB_TILES / Ly.t_out;
     const float *Wm = params + Ly.w_off;
     const float *bias = params + Ly.b_off;
     for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
@@ -74,12 +74,39 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;   // tiles of the trunk
     constexpr int TD = WIDTH / 32;  // tiles of the directional branch
-    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // RING_BYTES (SNERF_LAUNCH_RING)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
+    const int enc_pos_off = A.add_first ? A.add_dim : 0, enc_add_off = A.add_first ? 0 : A.pos_dim;
+    const int enc_dir_off = A.enc_stride - A.dir_dim;  // directions = x[..., -dir_dim:] (:43)
+
+    // Persistent workgroups: one per CU (the 99 KiB ring allows no more), each walking the sample tiles blockIdx.x,
+    // blockIdx.x + gridDim.x, ...  The weight ring keeps rolling from one tile into the next (the stream wraps around),
+    // so only the first tile of a workgroup pays the pipeline fill and no CU idles between two workgroups.
+    SlabPipe<NT> pipe;
+    // raw inputs of a tile (positions, direction), fetched while the previous tile's last layers run so that a tile
+    // never starts by waiting on HBM (inference variant; the training variant sits at the register limit)
+    // The training variant (at the register limit: the persistent loop would spill) runs one workgroup per tile.
+    constexpr bool PERSIST = !TRAIN;
+    constexpr bool PREFETCH = !ENCODED && PERSIST;
+    float raw_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_raw = [&](int64_t t) __attribute__((always_inline)) {
+        const int64_t s0 = (t * NWAVES + wave) * 16 + (lane & 15);
+        const int64_t s1 = s0 < A.n ? s0 : A.n - 1;
+        raw_in[0] = A.x[s1 * 3 + 0];
+        raw_in[1] = A.x[s1 * 3 + 1];
+        raw_in[2] = A.x[s1 * 3 + 2];
+        if (A.use_dir) {
+            const float *dp = A.dirs + (A.dirs_per_sample ? s1 : s1 / A.spr) * 3;
+            raw_in[3] = dp[0], raw_in[4] = dp[1], raw_in[5] = dp[2];
+        }
+    };
+    if (PREFETCH && blockIdx.x < A.n_tiles) load_raw(blockIdx.x);
+    int64_t tile = blockIdx.x;
+    do {
+    const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
     const int64_t sc = valid ? sample : A.n - 1;
 
@@ -91,13 +118,13 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     if (ENCODED) {
         c.enc = A.x + sc * A.enc_stride;
     } else {
-        c.px = A.x[sc * 3 + 0];
-        c.py = A.x[sc * 3 + 1];
-        c.pz = A.x[sc * 3 + 2];
+        if (!PREFETCH) load_raw(tile);
+        c.px = raw_in[0];
+        c.py = raw_in[1];
+        c.pz = raw_in[2];
         const int64_t ray = sc / A.spr;
         if (A.use_dir) {
-            const float *dp = A.dirs + (A.dirs_per_sample ? sc : ray) * 3;
-            const float ux = dp[0], uy = dp[1], uz = dp[2];
+            const float ux = raw_in[3], uy = raw_in[4], uz = raw_in[5];
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ux, ux), __fmul_rn(uy, uy)), __fmul_rn(uz, uz)));
             c.dx = __fdiv_rn(ux, nrm);  // models/nerf_pipeline.py:33-34
             c.dy = __fdiv_rn(uy, nrm);
@@ -105,11 +132,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         }
         if (A.add_dim) c.add = A.add + ray * A.add_dim;
     }
-    const int enc_pos_off = A.add_first ? A.add_dim : 0, enc_add_off = A.add_first ? 0 : A.pos_dim;
-    const int enc_dir_off = A.enc_stride - A.dir_dim;  // directions = x[..., -dir_dim:] (:43)
-
-    SlabPipe<NT> pipe;
-    pipe.prologue(A.packed, ring, tid);
+    if (tile == blockIdx.x) pipe.prologue(A.packed, ring, tid, PERSIST ? A.total_slabs : 0x7fffffff);
 
     f4 in[T], acc[T];
 
@@ -199,6 +222,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         run.finish();
         copy_into(ind, accd);
         if (TRAIN && valid) store_tiles(A.act, A.act_h1, A.n, sample, c.g, ind);
+        if (PREFETCH && tile + gridDim.x < A.n_tiles) load_raw(tile + gridDim.x);   // lands behind the last two layers
     }
     {  // directional_net[0] + relu (:58-59)
         LayerRun<TD, NT> run(pipe, lane);
@@ -224,6 +248,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
         f4 o = f4{rgb[0][0], rgb[0][1], rgb[0][2], sig[0][0]};
         reinterpret_cast<f4 *>(A.raw)[sample] = o;
     }
+    } while (PERSIST && (tile += gridDim.x) < A.n_tiles);
 }
 
 static int fill_args(const snerf_mlp_desc *desc, Plan &P, FwdArgs &A) {
@@ -258,12 +283,25 @@ constexpr int FWD_WAVES = 8;  // 128 samples per workgroup, one workgroup per CU
 template <int NW, bool ENCODED, bool TRAIN>
 static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
     const int64_t tile = NW * 16;
-    const int64_t grid = (A.n + tile - 1) / tile;
-    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd: n too large");
+    FwdArgs B = A;
+    B.n_tiles = (A.n + tile - 1) / tile;
+    B.total_slabs = P.total_slabs;
+    if (B.n_tiles > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd: n too large");
+    static int n_cu = 0;  // one persistent workgroup per CU
+    if (!n_cu) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            return fail(SNERF_E_LAUNCH, "mlp_fwd: cannot query the CU count");
+        n_cu = cus;
+    }
+    // SNERF_FWD_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
+    static const bool persistent = !(getenv("SNERF_FWD_PERSISTENT") && atoi(getenv("SNERF_FWD_PERSISTENT")) == 0);
+    const int64_t grid = (!TRAIN && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
     if (P.width == 256)
-        hipLaunchKernelGGL((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     else
-        hipLaunchKernelGGL((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     return check_launch("mlp_fwd");
 }
 

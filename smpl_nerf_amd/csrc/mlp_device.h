@@ -42,8 +42,8 @@ struct FwdArgs {
     // split-bf16 training forward only: encoder / additional k-block counts of the 16-wide (fp32) plan, which
     // defines the activation layout the backward kernels read
     int pos_nkb16, add_nkb16, dir_nkb16;
-    int total_slabs;   // split-bf16 kernels: slabs of the weight stream (persistent workgroups wrap around)
-    int64_t n_tiles;   // split-bf16 kernels: 128-sample tiles
+    int total_slabs;   // slabs of the weight stream (persistent workgroups wrap around)
+    int64_t n_tiles;   // sample tiles (NWAVES x 16 samples)
 };
 
 // one tile (16 features of this lane's sample) <-> the tile-row-major activation buffer
@@ -83,11 +83,27 @@ __device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, in
     *mask_ptr(buf, mask_row, idx, n, sample, g) = uint2{w[0], w[1]};
 }
 
+// The 3-slot ring (99 KiB) is dynamic LDS: a launch gets 64 KiB unless the limit is raised per kernel once.
+constexpr int RING_BYTES = 3 * SLAB_FLOATS * 4;
+#define SNERF_LAUNCH_RING(kernel, grid, block, stream, ...)                                                            \
+    do {                                                                                                               \
+        static bool snerf_lds_raised_ = false; /* idempotent; a race only repeats the call */                          \
+        if (!snerf_lds_raised_) {                                                                                      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    ::snerf::RING_BYTES) != hipSuccess)                                                \
+                return ::snerf::fail(SNERF_E_LAUNCH, "cannot raise the dynamic LDS limit to %d bytes", ::snerf::RING_BYTES); \
+            snerf_lds_raised_ = true;                                                                                  \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kernel, grid, block, ::snerf::RING_BYTES, stream, __VA_ARGS__);                             \
+    } while (0)
+
 // Streams the slab sequence global -> registers -> LDS ring (3 slots).
 template <int NT>
 struct SlabPipe {
     static constexpr int NA = SLAB_A_FLOATS / 4 / NT;  // f4 per thread in the A region (NT=256: 4, 512: 2)
     const f4 *g;   // this thread's read cursor in the packed stream
+    const f4 *g0;  // ... and its position at slab 0: persistent kernels run the stream once per sample tile and wrap
+    int src, total;
     float *ring;
     f4 st[NA], st_aux;
     f4 pa0, pa1;  // first A-operand pair of the next k-block, prefetched (see kblock)
@@ -98,6 +114,10 @@ struct SlabPipe {
         for (int i = 0; i < NA; ++i) st[i] = g[i * NT];
         if (tid < 64) st_aux = g[SLAB_A_FLOATS / 4];
         g += SLAB_FLOATS / 4;
+        if (++src == total) {
+            src = 0;
+            g = g0;
+        }
     }
     __device__ __forceinline__ void store(int slot) {
         f4 *d = reinterpret_cast<f4 *>(ring + slot * SLAB_FLOATS) + tid;
@@ -105,10 +125,14 @@ struct SlabPipe {
         for (int i = 0; i < NA; ++i) d[i * NT] = st[i];
         if (tid < 64) d[SLAB_A_FLOATS / 4] = st_aux;
     }
-    __device__ __forceinline__ void prologue(const float *packed, float *ring_, int tid_) {
+    // total_slabs: length of the stream for kernels that run it repeatedly (one pass per sample tile); a one-pass kernel
+    // leaves the default and reads on into the zero padding slabs
+    __device__ __forceinline__ void prologue(const float *packed, float *ring_, int tid_, int total_slabs = 0x7fffffff) {
         ring = ring_;
         tid = tid_;
-        g = reinterpret_cast<const f4 *>(packed) + tid;
+        g = g0 = reinterpret_cast<const f4 *>(packed) + tid;
+        src = 0;
+        total = total_slabs;
         load(); store(0);
         load(); store(1);
         load();
@@ -242,7 +266,7 @@ __device__ __forceinline__ void kblock(const float *a_kb, const float *a_next, f
 // visible since the barrier that ended slab p-1 (the ring holds p, p+1 and the slot being filled with p+2).
 template <int T_OUT, int NT>
 struct LayerRun {
-    static constexpr int KPS = 16 / T_OUT;
+    static constexpr int KPS = SLAB_TILES / T_OUT;
     SlabPipe<NT> &pipe;
     const float *slab;
     int kbl;  // k-block index inside the current slab

@@ -12,8 +12,8 @@
 //
 // k-block kb  = 4 k-steps r=0..3 = 16 input features; one ds_read_b128 per (kb, output tile) gives a
 //               lane its 4 A values: W[16*to + (l&15)][col(kb, g=l>>4, r)], r = 0..3.
-// slab        = 4096 floats of A tiles ([k-block in slab][to][lane][r]) + 256 floats of bias
-//               (valid in the first slab of a layer).  k-blocks per slab = 16 / t_out.
+// slab        = SLAB_TILES x 256 floats of A tiles ([k-block in slab][to][lane][r]) + 256 floats of bias
+//               (valid in the first slab of a layer).  k-blocks per slab = SLAB_TILES / t_out.
 // Input segments of a layer (columns of its weight matrix), each a whole number of k-blocks:
 //   HIDDEN  col = col_off + 16*kb + 4*g + r                     (previous layer's accumulator)
 //   PE      encoder output of a 3-vector (utils.py:114-131), two "units" per k-block per lane:
@@ -26,9 +26,14 @@
 
 namespace snerf {
 
-constexpr int SLAB_A_FLOATS = 4096;
+// fp32 streams: SLAB_TILES A tiles ((k-block, output tile) pairs, 1 KiB each) per slab = 32 MFMAs of 16x16x4 per tile
+// and wave between two workgroup barriers.  (16 tiles = one barrier per 64 MFMAs per wave left 8 % of the wave cycles
+// parked at the hand-over; 32 halves that.  The split-bf16 streams keep 16 tiles of NS parts.)
+constexpr int SLAB_TILES = 32;
+__host__ __device__ constexpr int slab_tiles(int kw) { return kw == 16 ? SLAB_TILES : 16; }
+constexpr int SLAB_A_FLOATS = SLAB_TILES * 256;
 constexpr int SLAB_AUX_FLOATS = 256;
-constexpr int SLAB_FLOATS = SLAB_A_FLOATS + SLAB_AUX_FLOATS;  // 4352 floats = 17 KiB
+constexpr int SLAB_FLOATS = SLAB_A_FLOATS + SLAB_AUX_FLOATS;  // 8448 floats = 33 KiB
 constexpr int SLAB_PAD = 3;                                    // zero slabs after the stream (prefetch overrun)
 constexpr int MAX_LAYERS = 21;  // n_layers <= 16, + 5 fixed layers
 constexpr int STAT_INTS = 32;    // per-layer statistics behind the activation / dY rows of a training step (f16x3)
@@ -154,7 +159,7 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
         Ly.n_in = col;
         Ly.nkb = 0;
         for (int i = 0; i < Ly.nseg; ++i) Ly.nkb += Ly.seg[i].nkb;
-        const int kps = 16 / Ly.t_out;
+        const int kps = slab_tiles(kw) / Ly.t_out;
         Ly.first_slab = slab;
         Ly.nslab = (Ly.nkb + kps - 1) / kps;
         slab += Ly.nslab;
@@ -312,7 +317,7 @@ inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false, in
         const int nkb = (nkb16 + kdiv - 1) / kdiv;
         BwdLayer &b = B.layer[nl++];
         b = BwdLayer{fwd, seg, t_out, nkb, aux, slab, 0};
-        const int kps = 16 / t_out;
+        const int kps = slab_tiles(kw) / t_out;
         b.nslab = (nkb + kps - 1) / kps;
         slab += b.nslab;
     };

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(Plan P, BwdPlan B, cons
     const BwdLayer &Bl = B.layer[bi];
     const Layer &Ly = P.layer[Bl.fwd];
     const int sl = slab - Bl.first_slab;
-    const int kps = 16 / Bl.t_out;
+    const int kps = SLAB_TILES / Bl.t_out;
     const float *Wm = params + Ly.w_off;
     for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
         float val = 0.f;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
     constexpr int T = WIDTH / 16;
     constexpr int TD = WIDTH / 32;
     constexpr int TPP = 4, TPD = 2;
-    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // RING_BYTES (SNERF_LAUNCH_RING)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -691,11 +691,11 @@ static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const f
     const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
     if (P.width == 256) {
-        if (input_grad) hipLaunchKernelGGL((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
-        else hipLaunchKernelGGL((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+        if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
     } else {
-        if (input_grad) hipLaunchKernelGGL((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
-        else hipLaunchKernelGGL((mlp_bwd_kernel<128, BW, false>), dim3((unsigned)grid), dim3(BW * 64), 0, s, A);
+        if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        else SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
     }
     int rc = check_launch("mlp_bwd(dgrad)");
     if (rc) return rc;

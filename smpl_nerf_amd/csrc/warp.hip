@@ -37,7 +37,7 @@ template <int WIDTH, int NWAVES, bool TRAIN>
 __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_kernel(WarpArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;
-    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // RING_BYTES (SNERF_LAUNCH_RING)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
@@ -117,7 +117,7 @@ template <int WIDTH, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void warp_bwd_kernel(WarpBwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;
-    __shared__ __attribute__((aligned(16))) float ring[3 * SLAB_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // RING_BYTES (SNERF_LAUNCH_RING)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
     const bool valid = sample < A.n;
@@ -202,9 +202,9 @@ extern "C" int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *pack
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_bwd: n too large");
     hipStream_t s = (hipStream_t)stream;
     if (P.width == 256)
-        hipLaunchKernelGGL((warp_bwd_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        SNERF_LAUNCH_RING((warp_bwd_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
     else
-        hipLaunchKernelGGL((warp_bwd_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        SNERF_LAUNCH_RING((warp_bwd_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
     int rc = check_launch("warp_bwd");
     if (rc) return rc;
     return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);
@@ -290,11 +290,11 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_fwd: n too large");
     hipStream_t s = (hipStream_t)stream;
     if (P.width == 256) {
-        if (act) hipLaunchKernelGGL((warp_fwd_kernel<256, NW, true>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
-        else hipLaunchKernelGGL((warp_fwd_kernel<256, NW, false>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        if (act) SNERF_LAUNCH_RING((warp_fwd_kernel<256, NW, true>), dim3((unsigned)grid), dim3(NW * 64), s, A);
+        else SNERF_LAUNCH_RING((warp_fwd_kernel<256, NW, false>), dim3((unsigned)grid), dim3(NW * 64), s, A);
     } else {
-        if (act) hipLaunchKernelGGL((warp_fwd_kernel<128, NW, true>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
-        else hipLaunchKernelGGL((warp_fwd_kernel<128, NW, false>), dim3((unsigned)grid), dim3(NW * 64), 0, s, A);
+        if (act) SNERF_LAUNCH_RING((warp_fwd_kernel<128, NW, true>), dim3((unsigned)grid), dim3(NW * 64), s, A);
+        else SNERF_LAUNCH_RING((warp_fwd_kernel<128, NW, false>), dim3((unsigned)grid), dim3(NW * 64), s, A);
     }
     return check_launch("warp_fwd");
 }

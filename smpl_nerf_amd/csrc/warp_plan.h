@@ -37,7 +37,7 @@ inline int make_warp_plan(const snerf_warp_desc &d, Plan &P, const char *&why, i
     L0.first_slab = 0;
     L0.nslab = L0.nkb;  // t_out = 16 or 8 ...
     {
-        const int kps = 16 / L0.t_out;
+        const int kps = slab_tiles(kw) / L0.t_out;
         L0.nslab = (L0.nkb + kps - 1) / kps;
     }
     L0.w_off = 0;
@@ -50,7 +50,7 @@ inline int make_warp_plan(const snerf_warp_desc &d, Plan &P, const char *&why, i
     L1.n_in = d.width;
     L1.nkb = d.width / kw;
     L1.first_slab = L0.nslab;
-    L1.nslab = (L1.nkb + 15) / 16;
+    L1.nslab = (L1.nkb + slab_tiles(kw) - 1) / slab_tiles(kw);
     L1.w_off = L0.b_off + L0.n_out;
     L1.b_off = L1.w_off + (int64_t)3 * d.width;
     P.nlayers = 2;

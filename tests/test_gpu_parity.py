@@ -827,9 +827,9 @@ def test_split_bf16_stress_against_fp32_kernel(dev):
                 for m in ("bf16x6", "f16x3"):
                     assert erms[m] <= 1.25 * erms["fp32"], (m,) + tag
                     assert emax[m] <= 1.6 * emax["fp32"], (m,) + tag
-            else:       # a handful of outputs: no statistics, only "same class"
-                for m in ("bf16x6", "f16x3"):
-                    assert emax[m] <= 4.0 * emax["fp32"] + 2e-7, (m,) + tag
+            else:       # a handful of outputs: no statistics (the fp32 kernel can be right to the last bit by luck), only
+                for m in ("bf16x6", "f16x3"):       # "same class": a few units of the 1e-6 x scale round-off level
+                    assert emax[m] <= 4.0 * emax["fp32"] + 3e-6, (m,) + tag
             assert emax["bf16x3"] <= 300.0 * emax["fp32"] + 2e-3, tag
     agg = {m: float(np.sqrt(sq[m] / cnt)) for m in modes}
     print("aggregate RMS error vs float64, relative to the fp32 kernel:", {m: round(agg[m] / agg["fp32"], 4) for m in modes})
