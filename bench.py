@@ -208,6 +208,16 @@ def cpu_baseline(workload, params, data_np, n_rays):
 
 
 # ---------------------------------------------------------------------------------------------------- HBM traffic
+def _profiler_env_key(k):
+    return k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX", "HSA_TOOLS", "RPD_", "OMNITRACE", "ROCPROFSYS"))
+
+
+def under_profiler():
+    if any(_profiler_env_key(k) for k in os.environ):
+        return True
+    return any(t in os.environ.get("LD_PRELOAD", "") for t in ("rocprof", "roctracer", "rocprofiler", "omnitrace"))
+
+
 def pmc_traffic(argv_child, kernel_substr, timeout_s=240):
     """HBM bytes per average launch of the dominant kernel from two separate rocprofv3 --pmc passes over a short run of
     this same script (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots').  Units:
@@ -217,8 +227,13 @@ def pmc_traffic(argv_child, kernel_substr, timeout_s=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    # never nest: when this process already runs under a profiler (rocprofv3 --kernel-trace ... -- python bench.py), a
+    # --pmc child would combine counter collection with the parent's tracing in one process tree
+    if under_profiler():
+        return None, "skipped: bench.py itself runs under a profiler (counter passes are not nested inside a trace)"
     out = {}
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = {k: v for k, v in os.environ.items() if not _profiler_env_key(k)}
+    env["TMPDIR"] = "/tmp"
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="snerf_pmc_", dir="/tmp")
         try:
@@ -346,7 +361,11 @@ def main():
     from smpl_nerf_amd import _lib
     from smpl_nerf_amd.dist import barrier, max_over_ranks, shard_frames
 
-    pipe, params, _ = build_pipeline(dev, a.precision, a.workload)
+    global FLOP_PER_EVAL
+    pipe, params, nets = build_pipeline(dev, a.precision, a.workload)
+    # algorithmic FLOPs of one RenderRayNet evaluation of THIS workload (2 x weight elements the output depends on: the
+    # additional-input columns of the pose-conditioned nets count, AppendVerticesNet's dead vertices_net branch does not)
+    FLOP_PER_EVAL = 2 * sum(p.numel() for k, p in nets[0].named_parameters() if k.endswith("weight") and not k.startswith("vertices_net"))
     # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
     frame_id = shard_frames(world, rank)
     data_np = frame_inputs(a.workload, a.res, frame_id)

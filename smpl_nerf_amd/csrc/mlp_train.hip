@@ -91,6 +91,19 @@ __device__ __forceinline__ void mask_into(f4 (&dst)[N], const f4 (&src)[N], cons
     }
 }
 
+// The same from the 1-bit-per-output sign masks the training forward leaves behind the activation rows (store_mask,
+// mlp_device.h): 8 bytes per lane and layer instead of a 1 KiB tile-row per 16 samples and tile - the dgrad then reads
+// 0.3 GB instead of 3.6 GB per 786 k-sample launch.  The word is fetched before the layer's MFMA run and used after it.
+template <int N>
+__device__ __forceinline__ void mask_bits_into(f4 (&dst)[N], const f4 (&src)[N], uint2 w) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const unsigned word = (t >> 3) ? w.y : w.x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[t][r] = ((word >> (((t & 7) << 2) | r)) & 1u) ? src[t][r] : 0.f;
+    }
+}
+
 // INPUT_GRAD: additionally back-propagates into the network inputs (SmplNerfPipeline: the warped samples and
 // their per-sample view directions are functions of the warp net, models/smpl_nerf_pipeline.py:49-56); only
 // for the default encoders (position k-blocks <= TPP = 4, direction k-blocks <= TPD = 2).
@@ -123,11 +136,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
 
     f4 ind[TD], accd[TD];
     {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
+        const uint2 mw = *mask_ptr(A.act, A.act_mask, nh + 1, A.n, sc, g);
         LayerRun<TD, NT> run(pipe, lane);
         run.init(accd);
         run.step(g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, accd);
         run.finish();
-        mask_into(ind, accd, A.act, A.act_h2, A.n, sc, g);
+        mask_bits_into(ind, accd, mw);
         if (valid) store_tiles(A.dy, A.dy_dn0, A.n, sample, g, ind);
     }
     {  // directional_net[0]^T; directional_input has no activation (:54-57)
@@ -201,12 +215,13 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
     // additional^T, positional_net[nh-1]^T ... positional_net[0]^T: forward layer l+1 transposed yields
     // d X_{l+1}; masking with X_{l+1} > 0 gives d Y of forward layer l (:46-50)
     for (int l = nh; l >= 0; --l) {
+        const uint2 mw = *mask_ptr(A.act, A.act_mask, l, A.n, sc, g);   // lands behind the layer's MFMAs
         LayerRun<T, NT> run(pipe, lane);
         run.init(acc);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], acc);
         run.finish();
-        mask_into(in, acc, A.act, A.act_x1 + l * T, A.n, sc, g);
+        mask_bits_into(in, acc, mw);
         if (valid) store_tiles(A.dy, l * T, A.n, sample, g, in);
         pe_columns(l);
     }

@@ -42,9 +42,10 @@ def make_net(dev, params, **kw):
     return net.to(dev)
 
 
-# matrix-core arithmetic of the training step: exact fp32 MFMA everywhere, or split-bf16 with fp32-class accuracy for the
-# forward, the dgrad and the wide wgrad jobs; both are held to the same tolerances
-PRECISIONS = ["fp32", "bf16x6", "f16x3"]   # (f16x3: two-fp16-part forward, bf16x6 backward)
+# matrix-core arithmetic of the training step: exact fp32 MFMA everywhere ("fp32"), or split operands on the 16-bit matrix
+# cores for the forward, the dgrad and the wgrad GEMMs ("bf16x6": three bf16 parts; "f16x3": two fp16 parts of scaled
+# operands, in all three kernels) - all held to the same tolerances
+PRECISIONS = ["fp32", "bf16x6", "f16x3"]
 
 
 # ------------------------------------------------------------------------------------------ a4 backward

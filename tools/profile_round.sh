@@ -10,7 +10,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-pmc > $OUT/bench_under_rocprof.json.log 2> $OUT/trace.err
+# (a) render only: every dispatch of a render kernel is one of the bench's frame launches (12 steps x {coarse, fine})
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-pmc --train-rays 0 > $OUT/bench_under_rocprof.json.log 2> $OUT/trace.err
+# (b) the training section (all precisions) behind a one-step render
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --cpu-rays 0 > $OUT/train_under_rocprof.json.log 2> $OUT/trace_train.err
 RENDER="--steps 3 --warmup 1 --cpu-rays 0 --train-rays 0 --no-pmc"
 TRAIN="--steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc"
 timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py $RENDER > $OUT/pmc_sq.log 2>&1
@@ -22,7 +25,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmct_write --
 cd $ROOT
 python tools/make_pmc_profile.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
-find $OUT/trace -name "*kernel_trace.csv" -exec cp {} $OUT/bench_kernel_trace.csv \;
+find $OUT/trace_train -name "*kernel_stats.csv" -exec cp {} $OUT/train_kernel_stats.csv \;
 # keep what travels back small: the raw per-dispatch counter CSVs are reduced above
-rm -rf $OUT/trace $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write
+rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write
 ls -la $OUT
