@@ -1,0 +1,85 @@
+"""Host-side logic of bench.py that needs no GPU: launcher command, profiler detection, PMC CSV reduction, roofline
+arithmetic of the JSON line, CPU-baseline leg on a tiny sample."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_profiler_detection_and_child_environment(monkeypatch):
+    for k in list(os.environ):
+        if bench._profiler_env_key(k):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("LD_PRELOAD", "")
+    assert not bench.under_profiler()
+    monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
+    assert bench.under_profiler()          # a --pmc child would nest inside a traced run: bench.py must skip it
+    monkeypatch.delenv("ROCPROFILER_REGISTER_FORCE_LOAD")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.under_profiler()
+    out, err = bench.pmc_traffic(["--steps", "1"], "mlp_fwd_kernel")
+    assert out is None and ("profiler" in err or "rocprofv3 not found" in err)
+
+
+def test_self_launch_command(monkeypatch):
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_flop_count_and_modes():
+    assert bench.FLOP_PER_EVAL == 1215744                      # 607 872 MAC per ray-sample
+    assert set(bench.MODES) == {"fp32", "bf16x6", "f16x3", "bf16x3"} and bench.MODES["fp32"][2] == "f32"
+    assert bench.PEAK_F32_MFMA_TFLOPS == 157.3 and bench.PEAK_16BIT_MFMA_TFLOPS == 2500.0
+
+
+def test_committed_bench_line_is_self_consistent():
+    """The r02 driver-style line under profiles/: value = units / time, frac = achieved / peak with achieved from the
+    algorithmic FLOP count and the average launch duration, and the kernel-stats CSV of the profiled run agrees."""
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_under_rocprof.json.log")).read().strip().splitlines()[-1])
+    r = line["roofline"]
+    assert line["dtype"] == "f32" and line["unit"] == "ray-samples/s" and line["vs_baseline"] is None
+    assert abs(line["value"] - line["n_gpus"] * 16384 * 256 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    ach = r["flop_per_unit"] * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
+    assert r["flop_per_unit"] == 1215744 and abs(ach - r["achieved"]) <= 1e-9 * ach
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and r["peak"] == 157.3
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv"))))
+    k = [x for x in rows if x["Name"].startswith("void snerf::mlp_fwd_kernel<256, 8, false, false>")][0]
+    assert int(k["Calls"]) == 2 * (line["steps"] + line["warmup"])        # frame launches only
+    assert abs(float(k["AverageNs"]) * 1e-6 - r["avg_launch_ms"]) <= 0.02 * r["avg_launch_ms"]
+    for prec, alt in line["other_precisions_1gpu"].items():
+        ra = alt["roofline"]
+        assert abs(ra["frac"] - ra["achieved"] / 2500.0) <= 1e-12
+        assert abs(ra["mfma_issue_frac"] - ra["products_per_fp32_mac"] * ra["frac"]) <= 1e-12
+
+
+def test_cpu_baseline_leg_runs_and_matches_the_numpy_oracle():
+    from oracle import nerf_oracle as O
+    from smpl_nerf_amd import synthetic as syn
+    params = list(syn.make_scene_nets(101))
+    data = bench.frame_inputs("nerf", 128, 0)
+    info, out = bench.cpu_baseline("nerf", params, data, 32)
+    assert info["kind"] == "port" and info["unit"] == "ray-samples/s" and info["value"] > 0 and info["cores"] >= 1
+    assert info["calibration_vs_reference_in_build_container"]["outputs_bit_identical"] is True
+    import torch
+    ref = O.nerf_pipeline_forward(params[0], params[1], O.Args(u=torch.linspace(0., 1., steps=128).numpy()),
+                                  O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0), [a[:32] for a in data])
+    assert float(np.max(np.abs(out[1] - ref[1]))) <= 1e-4 and float(np.max(np.abs(out[0] - ref[0]))) <= 1e-5
