@@ -52,8 +52,8 @@ def test_mlp_descriptor_arithmetic(lib):
     assert lib.snerf_mlp_param_floats(d) == 610436        # skips=[4]
     d0 = _lib.MlpDesc(8, 256, 10, 0, 4, 0, 0, 0, 1)
     assert lib.snerf_mlp_param_floats(d0) == 595076       # skips=[]
-    # 151 slabs of 17 KiB + 3 pad slabs (mlp_plan.h)
-    assert lib.snerf_mlp_packed_floats(d) == (151 + 3) * 4352
+    # 77 slabs of 33 KiB (32 A tiles + bias) + 3 pad slabs (mlp_plan.h)
+    assert lib.snerf_mlp_packed_floats(d) == (77 + 3) * 8448
     bad = _lib.MlpDesc(8, 200, 10, 0, 4, 0, 0, 0, 1)
     assert lib.snerf_mlp_param_floats(bad) < 0
     assert lib.snerf_mlp_pack_f32(d, None, None, None) == -1
