@@ -226,8 +226,10 @@ int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const f
 
 /* snerf_mlp_bwd_f32 that also back-propagates into the inputs of snerf_mlp_fwd_train_f32: d_x [n,3] (through
  * the position encoding of layer 0 and the skip layers) and d_dirs [n,3] (through the direction encoding and
- * the normalisation d/|d|, models/smpl_nerf_pipeline.py:54-56).  Needs the input_grad=1 transposed stream;
- * default encoders only (<= 4 position / 2 direction k-blocks). */
+ * the normalisation d/|d|, models/smpl_nerf_pipeline.py:54-56).  Needs the input_grad=1 transposed stream.
+ * Encoders of up to 8 position / 8 direction k-blocks of 16 slots (identity columns, up to 16 frequencies); the
+ * split-precision variant (snerf_mlp_bwd_inputs_bf16_f32) takes the default-sized ones (<= 4 / 2 k-blocks: L = 10 / 4
+ * without identity columns, or smaller). */
 int snerf_mlp_bwd_inputs_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
                              const float *d_raw, const float *x, const float *dirs, int dirs_per_sample,
                              int samples_per_ray, int64_t n, float *dy, float *gpart, float *flat_grad,

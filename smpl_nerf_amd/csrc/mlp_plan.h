@@ -309,6 +309,15 @@ inline int pe_seg_of(const Layer &Ly) {
 }
 // kw = 16: the fp32 stream (k-blocks of 16 forward output rows); kw = 32: the split-bf16 stream (k-blocks of 32;
 // the output tiles stay 16 wide).  P is always the 16-wide plan.
+// Output tiles of the encoder-column transposes the input-gradient dgrad variants are compiled for: the default encoders
+// (<= 4 position / 2 direction k-blocks: L = 10 / 4 without identity columns) or the wide variant (<= 8 / 8: identity
+// columns, up to 16 frequencies).  The packer and the kernel launch make the same choice from the plan.
+struct PeTiles {
+    int pos, dir;
+};
+inline PeTiles bwd_pe_tiles(const Plan &P) {
+    return (P.pos_nkb <= 4 && P.dir_nkb <= 2) ? PeTiles{4, 2} : PeTiles{8, 8};
+}
 inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false, int kw = 16) {
     const int T = P.width / 16, TD = P.width / 32, nh = P.n_hidden;
     const int kdiv = kw / 16;
@@ -321,13 +330,12 @@ inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false, in
         b.nslab = (nkb + kps - 1) / kps;
         slab += b.nslab;
     };
+    const PeTiles pt = bwd_pe_tiles(P);
     auto add_pe = [&](int fwd, int nkb_out_rows) {
         const int s = pe_seg_of(P.layer[fwd]);
         if (input_grad && s >= 0 && P.layer[fwd].seg[s].nkb > 0) {
-            // t_out must divide 16: pad the tile count up to 1, 2, 4, 8 or 16
-            int t = P.layer[fwd].seg[s].nkb, tp = 1;
-            while (tp < t) tp *= 2;
-            add(fwd, s, tp, nkb_out_rows, -1);
+            // padded to the tile count the kernel variant is compiled for (a power of two, so that it divides the slab)
+            add(fwd, s, fwd == nh + 3 ? pt.dir : pt.pos, nkb_out_rows, -1);
         }
     };
     add(nh + 5, 0, TD, 1, -1);       // rgb head^T : d rgb (3) -> d h2

@@ -105,14 +105,14 @@ __device__ __forceinline__ void mask_bits_into(f4 (&dst)[N], const f4 (&src)[N],
 }
 
 // INPUT_GRAD: additionally back-propagates into the network inputs (SmplNerfPipeline: the warped samples and
-// their per-sample view directions are functions of the warp net, models/smpl_nerf_pipeline.py:49-56); only
-// for the default encoders (position k-blocks <= TPP = 4, direction k-blocks <= TPD = 2).
-template <int WIDTH, int NWAVES, bool INPUT_GRAD>
+// their per-sample view directions are functions of the warp net, models/smpl_nerf_pipeline.py:49-56), for
+// encoders of up to TPP position / TPD direction k-blocks (mlp_plan.h: bwd_pe_tiles - 4 / 2 for the default
+// encoders, 8 / 8 for identity columns and up to 16 frequencies).
+template <int WIDTH, int NWAVES, bool INPUT_GRAD, int TPP = 4, int TPD = 2>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;
     constexpr int TD = WIDTH / 32;
-    constexpr int TPP = 4, TPD = 2;
     extern __shared__ __attribute__((aligned(16))) float ring[];  // RING_BYTES (SNERF_LAUNCH_RING)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -667,8 +667,8 @@ static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const f
     const bool input_grad = d_x != nullptr;
     if (input_grad) {
         if (!x || !d_dirs || (desc->use_dir && !dirs) || spr < 1) return fail(SNERF_E_BADARG, "mlp_bwd: input gradients need x, dirs, d_x, d_dirs");
-        if (P.pos_nkb > 4 || P.dir_nkb > 2)
-            return fail(SNERF_E_BADARG, "mlp_bwd: input gradients support at most 4 position / 2 direction encoder k-blocks");
+        if (P.pos_nkb > 8 || P.dir_nkb > 8)
+            return fail(SNERF_E_BADARG, "mlp_bwd: input gradients support at most 8 position / 8 direction encoder k-blocks");
     }
     hipStream_t s = (hipStream_t)stream;
     TrainLayout L;
@@ -705,11 +705,14 @@ static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const f
     constexpr int BW = 8;  // 8 waves = 128 samples per workgroup, like the forward
     const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
+    const bool wide_pe = input_grad && bwd_pe_tiles(P).pos == 8;
     if (P.width == 256) {
-        if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
         else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
     } else {
-        if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
         else SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
     }
     int rc = check_launch("mlp_bwd(dgrad)");

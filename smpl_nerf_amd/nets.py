@@ -93,6 +93,14 @@ def _extra_input_grads(net, desc, dy, n, want_pos, want_dir):
     return d_pa, d_dir
 
 
+def _wide_encoders(desc) -> bool:
+    """More than 4 position / 2 direction encoder k-blocks of 16 slots (csrc/mlp_plan.h: pe_nkb, bwd_pe_tiles)."""
+    def nkb(L, ident):
+        per_lane = (3 * (1 if ident else 0) + 3 * L + 3) // 4
+        return (2 * per_lane + 3) // 4
+    return nkb(desc.pos_freqs, desc.pos_identity) > 4 or (desc.use_dir and nkb(desc.dir_freqs, desc.dir_identity) > 2)
+
+
 def _grads_from_flat(flat, shapes):
     grads, off = [], 0
     for shp in shapes:
@@ -157,6 +165,8 @@ class _FusedMlpFn(torch.autograd.Function):
         dev = d_raw.device
         d_raw = d_raw.contiguous().float()
         ns = ctx.ns      # split-bf16 dgrad and wide wgrad jobs when the forward ran in that mode
+        if ns and ctx.input_grad and _wide_encoders(desc):
+            ns = 0       # input gradients through encoders with identity columns / more frequencies: fp32 dgrad variant only
         packed_t = net.packed_weights_t_bf16(desc, ns, ctx.input_grad) if ns else net.packed_weights_t(desc, ctx.input_grad)
         dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
         gpart = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)

@@ -359,7 +359,7 @@ def test_append_vertices_estimator_receives_gradient(dev):
         total = total + torch.nn.functional.mse_loss(rgb, torch.from_numpy(data[4][sub]))
     total.backward()
     ref = poses.grad.numpy()
-    assert abs(float(loss) - float(total)) <= 2e-6
+    assert abs(loss.item() - total.item()) <= 2e-6
     assert np.abs(ref).max() > 0
     assert np.linalg.norm(got - ref) <= 2e-3 * np.linalg.norm(ref)
 
@@ -390,7 +390,7 @@ def test_additional_inputs_together_with_position_and_direction_gradients(dev, p
     rows = torch.cat(cols + [R.posenc(dn, 4, 0)], -1).view(B * Ns, -1)
     ref_raw = R.render_ray_net(P, rows, **kw)
     (ref_raw * torch.from_numpy(gout)).sum().backward()
-    np.testing.assert_allclose(N(raw), ref_raw.detach().numpy(), rtol=0, atol=2e-4 * float(ref_raw.abs().max()))
+    np.testing.assert_allclose(N(raw), ref_raw.detach().numpy(), rtol=0, atol=2e-4 * float(ref_raw.detach().abs().max()))
     for got, ref, tag in ((x.grad, xc.grad, "x"), (d.grad, dc.grad, "d"), (a.grad, ac.grad, "add")):
         ref = ref.numpy().astype(np.float64)
         assert got is not None, tag
@@ -509,7 +509,7 @@ def _dp_worker(rank, world, port, backend, prec, q):
         sinks = sum(int(p.grad.data_ptr() == v.data_ptr()) for p, v in zip(tr.params, tr._views))
         tr.sync_gradients()
         if rank == 0:
-            q.put(([N(p.grad) for p in tr.params], float(loss), sinks, len(tr.params)))
+            q.put(([N(p.grad) for p in tr.params], loss.item(), sinks, len(tr.params)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -580,3 +580,44 @@ def test_reference_checkpoints_render_on_the_hip_path(dev):
         ow = mw.to(dev)(T(e["warp_rows"], dev))
     assert maxabs(N(oc), e["out_coarse"]) <= 2e-6 and maxabs(N(of), e["out_fine"]) <= 2e-6
     assert maxabs(N(ow), e["out_warp"]) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------ input gradients, other encoders
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("pos,dirs", [((10, 1), (4, 1)), ((16, 0), (8, 1)), ((4, 0), (2, 0)), ((10, 0), (4, 0))])
+def test_position_and_direction_gradients_for_other_encoders(dev, prec, pos, dirs):
+    """d x / d dir through encoders other than the default L = 10 / 4: identity columns (63 / 27 inputs), more
+    frequencies (the wide dgrad variant, 8 encoder k-blocks; split precisions route their backward to it) and fewer
+    (padded encoder tiles).  Against the pinned torch reference: inputs and every parameter."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(23)
+    (pL, pid), (dL, did) = pos, dirs
+    pdim, ddim = 3 * (pid + 2 * pL), 3 * (did + 2 * dL)
+    kw = dict(n_layers=6, skips=(2,), positions_dim=pdim, directions_dim=ddim)
+    params = syn.make_render_ray_net_params(901, 5.0, 3.0, **kw)
+    # damp the high bands so that fp32 round-off in 2^15 x does not dominate the comparison
+    net = RenderRayNet(6, 256, pdim, ddim, skips=[2])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.to(dev)
+    net.precision = prec
+    B, Ns = 19, 5
+    pts = rng.uniform(-1, 1, (B, Ns, 3)).astype(F32) * (2.0 ** -6 if pL > 10 else 1.0)
+    sd = rng.normal(size=(B, Ns, 3)).astype(F32)
+    gout = rng.normal(size=(B * Ns, 4)).astype(F32)
+    x, d = T(pts, dev).requires_grad_(True), T(sd, dev).requires_grad_(True)
+    raw = net.forward_fused(x, d, Ns, PositionalEncoder(pL, pid), PositionalEncoder(dL, did))
+    (raw * T(gout, dev)).sum().backward()
+    P = R.tparams(params)
+    xc, dc = torch.from_numpy(pts).clone().requires_grad_(True), torch.from_numpy(sd).clone().requires_grad_(True)
+    dn = dc / torch.norm(dc, dim=-1, keepdim=True)
+    rows = torch.cat([R.posenc(xc, pL, pid), R.posenc(dn, dL, did)], -1).view(B * Ns, -1)
+    ref_raw = R.render_ray_net(P, rows, **kw)
+    (ref_raw * torch.from_numpy(gout)).sum().backward()
+    np.testing.assert_allclose(N(raw), ref_raw.detach().numpy(), rtol=0, atol=3e-4 * float(ref_raw.detach().abs().max()))
+    for got, ref, tag in ((x.grad, xc.grad, "x"), (d.grad, dc.grad, "d")):
+        ref = ref.numpy().astype(np.float64)
+        assert got is not None and np.linalg.norm(N(got) - ref) <= 3e-3 * np.linalg.norm(ref), (tag, np.linalg.norm(N(got) - ref) / np.linalg.norm(ref))
+    for k, p in net.named_parameters():
+        ref = P[k].grad.numpy().astype(np.float64)
+        assert np.linalg.norm(N(p.grad) - ref) <= 3e-3 * np.linalg.norm(ref), k
