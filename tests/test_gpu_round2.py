@@ -257,8 +257,11 @@ def test_guard_bands_around_every_output_and_scratch_buffer(dev, prec):
             w = T(rng.uniform(0, 1, (B, nc)).astype(F32), dev)
             o, d = T(rng.normal(size=(B, 3)).astype(F32), dev), T(rng.normal(size=(B, 3)).astype(F32), dev)
             ops.hierarchical_samples(o, d, z, w, nf, want_inds=True, want_samples=True)
+            ops.hierarchical_samples(o, d, z, w, nf, want_inds=True, strict=True)      # snerf_sample_pdf_strict_f32
             ops.sample_pdf(T(np.sort(rng.uniform(1, 4, (B, nc)).astype(F32), -1), dev), w[:, :nc - 1].contiguous(),
                            O.Args(number_fine_samples=nf))
+            ops.sample_pdf(T(np.sort(rng.uniform(1, 4, (B, nc)).astype(F32), -1), dev), w[:, :nc - 1].contiguous(),
+                           O.Args(number_fine_samples=nf, strict_cumsum=1))
         gen = RayGenerator(np.stack([syn.sphere_pose(3.0, 4.0, 2.4)] * 2), 16, 24, np.pi / 3, 1.0, 4.0, 64, dev)
         gen.random_batch(37)
         gen.batch(torch.tensor([0, 16 * 24 * 2 - 1, 16 * 24 * 2, -1], device=dev), torch.zeros(4, dtype=torch.float64, device=dev))
