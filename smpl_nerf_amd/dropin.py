@@ -1,0 +1,128 @@
+"""Turn-key drop-in: make an UNMODIFIED checkout of HannesStark/SMPL-NeRF run its ray-march path on
+libsmplnerf_hip.so.
+
+    import smpl_nerf_amd.dropin as dropin
+    dropin.install("/path/to/SMPL-NeRF")      # before (or after) importing the reference's train / inference modules
+
+What it does (INTEGRATION.md sections 1-2 as code):
+  * registers a `torchsearchsorted` package whose `searchsorted` is ops.searchsorted (the reference imports it at
+    utils.py:14 and calls it at utils.py:212);
+  * rebinds, in every module of the reference that is (or later gets) imported, the names of the path's operators and
+    plugin classes to their HIP-backed mirrors: utils.{raw2outputs, sample_pdf, fine_sampling, searchsorted},
+    models.render_ray_net.RenderRayNet, models.warp_field_net.WarpFieldNet, models.append_vertices_net.AppendVerticesNet,
+    models.{nerf,smpl_nerf,append_vertices,append_smpl_params,append_to_nerf}_pipeline.* - including the copies that
+    `from x import y` left in solver/*.py, train.py, inference.py.
+The reference's PositionalEncoder is left alone: the pipelines only read its number_frequencies / include_identity (the
+encoding itself is fused into the MLP kernel), and its encode() works on GPU tensors where a pipeline calls it.
+
+Nothing of the reference is imported unless it already is or `reference_root` is given; nothing is copied.
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.abc
+import sys
+import types
+
+from . import nets, ops, pipelines
+
+# reference module -> {attribute: replacement}
+REPLACEMENTS = {
+    "utils": {"raw2outputs": ops.raw2outputs, "sample_pdf": ops.sample_pdf, "fine_sampling": ops.fine_sampling,
+              "searchsorted": ops.searchsorted},
+    "models.render_ray_net": {"RenderRayNet": nets.RenderRayNet},
+    "models.warp_field_net": {"WarpFieldNet": nets.WarpFieldNet},
+    "models.append_vertices_net": {"AppendVerticesNet": nets.AppendVerticesNet},
+    "models.nerf_pipeline": {"NerfPipeline": pipelines.NerfPipeline},
+    "models.smpl_nerf_pipeline": {"SmplNerfPipeline": pipelines.SmplNerfPipeline},
+    "models.append_vertices_pipeline": {"AppendVerticesPipeline": pipelines.AppendVerticesPipeline},
+    "models.append_smpl_params_pipeline": {"AppendSmplParamsPipeline": pipelines.AppendSmplParamsPipeline},
+    "models.append_to_nerf_pipeline": {"AppendToNerfPipeline": pipelines.AppendToNerfPipeline},
+}
+_NAMES = {name: obj for table in REPLACEMENTS.values() for name, obj in table.items()}
+_originals = {}      # name -> the reference's own object (once seen), to recognise `from x import y` copies
+_installed = False
+
+
+def _register_torchsearchsorted():
+    mod = types.ModuleType("torchsearchsorted")
+    mod.__doc__ = "smpl_nerf_amd drop-in for the reference's native extension package"
+    mod.searchsorted = ops.searchsorted
+    mod.__all__ = ["searchsorted"]
+    sys.modules["torchsearchsorted"] = mod
+
+
+def _patch_module(mod):
+    """Rebind the path's names in one (reference) module; returns how many bindings changed."""
+    table = REPLACEMENTS.get(getattr(mod, "__name__", ""), {})
+    changed = 0
+    for name, new in table.items():           # the defining module: remember the original, then replace it
+        cur = mod.__dict__.get(name)
+        if cur is not None and cur is not new:
+            _originals.setdefault(name, cur)
+            setattr(mod, name, new)
+            changed += 1
+    for name, new in _NAMES.items():          # `from models.x import Y` / `from utils import y` copies elsewhere
+        cur = mod.__dict__.get(name)
+        if cur is not None and cur is not new and cur is _originals.get(name):
+            setattr(mod, name, new)
+            changed += 1
+    return changed
+
+
+def _is_reference_module(mod, root):
+    f = getattr(mod, "__file__", None)
+    return bool(f) and (root is None or f.startswith(root.rstrip("/") + "/"))
+
+
+class _PatchOnImport(importlib.abc.MetaPathFinder):
+    """After any later import of a reference module, patch it (and re-sweep: it may have pulled in others)."""
+
+    def __init__(self, root):
+        self.root = root
+        self._busy = False
+
+    def find_spec(self, fullname, path, target=None):
+        if self._busy or not (fullname in REPLACEMENTS or fullname.split(".")[0] in ("solver", "models", "train", "inference",
+                                                                                     "utils", "render")):
+            return None
+        self._busy = True
+        try:
+            spec = importlib.util.find_spec(fullname)
+        finally:
+            self._busy = False
+        if spec is None or spec.loader is None or not (spec.origin or "").startswith((self.root or "") ):
+            return None
+        loader, root = spec.loader, self.root
+
+        class _Loader(importlib.abc.Loader):
+            def create_module(self, s):
+                return loader.create_module(s)
+
+            def exec_module(self, module):
+                loader.exec_module(module)
+                sweep(root)
+
+        spec.loader = _Loader()
+        return spec
+
+
+def sweep(reference_root=None) -> int:
+    """Patch every already-imported module of the reference (defining modules first); returns the number of rebindings."""
+    mods = [m for m in list(sys.modules.values()) if isinstance(m, types.ModuleType) and _is_reference_module(m, reference_root)]
+    mods.sort(key=lambda m: 0 if m.__name__ in REPLACEMENTS else 1)
+    return sum(_patch_module(m) for m in mods)
+
+
+def install(reference_root: str = None) -> int:
+    """See the module docstring.  Idempotent; returns the number of names rebound by this call."""
+    global _installed
+    import importlib.util  # noqa: F401  (used by the finder)
+    _register_torchsearchsorted()
+    if reference_root and reference_root not in sys.path:
+        sys.path.insert(0, reference_root)
+    n = sweep(reference_root)
+    if not _installed:
+        sys.meta_path.insert(0, _PatchOnImport(reference_root))
+        _installed = True
+    return n

@@ -1,0 +1,72 @@
+"""smpl_nerf_amd.dropin against the real reference checkout (build container only: skipped where /root/reference is
+absent, i.e. on the GPU box).  Wiring only - no compute: after install() the reference's own Solver / inference modules
+hold the HIP-backed classes and operators."""
+import importlib
+import importlib.util
+import os
+import sys
+
+import pytest
+
+REF = os.environ.get("SNERF_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "models")), reason="reference checkout not present")
+
+
+def test_install_rebinds_the_reference_modules():
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    before = set(sys.modules)
+    for name in ("cv2", "imageio"):                      # third-party modules the image lacks; never called here
+        mg._stub(name)
+    tm = mg._stub("trimesh")
+    tm.base = mg._stub("trimesh.base", Trimesh=object)
+    tm.ray = mg._stub("trimesh.ray")
+    tm.ray.ray_triangle = mg._stub("trimesh.ray.ray_triangle", RayMeshIntersector=object)
+    try:
+        importlib.import_module("torch.utils.tensorboard")
+    except Exception:
+        mg._stub("torch.utils.tensorboard", SummaryWriter=object)
+    saved = {k: sys.modules.get(k) for k in list(sys.modules)
+             if k.split(".")[0] in ("utils", "models", "solver", "torchsearchsorted")}
+    saved_path, saved_meta = list(sys.path), list(sys.meta_path)
+    from smpl_nerf_amd import dropin, nets, ops, pipelines
+    try:
+        for k in list(saved):
+            sys.modules.pop(k, None)
+        dropin._installed = False
+        dropin._originals.clear()
+        dropin.install(REF)
+        import torchsearchsorted
+        assert torchsearchsorted.searchsorted is ops.searchsorted
+        U = importlib.import_module("utils")                       # the reference's utils.py (imports torchsearchsorted)
+        assert U.searchsorted is ops.searchsorted and U.raw2outputs is ops.raw2outputs
+        assert U.fine_sampling is ops.fine_sampling and U.sample_pdf is ops.sample_pdf
+        NS = importlib.import_module("solver.nerf_solver")         # solver/nerf_solver.py:5 `from models.nerf_pipeline import ...`
+        assert NS.NerfPipeline is pipelines.NerfPipeline
+        SS = importlib.import_module("solver.smpl_nerf_solver")
+        assert SS.SmplNerfPipeline is pipelines.SmplNerfPipeline
+        M = importlib.import_module("models.render_ray_net")
+        assert M.RenderRayNet is nets.RenderRayNet
+        NP = importlib.import_module("models.nerf_pipeline")
+        assert NP.NerfPipeline is pipelines.NerfPipeline and NP.raw2outputs is ops.raw2outputs
+        assert importlib.import_module("models.warp_field_net").WarpFieldNet is nets.WarpFieldNet
+        AP = importlib.import_module("models.append_smpl_params_pipeline")
+        assert AP.AppendSmplParamsPipeline is pipelines.AppendSmplParamsPipeline
+        # the reference's own encoder class is kept and is what our pipelines accept
+        enc = U.PositionalEncoder(10, False)
+        pipe = NS.NerfPipeline(nets.RenderRayNet(), nets.RenderRayNet(), object(), enc, U.PositionalEncoder(4, False))
+        d = pipe.model_coarse.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder)
+        assert (d.pos_freqs, d.dir_freqs, d.pos_identity) == (10, 4, 0)
+        assert dropin.install(REF) == 0                            # idempotent
+    finally:
+        sys.meta_path[:] = saved_meta
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "models", "solver", "torchsearchsorted")]:
+            sys.modules.pop(k, None)
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+        dropin._installed = False
+        for k in set(sys.modules) - before:               # the stand-ins and whatever the reference pulled in
+            if k.split(".")[0] in ("cv2", "imageio", "trimesh", "camera", "render", "make_golden") or k == "torch.utils.tensorboard":
+                sys.modules.pop(k, None)
