@@ -113,10 +113,12 @@ def _grads_from_flat(flat, shapes):
 
 
 class _FusedMlpFn(torch.autograd.Function):
-    """raw = RenderRayNet(encode(x), encode(normalise(d))) with gradients for every weight and bias.
-    Forward saves the layer inputs in the tile-row-major activation buffer; backward = dgrad + split-K
-    wgrad + reduce (snerf_mlp_bwd_f32).  Positions and directions get no gradient (they are leaves in
-    NerfPipeline: the hierarchical samples are detached, utils.py:260)."""
+    """raw = RenderRayNet(encode(x), encode(normalise(d))) with gradients for every weight and bias and, where the caller's
+    graph asks for them, for the inputs: positions / per-sample directions (SmplNerfPipeline: the dgrad kernel's
+    input-gradient variant), per-ray additional inputs and already-encoded rows (contractions of the stored d Y_l,
+    _extra_input_grads).  Forward saves the layer inputs in the tile-row-major activation buffer; backward = dgrad +
+    split-K wgrad + reduce (snerf_mlp_bwd_*).  In NerfPipeline positions and directions are leaves (the hierarchical
+    samples are detached, utils.py:260) and only the parameters receive gradients."""
 
     @staticmethod
     def forward(ctx, net, desc, x, d, per_sample, spr, add, *params):
@@ -126,7 +128,7 @@ class _FusedMlpFn(torch.autograd.Function):
         net._begin_training_forward()
         split = net.width == 256 and per_sample != _ENCODED_ROWS
         ns_fwd = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}.get(net.precision, 0) if split else 0
-        ns = ns_fwd   # (the f16x3 backward: dgrad with two fp16 parts, wide wgrad with three bf16 parts)
+        ns = ns_fwd   # the backward runs in the forward's mode (f16x3: dgrad and wgrad GEMMs with two fp16 parts)
         packed = net.packed_weights_bf16(desc, ns_fwd, training=True) if ns else net.packed_weights(desc, training=True)
         sizes = [ctypes.c_int64() for _ in range(4)]
         cnt = ctypes.c_int32()
