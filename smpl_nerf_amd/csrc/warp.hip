@@ -6,6 +6,8 @@
 // layer runs on v_mfma_f32_16x16x4_f32 with the encoding evaluated in registers (the pose encoding is a
 // per-ray constant read as "additional input"), the 256 -> 3 head is one padded tile.  52 736 FLOP per
 // sample (4 % of a RenderRayNet evaluation); HBM: 12 B in, 36 B out per sample.
+#include <stdlib.h>
+
 #include "warp_plan.h"
 
 namespace snerf {
@@ -99,6 +101,100 @@ __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_kernel(WarpArgs A) {
                 s[0] = __fsub_rn(wx, op[0]);
                 s[1] = __fsub_rn(wy, op[1]);
                 s[2] = __fsub_rn(wz, op[2]);
+            }
+        }
+    }
+}
+
+// The same forward with the WHOLE net resident in LDS.  The streaming kernel above pays 5 slabs (165 KB of L2 -> LDS
+// traffic, five workgroup barriers) per 64 samples for 128 MFMAs per wave, one wave per SIMD: 3.3 ms per 128x128 frame,
+// a quarter of the matrix peak.  The warp net is small - linear1: T x nkb tiles of 1 KiB, linear2: T tiles, two bias
+// blocks: 130 KiB at width 256 with the default encoders - so a persistent workgroup copies it into LDS once and then
+// walks its sample tiles with no barrier and no weight traffic at all; the A-operand prefetch of kblock() runs on across
+// layers and tiles.  Used whenever the net fits (warp_resident_bytes <= 160 KiB - what the hardware has).
+__host__ __device__ inline int warp_resident_bytes(int T, int nkb0) { return (T * nkb0 + T + 2) * 1024; }
+
+template <int WIDTH, int NWAVES, bool TRAIN>
+__global__ __launch_bounds__(NWAVES * 64) void warp_fwd_resident_kernel(WarpArgs A) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int T = WIDTH / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nkb0 = A.pos_nkb + A.add_nkb;
+    float *w1 = lds;                       // [nkb0][T][64 lanes][4]
+    float *w2 = w1 + nkb0 * T * 256;       // [T k-blocks][1 tile]
+    float *b1 = w2 + T * 256;              // 256 floats (the aux block of linear1's first slab)
+    float *b2 = b1 + 256;
+    {   // slab stream -> dense LDS image (tile t of a layer sits in slab t / SLAB_TILES at index t % SLAB_TILES)
+        const f4 *src = reinterpret_cast<const f4 *>(A.packed);
+        f4 *dst = reinterpret_cast<f4 *>(lds);
+        const int n1 = nkb0 * T * 64, n2 = T * 64;   // f4 counts
+        for (int e = tid; e < n1; e += NT) {
+            const int t = e >> 6;
+            dst[e] = src[(int64_t)(t / SLAB_TILES) * (SLAB_FLOATS / 4) + (t % SLAB_TILES) * 64 + (e & 63)];
+        }
+        for (int e = tid; e < n2; e += NT) dst[n1 + e] = src[(int64_t)A.l1_slab * (SLAB_FLOATS / 4) + e];
+        for (int e = tid; e < 64; e += NT) {
+            dst[n1 + n2 + e] = src[SLAB_A_FLOATS / 4 + e];
+            dst[n1 + n2 + 64 + e] = src[(int64_t)A.l1_slab * (SLAB_FLOATS / 4) + SLAB_A_FLOATS / 4 + e];
+        }
+    }
+    __syncthreads();
+    const f4 *first = reinterpret_cast<const f4 *>(w1) + lane;
+    f4 pa0 = first[0], pa1 = first[64];   // first A pair of the first k-block; kblock() keeps the prefetch rolling
+    for (int64_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
+        const bool valid = sample < A.n;
+        const int64_t sc = valid ? sample : A.n - 1;
+        const int64_t ray = sc / A.spr;
+        SampleCtx c;
+        c.g = lane >> 4;
+        c.enc = nullptr;
+        c.px = c.py = c.pz = c.dx = c.dy = c.dz = 0.f;
+        if (A.x) {
+            c.px = A.x[sc * 3 + 0];
+            c.py = A.x[sc * 3 + 1];
+            c.pz = A.x[sc * 3 + 2];
+        }
+        c.add = A.add_dim ? A.add + ray * A.add_dim : nullptr;
+        f4 in[T], acc[T];
+        {
+            const f4 *aux = reinterpret_cast<const f4 *>(b1) + (lane >> 4);
+#pragma unroll
+            for (int to = 0; to < T; ++to) acc[to] = aux[to * 4];
+        }
+        for (int kb = 0; kb < nkb0; ++kb) {
+            f4 b;
+            if (kb < A.pos_nkb) b = pe_operand<false>(c, false, A.pos_L, A.pos_id, kb, 0);
+            else b = add_operand(c, A.add_dim, kb - A.pos_nkb);
+            if (TRAIN && valid) store_tile(A.act, kb, A.n, sample, c.g, b);
+            const float *cur = w1 + kb * (T * 256);
+            kblock<T>(cur, kb + 1 < nkb0 ? cur + T * 256 : w2, b, acc, pa0, pa1, lane);
+        }
+        relu_into(in, acc);
+        if (TRAIN && valid) store_tiles(A.act, nkb0, A.n, sample, c.g, in);
+        f4 w[1];
+        w[0] = reinterpret_cast<const f4 *>(b2)[lane >> 4];
+#pragma unroll
+        for (int kb = 0; kb < T; ++kb) kblock<1>(w2 + kb * 256, kb + 1 < T ? w2 + (kb + 1) * 256 : w1, in[kb], w, pa0, pa1, lane);
+        if (valid && c.g == 0) {
+            float *wp = A.warp + sample * 3;
+            wp[0] = w[0][0];
+            wp[1] = w[0][1];
+            wp[2] = w[0][2];
+            if (A.warped) {
+                const float wx = __fadd_rn(c.px, w[0][0]), wy = __fadd_rn(c.py, w[0][1]), wz = __fadd_rn(c.pz, w[0][2]);
+                float *q = A.warped + sample * 3;
+                q[0] = wx;
+                q[1] = wy;
+                q[2] = wz;
+                if (A.sdirs) {
+                    const float *op = A.o + ray * 3;
+                    float *s = A.sdirs + sample * 3;
+                    s[0] = __fsub_rn(wx, op[0]);
+                    s[1] = __fsub_rn(wy, op[1]);
+                    s[2] = __fsub_rn(wz, op[2]);
+                }
             }
         }
     }
@@ -285,10 +381,50 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
     A.add_dim = P.add_dim;
     A.add_nkb = P.add_nkb;
     A.act = act;
+    hipStream_t s = (hipStream_t)stream;
+    {   // the LDS-resident persistent kernel whenever the net fits the 160 KiB of a CU (SNERF_WARP_RESIDENT=0: streaming kernel)
+        static const bool resident = !(getenv("SNERF_WARP_RESIDENT") && atoi(getenv("SNERF_WARP_RESIDENT")) == 0);
+        const int T = P.width / 16, nkb0 = P.pos_nkb + P.add_nkb;
+        const int bytes = warp_resident_bytes(T, nkb0);
+        if (resident && bytes <= 160 * 1024) {
+            // inference: 16 waves (121 registers: 4 waves per SIMD cover each other's sincos phases); training forward: 8
+            const int RW = act ? 8 : 16;
+            A.l1_slab = P.layer[1].first_slab;
+            A.n_tiles = (n + RW * 16 - 1) / (RW * 16);
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+                    return fail(SNERF_E_LAUNCH, "warp_fwd: cannot query the CU count");
+                n_cu = cus;
+            }
+            const int64_t g = A.n_tiles < n_cu ? A.n_tiles : n_cu;
+#define SNERF_WARP_RES(W_, RW_, TR_)                                                                                      \
+    do {                                                                                                                  \
+        static int raised = 0;                                                                                            \
+        if (raised < bytes) {                                                                                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(warp_fwd_resident_kernel<W_, RW_, TR_>),                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                \
+                return fail(SNERF_E_LAUNCH, "warp_fwd: cannot raise the dynamic LDS limit");                              \
+            raised = 160 * 1024;                                                                                          \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((warp_fwd_resident_kernel<W_, RW_, TR_>), dim3((unsigned)g), dim3(RW_ * 64), bytes, s, A);      \
+    } while (0)
+            if (P.width == 256) {
+                if (act) SNERF_WARP_RES(256, 8, true);
+                else SNERF_WARP_RES(256, 16, false);
+            } else {
+                if (act) SNERF_WARP_RES(128, 8, true);
+                else SNERF_WARP_RES(128, 16, false);
+            }
+#undef SNERF_WARP_RES
+            return check_launch("warp_fwd(resident)");
+        }
+    }
     constexpr int NW = 4;
     const int64_t grid = (n + NW * 16 - 1) / (NW * 16);
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_fwd: n too large");
-    hipStream_t s = (hipStream_t)stream;
     if (P.width == 256) {
         if (act) SNERF_LAUNCH_RING((warp_fwd_kernel<256, NW, true>), dim3((unsigned)grid), dim3(NW * 64), s, A);
         else SNERF_LAUNCH_RING((warp_fwd_kernel<256, NW, false>), dim3((unsigned)grid), dim3(NW * 64), s, A);

@@ -15,6 +15,8 @@ struct WarpArgs {
     int spr;
     int pos_L, pos_id, pos_nkb, add_dim, add_nkb;
     float *act;  // training: tile-row-major [pe | pose | h] (see warp_train_layout)
+    int l1_slab;        // first slab of linear2 in the stream (resident kernel)
+    int64_t n_tiles;    // sample tiles (resident kernel: persistent workgroups)
 };
 
 }  // namespace snerf
