@@ -239,6 +239,47 @@ __global__ __launch_bounds__(NWAVES * 64) void warp_bwd_kernel(WarpBwdArgs A) {
     if (valid) store_tiles(A.dy, 0, A.n, sample, g, dh);
 }
 
+// The same without the slab ring: the transposed head is ONE k-block of T tiles (T KiB), so a workgroup keeps it in a
+// small static LDS block and walks its sample tiles; the ring version above loaded three 33 KiB slabs per 64 samples and,
+// with its 99 KiB of LDS, ran one 4-wave workgroup per CU - for a kernel that only moves 2 KB per sample.
+template <int WIDTH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void warp_bwd_light_kernel(WarpBwdArgs A, int64_t n_tiles) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int T = WIDTH / 16;
+    __shared__ __attribute__((aligned(16))) float wt[T * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    for (int e = tid; e < T * 64; e += NT) reinterpret_cast<f4 *>(wt)[e] = reinterpret_cast<const f4 *>(A.packed_t)[e];
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t sample = (tile * NWAVES + wave) * 16 + (lane & 15);
+        const bool valid = sample < A.n;
+        const int64_t sc = valid ? sample : A.n - 1;
+        const float *dp = A.d_warp + sc * 3;
+        const f4 dw = g == 0 ? f4{dp[0], dp[1], dp[2], 0.f} : f4{0.f, 0.f, 0.f, 0.f};
+        if (valid) store_tile(A.dy, T, A.n, sample, g, dw);
+        f4 m[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) m[t] = load_tile(A.act, A.h_row + t, A.n, sc, g);   // in flight behind the MFMAs
+        f4 dh[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f4 a = reinterpret_cast<const f4 *>(wt)[t * 64 + lane];
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], dw[r], acc, 0, 0, 0);
+            dh[t] = acc;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            dh[t][0] = m[t][0] > 0.f ? dh[t][0] : 0.f;
+            dh[t][1] = m[t][1] > 0.f ? dh[t][1] : 0.f;
+            dh[t][2] = m[t][2] > 0.f ? dh[t][2] : 0.f;
+            dh[t][3] = m[t][3] > 0.f ? dh[t][3] : 0.f;
+        }
+        if (valid) store_tiles(A.dy, 0, A.n, sample, g, dh);
+    }
+}
+
 // in mlp_train.hip
 int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, float *packed_t, hipStream_t s, const char *what);
 
@@ -293,14 +334,23 @@ extern "C" int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *pack
     TrainLayout L;
     warp_train_layout(P, L);
     WarpBwdArgs A{packed_t, act, d_warp, dy, n, L.x[1]};
-    constexpr int NW = 4;
-    const int64_t grid = (n + NW * 16 - 1) / (NW * 16);
-    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_bwd: n too large");
     hipStream_t s = (hipStream_t)stream;
-    if (P.width == 256)
-        SNERF_LAUNCH_RING((warp_bwd_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
-    else
-        SNERF_LAUNCH_RING((warp_bwd_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
+    static const bool light = !(getenv("SNERF_WARP_BWD_RING") && atoi(getenv("SNERF_WARP_BWD_RING")) == 1);
+    if (light) {   // ring-free kernel (SNERF_WARP_BWD_RING=1: the slab-ring version, for A/B runs)
+        constexpr int LW = 8;
+        const int64_t n_tiles = (n + LW * 16 - 1) / (LW * 16);
+        const int64_t g = n_tiles < 2048 ? n_tiles : 2048;   // grid-stride over the sample tiles
+        if (P.width == 256) hipLaunchKernelGGL((warp_bwd_light_kernel<256, LW>), dim3((unsigned)g), dim3(LW * 64), 0, s, A, n_tiles);
+        else hipLaunchKernelGGL((warp_bwd_light_kernel<128, LW>), dim3((unsigned)g), dim3(LW * 64), 0, s, A, n_tiles);
+    } else {
+        constexpr int NW = 4;
+        const int64_t grid = (n + NW * 16 - 1) / (NW * 16);
+        if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_bwd: n too large");
+        if (P.width == 256)
+            SNERF_LAUNCH_RING((warp_bwd_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
+        else
+            SNERF_LAUNCH_RING((warp_bwd_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
+    }
     int rc = check_launch("warp_bwd");
     if (rc) return rc;
     return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);
