@@ -20,7 +20,26 @@
  *   - return value: 0 on success, <0 = SNERF_E_*; nothing throws across the ABI.
  *     snerf_last_error_string() describes the last failure on the calling thread.
  *   - row-major, densely packed fp32 tensors; indices are int64 (torch.long) like the reference.
- *   - no global mutable state; re-entrant and thread-safe.
+ *   - re-entrant and thread-safe; calls act on the calling thread's current HIP device.
+ *
+ * State.  The library keeps no caller-visible state between calls.  What it does keep, process-wide:
+ *   - the error text of the last failure, per thread (snerf_last_error_string);
+ *   - per HIP device ordinal (up to 64 devices): the CU count and, per kernel, whether its dynamic-LDS limit was
+ *     raised (hipFuncSetAttribute is per device) - so one process may drive several GPUs through the library;
+ *   - tuning knobs: the environment variables below are read ONCE, at the first call that consults them.  They choose
+ *     between equivalent kernels / launch shapes for A/B measurements; results are identical under every setting, and
+ *     a release build can ignore them.  (unset = default)
+ *       SNERF_FWD_PERSISTENT=0            fp32 render kernel: one workgroup per 128-sample tile instead of one per CU
+ *       SNERF_FWD_WAVES=4                 fp32 kernels: two 4-wave workgroups per CU instead of one 8-wave workgroup
+ *       SNERF_BF16_PERSISTENT=0           split-precision forward / dgrad: one workgroup per tile
+ *       SNERF_WARP_RESIDENT=0             warp net: slab-streaming kernel instead of the LDS-resident one
+ *       SNERF_WARP_BWD_RING=1             warp backward: slab-ring dgrad instead of the ring-free one
+ *       SNERF_WGRAD_BF16=0                split-precision steps: all weight-gradient GEMMs in fp32
+ *       SNERF_WGRAD_F16=0                 f16x3 steps: three bf16 parts for the wide weight-gradient GEMMs
+ *       SNERF_WGRAD_NARROW_F16=0          f16x3 steps: narrow weight-gradient jobs in fp32
+ *       SNERF_WGRAD_F16_SPLIT_PER_WAVE=1  f16x3 wide weight-gradient GEMMs: every wave converts its own operands
+ *       SNERF_WGRAD_NARROW_STAGED=0       fp32 steps: narrow weight-gradient jobs in the single-wave direct kernel
+ *     (smpl_nerf_amd/ reads one more, on the Python side only: SNERF_PRECISION = default arithmetic of new nets.)
  */
 #ifndef SMPLNERF_H
 #define SMPLNERF_H
@@ -32,7 +51,8 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 101 /* 0.1.1 */
+#define SNERF_VERSION 102 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+                             snerf_composite_bwd_all_f32, snerf_mlp_bwd_chunk_*; composite forward accepts any N */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -57,19 +77,35 @@ int snerf_searchsorted_f32(const float *a, int64_t nrow_a, int64_t ncol_a,
                            const float *v, int64_t nrow_v, int64_t ncol_v,
                            int64_t *out, int side_left, snerf_stream_t stream);
 
+/* The same for every scalar type the reference dispatches (AT_DISPATCH_ALL_TYPES, searchsorted_cpu_wrapper.cpp:100,
+ * searchsorted_cuda_kernel.cu:132); `a` and `v` have the same element type `dtype`. */
+#define SNERF_DTYPE_F32 0
+#define SNERF_DTYPE_F64 1
+#define SNERF_DTYPE_I32 2
+#define SNERF_DTYPE_I64 3
+#define SNERF_DTYPE_I16 4
+#define SNERF_DTYPE_I8 5
+#define SNERF_DTYPE_U8 6
+int snerf_searchsorted(int dtype, const void *a, int64_t nrow_a, int64_t ncol_a, const void *v, int64_t nrow_v,
+                       int64_t ncol_v, int64_t *out, int side_left, snerf_stream_t stream);
+
 /* ---- a1: positional encoding ----------------------------------------------------------------
  * x [n, c] -> out [n, c*(identity + 2*L)], frequency-major: [x] [sin(2^0 x) cos(2^0 x)] ...
  * (utils.py:116-131; no pi factor). */
 int snerf_posenc_f32(const float *x, int64_t n, int c, int L, int identity, float *out,
                      snerf_stream_t stream);
 
+/* Backward of the encoding: d_out [n, c*(identity + 2*L)] -> d_x [n, c] (autograd through utils.py:123-131). */
+int snerf_posenc_bwd_f32(const float *x, const float *d_out, int64_t n, int c, int L, int identity, float *d_x,
+                         snerf_stream_t stream);
+
 /* ---- a4: alpha compositing --------------------------------------------------------------------
  * raw [B, N, 4] (r, g, b, sigma), z [B, N], dirs: [B, 3] when dirs_per_sample == 0 (the ray
  * direction broadcast over samples) or [B, N, 3]; dists are scaled by ||dirs|| (utils.py:165).
  * noise: nullable [B, N], added to sigma before relu (utils.py:171-173; the caller draws it).
  * rgb [B, 3], weights [B, N], alpha [B, N] (any of the three may be NULL to skip the store).
- * N == 1 reproduces the reference's early return (utils.py:168-169): weights = alpha = 1.  1 <= N <= 4096 (forward and
- * backward accept the same range). */
+ * N == 1 reproduces the reference's early return (utils.py:168-169): weights = alpha = 1.  Any N >= 1 (the backward
+ * entry points take N <= 4096). */
 int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
                             const float *noise, int64_t B, int N, int white_background,
                             float *rgb, float *weights, float *alpha, snerf_stream_t stream);
@@ -82,6 +118,16 @@ int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs,
                             const float *noise, int64_t B, int N, int white_background,
                             const float *d_rgb, float *d_raw, float *d_dirs /* nullable, [B,N,3]: only with per-sample
                             directions (dists are scaled by their norm, utils.py:165) */, snerf_stream_t stream);
+
+/* The complete backward of raw2outputs (utils.py:134-191 under autograd): gradients arriving at ALL three outputs -
+ * d_rgb [B,3], d_weights [B,N], d_alpha [B,N], each nullable (= zeros) - are propagated to d_raw [B,N,4] and, on request,
+ * to the directions (d_dirs: [B,N,3] with per-sample directions, [B,3] otherwise; dists are scaled by their norm,
+ * utils.py:165) and to the depths (d_z [B,N]; the last interval is the constant 1e10, utils.py:164).  N <= 4096.  N == 1:
+ * weights and alpha are constants, d_dirs = d_z = 0. */
+int snerf_composite_bwd_all_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+                                const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
+                                const float *d_weights, const float *d_alpha, float *d_raw, float *d_dirs /* nullable */,
+                                float *d_z /* nullable */, snerf_stream_t stream);
 
 /* ---- a5: inverse-CDF hierarchical sampling + merge + point generation ------------------------------
  * z [B, Nc] coarse depths (ascending), weights [B, Nc] from compositing, u [Nf] = linspace(0,1,Nf)

@@ -1,4 +1,6 @@
 // Version / error plumbing of the C-ABI (include/smplnerf.h).
+#include <stdlib.h>
+
 #include "snerf_common.h"
 
 namespace snerf {
@@ -12,6 +14,61 @@ int fail(int code, const char *fmt, ...) {
     vsnprintf(err_buf(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+int device_cu_count(const char *what) {
+    static std::atomic<int> cus[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        (void)hipGetLastError();
+        return fail(SNERF_E_LAUNCH, "%s: cannot query the current device", what);
+    }
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return fail(SNERF_E_LAUNCH, "%s: cannot query the CU count of device %d", what, dev);
+    }
+    cus[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+int raise_dynamic_lds(const void *kernel, int bytes, LdsRaised &state, const char *what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        (void)hipGetLastError();
+        return fail(SNERF_E_LAUNCH, "%s: cannot query the current device", what);
+    }
+    if (state.bytes[dev].load(std::memory_order_relaxed) >= bytes) return SNERF_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(SNERF_E_LAUNCH, "%s: cannot raise the dynamic LDS limit to %d bytes on device %d", what, bytes, dev);
+    }
+    state.bytes[dev].store(bytes, std::memory_order_relaxed);
+    return SNERF_OK;
+}
+
+const Tuning &tuning() {
+    static const Tuning t = [] {   // C++11 magic static: initialised once, thread-safe
+        auto flag = [](const char *name, bool dflt) {
+            const char *e = getenv(name);
+            return e ? atoi(e) != 0 : dflt;
+        };
+        Tuning k;
+        k.fwd_persistent = flag("SNERF_FWD_PERSISTENT", true);
+        const char *w = getenv("SNERF_FWD_WAVES");
+        k.fwd_waves = (w && atoi(w) == 4) ? 4 : 8;
+        k.bf16_persistent = flag("SNERF_BF16_PERSISTENT", true);
+        k.warp_resident = flag("SNERF_WARP_RESIDENT", true);
+        k.warp_bwd_ring = flag("SNERF_WARP_BWD_RING", false);
+        k.wgrad_bf16 = flag("SNERF_WGRAD_BF16", true);
+        k.wgrad_f16 = flag("SNERF_WGRAD_F16", true);
+        k.wgrad_narrow_f16 = flag("SNERF_WGRAD_NARROW_F16", true);
+        k.wgrad_f16_split_per_wave = flag("SNERF_WGRAD_F16_SPLIT_PER_WAVE", false);
+        k.wgrad_narrow_staged = flag("SNERF_WGRAD_NARROW_STAGED", true);
+        return k;
+    }();
+    return t;
 }
 }  // namespace snerf
 

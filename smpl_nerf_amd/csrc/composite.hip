@@ -98,35 +98,43 @@ __global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
     }
 }
 
-// ---- backward: d rgb [B,3] -> d raw [B,N,4] --------------------------------------------------------
+// ---- backward: (d rgb [B,3], d weights [B,N], d alpha [B,N]) -> d raw [B,N,4] (, d dirs, d z) -------------------------
 // With c = sigmoid(raw.rgb), a = alpha, om = 1-a+1e-10, T = exclusive cumprod(om), w = a*T:
 //   d c_i  = w_i * d rgb                      d raw.rgb_i = d c_i * c_i (1 - c_i)
-//   d w_i  = <d rgb, c_i> - [white bg] sum(d rgb)
-//   d a_j  = d w_j T_j - (sum_{i>j} d w_i w_i) / om_j        (T_i depends on om_j for every i > j)
+//   G_i    = <d rgb, c_i> - [white bg] sum(d rgb) + d weights_i                  (everything that arrives at w_i)
+//   d a_j  = G_j T_j - (sum_{i>j} G_i w_i) / om_j + d alpha_j                    (T_i depends on om_j for every i > j)
 //   d sigma_j = d a_j * dist_j * exp(-relu(sigma_j) dist_j) * [sigma_j + noise_j > 0]
+//   d dist_j  = d a_j * relu(sigma_j) * exp(..);  dist_j = (z_{j+1} - z_j) |dir_j|  =>  d z, d dir
 // One wave per ray: a forward sweep records the transmittance carried into every 64-sample chunk, a
 // reverse sweep recomputes each chunk and runs the suffix sum as a reverse wavefront scan (fp64).
 // HBM: raw and z are read twice (40 B/sample), d raw written once (16 B/sample).
-constexpr int CP_MAX_CHUNKS = 64;  // N <= 4096 (forward and backward accept the same range)
+constexpr int CP_MAX_CHUNKS = 64;  // backward: N <= 4096
 
 __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
     const float4 *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs, int dirs_per_sample,
     const float *__restrict__ noise, int64_t B, int N, int white_bg, const float *__restrict__ d_rgb,
-    float4 *__restrict__ d_raw, float *__restrict__ d_dirs) {
+    const float *__restrict__ d_w, const float *__restrict__ d_a, float4 *__restrict__ d_raw, float *__restrict__ d_dirs,
+    float *__restrict__ d_z) {
     __shared__ double s_carry[CP_THREADS / WAVE][CP_MAX_CHUNKS];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * (CP_THREADS / WAVE) + wave;
     if (ray >= B) return;
     const int64_t base = ray * N;
-    const float gr = d_rgb[ray * 3 + 0], gg = d_rgb[ray * 3 + 1], gb = d_rgb[ray * 3 + 2];
+    float gr = 0.f, gg = 0.f, gb = 0.f;
+    if (d_rgb) {
+        gr = d_rgb[ray * 3 + 0];
+        gg = d_rgb[ray * 3 + 1];
+        gb = d_rgb[ray * 3 + 2];
+    }
     if (N == 1) {  // rgb = sigmoid(raw.rgb); weights/alpha are constants (utils.py:168-169)
         if (lane == 0) {
             const float4 r = raw[base];
             const float cr = sigmoidf_ref(r.x), cg = sigmoidf_ref(r.y), cb = sigmoidf_ref(r.z);
             d_raw[base] = make_float4(gr * cr * (1.f - cr), gg * cg * (1.f - cg), gb * cb * (1.f - cb), 0.f);
+            if (d_z) d_z[base] = 0.f;
         }
-        if (d_dirs && lane < 3) d_dirs[base * 3 + lane] = 0.f;
+        if (d_dirs && lane < 3) d_dirs[(dirs_per_sample ? base : ray) * 3 + lane] = 0.f;
         return;
     }
     float ray_norm = 0.f;
@@ -167,7 +175,9 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
     }
     const float gsum = white_bg ? (gr + gg + gb) : 0.f;
     // reverse sweep
-    double suffix = 0.0;  // sum_{i > last sample of this chunk} d w_i * w_i
+    double suffix = 0.0;   // sum_{i > last sample of this chunk} G_i * w_i
+    float ray_dd = 0.f;    // sum_i d dist_i * delta_i (ray-direction gradient)
+    float z_pend = 0.f;    // lane 0: -e_i of the first sample of the chunk processed last, waiting for e_{i-1}
     for (int c = nchunk - 1; c >= 0; --c) {
         const int i = c * WAVE + lane;
         const bool ok = i < N;
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
         const float T = (float)(s_carry[wave][c] * excl);
         const float w = a * T;
         const float cr = sigmoidf_ref(r.x), cg = sigmoidf_ref(r.y), cb = sigmoidf_ref(r.z);
-        const float dw = ok ? (gr * cr + gg * cg + gb * cb - gsum) : 0.f;
+        float dw = ok ? (gr * cr + gg * cg + gb * cb - gsum) : 0.f;
+        if (ok && d_w) dw += d_w[base + i];
         const double q = (double)dw * (double)w;
         // exclusive reverse scan of q over the lanes + what came from the later chunks
         double incl_rev = q;
@@ -191,20 +202,42 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
         }
         const double after = incl_rev - q + suffix;
         suffix += __shfl(incl_rev, 0, 64);
+        float e = 0.f;   // d loss / d delta_i = d dist_i * |dir_i|
         if (ok) {
-            const float da = dw * T - (float)(after / (double)om);
+            float da = dw * T - (float)(after / (double)om);
+            if (d_a) da += d_a[base + i];
             const float dsig = sig > 0.f ? da * dist * ex : 0.f;  // ex = exp(-relu(sigma) dist)
             d_raw[base + i] = make_float4(w * gr * cr * (1.f - cr), w * gg * cg * (1.f - cg), w * gb * cb * (1.f - cb), dsig);
-            if (d_dirs) {  // per-sample directions: dist = delta * |dir|  =>  d dir = d dist * delta * dir / |dir|
-                const float ddist = sig > 0.f ? da * sig * ex : 0.f;
-                const float s = nrm > 0.f ? ddist * delta / nrm : 0.f;  // torch.norm's subgradient at 0 is 0
-                const float *dp = dirs + (base + i) * 3;
-                float *q = d_dirs + (base + i) * 3;
-                q[0] = s * dp[0];
-                q[1] = s * dp[1];
-                q[2] = s * dp[2];
+            const float ddist = sig > 0.f ? da * sig * ex : 0.f;
+            e = (i + 1 < N) ? ddist * nrm : 0.f;   // the last interval is the constant 1e10 (utils.py:164)
+            if (d_dirs) {  // dist = delta * |dir|  =>  d dir = d dist * delta * dir / |dir|
+                if (dirs_per_sample) {
+                    const float s = nrm > 0.f ? ddist * delta / nrm : 0.f;  // torch.norm's subgradient at 0 is 0
+                    const float *dp = dirs + (base + i) * 3;
+                    float *q3 = d_dirs + (base + i) * 3;
+                    q3[0] = s * dp[0];
+                    q3[1] = s * dp[1];
+                    q3[2] = s * dp[2];
+                } else {
+                    ray_dd += ddist * delta;
+                }
             }
         }
+        if (d_z) {   // d z_i = e_{i-1} - e_i
+            const float e_last = __shfl(e, 63, 64);
+            if (lane == 0 && c + 1 < nchunk) d_z[base + (c + 1) * WAVE] = z_pend + e_last;
+            float prev = __shfl_up(e, 1, 64);
+            if (lane == 0) {
+                z_pend = -e;
+                if (c == 0) d_z[base] = -e;
+            } else if (ok) {
+                d_z[base + i] = prev - e;
+            }
+        }
+    }
+    if (d_dirs && !dirs_per_sample) {
+        ray_dd = wave_sum(ray_dd);
+        if (lane < 3) d_dirs[ray * 3 + lane] = ray_norm > 0.f ? ray_dd / ray_norm * dirs[ray * 3 + lane] : 0.f;
     }
 }
 
@@ -214,7 +247,7 @@ extern "C" int snerf_composite_fwd_f32(const float *raw, const float *z, const f
                                        const float *noise, int64_t B, int N, int white_background, float *rgb,
                                        float *weights, float *alpha, snerf_stream_t stream) {
     using namespace snerf;
-    if (B < 0 || N < 1 || N > WAVE * CP_MAX_CHUNKS) return fail(SNERF_E_BADARG, "composite: need B >= 0 and 1 <= N <= 4096");
+    if (B < 0 || N < 1) return fail(SNERF_E_BADARG, "composite: need B >= 0 and N >= 1");
     if (B == 0) return SNERF_OK;
     if (!raw || !z) return fail(SNERF_E_BADARG, "composite: raw/z is null");
     if (N > 1 && !dirs) return fail(SNERF_E_BADARG, "composite: dirs is null");
@@ -228,21 +261,39 @@ extern "C" int snerf_composite_fwd_f32(const float *raw, const float *z, const f
     return check_launch("composite_fwd");
 }
 
-extern "C" int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
-                                       const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
-                                       float *d_raw, float *d_dirs, snerf_stream_t stream) {
-    using namespace snerf;
+namespace snerf {
+static int launch_composite_bwd(const float *raw, const float *z, const float *dirs, int dirs_per_sample, const float *noise,
+                                int64_t B, int N, int white_background, const float *d_rgb, const float *d_weights,
+                                const float *d_alpha, float *d_raw, float *d_dirs, float *d_z, snerf_stream_t stream) {
     if (B < 0 || N < 1 || N > WAVE * CP_MAX_CHUNKS) return fail(SNERF_E_BADARG, "composite_bwd: need 1 <= N <= 4096");
     if (B == 0) return SNERF_OK;
-    if (!raw || !z || !d_rgb || !d_raw) return fail(SNERF_E_BADARG, "composite_bwd: null pointer");
+    if (!raw || !z || !d_raw) return fail(SNERF_E_BADARG, "composite_bwd: null pointer");
     if (N > 1 && !dirs) return fail(SNERF_E_BADARG, "composite_bwd: dirs is null");
-    if (d_dirs && !dirs_per_sample) return fail(SNERF_E_BADARG, "composite_bwd: d_dirs needs per-sample directions");
     if (!aligned(raw, 16) || !aligned(d_raw, 16)) return fail(SNERF_E_ALIGN, "composite_bwd: raw/d_raw must be 16-byte aligned");
     const int rays_per_block = CP_THREADS / WAVE;
     const int64_t grid = (B + rays_per_block - 1) / rays_per_block;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "composite_bwd: B too large");
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)grid), dim3(CP_THREADS), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4 *>(raw), z, dirs, dirs_per_sample ? 1 : 0, noise, B, N,
-                       white_background ? 1 : 0, d_rgb, reinterpret_cast<float4 *>(d_raw), d_dirs);
+                       white_background ? 1 : 0, d_rgb, d_weights, d_alpha, reinterpret_cast<float4 *>(d_raw), d_dirs, d_z);
     return check_launch("composite_bwd");
+}
+}  // namespace snerf
+
+extern "C" int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+                                       const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
+                                       float *d_raw, float *d_dirs, snerf_stream_t stream) {
+    using namespace snerf;
+    if (!d_rgb) return fail(SNERF_E_BADARG, "composite_bwd: d_rgb is null");
+    if (d_dirs && !dirs_per_sample) return fail(SNERF_E_BADARG, "composite_bwd: d_dirs needs per-sample directions");
+    return launch_composite_bwd(raw, z, dirs, dirs_per_sample, noise, B, N, white_background, d_rgb, nullptr, nullptr, d_raw,
+                                d_dirs, nullptr, stream);
+}
+
+extern "C" int snerf_composite_bwd_all_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+                                           const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
+                                           const float *d_weights, const float *d_alpha, float *d_raw, float *d_dirs,
+                                           float *d_z, snerf_stream_t stream) {
+    return snerf::launch_composite_bwd(raw, z, dirs, dirs_per_sample, noise, B, N, white_background, d_rgb, d_weights, d_alpha,
+                                       d_raw, d_dirs, d_z, stream);
 }

@@ -287,16 +287,10 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
     B.n_tiles = (A.n + tile - 1) / tile;
     B.total_slabs = P.total_slabs;
     if (B.n_tiles > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd: n too large");
-    static int n_cu = 0;  // one persistent workgroup per CU
-    if (!n_cu) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus < 1)
-            return fail(SNERF_E_LAUNCH, "mlp_fwd: cannot query the CU count");
-        n_cu = cus;
-    }
+    const int n_cu = device_cu_count("mlp_fwd");  // one persistent workgroup per CU
+    if (n_cu < 1) return n_cu;
     // SNERF_FWD_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
-    static const bool persistent = !(getenv("SNERF_FWD_PERSISTENT") && atoi(getenv("SNERF_FWD_PERSISTENT")) == 0);
+    const bool persistent = tuning().fwd_persistent;
     const int64_t grid = (!TRAIN && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
     if (P.width == 256)
         SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
@@ -310,11 +304,7 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // 8 waves (128 samples) per workgroup = one workgroup per CU, 2 waves per SIMD (85.7 % of the fp32 MFMA
     // peak on the 128x128 frame); SNERF_FWD_WAVES=4 selects two independent 4-wave workgroups per CU instead
     // (83.1 %; twice the L2->LDS weight traffic).  Tuning knob, read once.
-    static const int nw = [] {
-        const char *e = getenv("SNERF_FWD_WAVES");
-        return (e && atoi(e) == 4) ? 4 : FWD_WAVES;
-    }();
-    if (nw == 4) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
+    if (tuning().fwd_waves == 4) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
     return launch_fwd_nw<FWD_WAVES, ENCODED, TRAIN>(P, A, s);
 }
 

@@ -430,23 +430,14 @@ template <int NS, bool TRAIN, int FMT = FMT_BF16>
 static int launch_bf16(const FwdArgs &A, hipStream_t s) {
     constexpr int NW = 8;
     const int lds = 3 * slab16_bytes(NS);
-    static bool attr = false;  // idempotent; a race only repeats the call
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwd_bf16_kernel<256, NW, NS, TRAIN, FMT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return fail(SNERF_E_LAUNCH, "mlp_fwd_bf16: cannot raise the dynamic LDS limit to %d bytes", lds);
-        attr = true;
-    }
-    static int n_cu = 0;  // one persistent workgroup per CU
-    if (!n_cu) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus < 1)
-            return fail(SNERF_E_LAUNCH, "mlp_fwd_bf16: cannot query the CU count");
-        n_cu = cus;
-    }
+    static LdsRaised raised;   // per device
+    if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_fwd_bf16_kernel<256, NW, NS, TRAIN, FMT>), lds, raised,
+                                   "mlp_fwd_bf16"))
+        return rc;
+    const int n_cu = device_cu_count("mlp_fwd_bf16");  // one persistent workgroup per CU
+    if (n_cu < 1) return n_cu;
     // SNERF_BF16_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
-    static const bool persistent = !(getenv("SNERF_BF16_PERSISTENT") && atoi(getenv("SNERF_BF16_PERSISTENT")) == 0);
+    const bool persistent = tuning().bf16_persistent;
     const int64_t grid = (persistent && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: n too large");
     hipLaunchKernelGGL((mlp_fwd_bf16_kernel<256, NW, NS, TRAIN, FMT>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);

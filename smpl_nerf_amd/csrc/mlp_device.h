@@ -87,13 +87,10 @@ __device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, in
 constexpr int RING_BYTES = 3 * SLAB_FLOATS * 4;
 #define SNERF_LAUNCH_RING(kernel, grid, block, stream, ...)                                                            \
     do {                                                                                                               \
-        static bool snerf_lds_raised_ = false; /* idempotent; a race only repeats the call */                          \
-        if (!snerf_lds_raised_) {                                                                                      \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    ::snerf::RING_BYTES) != hipSuccess)                                                \
-                return ::snerf::fail(SNERF_E_LAUNCH, "cannot raise the dynamic LDS limit to %d bytes", ::snerf::RING_BYTES); \
-            snerf_lds_raised_ = true;                                                                                  \
-        }                                                                                                              \
+        static ::snerf::LdsRaised snerf_lds_raised_; /* per device (snerf_common.h) */                                 \
+        if (int snerf_rc_ = ::snerf::raise_dynamic_lds(reinterpret_cast<const void *>(kernel), ::snerf::RING_BYTES,    \
+                                                       snerf_lds_raised_, #kernel))                                    \
+            return snerf_rc_;                                                                                          \
         hipLaunchKernelGGL(kernel, grid, block, ::snerf::RING_BYTES, stream, __VA_ARGS__);                             \
     } while (0)
 

@@ -581,12 +581,8 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     const int G_narrow = wgrad_chunks(n);   // (the single-wave narrow jobs gain nothing from longer chunks)
     int G = G_narrow;
     {
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0, cus = 0;
-            n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-                    cus > 0) ? cus : 256;
-        }
+        const int n_cu = device_cu_count("wgrad");
+        if (n_cu < 1) return n_cu;
         const int jobs = wgrad_jobs(P);
         if (jobs > 0 && (int64_t)jobs * G > n_cu) {
             const int rounds = (int)((int64_t)jobs * G / n_cu);
@@ -601,14 +597,9 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     W.xstat = reinterpret_cast<const int *>(act + (int64_t)L.act_rows * n * 16);   // (f16x3 wide jobs only)
     W.ystat = reinterpret_cast<const int *>(dy + (int64_t)L.dy_rows * n * 16);
     W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
-    static bool attr = false;  // idempotent; a race only repeats the call
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                WL_LDS_BYTES) != hipSuccess)
-            return fail(SNERF_E_LAUNCH, "wgrad: cannot raise the dynamic LDS limit to %d bytes", WL_LDS_BYTES);
-        attr = true;
-    }
+    static LdsRaised raised;   // per device
     int rc;
+    if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_kernel), WL_LDS_BYTES, raised, "wgrad"))) return rc;
     if (const int jobs = wgrad_jobs(P)) {
         if (wide_nsplit) {   // the wide jobs on the bf16 matrix cores (mlp_train_bf16.hip)
             if ((rc = launch_wgrad_wide_bf16(P, L, W, jobs, G, wide_nsplit, s))) return rc;
@@ -620,7 +611,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     if (const int jobs = wgrad_direct_jobs(P)) {
         W.chunk = (((n + G_narrow - 1) / G_narrow) + 15) / 16 * 16;
         // f16x3 step: the narrow jobs with two fp16 parts as well (SNERF_WGRAD_NARROW_F16=0: fp32 MFMA)
-        static const bool narrow_f16 = !(getenv("SNERF_WGRAD_NARROW_F16") && atoi(getenv("SNERF_WGRAD_NARROW_F16")) == 0);
+        const bool narrow_f16 = tuning().wgrad_narrow_f16;
         if (wide_nsplit == SNERF_SPLIT_F16X3 && narrow_f16) {
             if ((rc = launch_wgrad_direct_f16(P, L, W, jobs, G_narrow, s))) return rc;
         } else {

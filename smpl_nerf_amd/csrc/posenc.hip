@@ -49,7 +49,48 @@ __global__ __launch_bounds__(PE_THREADS) void posenc_kernel(const float *__restr
     }
 }
 
+// backward of the encoding (autograd through utils.py:123-131): one thread per input value,
+//   d x = [identity] g_id + sum_k 2^k (g_sin_k cos(2^k x) - g_cos_k sin(2^k x))
+__global__ __launch_bounds__(PE_THREADS) void posenc_bwd_kernel(const float *__restrict__ x, const float *__restrict__ d_out,
+                                                               int64_t total, int c, int L, int identity,
+                                                               float *__restrict__ d_x) {
+    const int64_t i = (int64_t)blockIdx.x * PE_THREADS + threadIdx.x;
+    if (i >= total) return;
+    const int64_t p = i / c;
+    const int ch = (int)(i - p * c);
+    const int outdim = c * (identity + 2 * L);
+    const float *g = d_out + p * outdim;
+    const float xv = x[i];
+    float acc = 0.f;
+    for (int k = L - 1; k >= 0; --k) {   // autograd visits the last-used frequency first
+        float sv, cv;
+        sincosf(ldexpf(xv, k), &sv, &cv);
+        const float *blk = g + identity * c + k * 2 * c;
+        const float f = ldexpf(1.0f, k);
+        acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(-blk[c + ch], sv), f));   // cos branch: grad * -sin(x f) * f
+        acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(blk[ch], cv), f));       // sin branch: grad * cos(x f) * f
+    }
+    if (identity) acc = __fadd_rn(acc, g[ch]);
+    d_x[i] = acc;
+}
+
 }  // namespace snerf
+
+extern "C" int snerf_posenc_bwd_f32(const float *x, const float *d_out, int64_t n, int c, int L, int identity, float *d_x,
+                                    snerf_stream_t stream) {
+    using namespace snerf;
+    if (n < 0 || c <= 0 || L < 0 || L > 30) return fail(SNERF_E_BADARG, "posenc_bwd: bad n/c/L");
+    identity = identity ? 1 : 0;
+    if (n == 0) return SNERF_OK;
+    if (!x || !d_x) return fail(SNERF_E_BADARG, "posenc_bwd: null pointer");
+    if (!d_out && (identity + 2 * L) > 0) return fail(SNERF_E_BADARG, "posenc_bwd: d_out is null");
+    const int64_t total = n * c;
+    const int64_t grid = (total + PE_THREADS - 1) / PE_THREADS;
+    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "posenc_bwd: n too large");
+    hipLaunchKernelGGL(posenc_bwd_kernel, dim3((unsigned)grid), dim3(PE_THREADS), 0, (hipStream_t)stream, x, d_out, total, c,
+                       L, identity, d_x);
+    return check_launch("posenc_bwd");
+}
 
 extern "C" int snerf_posenc_f32(const float *x, int64_t n, int c, int L, int identity, float *out,
                                 snerf_stream_t stream) {

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "../../include/smplnerf.h"
 
 namespace snerf {
@@ -18,6 +20,35 @@ inline int check_launch(const char *what) {
     if (e != hipSuccess) return fail(SNERF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return SNERF_OK;
 }
+
+// ---- process-wide state of the library (all of it; include/smplnerf.h "State") ------------------------------------
+// The CU count and hipFuncAttributeMaxDynamicSharedMemorySize are PER DEVICE: both are cached per HIP device ordinal of
+// the calling thread's current device, so one process may drive several GPUs through the library.
+constexpr int MAX_DEVICES = 64;
+// CU count of the current device (cached per device); returns < 1 and sets the error text on failure
+int device_cu_count(const char *what);
+// "dynamic LDS limit of this kernel raised to N bytes on device d" - one per kernel instantiation (function-local static)
+struct LdsRaised {
+    std::atomic<int> bytes[MAX_DEVICES];
+};
+// raises the limit once per (kernel, device); idempotent, a race only repeats the driver call.  Returns 0 or SNERF_E_LAUNCH.
+int raise_dynamic_lds(const void *kernel, int bytes, LdsRaised &state, const char *what);
+
+// Tuning knobs: environment variables read ONCE, at the first call that consults them (include/smplnerf.h lists them).
+// They select between equivalent kernels / launch shapes for A/B measurements and never change results.
+struct Tuning {
+    bool fwd_persistent;            // SNERF_FWD_PERSISTENT            (default 1)
+    int fwd_waves;                  // SNERF_FWD_WAVES                 (8; 4 = two 4-wave workgroups per CU)
+    bool bf16_persistent;           // SNERF_BF16_PERSISTENT           (1)
+    bool warp_resident;             // SNERF_WARP_RESIDENT             (1)
+    bool warp_bwd_ring;             // SNERF_WARP_BWD_RING             (0)
+    bool wgrad_bf16;                // SNERF_WGRAD_BF16                (1)
+    bool wgrad_f16;                 // SNERF_WGRAD_F16                 (1)
+    bool wgrad_narrow_f16;          // SNERF_WGRAD_NARROW_F16          (1)
+    bool wgrad_f16_split_per_wave;  // SNERF_WGRAD_F16_SPLIT_PER_WAVE  (0)
+    bool wgrad_narrow_staged;       // SNERF_WGRAD_NARROW_STAGED       (1)
+};
+const Tuning &tuning();
 
 __host__ __device__ inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 

@@ -335,7 +335,7 @@ extern "C" int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *pack
     warp_train_layout(P, L);
     WarpBwdArgs A{packed_t, act, d_warp, dy, n, L.x[1]};
     hipStream_t s = (hipStream_t)stream;
-    static const bool light = !(getenv("SNERF_WARP_BWD_RING") && atoi(getenv("SNERF_WARP_BWD_RING")) == 1);
+    const bool light = !tuning().warp_bwd_ring;
     if (light) {   // ring-free kernel (SNERF_WARP_BWD_RING=1: the slab-ring version, for A/B runs)
         constexpr int LW = 8;
         const int64_t n_tiles = (n + LW * 16 - 1) / (LW * 16);
@@ -433,7 +433,7 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
     A.act = act;
     hipStream_t s = (hipStream_t)stream;
     {   // the LDS-resident persistent kernel whenever the net fits the 160 KiB of a CU (SNERF_WARP_RESIDENT=0: streaming kernel)
-        static const bool resident = !(getenv("SNERF_WARP_RESIDENT") && atoi(getenv("SNERF_WARP_RESIDENT")) == 0);
+        const bool resident = tuning().warp_resident;
         const int T = P.width / 16, nkb0 = P.pos_nkb + P.add_nkb;
         const int bytes = warp_resident_bytes(T, nkb0);
         if (resident && bytes <= 160 * 1024) {
@@ -441,24 +441,15 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
             const int RW = act ? 8 : 16;
             A.l1_slab = P.layer[1].first_slab;
             A.n_tiles = (n + RW * 16 - 1) / (RW * 16);
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0, cus = 0;
-                if (hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-                    return fail(SNERF_E_LAUNCH, "warp_fwd: cannot query the CU count");
-                n_cu = cus;
-            }
+            const int n_cu = device_cu_count("warp_fwd");
+            if (n_cu < 1) return n_cu;
             const int64_t g = A.n_tiles < n_cu ? A.n_tiles : n_cu;
 #define SNERF_WARP_RES(W_, RW_, TR_)                                                                                      \
     do {                                                                                                                  \
-        static int raised = 0;                                                                                            \
-        if (raised < bytes) {                                                                                             \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(warp_fwd_resident_kernel<W_, RW_, TR_>),                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                \
-                return fail(SNERF_E_LAUNCH, "warp_fwd: cannot raise the dynamic LDS limit");                              \
-            raised = 160 * 1024;                                                                                          \
-        }                                                                                                                 \
+        static LdsRaised raised; /* per device */                                                                         \
+        if (int rc_ = raise_dynamic_lds(reinterpret_cast<const void *>(warp_fwd_resident_kernel<W_, RW_, TR_>), 160 * 1024, \
+                                        raised, "warp_fwd"))                                                              \
+            return rc_;                                                                                                   \
         hipLaunchKernelGGL((warp_fwd_resident_kernel<W_, RW_, TR_>), dim3((unsigned)g), dim3(RW_ * 64), bytes, s, A);      \
     } while (0)
             if (P.width == 256) {

@@ -140,17 +140,10 @@ extern "C" int snerf_warp_fwd_bf16_f32(const snerf_warp_desc *desc, const void *
     A.add_nkb = P.add_nkb;
     constexpr int NW = 8;
     const int lds = 3 * slab16_bytes(WNS);
-    static bool attr = false;  // idempotent; a race only repeats the call
-    static int n_cu = 0;
-    if (!attr) {
-        int dev = 0;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(warp_fwd_bf16_kernel<256, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
-            return fail(SNERF_E_LAUNCH, "warp_fwd_bf16: cannot set up the launch (%d bytes of LDS)", lds);
-        attr = true;
-    }
+    static LdsRaised raised;   // per device
+    if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(warp_fwd_bf16_kernel<256, NW>), lds, raised, "warp_fwd_bf16"))) return rc;
+    const int n_cu = device_cu_count("warp_fwd_bf16");
+    if (n_cu < 1) return n_cu;
     const int64_t n_tiles = (n + NW * 16 - 1) / (NW * 16);
     const int64_t grid = n_tiles < n_cu ? n_tiles : n_cu;
     hipLaunchKernelGGL((warp_fwd_bf16_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, (hipStream_t)stream, A,

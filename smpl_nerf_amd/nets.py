@@ -495,27 +495,35 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
 
 
 class _WarpFn(torch.autograd.Function):
-    """(warp, warped, sdirs) = WarpFieldNet stage with gradients for linear1/linear2.  warped = x + warp and
-    sdirs = warped - o, so the three incoming gradients add up to d loss / d warp."""
+    """(warp, warped, sdirs) = WarpFieldNet stage with gradients for linear1/linear2 and for the per-ray pose rows.
+    warped = x + warp and sdirs = warped - o, so the three incoming gradients add up to d loss / d warp.  With x = None
+    (WarpFieldNet.forward(rows): desc.pos_freqs = pos_identity = 0, samples_per_ray = 1) the pose rows ARE the encoded
+    input rows of models/warp_field_net.py:17-21 and their gradient is what the reference's autograd leaves in x.grad:
+    d h @ linear1.weight, d h being the stored layer-0 d Y tile-rows of snerf_warp_bwd_f32.  The sample positions of the
+    fused form are leaves (the pipeline's ray samples, models/smpl_nerf_pipeline.py:27,68)."""
 
     @staticmethod
     def forward(ctx, net, desc, x, pose_enc, o, spr, *params):
         lib = _lib.load()
-        n = x.shape[0]
-        dev = x.device
+        n = x.shape[0] if x is not None else pose_enc.shape[0] * int(spr)
+        dev = pose_enc.device if x is None else x.device
         net._begin_training_forward()
         packed = net._packed(desc, training=True)
         sizes = [ctypes.c_int64() for _ in range(4)]
         check(lib.snerf_warp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes]), "snerf_warp_train_sizes")
         act = torch.empty(sizes[0].value, device=dev, dtype=torch.float32)
-        warp, warped, sdirs = (torch.empty((n, 3), device=dev, dtype=torch.float32) for _ in range(3))
+        warp = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        warped = sdirs = None
+        if x is not None:
+            warped, sdirs = (torch.empty((n, 3), device=dev, dtype=torch.float32) for _ in range(2))
         with torch.cuda.device(dev), _lib.timed(f"warp_fwd_train[n={n}]"):
             check(lib.snerf_warp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(pose_enc), ptr(o), n, int(spr), ptr(warp),
                                                ptr(warped), ptr(sdirs), ptr(act), current_stream()),
                   "snerf_warp_fwd_train_f32")
-        ctx.net, ctx.desc, ctx.n, ctx.act = net, desc, n, act
+        ctx.net, ctx.desc, ctx.n, ctx.act, ctx.spr = net, desc, n, act, int(spr)
         ctx.sizes = (sizes[1].value, sizes[2].value, sizes[3].value)
         ctx.shapes = [p.shape for p in params]
+        ctx.pose_grad = bool(ctx.needs_input_grad[3])
         ctx.set_materialize_grads(False)
         return warp, warped, sdirs
 
@@ -542,7 +550,14 @@ class _WarpFn(torch.autograd.Function):
             check(lib.snerf_warp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(total), n, ptr(dy), ptr(gpart), ptr(flat),
                                          current_stream()), "snerf_warp_bwd_f32")
         ctx.act = None
-        return (None, None, None, None, None, None) + tuple(_grads_from_flat(flat, ctx.shapes))
+        d_pose = None
+        if ctx.pose_grad:      # d h [n, width] (tile-rows 0 .. T-1 of dy) contracted with linear1's pose columns, summed per ray
+            T = desc.width // 16
+            with torch.no_grad():
+                dh = dy[:T * n * 16].view(T, n, 16).permute(1, 0, 2).reshape(n, T * 16)
+                pos_dim = 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
+                d_pose = (dh @ net.linear1.weight[:, pos_dim:]).view(-1, ctx.spr, desc.pose_dim).sum(1)
+        return (None, None, None, d_pose, None, None) + tuple(_grads_from_flat(flat, ctx.shapes))
 
 
 class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
@@ -601,19 +616,21 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
         return self._cached_pack(self._pack_cache, tuple(getattr(desc, f[0]) for f in desc._fields_) + ("bf16",),
                                  self._params(), build)
 
-    def _no_grad(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("WarpFieldNet: backward is not implemented yet; run under torch.no_grad()")
-
     def forward(self, x):
-        """x [..., positions_dim + pose_dim] (already encoded) -> warp [..., 3]."""
-        self._no_grad()
+        """x [..., positions_dim + pose_dim] (already encoded) -> warp [..., 3] (models/warp_field_net.py:17-21);
+        differentiable w.r.t. the rows and the parameters like the reference's module."""
         if not x.is_cuda:
             raise RuntimeError("WarpFieldNet.forward: input must be on the GPU (no CPU path)")
+        if x.shape[-1] != self.linear1.weight.shape[1]:
+            raise RuntimeError(f"WarpFieldNet.forward: rows of {x.shape[-1]} floats, linear1 expects "
+                               f"{self.linear1.weight.shape[1]}")
         rows = x.reshape(-1, x.shape[-1]).contiguous().float()
         desc = _lib.WarpDesc(self.width, 0, 0, rows.shape[1])
-        packed = self._packed(desc)
         n = rows.shape[0]
+        if torch.is_grad_enabled() and (rows.requires_grad or any(p.requires_grad for p in self.parameters())):
+            warp, _, _ = _WarpFn.apply(self, desc, None, rows, None, 1, *self._params())
+            return warp.reshape(x.shape[:-1] + (3,))
+        packed = self._packed(desc)
         warp = torch.empty((n, 3), device=x.device, dtype=torch.float32)
         lib = _lib.load()
         with torch.cuda.device(x.device):
@@ -635,8 +652,8 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
         o = ray_translation.reshape(-1, 3).contiguous()
         if pe.shape[0] * samples_per_ray != n or o.shape[0] * samples_per_ray != n:
             raise RuntimeError("forward_fused: per-ray inputs do not match positions / samples_per_ray")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _WarpFn.apply(self, desc, x.detach(), pe.detach(), o.detach(), int(samples_per_ray), *self._params())
+        if torch.is_grad_enabled() and (pe.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _WarpFn.apply(self, desc, x.detach(), pe, o.detach(), int(samples_per_ray), *self._params())
         warp, warped, sdirs = (torch.empty((n, 3), device=x.device, dtype=torch.float32) for _ in range(3))
         lib = _lib.load()
         if self.precision in ("bf16x6", "bf16x3", "f16x3") and self.width == 256:

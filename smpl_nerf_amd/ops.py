@@ -53,16 +53,27 @@ def searchsorted(a: torch.Tensor, v: torch.Tensor, out: Optional[torch.LongTenso
         assert out.shape == result_shape, "If the output tensor is provided, its shape must be correct."
     else:
         out = torch.empty(result_shape, device=v.device, dtype=torch.long)
-    _need_cuda("a", a)
-    _need_cuda("v", v)
+    for nm, t in (("a", a), ("v", v)):
+        if not t.is_cuda:
+            raise RuntimeError(f"smpl_nerf_amd: `{nm}` must live on the GPU (got {t.device}); there is no CPU path")
+    code = _SEARCHSORTED_DTYPES.get(a.dtype)
+    if code is None:     # the reference dispatches AT_DISPATCH_ALL_TYPES (searchsorted_cpu_wrapper.cpp:100): no half / bool
+        raise RuntimeError(f"searchsorted: unsupported dtype {a.dtype}")
+    if v.dtype != a.dtype:   # the reference reads `v` through a's scalar type and fails on a mismatch (:103)
+        raise RuntimeError(f"searchsorted: `a` ({a.dtype}) and `v` ({v.dtype}) must have the same dtype")
     if not a.is_contiguous() or not v.is_contiguous() or not out.is_contiguous():
         # the reference's CUDA wrapper asserts contiguity (searchsorted_cuda_wrapper.cpp:5-7)
         raise RuntimeError("searchsorted: a, v and out must be contiguous")
     lib = _lib.load()
     with torch.cuda.device(a.device):
-        check(lib.snerf_searchsorted_f32(ptr(a), a.shape[0], a.shape[1], ptr(v), v.shape[0], v.shape[1], ptr(out),
-                                         1 if side == "left" else 0, current_stream()), "snerf_searchsorted_f32")
+        check(lib.snerf_searchsorted(code, ptr(a), a.shape[0], a.shape[1], ptr(v), v.shape[0], v.shape[1], ptr(out),
+                                     1 if side == "left" else 0, current_stream()), "snerf_searchsorted")
     return out
+
+
+# torch dtype -> SNERF_DTYPE_* (include/smplnerf.h)
+_SEARCHSORTED_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3, torch.int16: 4, torch.int8: 5,
+                        torch.uint8: 6}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -79,7 +90,11 @@ class PositionalEncoder:
 
     def encode(self, coordinate: torch.Tensor) -> torch.Tensor:
         _need_cuda("coordinate", coordinate)
-        _no_grad_inputs(coordinate)
+        if torch.is_grad_enabled() and coordinate.requires_grad:     # differentiable like utils.py:123-131
+            return _PosEncFn.apply(coordinate, self.number_frequencies, 1 if self.include_identity else 0)
+        return self._encode(coordinate)
+
+    def _encode(self, coordinate: torch.Tensor) -> torch.Tensor:
         x = coordinate.contiguous()
         c = x.shape[-1]
         n = x.numel() // c if c else 0
@@ -91,6 +106,33 @@ class PositionalEncoder:
             check(lib.snerf_posenc_f32(ptr(x), n, c, self.number_frequencies, 1 if self.include_identity else 0,
                                        ptr(out), current_stream()), "snerf_posenc_f32")
         return out
+
+
+class _PosEncFn(torch.autograd.Function):
+    """encode() under autograd: snerf_posenc_f32 forward, snerf_posenc_bwd_f32 backward."""
+
+    @staticmethod
+    def forward(ctx, x, L, identity):
+        x = x.detach().contiguous()
+        ctx.save_for_backward(x)
+        ctx.cfg = (int(L), int(identity))
+        return PositionalEncoder(L, bool(identity))._encode(x)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        L, identity = ctx.cfg
+        c = x.shape[-1]
+        n = x.numel() // c if c else 0
+        d_x = torch.zeros_like(x)
+        if n == 0 or (identity + 2 * L) == 0:
+            return d_x, None, None
+        d_out = d_out.contiguous().float()
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            check(lib.snerf_posenc_bwd_f32(ptr(x), ptr(d_out), n, c, L, identity, ptr(d_x), current_stream()),
+                  "snerf_posenc_bwd_f32")
+        return d_x, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -112,36 +154,37 @@ def _directions_arg(samples_directions: torch.Tensor, B: int, N: int):
 
 
 class _CompositeFn(torch.autograd.Function):
-    """Differentiable alpha compositing: d rgb -> d raw (snerf_composite_bwd_f32).  weights and alpha
-    are returned without gradient: in the pipeline they only feed the detached hierarchical sampler
-    (utils.py:260) and the tuple handed back to the caller."""
+    """Differentiable alpha compositing, all of utils.py:134-191 under autograd: gradients arriving at rgb, weights and
+    alpha (SmplNerfSolver's density loss reads the returned alpha, solver/smpl_nerf_solver.py:40) flow to raw and, where the
+    caller's graph asks, to the directions (per-sample: SmplNerfPipeline's x' - o; per-ray) and to z_vals
+    (snerf_composite_bwd_all_f32)."""
 
     @staticmethod
     def forward(ctx, raw, z_vals, dirs, per_sample, white_background, noise, want_weights, want_alpha):
         rgb, weights, alpha = _composite_launch(raw, z_vals, dirs, per_sample, white_background, noise,
                                                 want_weights, want_alpha)
         ctx.save_for_backward(raw, z_vals, dirs, noise)
-        ctx.cfg = (per_sample, white_background, bool(ctx.needs_input_grad[2]) and bool(per_sample))
+        ctx.cfg = (per_sample, white_background, bool(ctx.needs_input_grad[1]), bool(ctx.needs_input_grad[2]))
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(*[t for t in (weights, alpha) if t is not None])
         return rgb, weights, alpha
 
     @staticmethod
     def backward(ctx, d_rgb, d_w, d_a):
         raw, z_vals, dirs, noise = ctx.saved_tensors
-        per_sample, wb, want_ddirs = ctx.cfg
-        if d_rgb is None:
+        per_sample, wb, want_dz, want_ddirs = ctx.cfg
+        if d_rgb is None and d_w is None and d_a is None:
             return (None,) * 8
         B, N = z_vals.shape
-        d_rgb = d_rgb.contiguous().float()
+        d_rgb, d_w, d_a = (None if g is None else g.contiguous().float() for g in (d_rgb, d_w, d_a))
         d_raw = torch.empty_like(raw)
         d_dirs = torch.empty_like(dirs) if want_ddirs else None
+        d_z = torch.empty_like(z_vals) if want_dz else None
         lib = _lib.load()
         with torch.cuda.device(raw.device), _lib.timed(f"composite_bwd[N={N}]"):
-            check(lib.snerf_composite_bwd_f32(ptr(raw), ptr(z_vals), ptr(dirs), per_sample, ptr(noise), B, N,
-                                              1 if wb else 0, ptr(d_rgb), ptr(d_raw), ptr(d_dirs), current_stream()),
-                  "snerf_composite_bwd_f32")
-        return (d_raw, None, d_dirs) + (None,) * 5
+            check(lib.snerf_composite_bwd_all_f32(ptr(raw), ptr(z_vals), ptr(dirs), per_sample, ptr(noise), B, N,
+                                                  1 if wb else 0, ptr(d_rgb), ptr(d_w), ptr(d_a), ptr(d_raw), ptr(d_dirs),
+                                                  ptr(d_z), current_stream()), "snerf_composite_bwd_all_f32")
+        return (d_raw, d_z, d_dirs) + (None,) * 5
 
 
 def composite(raw, z_vals, samples_directions, white_background: bool, noise=None,
@@ -155,11 +198,9 @@ def composite(raw, z_vals, samples_directions, white_background: bool, noise=Non
     z_vals = z_vals.contiguous()
     if noise is not None:
         noise = noise.contiguous()
-    if torch.is_grad_enabled() and raw.requires_grad:
-        # per-sample directions (SmplNerfPipeline's x' - o) carry gradient: dists are scaled by their norm
-        dirs_in = dirs if (per_sample and dirs.requires_grad) else dirs.detach()
-        return _CompositeFn.apply(raw.view(B, N, 4), z_vals.detach(), dirs_in, per_sample, bool(white_background),
-                                  noise, want_weights, want_alpha)
+    if torch.is_grad_enabled() and (raw.requires_grad or z_vals.requires_grad or dirs.requires_grad):
+        return _CompositeFn.apply(raw.view(B, N, 4), z_vals, dirs, per_sample, bool(white_background), noise, want_weights,
+                                  want_alpha)
     return _composite_launch(raw, z_vals, dirs, per_sample, white_background, noise, want_weights, want_alpha)
 
 
@@ -184,7 +225,6 @@ def raw2outputs(raw: torch.Tensor, z_vals: torch.Tensor, samples_directions: tor
     torch.normal exactly where the reference draws it (utils.py:171-173) - also in eval mode."""
     for nm, t in (("raw", raw), ("z_vals", z_vals), ("samples_directions", samples_directions)):
         _need_cuda(nm, t)
-    _no_grad_inputs(z_vals, samples_directions)
     noise = None
     if z_vals.shape[-1] > 1 and args.sigma_noise_std > 0.:
         noise = torch.normal(0, args.sigma_noise_std, raw[..., 3].shape, device=raw.device)

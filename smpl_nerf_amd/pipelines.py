@@ -145,8 +145,14 @@ class SmplNerfPipeline(NerfPipeline):
     run_fine = 0, (rgb, rgb, warp, ray_samples, warped_samples, densities).  Quirks kept: joints 38 and 41
     are hard-coded (:28); the coarse compositing scales distances by |x' - o| per sample (:63) while the
     fine one uses the ray direction (:95-98); hierarchical samples are drawn on the un-warped ray (:68).
-    Only human_pose_encoding = 1 is supported (with 0 the reference itself crashes once run_fine = 1, Q5).
-    """
+    human_pose_encoding = 0 (the parser default, config_parser.py:72): the warp net reads [x | two joint angles] un-encoded
+    (:40-45; WarpFieldNet(positions_dim=3, pose_dim=2), train.py:111-114) - the fused warp kernel with an identity-only
+    position "encoder".  The fine branch always builds encoded rows (:71-77), so with run_fine = 1 that mode fails at
+    the fine warp evaluation exactly like the reference (quirk Q5: a RuntimeError from the 5-column linear1)."""
+
+    class _RawPositions:
+        """PositionalEncoder(0, True): the identity columns only (warp-net input of human_pose_encoding = 0)."""
+        number_frequencies, include_identity, output_dim = 0, True, 1
 
     def __init__(self, model_coarse, model_fine, model_warp_field, args, position_encoder, direction_encoder,
                  human_pose_encoder):
@@ -154,24 +160,25 @@ class SmplNerfPipeline(NerfPipeline):
         self.human_pose_encoder = human_pose_encoder
         self.model_warp_field = model_warp_field
 
-    def _stage(self, net, samples, ray_translation, pose_enc, n_per_ray):
+    def _stage(self, net, samples, ray_translation, pose_enc, n_per_ray, warp_encoder=None):
         warp, warped, sdirs = self.model_warp_field.forward_fused(samples, pose_enc, ray_translation, n_per_ray,
-                                                                  self.position_encoder)
+                                                                  warp_encoder or self.position_encoder)
         raw = net.forward_fused(warped, sdirs, n_per_ray, self.position_encoder, self.direction_encoder)
         return warp, warped, sdirs, raw
 
     def forward(self, data):
         ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
         args = self.args
-        if not args.human_pose_encoding:
-            raise NotImplementedError("SmplNerfPipeline: human_pose_encoding=0 is not supported (the reference "
-                                      "crashes in the fine branch in that mode, models/smpl_nerf_pipeline.py:71-77)")
         B, Nc = z_vals.shape
         wb = bool(args.white_background)
         dev = ray_samples.device
-        goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)                      # :28
-        pose_enc = self.human_pose_encoder.encode(goal_pose.contiguous())                          # :30
-        warp, warped, sdirs, raw = self._stage(self.model_coarse, ray_samples, ray_translation, pose_enc, Nc)
+        goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1).contiguous()         # :28
+        pose_enc = self.human_pose_encoder.encode(goal_pose)                                       # :30
+        if args.human_pose_encoding:                                                               # :37-39
+            warp, warped, sdirs, raw = self._stage(self.model_coarse, ray_samples, ray_translation, pose_enc, Nc)
+        else:                                                                                      # :40-45
+            warp, warped, sdirs, raw = self._stage(self.model_coarse, ray_samples, ray_translation, goal_pose, Nc,
+                                                   self._RawPositions)
         rgb, weights, densities = ops.composite(raw.view(B, Nc, 4), z_vals, sdirs.view(B, Nc, 3), wb,
                                                 self._noise((B, Nc), dev))                        # :63
         if not args.run_fine:

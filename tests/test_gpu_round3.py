@@ -1,0 +1,273 @@
+"""Round-3 GPU parity: the API surface VERDICT r02 listed as missing, against vectors the reference itself produced
+(tests/golden/make_golden_r3.py): SmplNerfPipeline with human_pose_encoding = 0, WarpFieldNet.forward(x) under autograd,
+differentiable PositionalEncoder.encode / raw2outputs, searchsorted for every scalar type the reference dispatches."""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as R
+from oracle import nerf_oracle as O
+from smpl_nerf_amd import synthetic as syn
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+PRECISIONS = ["fp32", "bf16x6", "f16x3"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+def _net(dev, params, precision="fp32"):
+    from smpl_nerf_amd.nets import RenderRayNet
+    net = RenderRayNet(8, 256, 60, 24, skips=[4])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net.precision = precision
+    return net.to(dev)
+
+
+def _warp(dev, params, pdim, qdim, precision="fp32"):
+    from smpl_nerf_amd.nets import WarpFieldNet
+    mw = WarpFieldNet(8, 256, pdim, qdim)
+    mw.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    mw.precision = precision
+    return mw.to(dev)
+
+
+# ------------------------------------------------------------------------------------------ a7: human_pose_encoding = 0
+@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("wb", [0, 1])
+def test_smpl_nerf_raw_pose_inputs_forward_and_gradients(dev, wb, prec):
+    """human_pose_encoding = 0 (config_parser.py:72, the parser default): the warp net reads [x | two joint angles]
+    (models/smpl_nerf_pipeline.py:40-45).  run_fine = 0 - the reference's only working mode - forward tuple, loss and the
+    gradients of the coarse and warp nets against the reference's."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import SmplNerfPipeline
+    g = load_golden("g12_smpl_raw_pose.npz")
+    pc, pf = syn.make_scene_nets(101)
+    pw = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("warp_param/")}
+    mc, mf, mw = _net(dev, pc, prec), _net(dev, pf, prec), _warp(dev, pw, 3, 2, prec)
+    args = O.Args(white_background=wb, run_fine=0, human_pose_encoding=0)
+    pipe = SmplNerfPipeline(mc, mf, mw, args, PositionalEncoder(10, 0), PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    d = [T(a[g["sub"]], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][g["sub"]], dev)]
+    with torch.no_grad():
+        out = pipe(d)
+    tol = 1e-4 if prec == "fp32" else 2e-4
+    for nm, o_, t_ in zip(("rgb", "rgb_fine", "warp", "samples", "warped", "alpha"), out, (tol, tol, 1e-5, 0, 1e-5, 2e-4)):
+        assert o_.shape == g[f"{nm}_wb{wb}"].shape, nm
+        close(o_.cpu().numpy(), g[f"{nm}_wb{wb}"], 0, max(t_, 1e-12))
+    out = pipe(d)
+    loss = torch.nn.functional.mse_loss(out[0], d[-1]) + torch.nn.functional.mse_loss(out[1], d[-1])
+    loss.backward()
+    close([loss.item()], g[f"loss_wb{wb}"], 2e-5, 1e-7)
+    for k, p in mc.named_parameters():
+        ref = g[f"grad_wb{wb}/coarse.{k}"]
+        scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
+        close(R.digest(p.grad), ref, 2e-2, 1e-2 * scale)
+    assert all(p.grad is None for p in mf.parameters())      # run_fine = 0: the fine net is not evaluated (quirk Q10)
+    for k, p in mw.named_parameters():
+        ref = g[f"warpgrad_wb{wb}/{k}"].astype(np.float64)
+        got = p.grad.cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(got - ref) <= 1e-2 * np.linalg.norm(ref), (k, np.linalg.norm(got - ref) / np.linalg.norm(ref))
+
+
+def test_smpl_nerf_raw_pose_inputs_fine_branch_fails_like_the_reference(dev):
+    """Quirk Q5: with human_pose_encoding = 0 the fine branch feeds 100 encoded columns into the 5-column linear1
+    (models/smpl_nerf_pipeline.py:71-77) - a RuntimeError in the reference (recorded in the fixture) and here."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import SmplNerfPipeline
+    g = load_golden("g12_smpl_raw_pose.npz")
+    assert int(g["fine_branch_raises"][0]) == 1
+    pc, pf = syn.make_scene_nets(101)
+    pw = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("warp_param/")}
+    pipe = SmplNerfPipeline(_net(dev, pc), _net(dev, pf), _warp(dev, pw, 3, 2), O.Args(run_fine=1, human_pose_encoding=0),
+                            PositionalEncoder(10, 0), PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    d = [T(a[g["sub"]], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][g["sub"]], dev)]
+    with pytest.raises(RuntimeError), torch.no_grad():
+        pipe(d)
+
+
+@pytest.mark.parametrize("tag,pdim,qdim", [("enc", 60, 40), ("raw", 3, 2)])
+def test_warp_field_net_forward_under_autograd(dev, tag, pdim, qdim):
+    """WarpFieldNet.forward(x) in training mode (models/warp_field_net.py:17-22): output, the gradient of the rows and
+    every parameter gradient against the reference under autograd."""
+    g = load_golden("g13_warp_net_grad.npz")
+    params = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(f"param_{tag}/")}
+    net = _warp(dev, params, pdim, qdim).train()
+    x = T(g[f"x_{tag}"], dev).requires_grad_(True)
+    out = net(x)
+    assert out.requires_grad
+    close(out.detach().cpu().numpy(), g[f"out_{tag}"], 1e-5, 1e-6)
+    (out * T(g[f"gout_{tag}"], dev)).sum().backward()
+    close(x.grad.cpu().numpy(), g[f"dx_{tag}"], 1e-4, 1e-5)
+    for k, p in net.named_parameters():
+        ref = g[f"grad_{tag}/{k}"]
+        close(p.grad.cpu().numpy(), ref, 2e-4, 2e-5 * np.abs(ref).max())
+    # 3-D input (batch, samples, columns) keeps its leading shape; parameters frozen -> rows still get their gradient
+    for p in net.parameters():
+        p.requires_grad_(False)
+    x3 = T(g[f"x_{tag}"].reshape(8, 25, -1), dev).requires_grad_(True)
+    out3 = net(x3)
+    assert out3.shape == (8, 25, 3)
+    (out3 * T(g[f"gout_{tag}"].reshape(8, 25, 3), dev)).sum().backward()
+    close(x3.grad.cpu().numpy().reshape(200, -1), g[f"dx_{tag}"], 1e-4, 1e-5)
+    with torch.no_grad():
+        close(net(x3).cpu().numpy().reshape(200, 3), g[f"out_{tag}"], 1e-5, 1e-6)
+
+
+def test_smpl_nerf_density_loss_reaches_the_nets(dev):
+    """SmplNerfSolver's optional density loss (solver/smpl_nerf_solver.py:35-43) differentiates the returned `densities`
+    and `warped_samples`: both carry gradient here.  The fine net's gradient of such a loss is checked by central
+    differences of the loss along the gradient direction (the fine net does not move the hierarchical samples, so the loss
+    is a smooth function of it; the warp net does, which autograd ignores like the reference - utils.py:260 - so for it
+    only "finite and non-zero" is asserted)."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import SmplNerfPipeline
+    g6 = load_golden("g6_smpl_nerf_pipeline.npz")
+    pc, pf = syn.make_scene_nets(101)
+    mc, mf = _net(dev, pc), _net(dev, pf)
+    mw = _warp(dev, syn.make_warp_field_params(103, out_scale=0.3), 60, 40)
+    pipe = SmplNerfPipeline(mc, mf, mw, O.Args(), PositionalEncoder(10, 0), PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    d = [T(a[g6["sub"]], dev) for a in data[:4]] + [T(g6["goal_pose"], dev), T(data[4][g6["sub"]], dev)]
+    target = torch.rand((d[0].shape[0], 192), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+
+    def loss_of():
+        out = pipe(d)
+        return torch.nn.functional.mse_loss(out[5], target) + 0.1 * out[4].square().mean()
+
+    loss = loss_of()
+    loss.backward()
+    grads = {id(p): p.grad.clone() for m in (mf, mw) for p in m.parameters()}
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values())
+    assert sum(float(v.abs().sum()) for v in grads.values()) > 0
+    assert sum(float(grads[id(p)].abs().sum()) for p in mw.parameters()) > 0
+    # directional central difference along the gradient of two fine-net tensors
+    for p in (mf.sigma_out_layer.weight, mf.additional_linear_layer.bias):
+        gdir = grads[id(p)]
+        gn = float(gdir.norm())
+        if gn == 0:
+            continue
+        eps = 1e-2 / gn * float(p.detach().abs().max() + 1e-3)
+        with torch.no_grad():
+            p.add_(eps * gdir)
+            for m in (mf, mw):
+                m.mark_weights_changed()
+            lp = float(loss_of())
+            p.sub_(2 * eps * gdir)
+            for m in (mf, mw):
+                m.mark_weights_changed()
+            lm = float(loss_of())
+            p.add_(eps * gdir)
+            for m in (mf, mw):
+                m.mark_weights_changed()
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - gn * gn) <= 0.1 * gn * gn + 1e-7, (fd, gn * gn)
+
+
+# ------------------------------------------------------------------------------------------ differentiable stand-alone ops
+@pytest.mark.parametrize("L,ident", [(10, 0), (4, 1), (0, 1), (6, 0)])
+def test_positional_encoder_is_differentiable(dev, L, ident):
+    """PositionalEncoder.encode under autograd (utils.py:123-131) vs the reference's gradient."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    g = load_golden("g14_ops_grads.npz")
+    x = T(g["pe_x"], dev).requires_grad_(True)
+    out = PositionalEncoder(L, ident).encode(x)
+    (out * T(g[f"pe_gout_L{L}_id{ident}"], dev)).sum().backward()
+    ref = g[f"pe_dx_L{L}_id{ident}"]
+    close(x.grad.cpu().numpy(), ref, 1e-5, 1e-5 * np.abs(ref).max())
+    if (L, ident) == (10, 0):
+        p = T(g["pe_pose"], dev).requires_grad_(True)
+        (PositionalEncoder(10, 0).encode(p) * T(g["pe_pose_gout"], dev)).sum().backward()
+        close(p.grad.cpu().numpy(), g["pe_pose_dx"], 1e-5, 1e-5 * np.abs(g["pe_pose_dx"]).max())
+
+
+@pytest.mark.parametrize("N", [1, 2, 64, 192, 100])
+@pytest.mark.parametrize("wb", [0, 1])
+@pytest.mark.parametrize("mode", ["ray", "smp"])
+def test_raw2outputs_all_outputs_and_inputs_differentiable(dev, N, wb, mode):
+    """raw2outputs(raw, z_vals, dirs, args) under autograd with gradients arriving at rgb, weights AND alpha, flowing to
+    raw, z_vals and the directions (utils.py:134-191) - against the reference's autograd."""
+    from smpl_nerf_amd import ops
+    if N == 1 and mode == "smp":
+        pytest.skip("N==1 ignores directions")
+    g3, g = load_golden("g3_raw2outputs.npz"), load_golden("g14_ops_grads.npz")
+    B = g3[f"raw_N{N}"].shape[0]
+    raw = T(g3[f"raw_N{N}"], dev).requires_grad_(True)
+    z = T(g3[f"z_N{N}"], dev).requires_grad_(True)
+    d0 = T(g3[f"dray_N{N}"] if mode == "ray" else g3[f"dsmp_N{N}"], dev).requires_grad_(True)
+    d = d0[:, None, :].expand(B, N, 3) if mode == "ray" else d0
+    rgb, w, a = ops.raw2outputs(raw, z, d, O.Args(white_background=wb))
+    ((rgb * T(g[f"c_grgb_N{N}"], dev)).sum() + (w * T(g[f"c_gw_N{N}"], dev)).sum() + (a * T(g[f"c_ga_N{N}"], dev)).sum()).backward()
+    key = f"N{N}_wb{wb}_{mode}"
+    for got, ref in ((raw.grad, g[f"c_draw_{key}"]), (z.grad, g[f"c_dz_{key}"]), (d0.grad, g[f"c_ddir_{key}"])):
+        got = np.zeros_like(ref) if got is None else got.cpu().numpy()
+        close(got, ref, 2e-4, 2e-5 * max(np.abs(ref).max(), 1e-12))
+
+
+# ------------------------------------------------------------------------------------------ a6: every scalar type
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.int32, torch.int64, torch.int16, torch.int8, torch.uint8])
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_searchsorted_every_scalar_type(dev, dtype, side):
+    """AT_DISPATCH_ALL_TYPES (searchsorted_cpu_wrapper.cpp:100): bit-exact against numpy.searchsorted, the reference's
+    own test oracle (test/test_searchsorted.py:41-44), incl. ties, broadcast rows and rows longer than the LDS stage."""
+    from smpl_nerf_amd.ops import searchsorted
+    rng = np.random.default_rng(11)
+    npdt = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64,
+            torch.int16: np.int16, torch.int8: np.int8, torch.uint8: np.uint8}[dtype]
+
+    def draw(shape):
+        if np.issubdtype(npdt, np.floating):
+            return rng.normal(size=shape).astype(npdt)
+        info = np.iinfo(npdt)
+        lo, hi = max(info.min, -1000), min(info.max, 1000)
+        return rng.integers(lo, hi + 1, size=shape).astype(npdt)      # narrow range -> many ties
+
+    for (ra, ca, rv, cv) in [(7, 63, 7, 128), (1, 200, 9, 33), (5, 50, 1, 17), (3, 40000, 3, 70), (4, 0, 4, 5), (2, 1, 2, 300)]:
+        a = np.sort(draw((ra, ca)), -1)
+        v = draw((rv, cv))
+        if ca >= 8:
+            v[:, :4] = a[0, 2:6] if ra == 1 else (a[:rv, 2:6] if rv <= ra else a[:1, 2:6])     # exact hits
+        out = searchsorted(T(a, dev), T(v, dev), side=side).cpu().numpy()
+        rows = max(ra, rv)
+        ref = np.stack([np.searchsorted(a[0 if ra == 1 else r], v[0 if rv == 1 else r], side=side) for r in range(rows)])
+        assert out.dtype == np.int64 and out.shape == ref.shape
+        np.testing.assert_array_equal(out, ref)
+
+
+def test_searchsorted_rejects_mixed_and_unsupported_types(dev):
+    from smpl_nerf_amd.ops import searchsorted
+    a = torch.zeros((2, 4), device=dev)
+    with pytest.raises(RuntimeError):
+        searchsorted(a, a.double())
+    with pytest.raises(RuntimeError):
+        searchsorted(a.half(), a.half())
+
+
+def test_composite_forward_accepts_long_rays(dev):
+    """The forward has no upper bound on N (the backward takes N <= 4096): 5000 samples per ray against the oracle."""
+    from smpl_nerf_amd import ops
+    rng = np.random.default_rng(5)
+    B, N = 3, 5000
+    raw = rng.normal(0, 1.0, (B, N, 4)).astype(F32)
+    raw[..., 3] *= 3.0
+    z = np.sort(rng.uniform(1, 4, (B, N)).astype(F32), -1)
+    d = rng.normal(size=(B, 3)).astype(F32)
+    rgb, w, a = ops.composite(T(raw, dev), T(z, dev), T(d, dev), False)
+    ref = O.raw2outputs(raw, z, np.broadcast_to(d[:, None, :], (B, N, 3)), 0)
+    close(rgb.cpu().numpy(), ref[0], 0, 2e-6)
+    close(w.cpu().numpy(), ref[1], 0, 2e-6)
+    close(a.cpu().numpy(), ref[2], 0, 2e-6)

@@ -1,0 +1,75 @@
+"""CPU: the oracle (oracle/nerf_oracle.py) and the tests' torch gradient reference (tests/torch_ref.py) against the round-3
+vectors the reference produced (tests/golden/make_golden_r3.py): SmplNerfPipeline with human_pose_encoding = 0,
+WarpFieldNet under autograd, the differentiable stand-alone ops."""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as R
+from oracle import nerf_oracle as O
+from smpl_nerf_amd import synthetic as syn
+from conftest import load_golden
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("wb", [0, 1])
+def test_oracle_smpl_nerf_raw_pose_inputs(wb):
+    """models/smpl_nerf_pipeline.py:40-45 (human_pose_encoding = 0), run_fine = 0."""
+    g = load_golden("g12_smpl_raw_pose.npz")
+    pc, pf = syn.make_scene_nets(101)
+    pw = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("warp_param/")}
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    d = [a[g["sub"]] for a in data[:4]] + [g["goal_pose"], data[4][g["sub"]]]
+    out = O.smpl_nerf_pipeline_forward(pc, pf, pw, O.Args(white_background=wb, run_fine=0, human_pose_encoding=0),
+                                       O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0), O.PositionalEncoder(10, 0), d)
+    for nm, o_, tol in zip(("rgb", "rgb_fine", "warp", "samples", "warped", "alpha"), out, (2e-5, 2e-5, 2e-6, 0, 2e-6, 5e-5)):
+        close(o_, g[f"{nm}_wb{wb}"], 0, max(tol, 1e-12))
+
+
+@pytest.mark.parametrize("tag", ["enc", "raw"])
+def test_warp_field_net_gradients_of_the_torch_reference(tag):
+    g = load_golden("g13_warp_net_grad.npz")
+    P = R.tparams({k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(f"param_{tag}/")})
+    x = torch.from_numpy(g[f"x_{tag}"]).requires_grad_(True)
+    h = torch.relu(torch.nn.functional.linear(x, P["linear1.weight"], P["linear1.bias"]))
+    out = torch.nn.functional.linear(h, P["linear2.weight"], P["linear2.bias"])
+    close(out.detach().numpy(), O.warp_field_net_forward({k: v.detach().numpy() for k, v in P.items()}, g[f"x_{tag}"]), 0, 2e-6)
+    close(out.detach().numpy(), g[f"out_{tag}"], 0, 2e-6)
+    (out * torch.from_numpy(g[f"gout_{tag}"])).sum().backward()
+    close(x.grad.numpy(), g[f"dx_{tag}"], 1e-5, 1e-6)
+    for k, p in P.items():
+        close(p.grad.numpy(), g[f"grad_{tag}/{k}"], 1e-5, 1e-6 * np.abs(g[f"grad_{tag}/{k}"]).max())
+
+
+@pytest.mark.parametrize("L,ident", [(10, 0), (4, 1), (0, 1), (6, 0)])
+def test_posenc_gradient_of_the_torch_reference(L, ident):
+    g = load_golden("g14_ops_grads.npz")
+    x = torch.from_numpy(g["pe_x"]).requires_grad_(True)
+    out = R.posenc(x, L, ident)
+    close(out.detach().numpy(), O.PositionalEncoder(L, ident).encode(g["pe_x"]), 0, 1e-6)
+    (out * torch.from_numpy(g[f"pe_gout_L{L}_id{ident}"])).sum().backward()
+    close(x.grad.numpy(), g[f"pe_dx_L{L}_id{ident}"], 1e-5, 1e-6 * max(np.abs(g[f"pe_dx_L{L}_id{ident}"]).max(), 1e-12))
+
+
+@pytest.mark.parametrize("N", [1, 2, 64, 192, 100])
+@pytest.mark.parametrize("wb", [0, 1])
+@pytest.mark.parametrize("mode", ["ray", "smp"])
+def test_raw2outputs_full_backward_of_the_torch_reference(N, wb, mode):
+    if N == 1 and mode == "smp":
+        pytest.skip("N==1 ignores directions")
+    g3, g = load_golden("g3_raw2outputs.npz"), load_golden("g14_ops_grads.npz")
+    B = g3[f"raw_N{N}"].shape[0]
+    raw = torch.from_numpy(g3[f"raw_N{N}"]).requires_grad_(True)
+    z = torch.from_numpy(g3[f"z_N{N}"]).requires_grad_(True)
+    d0 = torch.from_numpy(g3[f"dray_N{N}"] if mode == "ray" else g3[f"dsmp_N{N}"]).requires_grad_(True)
+    d = d0[:, None, :].expand(B, N, 3) if mode == "ray" else d0
+    rgb, w, a = R.raw2outputs(raw, z, d, wb)
+    F = torch.from_numpy
+    ((rgb * F(g[f"c_grgb_N{N}"])).sum() + (w * F(g[f"c_gw_N{N}"])).sum() + (a * F(g[f"c_ga_N{N}"])).sum()).backward()
+    key = f"N{N}_wb{wb}_{mode}"
+    for got, ref in ((raw.grad, g[f"c_draw_{key}"]), (z.grad, g[f"c_dz_{key}"]), (d0.grad, g[f"c_ddir_{key}"])):
+        got = np.zeros_like(ref) if got is None else got.numpy()
+        close(got, ref, 1e-4, 1e-6 * max(np.abs(ref).max(), 1e-12))
