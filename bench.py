@@ -53,6 +53,10 @@ MODES = {
     "bf16x3": ("snerf::mlp_fwd_bf16_kernel<256, 8, 2, false, 0>", 3,
                "f32 via bf16x3 (two bf16 parts: 16 significand bits) - narrower than fp32"),
 }
+COARSE_ONLY = ("nerf {r}x{r} frame per GPU, coarse-only 64 samples/ray, run_fine=0, netdepth 8, width 256, skips [4], forward "
+               "render (BASELINE configs[0], the reference's CPU-runnable case)")
+WARP_FLOP_PER_EVAL = 2 * (256 * 100 + 3 * 256)      # WarpFieldNet 100 -> 256 -> 3: 52 736 FLOP (SURVEY.md 8d / BASELINE.md 3)
+WARP_FLOP_PADDED = 2 * (256 * 112 + 16 * 256)       # as executed: 7 k-blocks of 16 input slots, the 3-wide head in a 16-wide tile
 WORKLOADS = {
     "nerf": "nerf {r}x{r} frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, width 256, skips [4], "
             "forward render (BASELINE configs[1])",
@@ -60,7 +64,9 @@ WORKLOADS = {
                  "width 256 nets, forward render (BASELINE configs[2] at 128, configs[3] at 256); roofline counts the "
                  "RenderRayNet kernel only",
     "append_vertices": "append_vertices {r}x{r} frame per GPU, SMPL-vertex-conditioned nets (per-ray constant inputs, quirk "
-                       "Q7), coarse+fine 64+128 samples/ray (BASELINE configs[4]); synthetic linear body model",
+                       "Q7), coarse+fine 64+128 samples/ray (BASELINE configs[4]); vertices from synthetic_smpl.LinearBodyModel "
+                       "(no smplx / SMPL model file in the image: parity unpinned for real SMPL vertices and for the fine "
+                       "branch, which the reference itself cannot run)",
     "append_smpl_params": "append_smpl_params {r}x{r} frame per GPU, 69 pose columns in front of the encoding, coarse+fine "
                           "64+128 samples/ray (SURVEY 8f-4, the paper's headline model)",
 }
@@ -84,7 +90,7 @@ def self_launch(n):
 
 
 # ---------------------------------------------------------------------------------------------------- workload
-def build_pipeline(dev, precision="fp32", workload="nerf"):
+def build_pipeline(dev, precision="fp32", workload="nerf", run_fine=1):
     """(pipeline, parameter dicts, trainable models) of `workload` with seeded synthetic-scene weights."""
     import torch
     from smpl_nerf_amd import synthetic as syn
@@ -97,7 +103,8 @@ def build_pipeline(dev, precision="fp32", workload="nerf"):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
         return m.to(dev).eval()
 
-    args = PipelineArgs(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0, human_pose_encoding=1)
+    args = PipelineArgs(white_background=0, run_fine=run_fine, number_fine_samples=128, sigma_noise_std=0.0,
+                        human_pose_encoding=1)
     enc = (PositionalEncoder(10, 0), PositionalEncoder(4, 0))
     if workload == "append_vertices":
         from smpl_nerf_amd.synthetic_smpl import IndexPoseEstimator, LinearBodyModel
@@ -150,7 +157,23 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, params, data_np, n_rays):
+def _calibration(section=None):
+    try:
+        with open(os.path.join(ROOT, "oracle", "cpu_baseline_calibration.json")) as f:
+            c = json.load(f)
+        if section:
+            c = dict(c[section], host_cpu=c["host_cpu"], threads=c["threads"])
+            keys = ("host_cpu", "threads", "rays", "reference_ray_samples_per_s", "port_ray_samples_per_s",
+                    "port_over_reference_speed", "losses_bit_identical", "steps_compared")
+        else:
+            keys = ("host_cpu", "threads", "reference_ray_samples_per_s", "port_ray_samples_per_s",
+                    "port_over_reference_speed", "outputs_bit_identical")
+        return {k: c[k] for k in keys if k in c}
+    except Exception:
+        return None
+
+
+def cpu_baseline(workload, params, data_np, n_rays, run_fine=1):
     """The reference's CPU path, as restated op for op in PyTorch-CPU fp32 by oracle/torch_cpu_path.py (calibrated against
     the reference itself in the build container: oracle/cpu_baseline_calibration.json), timed on this host on a bounded
     sample of the same workload: the first n_rays rays of the same frame, same weights; warm-up 1, median of 5.
@@ -162,12 +185,14 @@ def cpu_baseline(workload, params, data_np, n_rays):
     default_threads = torch.get_num_threads()
     P = [T.tparams(p) for p in params]
     pe, de = T.PositionalEncoder(10, False), T.PositionalEncoder(4, False)
+    targs = T.Args(run_fine=run_fine)
+    per_ray = 256 if run_fine else 64
 
     def make_fwd(n):
         data = [torch.from_numpy(np.ascontiguousarray(a[:n])) for a in data_np]
         if workload == "smpl_nerf":
-            return lambda: T.smpl_nerf_pipeline_forward(P[0], P[1], P[2], T.Args(), pe, de, T.PositionalEncoder(10, False), data)
-        return lambda: T.nerf_pipeline_forward(P[0], P[1], T.Args(), pe, de, data)
+            return lambda: T.smpl_nerf_pipeline_forward(P[0], P[1], P[2], targs, pe, de, T.PositionalEncoder(10, False), data)
+        return lambda: T.nerf_pipeline_forward(P[0], P[1], targs, pe, de, data)
 
     probe, small = {}, make_fwd(min(256, n_rays))
     with torch.no_grad():
@@ -176,7 +201,7 @@ def cpu_baseline(workload, params, data_np, n_rays):
             small()
             t0 = time.perf_counter()
             small()
-            probe[t] = min(256, n_rays) * 256 / (time.perf_counter() - t0)
+            probe[t] = min(256, n_rays) * per_ray / (time.perf_counter() - t0)
         threads = max(probe, key=probe.get)
         torch.set_num_threads(threads)
         fwd = make_fwd(n_rays)
@@ -188,23 +213,44 @@ def cpu_baseline(workload, params, data_np, n_rays):
             ts.append(time.perf_counter() - t0)
         torch.set_num_threads(default_threads)
     dt = statistics.median(ts)
-    cal = None
-    try:
-        with open(os.path.join(ROOT, "oracle", "cpu_baseline_calibration.json")) as f:
-            c = json.load(f)
-        cal = {k: c[k] for k in ("host_cpu", "threads", "reference_ray_samples_per_s", "port_ray_samples_per_s",
-                                 "port_over_reference_speed", "outputs_bit_identical")}
-    except Exception:
-        pass
-    info = {"value": n_rays * 256 / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+    info = {"value": n_rays * per_ray / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
             "host_cpu": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch_default_threads": default_threads,
             "thread_probe_ray_samples_per_s": {str(k): v for k, v in sorted(probe.items())},
-            "sample": f"first {n_rays} rays of the same frame, same weights ({n_rays * 256} ray-samples per pass; warm-up 1, "
+            "sample": f"first {n_rays} rays of the same frame, same weights ({n_rays * per_ray} ray-samples per pass; warm-up 1, "
                       f"median of 5 passes, {dt:.2f} s each): oracle/torch_cpu_path.py = the reference's NerfPipeline.forward "
                       f"restated op for op on PyTorch-CPU fp32, torch.set_num_threads({threads}) = the fastest of the probed "
                       f"counts",
-            "calibration_vs_reference_in_build_container": cal}
+            "calibration_vs_reference_in_build_container": _calibration()}
     return info, [o.numpy() for o in out]
+
+
+def cpu_train_baseline(workload, params, data_np, n_rays, threads, lr):
+    """The reference's training step on this host's CPU: oracle/torch_cpu_path.train_step = the per-batch body of
+    NerfSolver.train (solver/nerf_solver.py:76-89: forward under autograd, zero_grad, MSE coarse + fine, backward, Adam.step,
+    loss.item()), calibrated against the reference's own NerfSolver object in the build container (losses bit-identical).
+    Bounded sample: n_rays rays of the same frame, same initial weights; warm-up 1, median of 3 steps."""
+    import numpy as np
+    import torch
+    from oracle import torch_cpu_path as T
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        state = T.TrainState(params, lr=lr, workload=workload)
+        data = [torch.from_numpy(np.ascontiguousarray(a[:n_rays])) for a in data_np]
+        losses, ts = [T.train_step(state, data)], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            losses.append(T.train_step(state, data))
+            ts.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(default_threads)
+    dt = statistics.median(ts)
+    return {"value": n_rays * 256 / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+            "seconds_per_step": dt, "loss_first": losses[0], "loss_last": losses[-1],
+            "sample": f"{n_rays} rays of the same frame per step ({n_rays * 256} ray-samples), same initial weights, Adam lr {lr}; "
+                      f"warm-up 1, median of 3 steps: oracle/torch_cpu_path.train_step = NerfSolver.train's per-batch body "
+                      f"(solver/nerf_solver.py:76-89) on PyTorch-CPU fp32 autograd, torch.set_num_threads({threads})",
+            "calibration_vs_reference_in_build_container": _calibration("train")}
 
 
 # ---------------------------------------------------------------------------------------------------- HBM traffic
@@ -257,6 +303,9 @@ def pmc_traffic(argv_child, kernel_substr, timeout_s=240):
 
 
 # ---------------------------------------------------------------------------------------------------- training
+TRAIN_LR = 3e-5
+
+
 def train_section(precision, workload, data, rays, steps, world, rank, dev):
     """Secondary measurement (not `value`): data-parallel training steps - forward with saved activations, MSE
     coarse+fine, HIP backward, one flat all-reduce of the gradients, Adam - on `rays` rays per GPU drawn from this rank's
@@ -273,7 +322,7 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev):
     # lr: small enough that both nets stay alive on this synthetic scene (at 1e-4 and above Adam's first steps push the
     # fine net's densities below zero everywhere: the rendered colour and every gradient become exactly 0, and the
     # backward kernels would be timed on all-zero operands)
-    tr = DataParallelTrainer(pipe, models, lr=3e-5)
+    tr = DataParallelTrainer(pipe, models, lr=TRAIN_LR)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     n_total = data[0].shape[0]
     batches = []
@@ -285,14 +334,17 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev):
         losses.append(tr.step(batches[i % 4]))
     barrier(dev)
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
     with _lib.profile() as prof:
         t0 = time.perf_counter()
         for i in range(steps):
             losses.append(tr.step(batches[i % 4]))
+        t_host = time.perf_counter() - t0          # the Python loop returned: everything is enqueued
         torch.cuda.synchronize()
         barrier(dev)
         dt = time.perf_counter() - t0
     kern = prof.summary()
+    peak_mem = torch.cuda.max_memory_allocated(dev)
     dt = max_over_ranks(dt, dev)
     with torch.no_grad():   # the trained nets still render something (not collapsed to zero density)
         fine_std = float(pipe(batches[0])[1].std())
@@ -304,6 +356,8 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev):
     tf = flop_step / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None
     return {"metric": "ray-samples/s, training step (fwd+bwd+all-reduce+Adam)", "value": evals / dt, "precision": precision,
             "rays_per_step_per_gpu": rays, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "host_enqueue_ms_per_step": t_host / steps * 1e3, "c_abi_calls_per_step": sum(v[0] for v in kern.values()) / steps,
+            "peak_allocated_bytes": int(peak_mem),
             "loss_first": losses[0], "loss_last": losses[-1], "rgb_fine_std_last_step": fine_std,
             "mlp_kernels_ms_per_step": mlp_ms, "mlp_algorithmic_tflops": tf, "mlp_peak_tflops": peak,
             "mlp_roofline_frac": tf / peak if tf else None,
@@ -328,6 +382,15 @@ def main():
     ap.add_argument("--res", type=int, default=128, help="frame edge in pixels (BASELINE configs[3]/[4] use 256)")
     ap.add_argument("--train-rays", type=int, default=4096, help="rays per GPU per training step (0 = skip the train section)")
     ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--coarse-only", action="store_true",
+                    help="BASELINE configs[0]: run_fine=0, 64 samples per ray (nerf workload)")
+    ap.add_argument("--rays", type=int, default=0,
+                    help="rays per step per GPU (default: the whole frame, res*res); the reference's own operating points are "
+                         "2048 (train batch, config_parser.py:53), 800 (inference.py:231) and 64 (README quickstart)")
+    ap.add_argument("--cpu-train-rays", type=int, default=512, help="rays per step of the CPU training baseline (0 = skip)")
+    ap.add_argument("--points", default="64,800,2048",
+                    help="comma-separated ray counts of the extra operating points (render; training at 2048 when among them); "
+                         "empty = skip")
     ap.add_argument("--no-alt", action="store_true", help="skip the other precision modes")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     a = ap.parse_args()
@@ -362,16 +425,24 @@ def main():
     from smpl_nerf_amd.dist import barrier, max_over_ranks, shard_frames
 
     global FLOP_PER_EVAL
-    pipe, params, nets = build_pipeline(dev, a.precision, a.workload)
+    if a.coarse_only and a.workload != "nerf":
+        raise SystemExit("--coarse-only is BASELINE configs[0]: the nerf workload")
+    run_fine = 0 if a.coarse_only else 1
+    per_ray = 256 if run_fine else 64
+    pipe, params, nets = build_pipeline(dev, a.precision, a.workload, run_fine)
     # algorithmic FLOPs of one RenderRayNet evaluation of THIS workload (2 x weight elements the output depends on: the
     # additional-input columns of the pose-conditioned nets count, AppendVerticesNet's dead vertices_net branch does not)
     FLOP_PER_EVAL = 2 * sum(p.numel() for k, p in nets[0].named_parameters() if k.endswith("weight") and not k.startswith("vertices_net"))
     # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
     frame_id = shard_frames(world, rank)
     data_np = frame_inputs(a.workload, a.res, frame_id)
-    data = [torch.from_numpy(x).to(dev) for x in data_np]
+    if a.rays:
+        if a.rays > data_np[0].shape[0]:
+            raise SystemExit(f"--rays {a.rays} exceeds the {a.res}x{a.res} frame")
+        data_np = [x[:a.rays] for x in data_np]
+    data = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in data_np]
     rays = data[0].shape[0]
-    evals_per_step = rays * 256
+    evals_per_step = rays * per_ray
 
     with torch.no_grad():
         for _ in range(a.warmup):
@@ -382,11 +453,44 @@ def main():
             t0 = time.perf_counter()
             for _ in range(a.steps):
                 out = pipe(data)
+            t_host = time.perf_counter() - t0      # the Python loop returned: everything is enqueued
             torch.cuda.synchronize()
             barrier(dev)
             elapsed = time.perf_counter() - t0
         kern = prof.summary()
     elapsed = max_over_ranks(elapsed, dev)
+
+    def operating_point(n, steps=20):
+        """Render `n` rays per step (the first n of the frame): ms per step, host enqueue time, C-ABI calls."""
+        sub = [t[:n].contiguous() for t in data]
+        with torch.no_grad():
+            for _ in range(3):
+                pipe(sub)
+            torch.cuda.synchronize()
+            with _lib.profile() as pp:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    pipe(sub)
+                th = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            k = pp.summary()
+            # the same steps without the per-call event pairs of the profile: the host cost a user pays
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pipe(sub)
+            th_plain = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            dt_plain = time.perf_counter() - t0
+        return {"rays_per_step": n, "ms_per_step": dt_plain / steps * 1e3, "host_enqueue_ms_per_step": th_plain / steps * 1e3,
+                "ray_samples_per_s": n * per_ray * steps / dt_plain, "c_abi_calls_per_step": sum(v[0] for v in k.values()) / steps,
+                "gpu_kernels_ms_per_step": sum(v[1] for v in k.values()) / steps,
+                "ms_per_step_with_event_pairs": dt / steps * 1e3, "host_ms_with_event_pairs": th / steps * 1e3}
+
+    points = None
+    if a.points and world == 1:
+        points = [operating_point(n) for n in sorted({int(v) for v in a.points.split(",") if v.strip()}) if n <= rays]
 
     def mlp_launch_stats(k, steps):
         mlp = {n: v for n, v in k.items() if n.startswith("mlp_fwd")}
@@ -436,14 +540,19 @@ def main():
             pipe.set_precision(a.precision)
 
     train = train_alt = None
-    if a.train_rays > 0:
+    if a.train_rays > 0 and run_fine:
         try:
-            train = train_section(a.precision, a.workload, data, a.train_rays, a.train_steps, world, rank, dev)
+            train = train_section(a.precision, a.workload, data, min(a.train_rays, rays), a.train_steps, world, rank, dev)
+            if a.points and "2048" in [v.strip() for v in a.points.split(",")] and a.train_rays != 2048 and rays >= 2048:
+                t = train_section(a.precision, a.workload, data, 2048, a.train_steps, world, rank, dev)
+                train["operating_point_2048_rays"] = {k: t[k] for k in (
+                    "value", "rays_per_step_per_gpu", "ms_per_step", "host_enqueue_ms_per_step", "c_abi_calls_per_step",
+                    "mlp_kernels_ms_per_step", "mlp_roofline_frac", "peak_allocated_bytes")}
             if not a.no_alt:
                 train_alt = {}
                 for prec in ("bf16x6", "f16x3", "fp32"):
                     if prec != a.precision:
-                        t = train_section(prec, a.workload, data, a.train_rays, a.train_steps, world, rank, dev)
+                        t = train_section(prec, a.workload, data, min(a.train_rays, rays), a.train_steps, world, rank, dev)
                         train_alt[prec] = {k: t[k] for k in ("value", "ms_per_step", "loss_first", "loss_last",
                                                              "mlp_kernels_ms_per_step", "mlp_algorithmic_tflops",
                                                              "mlp_roofline_frac")}
@@ -461,7 +570,11 @@ def main():
         roof["algorithmic_hbm_bytes_per_launch"] = alg_bytes
         if world == 1 and not a.no_pmc:
             child = ["--steps", "3", "--warmup", "1", "--cpu-rays", "0", "--train-rays", "0", "--no-alt", "--no-pmc",
-                     "--precision", a.precision, "--workload", a.workload, "--res", str(a.res)]
+                     "--precision", a.precision, "--workload", a.workload, "--res", str(a.res), "--points", ""]
+            if a.coarse_only:
+                child.append("--coarse-only")
+            if a.rays:
+                child += ["--rays", str(a.rays)]
             t, err = pmc_traffic(child, MODES[a.precision][0].replace("snerf::", ""))
             if t:
                 roof["traffic"] = t["FETCH_SIZE"][0] + t["WRITE_SIZE"][0]
@@ -471,17 +584,23 @@ def main():
                                                     "`bench.py " + " ".join(child) + "`, per average launch"}
             else:
                 roof["traffic_detail"] = {"error": err}
+        if a.coarse_only:
+            metric = f"ray-samples/sec (coarse-only) at {a.res}^2 / 64 samples"
+        else:
+            metric = f"ray-samples/sec (coarse+fine) at {a.res}^2 / 64+128 samples"
         line = {
-            "metric": "ray-samples/sec (coarse+fine) at 128^2 / 64+128 samples" if a.res == 128 else
-                      f"ray-samples/sec (coarse+fine) at {a.res}^2 / 64+128 samples",
+            "metric": metric,
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": MODES[a.precision][2], "data": "synthetic",
-            "config": {"workload": WORKLOADS[a.workload].format(r=a.res), "rays_per_step_per_gpu": rays,
-                       "ray_samples_per_ray": 256,
+            "config": {"workload": (COARSE_ONLY if a.coarse_only else WORKLOADS[a.workload]).format(r=a.res)
+                                   + (f"; first {rays} rays of the frame per step" if a.rays else ""),
+                       "rays_per_step_per_gpu": rays, "ray_samples_per_ray": per_ray,
                        "parallelism": f"dp{world} (rays of independent frames per rank, no data-path collective"
                                       + (f"; process group on {backend}" if backend else "") + ")"},
             "rays_per_s": world * a.steps * rays / elapsed,
+            "host_enqueue_ms_per_step": t_host / a.steps * 1e3,
+            "c_abi_calls_per_step": sum(v[0] for v in kern.values()) / a.steps,
             "roofline": roof,
             "precision": a.precision,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(kern.items())},
@@ -489,24 +608,40 @@ def main():
         if alt:
             line["other_precisions_1gpu"] = alt
             if "bf16x6" in alt and a.precision == "fp32":
-                # the fastest mode whose measured error against float64 is <= the exact-fp32 kernel's own (tests hold
-                # bf16x6 to <= 1.0 x in aggregate RMS; profiles/r02_precision_study.log: 0.89) - reported, not the headline:
-                # `value` stays on the reference's own arithmetic
+                # the fastest mode whose error against float64 the tests hold to <= the exact-fp32 kernel's own
+                # (test_split_bf16_stress_against_fp32_kernel: aggregate RMS <= 1.0 x; tools/precision_study_gpu.py measures
+                # it) - reported, not the headline: `value` stays on the reference's own arithmetic
                 b = alt["bf16x6"]
                 line["fastest_mode_with_fp32_kernel_accuracy"] = {
                     "precision": "bf16x6", "ray_samples_per_s_per_gpu": b["ray_samples_per_s_per_gpu"],
                     "speedup_vs_value": b["ray_samples_per_s_per_gpu"] * world / value,
                     "rgb_fine_max_abs_diff_vs_fp32": b["rgb_fine_max_abs_diff_vs_fp32"],
-                    "aggregate_rms_error_vs_float64_relative_to_fp32_kernel": 0.894,
                     "roofline_frac_vs_16bit_peak": b["roofline"]["frac"], "mfma_issue_frac": b["roofline"]["mfma_issue_frac"]}
+        warp = {n: v for n, v in kern.items() if n.startswith("warp_fwd")}
+        if warp:    # smpl_nerf: the warp-field kernel beside the RenderRayNet kernel, on ALGORITHMIC FLOPs
+            wcalls, wms = sum(v[0] for v in warp.values()), sum(v[1] for v in warp.values())
+            wupl = a.steps * evals_per_step / wcalls
+            wtf = WARP_FLOP_PER_EVAL * wupl / (wms / wcalls * 1e-3) / 1e12
+            wpeak = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
+            line["warp_roofline"] = {
+                "bound": "mfma", "kernel": "snerf::warp_fwd_resident_kernel<256, 16, false>" if a.precision == "fp32"
+                else "snerf::warp_fwd_bf16_kernel<256, 8>", "achieved": wtf, "peak": wpeak, "unit": "TFLOP/s",
+                "frac": wtf / wpeak, "avg_launch_ms": wms / wcalls, "launches": wcalls, "flop_per_unit": WARP_FLOP_PER_EVAL,
+                "units_per_launch": wupl, "frac_on_padded_flops_as_executed": wtf / wpeak * WARP_FLOP_PADDED / WARP_FLOP_PER_EVAL,
+                "padded_flop_per_unit": WARP_FLOP_PADDED}
+        if points:
+            line["operating_points_render"] = points
         if train is not None:
             line["train"] = train
         if train_alt:
             line["train_other_precisions"] = train_alt
         if world == 1 and a.cpu_rays > 0 and a.workload in ("nerf", "smpl_nerf"):
             n = min(a.cpu_rays, rays)
-            info, ref = cpu_baseline(a.workload, params, data_np, n)
+            info, ref = cpu_baseline(a.workload, params, data_np, n, run_fine)
             line["cpu_baseline"] = info
+            if isinstance(train, dict) and "error" not in train and a.cpu_train_rays > 0 and run_fine:
+                train["cpu_baseline"] = cpu_train_baseline(a.workload, params, data_np, min(a.cpu_train_rays, rays),
+                                                           info["cores"], TRAIN_LR)
             line["rgb_fine_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[1][:n].cpu().numpy() - ref[1])))
             line["rgb_coarse_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[0][:n].cpu().numpy() - ref[0])))
         print(json.dumps(line), flush=True)

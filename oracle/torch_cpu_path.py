@@ -19,6 +19,12 @@ Reference lines followed:
     NerfPipeline.forward         models/nerf_pipeline.py:14-67
     WarpFieldNet.forward         models/warp_field_net.py:17-22
     SmplNerfPipeline.forward     models/smpl_nerf_pipeline.py:16-100
+    NerfSolver's training step   solver/nerf_solver.py:31-33 (Adam), :48-52 (loss), :76-87 (per-batch body)
+    SmplNerfSolver's step        solver/smpl_nerf_solver.py:26-28 (one Adam over the three nets), :35-43, :75-86
+
+The training step (TrainState / train_step) is the same forward under autograd followed by the reference's own sequence
+zero_grad -> loss -> backward -> Adam.step -> loss.item(); oracle/calibrate_cpu_baseline.py times it beside the imported
+reference's NerfSolver objects (losses bit-identical, speed within +-10 %).
 """
 from __future__ import annotations
 
@@ -194,3 +200,39 @@ def smpl_nerf_pipeline_forward(Pc, Pf, Pw, args, position_encoder, direction_enc
     fsd = ray_direction[..., None, :].expand(ray_direction.shape[0], ray_samples_fine.shape[1], ray_direction.shape[-1])
     rgb_fine, _, densities_fine = raw2outputs(raw_f, z_fine, fsd, args)
     return rgb, rgb_fine, warp_f, ray_samples_fine, warped_f, densities_fine
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# training step (solver/nerf_solver.py:76-87, solver/smpl_nerf_solver.py:75-86)
+# ----------------------------------------------------------------------------------------------------------------
+class TrainState:
+    """Leaf parameter dicts of the nets + the reference's optimiser: torch.optim.Adam over coarse, fine (, warp field)
+    parameters in registration order with NerfSolver.default_adam_args overridden by lr / weight_decay
+    (solver/nerf_solver.py:10-14, 31-33; smpl: solver/smpl_nerf_solver.py:26-28)."""
+
+    def __init__(self, params_list, lr=5e-4, weight_decay=0.0, workload="nerf", args=None):
+        self.P = [{k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).clone().requires_grad_(True)
+                   for k, v in p.items()} for p in params_list]
+        self.workload = workload
+        self.args = args or Args()
+        self.optim = torch.optim.Adam([t for P in self.P for t in P.values()], lr=lr, betas=(0.9, 0.999), eps=1e-8,
+                                      weight_decay=weight_decay)
+        self.loss_func = torch.nn.MSELoss()
+        self.pe, self.de, self.he = PositionalEncoder(10, False), PositionalEncoder(4, False), PositionalEncoder(10, False)
+
+    def forward(self, data):
+        if self.workload == "smpl_nerf":
+            return smpl_nerf_pipeline_forward(self.P[0], self.P[1], self.P[2], self.args, self.pe, self.de, self.he, data)
+        return nerf_pipeline_forward(self.P[0], self.P[1], self.args, self.pe, self.de, data)
+
+
+def train_step(state: TrainState, data) -> float:
+    """One batch of NerfSolver.train (solver/nerf_solver.py:76-87), statement for statement."""
+    rgb_truth = data[-1]
+    out = state.forward(data)                                                    # :81
+    rgb, rgb_fine = out[0], out[1]
+    state.optim.zero_grad()                                                      # :83
+    loss = state.loss_func(rgb, rgb_truth) + state.loss_func(rgb_fine, rgb_truth)   # :85, :48-52
+    loss.backward()                                                              # :86
+    state.optim.step()                                                           # :87
+    return loss.item()                                                           # :89

@@ -65,7 +65,7 @@ const Tuning &tuning() {
         k.wgrad_f16 = flag("SNERF_WGRAD_F16", true);
         k.wgrad_narrow_f16 = flag("SNERF_WGRAD_NARROW_F16", true);
         k.wgrad_f16_split_per_wave = flag("SNERF_WGRAD_F16_SPLIT_PER_WAVE", false);
-        k.wgrad_narrow_staged = flag("SNERF_WGRAD_NARROW_STAGED", true);
+        k.wgrad_fold = flag("SNERF_WGRAD_FOLD", true);
         return k;
     }();
     return t;

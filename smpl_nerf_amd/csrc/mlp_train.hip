@@ -256,15 +256,24 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
 constexpr int WL_WAVES = 16, WL_THREADS = WL_WAVES * 64;
 constexpr int WL_STAGE = 16;                      // samples per stage (4 MFMA k-steps)
 constexpr int WL_ROW_FLOATS = WL_STAGE * 16;      // one tile-row of a stage: 1 KiB
-constexpr int WL_SLOT_FLOATS = 32 * WL_ROW_FLOATS;  // 16 dY rows + 16 X rows
+constexpr int WL_XROW0 = 32, WL_YROW0 = 36;         // LDS rows of the folded operands: <= 4 extra X rows, one extra dY row
+constexpr int WL_SLOT_FLOATS = 37 * WL_ROW_FLOATS;  // 16 dY rows + 16 X rows + the folded rows (mlp_train_device.h)
 constexpr int WL_SLOTS = 4;                          // ring depth: up to WL_SLOTS - 2 stages in flight behind the one awaited
 constexpr int WL_LDS_BYTES = WL_SLOTS * WL_SLOT_FLOATS * 4;
 
 // the stage loop and the epilogue for one wave that owns TI x TJ accumulator tiles
+// what rides with a wide job (mlp_train_device.h: wgrad_kind == 1)
+struct WgradFold {
+    int ex;            // extra X tile-rows: the folded segment's k-blocks (0 = none)
+    int ex_tj0;        // ... whose partial tiles are columns ex_tj0 .. of the SAME layer
+    int ey_layer;      // forward layer whose single dY tile-row rides as extra dY row (the sigma head), or -1
+    const float *src;  // this wave's third piece per stage (extra X row `wave` < ex, or the extra dY row for wave 4), or null
+};
+
 template <int TI, int TJ>
-__device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L, const WgradArgs &A, float *ring, int l,
-                                           int kb0, int jb, int n_rows_y, int n_rows_x, bool bias_job,
-                                           const float *const (&row_src)[2], int wave, int lane) {
+__device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const TrainLayout &L, const WgradArgs &A, float *ring,
+                                           int l, int kb0, int jb, int n_rows_y, int n_rows_x, bool bias_job,
+                                           const float *const (&row_src)[2], const WgradFold &F, int wave, int lane) {
     const int nbj = (n_rows_x + TJ - 1) / TJ, nbi = (n_rows_y + TI - 1) / TI;
     const int bi = wave / nbj, bj = wave - bi * nbj;
     const bool active = bi < nbi;
@@ -275,6 +284,9 @@ __device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L
     const int64_t begin = (int64_t)blockIdx.y * A.chunk;
     const int64_t end = min(n, begin + A.chunk);
     const int nstages = begin < end ? (int)((end - begin + WL_STAGE - 1) / WL_STAGE) : 0;
+    const bool has3 = F.src != nullptr;
+    // folded tiles of this wave: (dY rows TI*bi .., extra X row bj) and (extra dY row, X row TJ*bj + bi)
+    const bool fx = active && bj < F.ex, fy = active && F.ey_layer >= 0 && bi < TJ && TJ * bj + bi < n_rows_x;
 
     auto issue = [&](int stage, int slot) {
         // lane covers 16 B: features 4*(lane&3).. of sample (lane>>2) of the stage; clamped at the end of the buffer
@@ -284,6 +296,10 @@ __device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(row_src[q] + smp * 16 + (lane & 3) * 4),
                 (__attribute__((address_space(3))) void *)(ring + slot * WL_SLOT_FLOATS + (2 * wave + q) * WL_ROW_FLOATS), 16, 0, 0);
+        if (has3)   // wave-uniform: the folded rows are brought by waves 0 .. 4
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(F.src + smp * 16 + (lane & 3) * 4),
+                (__attribute__((address_space(3))) void *)(ring + slot * WL_SLOT_FLOATS + (WL_XROW0 + wave) * WL_ROW_FLOATS), 16, 0, 0);
     };
 
     f4 acc[TI][TJ];
@@ -294,13 +310,23 @@ __device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L
     float bsum[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
+    f4 accx[TI], accy = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TI; ++i) accx[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float ysum = 0.f;
 
-    // stage st lives in slot st % WL_SLOTS.  Every wave issues exactly two pieces per stage, so `vmcnt(2k)` leaves the
-    // k newest stages in flight.
+    // stage st lives in slot st % WL_SLOTS.  A wave issues exactly two (three with a folded row) pieces per stage, so
+    // `vmcnt(2k)` (`vmcnt(3k)`) leaves its k newest stages in flight.
     auto wait_landed = [&](int k) {  // k = stages allowed to stay in flight, 0 .. WL_SLOTS - 2
-        if (k >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (k == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (has3) {
+            if (k >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (k == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (k >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (k == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     };
     static_assert(WL_SLOTS == 4, "wait_landed covers k <= 2");
     if (nstages > 0) {
@@ -338,6 +364,20 @@ __device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L
                     for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
                     bsum[i] += a[i];
                 }
+                if (fx) {   // wave-uniform: this wave's dY rows x folded X row bj
+                    const float bx = ring[slot * WL_SLOT_FLOATS + (WL_XROW0 + bj) * WL_ROW_FLOATS + lane + 64 * step];
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) accx[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bx, accx[i], 0, 0, 0);
+                }
+                if (fy) {   // folded dY row x this wave's X row bi
+                    const float va = ring[slot * WL_SLOT_FLOATS + WL_YROW0 * WL_ROW_FLOATS + lane + 64 * step];
+                    const float ay = ok ? va : 0.f;
+                    float by = b[0];
+#pragma unroll
+                    for (int t = 1; t < TJ; ++t) by = (bi == t) ? b[t] : by;
+                    accy = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, by, accy, 0, 0, 0);
+                    ysum += ay;
+                }
             }
         }
         if (st + 1 < nstages) {
@@ -365,6 +405,20 @@ __device__ __forceinline__ void wgrad_wave(const Layer &Ly, const TrainLayout &L
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (TI * bi + i) * 16 + lane] = v;
+        }
+        if (fx)   // folded segment of the same layer: tile column ex_tj0 + bj
+            *reinterpret_cast<f4 *>(part + ((int64_t)((TI * bi + i) * Ly.nkb + F.ex_tj0 + bj) * 64 + lane) * 4) = accx[i];
+    }
+    if (fy) {     // the folded layer's (one output tile) partial: tile column = this wave's X row
+        const Layer &Le = P.layer[F.ey_layer];
+        float *pe = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[F.ey_layer];
+        const int tj = TJ * bj + bi;
+        *reinterpret_cast<f4 *>(pe + ((int64_t)tj * 64 + lane) * 4) = accy;
+        if (tj == 0) {   // its bias sums
+            float v = ysum;
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) pe[(int64_t)Le.t_out * Le.nkb * 256 + lane] = v;
         }
     }
 }
@@ -411,11 +465,26 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
             row_src[q] = A.dy + grow * n * 16;
         }
     }
+    // ---- what rides with this job (first group of the layer's first wide segment only) ------------------------------
+    WgradFold F{0, 0, -1, nullptr};
+    if (A.fold && jb == 0 && s == wgrad_first_wide_seg(Ly)) {
+        const int xs = wgrad_fold_xseg(P, l);
+        if (xs >= 0) {
+            F.ex = Ly.seg[xs].nkb;
+            F.ex_tj0 = 0;
+            for (int q = 0; q < xs; ++q) F.ex_tj0 += Ly.seg[q].nkb;
+            if (wave < F.ex) F.src = A.act + (int64_t)(seg_act_row(P, L, l, xs) + wave) * n * 16;
+        }
+        if (l == P.n_hidden + 3 && wgrad_fold_sigma(P)) {
+            F.ey_layer = P.n_hidden + 2;
+            if (wave == WL_YROW0 - WL_XROW0) F.src = A.dy + (int64_t)L.dy[F.ey_layer] * n * 16;
+        }
+    }
     // wave block shape: the job's <=16 x <=16 tiles are cut so that (up to) all 16 waves own a block
     const int ti = n_rows_y > 8 ? 4 : (n_rows_y > 4 ? 2 : 1), tj = n_rows_x > 8 ? 4 : (n_rows_x > 4 ? 2 : 1);
 #define SNERF_WG_CASE(TI_, TJ_)                                                                                       \
     if (ti == TI_ && tj == TJ_)                                                                                       \
-        return wgrad_wave<TI_, TJ_>(Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, wave, lane);
+        return wgrad_wave<TI_, TJ_>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
     SNERF_WG_CASE(4, 4)
     SNERF_WG_CASE(4, 2)
     SNERF_WG_CASE(4, 1)
@@ -443,7 +512,7 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_direct_kernel(Plan P, Tr
         kb0 = 0;
         for (s = 0; s < P.layer[l].nseg; ++s) {
             nbj = (P.layer[l].seg[s].nkb + 3) / 4;
-            const int cnt = wgrad_wide(P.layer[l], s) ? 0 : ((P.layer[l].t_out + 3) / 4) * nbj;
+            const int cnt = wgrad_kind(P, l, s, A.fold != 0) == 2 ? ((P.layer[l].t_out + 3) / 4) * nbj : 0;
             if (job < cnt) { found = true; break; }
             job -= cnt;
             kb0 += P.layer[l].seg[s].nkb;
@@ -536,7 +605,7 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_direct_kernel(Plan P, Tr
 // sum over the G partials and scatter slot order -> state_dict order
 // G_wide / G_narrow: number of sample chunks (partials) the wide and the narrow jobs were split into
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayout L, const float *__restrict__ part,
-                                                               int G_wide, int G_narrow, float *__restrict__ flat_grad) {
+                                                               int G_wide, int G_narrow, int fold, float *__restrict__ flat_grad) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= L.gp_floats) return;
     int l = 0;
@@ -561,7 +630,8 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
         if (row < Ly.n_out) dst = Ly.b_off + row;
     }
     if (dst < 0) return;
-    const int G = (seg < Ly.nseg && wgrad_wide(Ly, seg)) ? G_wide : G_narrow;
+    // the bias sums of a layer ride with its first non-empty segment; a folded pair was written by the wide job's chunks
+    const int G = (seg < Ly.nseg && wgrad_kind(P, l, seg, fold != 0) != 2) ? G_wide : G_narrow;
     float sum = 0.f;
     for (int c = 0; c < G; ++c) sum += part[(int64_t)c * L.gp_floats + e];
     flat_grad[dst] = sum;
@@ -597,6 +667,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     W.xstat = reinterpret_cast<const int *>(act + (int64_t)L.act_rows * n * 16);   // (f16x3 wide jobs only)
     W.ystat = reinterpret_cast<const int *>(dy + (int64_t)L.dy_rows * n * 16);
     W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
+    W.fold = (!wide_nsplit && tuning().wgrad_fold) ? 1 : 0;   // the split-precision wide kernels do not carry folded tiles
     static LdsRaised raised;   // per device
     int rc;
     if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_kernel), WL_LDS_BYTES, raised, "wgrad"))) return rc;
@@ -608,7 +679,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             if ((rc = check_launch("wgrad"))) return rc;
         }
     }
-    if (const int jobs = wgrad_direct_jobs(P)) {
+    if (const int jobs = wgrad_direct_jobs(P, W.fold != 0)) {
         W.chunk = (((n + G_narrow - 1) / G_narrow) + 15) / 16 * 16;
         // f16x3 step: the narrow jobs with two fp16 parts as well (SNERF_WGRAD_NARROW_F16=0: fp32 MFMA)
         const bool narrow_f16 = tuning().wgrad_narrow_f16;
@@ -619,7 +690,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             if ((rc = check_launch("wgrad_direct"))) return rc;
         }
     }
-    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, G_narrow, flat_grad);
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, G_narrow, W.fold, flat_grad);
     return check_launch("wgrad_reduce");
 }
 

@@ -70,6 +70,7 @@ struct WgradArgs {
     int64_t n;
     int64_t chunk;  // samples per K-split, multiple of 16
     const int *xstat, *ystat;  // f16x3 wide wgrad: exponents of the largest |X| entering / |dY| leaving forward layer l
+    int fold;                  // fp32 step: narrow pairs that share an operand with a wide job ride with it (wgrad_kind)
 };
 
 
@@ -80,6 +81,43 @@ struct WgradArgs {
 // would read dY and X from HBM once per job rather than 2-4 times, is 0.3 ms per 10^6 samples SLOWER - the re-reads
 // of concurrently running blocks hit L2.)
 __host__ __device__ inline bool wgrad_wide(const Layer &Ly, int s) { return Ly.t_out >= 8 && Ly.seg[s].nkb >= 16; }
+// Folding (fp32 steps).  The narrow pairs are bound by HBM, not by the matrix pipe: a single-wave 4x4-tile job needs 2 KB of
+// operands per 16 MFMAs and the 20 narrow jobs of the default net move 8.7 KB per sample - while most of those bytes are
+// ALREADY staged in LDS by a wide job: the position-encoding columns of a skip layer and the direction-encoding columns of
+// directional_input contract the same d Y rows as the layer's 256-column job (only 4 / 2 more X tile-rows), and the sigma
+// head contracts the same X rows (`o`) as directional_input's job (one more d Y tile-row).  mlp_wgrad_kernel computes those
+// as extra accumulator tiles of the wide job: no extra d Y / X traffic beyond the few extra rows, no extra barrier, +3 % wide
+// MFMAs - and 10 of the 20 narrow jobs (4 KB per sample) disappear.
+//   xseg fold: one narrow segment (<= 4 k-blocks) of a layer that also has a wide segment -> extra X rows of that job
+//   sigma fold: the 1-row sigma head -> extra d Y row of directional_input's hidden-segment job (same X rows, same width)
+__host__ __device__ inline int wgrad_first_wide_seg(const Layer &Ly) {
+    for (int s = 0; s < Ly.nseg; ++s)
+        if (wgrad_wide(Ly, s)) return s;
+    return -1;
+}
+__host__ __device__ inline int wgrad_fold_xseg(const Plan &P, int l) {   // folded segment of layer l, or -1
+    const Layer &Ly = P.layer[l];
+    if (wgrad_first_wide_seg(Ly) < 0) return -1;
+    for (int s = 0; s < Ly.nseg; ++s)
+        if (!wgrad_wide(Ly, s) && Ly.seg[s].nkb >= 1 && Ly.seg[s].nkb <= 4) return s;
+    return -1;
+}
+__host__ __device__ inline bool wgrad_fold_sigma(const Plan &P) {
+    const int nh = P.n_hidden;
+    if (P.nlayers != nh + 6) return false;   // a RenderRayNet plan (the warp net's two-layer plan has no heads)
+    const Layer &Ls = P.layer[nh + 2], &Ld = P.layer[nh + 3];
+    return Ls.t_out == 1 && Ls.nseg == 1 && wgrad_first_wide_seg(Ld) == 0 && Ld.seg[0].nkb == Ls.seg[0].nkb && Ld.seg[0].nkb == 16 &&
+           Ld.t_out == 8;
+}
+// how the pair (layer l, segment s) is computed: 0 = wide job, 1 = rides with a wide job, 2 = direct narrow job
+__host__ __device__ inline int wgrad_kind(const Plan &P, int l, int s, bool fold) {
+    if (wgrad_wide(P.layer[l], s)) return 0;
+    if (fold) {
+        if (wgrad_fold_xseg(P, l) == s) return 1;
+        if (l == P.n_hidden + 2 && wgrad_fold_sigma(P)) return 1;
+    }
+    return 2;
+}
 __host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups of <= 16 input k-blocks
     int jobs = 0;
     for (int l = 0; l < P.nlayers; ++l)
@@ -87,11 +125,11 @@ __host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups
             if (wgrad_wide(P.layer[l], s)) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
     return jobs;
 }
-__host__ __device__ inline int wgrad_direct_jobs(const Plan &P) {  // narrow jobs: 4x4-tile blocks
+__host__ __device__ inline int wgrad_direct_jobs(const Plan &P, bool fold = false) {  // narrow jobs: 4x4-tile blocks
     int jobs = 0;
     for (int l = 0; l < P.nlayers; ++l)
         for (int s = 0; s < P.layer[l].nseg; ++s)
-            if (!wgrad_wide(P.layer[l], s)) jobs += ((P.layer[l].t_out + 3) / 4) * ((P.layer[l].seg[s].nkb + 3) / 4);
+            if (wgrad_kind(P, l, s, fold) == 2) jobs += ((P.layer[l].t_out + 3) / 4) * ((P.layer[l].seg[s].nkb + 3) / 4);
     return jobs;
 }
 

@@ -25,6 +25,12 @@ def shard_frames(world: int, rank: int, frame0: int = 0) -> int:
     return frame0 + rank
 
 
+def shard_frame_indices(n_frames: int, world: int, rank: int):
+    """Frames of a data set held by `rank` in data-parallel training: rank, rank + world, ... (shard by image).
+    The union over ranks is range(n_frames), every frame exactly once; counts differ by at most one."""
+    return list(range(rank, n_frames, world))
+
+
 def shard_range(n: int, world: int, rank: int):
     """Contiguous [begin, end) slice of n rays for `rank`; sizes differ by at most one and the
     concatenation over ranks is exactly range(n) (ragged n is fine)."""

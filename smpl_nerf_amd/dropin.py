@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import importlib
 import importlib.abc
+import os
 import sys
 import types
 
@@ -70,9 +71,18 @@ def _patch_module(mod):
     return changed
 
 
+def _norm_root(root):
+    """Absolute, symlink-free root with a trailing separator (module __file__ / spec.origin are absolute paths, so a
+    relative or symlinked root would match nothing; the separator keeps '/x/SMPL-NeRF' from matching '/x/SMPL-NeRF2')."""
+    return None if not root else os.path.join(os.path.realpath(root), "")
+
+
+def _under(path, root):
+    return bool(path) and (root is None or os.path.realpath(path).startswith(root))
+
+
 def _is_reference_module(mod, root):
-    f = getattr(mod, "__file__", None)
-    return bool(f) and (root is None or f.startswith(root.rstrip("/") + "/"))
+    return _under(getattr(mod, "__file__", None), root)
 
 
 class _PatchOnImport(importlib.abc.MetaPathFinder):
@@ -91,7 +101,7 @@ class _PatchOnImport(importlib.abc.MetaPathFinder):
             spec = importlib.util.find_spec(fullname)
         finally:
             self._busy = False
-        if spec is None or spec.loader is None or not (spec.origin or "").startswith((self.root or "") ):
+        if spec is None or spec.loader is None or not _under(spec.origin, self.root):
             return None
         loader, root = spec.loader, self.root
 
@@ -119,10 +129,18 @@ def install(reference_root: str = None) -> int:
     global _installed
     import importlib.util  # noqa: F401  (used by the finder)
     _register_torchsearchsorted()
-    if reference_root and reference_root not in sys.path:
-        sys.path.insert(0, reference_root)
+    if reference_root:
+        if not os.path.isdir(reference_root):
+            raise FileNotFoundError(f"dropin.install: {reference_root!r} is not a directory")
+        reference_root = _norm_root(reference_root)
+        if reference_root.rstrip(os.sep) not in [os.path.realpath(p) for p in sys.path if p]:
+            sys.path.insert(0, reference_root.rstrip(os.sep))
     n = sweep(reference_root)
     if not _installed:
         sys.meta_path.insert(0, _PatchOnImport(reference_root))
         _installed = True
+    if n == 0 and reference_root and importlib.util.find_spec("utils") is None:
+        import warnings
+        warnings.warn(f"dropin.install({reference_root!r}): nothing rebound and the reference's modules are not importable "
+                      "from there - the reference would keep running its own torch path")
     return n

@@ -112,104 +112,219 @@ def _grads_from_flat(flat, shapes):
     return grads
 
 
+def _split_code(net, per_sample):
+    """nsplit / precision code of the net's matrix-core arithmetic for a fused call (0 = exact fp32 kernels)."""
+    if net.width != 256 or per_sample == _ENCODED_ROWS:
+        return 0
+    return {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}.get(net.precision, 0)
+
+
+def _train_sizes(desc, n):
+    """(act_floats, dy_floats, gpart_floats) of snerf_mlp_train_sizes for n samples."""
+    lib = _lib.load()
+    sizes = [ctypes.c_int64() for _ in range(4)]
+    cnt = ctypes.c_int32()
+    check(lib.snerf_mlp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes], ctypes.byref(cnt)), "snerf_mlp_train_sizes")
+    return sizes[0].value, sizes[1].value, sizes[3].value
+
+
+def _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, act=None):
+    """One launch of the fused encode + MLP kernel on n = raw.shape[0] samples: inference (act None) or the training
+    forward that also saves the layer inputs into `act`."""
+    lib = _lib.load()
+    n = raw.shape[0]
+    train = act is not None
+    tag = "mlp_fwd_train" if train else "mlp_fwd"
+    with torch.cuda.device(raw.device), _lib.timed(f"{tag}[n={n}]"):
+        if per_sample == _ENCODED_ROWS:      # x holds already-encoded rows (RenderRayNet.forward(x))
+            packed = net.packed_weights(desc, training=True)
+            if train:
+                check(lib.snerf_mlp_fwd_encoded_train_f32(desc, ptr(packed), ptr(x), n, x.shape[1], ptr(raw), ptr(act),
+                                                          current_stream()), "snerf_mlp_fwd_encoded_train_f32")
+            else:
+                check(lib.snerf_mlp_fwd_encoded_f32(desc, ptr(packed), ptr(x), n, x.shape[1], ptr(raw), current_stream()),
+                      "snerf_mlp_fwd_encoded_f32")
+        elif ns:                             # on the 16-bit matrix cores; saved activations are fp32 all the same
+            packed = net.packed_weights_bf16(desc, ns, training=True)
+            if train:
+                check(lib.snerf_mlp_fwd_train_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n,
+                                                       int(spr), ptr(raw), ptr(act), current_stream()),
+                      "snerf_mlp_fwd_train_bf16_f32")
+            else:
+                check(lib.snerf_mlp_fwd_bf16_f32(desc, ptr(packed), ns, ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
+                                                 ptr(raw), current_stream()), "snerf_mlp_fwd_bf16_f32")
+        else:
+            packed = net.packed_weights(desc, training=True)
+            if train:
+                check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
+                                                  ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
+            else:
+                check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr), ptr(raw),
+                                            current_stream()), "snerf_mlp_fwd_f32")
+
+
+def _launch_backward(net, desc, ns, act, d_raw, n, sizes, flat, input_grad, x=None, d=None, per_sample=0, spr=1,
+                     d_x=None, d_d=None):
+    """dgrad + split-K wgrad + reduce on one block of n samples: flat (snerf_mlp_param_floats floats) is overwritten; returns
+    the d Y buffer (tile-row-major, snerf_mlp_dy_layout) for the contractions of _extra_input_grads."""
+    lib = _lib.load()
+    dev = d_raw.device
+    if ns and input_grad and _wide_encoders(desc):
+        ns = 0       # input gradients through encoders with identity columns / more frequencies: fp32 dgrad variant only
+    packed_t = net.packed_weights_t_bf16(desc, ns, input_grad) if ns else net.packed_weights_t(desc, input_grad)
+    dy = torch.empty(sizes[1], device=dev, dtype=torch.float32)
+    gpart = torch.empty(sizes[2], device=dev, dtype=torch.float32)
+    if input_grad:
+        with torch.cuda.device(dev), _lib.timed(f"mlp_bwd_inputs[n={n}]"):
+            if ns:
+                check(lib.snerf_mlp_bwd_inputs_bf16_f32(desc, ptr(packed_t), ns, ptr(act), ptr(d_raw), ptr(x), ptr(d),
+                                                        per_sample, spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x),
+                                                        ptr(d_d), current_stream()), "snerf_mlp_bwd_inputs_bf16_f32")
+            else:
+                check(lib.snerf_mlp_bwd_inputs_f32(desc, ptr(packed_t), ptr(act), ptr(d_raw), ptr(x), ptr(d), per_sample,
+                                                   spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x), ptr(d_d),
+                                                   current_stream()), "snerf_mlp_bwd_inputs_f32")
+    else:
+        with torch.cuda.device(dev), _lib.timed(f"mlp_bwd[n={n}]"):
+            if ns:
+                check(lib.snerf_mlp_bwd_bf16_f32(desc, ptr(packed_t), ns, ptr(act), ptr(d_raw), n, ptr(dy), ptr(gpart),
+                                                 ptr(flat), current_stream()), "snerf_mlp_bwd_bf16_f32")
+            else:
+                check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(act), ptr(d_raw), n, ptr(dy), ptr(gpart), ptr(flat),
+                                            current_stream()), "snerf_mlp_bwd_f32")
+    return dy
+
+
 class _FusedMlpFn(torch.autograd.Function):
     """raw = RenderRayNet(encode(x), encode(normalise(d))) with gradients for every weight and bias and, where the caller's
     graph asks for them, for the inputs: positions / per-sample directions (SmplNerfPipeline: the dgrad kernel's
     input-gradient variant), per-ray additional inputs and already-encoded rows (contractions of the stored d Y_l,
     _extra_input_grads).  Forward saves the layer inputs in the tile-row-major activation buffer; backward = dgrad +
     split-K wgrad + reduce (snerf_mlp_bwd_*).  In NerfPipeline positions and directions are leaves (the hierarchical
-    samples are detached, utils.py:260) and only the parameters receive gradients."""
+    samples are detached, utils.py:260) and only the parameters receive gradients.
+
+    Memory bound ("store only x, d"): the saved layer inputs and the d Y buffer cost ~21 KB per sample
+    (256-wide, depth 8) - 89 GB for a 128x128 frame, 357 GB for a 256x256 one.  When that exceeds the net's
+    `activation_budget_bytes`, the forward runs the inference kernel and keeps only its inputs; the backward then walks the
+    samples in blocks of whole rays that fit the budget: training forward (recomputed: the same arithmetic, so the same
+    ReLU masks) -> dgrad -> wgrad -> reduce per block, parameter gradients summed over the blocks in fp32.  One third more
+    matrix work than the stored form, any batch size."""
 
     @staticmethod
     def forward(ctx, net, desc, x, d, per_sample, spr, add, *params):
-        lib = _lib.load()
         n = x.shape[0]
         dev = x.device
+        spr = int(spr)
         net._begin_training_forward()
-        split = net.width == 256 and per_sample != _ENCODED_ROWS
-        ns_fwd = {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}.get(net.precision, 0) if split else 0
-        ns = ns_fwd   # the backward runs in the forward's mode (f16x3: dgrad and wgrad GEMMs with two fp16 parts)
-        packed = net.packed_weights_bf16(desc, ns_fwd, training=True) if ns else net.packed_weights(desc, training=True)
-        sizes = [ctypes.c_int64() for _ in range(4)]
-        cnt = ctypes.c_int32()
-        check(lib.snerf_mlp_train_sizes(desc, n, *[ctypes.byref(v) for v in sizes], ctypes.byref(cnt)),
-              "snerf_mlp_train_sizes")
-        act = torch.empty(sizes[0].value, device=dev, dtype=torch.float32)
+        ns = _split_code(net, per_sample)
+        act_floats, dy_floats, gpart_floats = _train_sizes(desc, n)
         raw = torch.empty((n, 4), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), _lib.timed(f"mlp_fwd_train[n={n}]"):
-            if per_sample == _ENCODED_ROWS:      # x holds already-encoded rows (RenderRayNet.forward(x))
-                check(lib.snerf_mlp_fwd_encoded_train_f32(desc, ptr(packed), ptr(x), n, x.shape[1], ptr(raw), ptr(act),
-                                                          current_stream()), "snerf_mlp_fwd_encoded_train_f32")
-            elif ns:                             # forward on the bf16 matrix cores, saving fp32 activations
-                check(lib.snerf_mlp_fwd_train_bf16_f32(desc, ptr(packed), ns_fwd, ptr(x), ptr(d), per_sample, ptr(add), n,
-                                                       int(spr), ptr(raw), ptr(act), current_stream()),
-                      "snerf_mlp_fwd_train_bf16_f32")
-            else:
-                check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
-                                                  ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
-        ctx.net, ctx.desc, ctx.n, ctx.act, ctx.ns = net, desc, n, act, ns
-        ctx.sizes = (sizes[1].value, sizes[3].value)
+        group = 1 if per_sample == _ENCODED_ROWS else spr            # blocks are whole rays (per-ray directions / inputs)
+        budget = int(getattr(net, "activation_budget_bytes", 0) or 0)
+        ctx.block = 0
+        if budget > 0 and 4 * (act_floats + dy_floats) > budget and n > group:
+            per_sample_bytes = 4.0 * (act_floats + dy_floats) / n
+            ctx.block = max(group, int(budget / per_sample_bytes) // group * group)
+        if ctx.block and ctx.block < n:
+            _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw)          # inference kernel: nothing saved
+            ctx.act = None
+            ctx.inputs = (x, d, add)
+        else:
+            ctx.block = 0
+            act = torch.empty(act_floats, device=dev, dtype=torch.float32)
+            _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, act)
+            ctx.act = act
+        ctx.net, ctx.desc, ctx.n, ctx.ns, ctx.per_sample = net, desc, n, ns, per_sample
+        ctx.sizes = (act_floats, dy_floats, gpart_floats)
         ctx.shapes = [p.shape for p in params]
         ctx.input_grad = bool(ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and per_sample != _ENCODED_ROWS
         if ctx.input_grad:       # SmplNerfPipeline: positions / per-sample directions depend on the warp net
-            ctx.xd = (x, d, per_sample, int(spr))
+            ctx.xd = (x, d, per_sample, spr)
         # gradients w.r.t. already-encoded rows (RenderRayNet.forward(x) feeding an upstream module) and w.r.t. the per-ray
         # additional inputs (AppendVerticesPipeline: vertices <- smpl_model <- smpl_estimator)
         ctx.rows_grad = bool(ctx.needs_input_grad[2]) and per_sample == _ENCODED_ROWS
         ctx.add_grad = bool(ctx.needs_input_grad[6]) and add is not None
-        ctx.spr, ctx.row_floats = int(spr), (x.shape[1] if per_sample == _ENCODED_ROWS else 0)
+        ctx.spr, ctx.row_floats = spr, (x.shape[1] if per_sample == _ENCODED_ROWS else 0)
         return raw
+
+    @staticmethod
+    def _input_grads_from_dy(ctx, dy, n, d_x_rows, d_add):
+        """Contractions of the stored d Y_l of a block of n samples: encoded-row gradients into d_x_rows [n, row_floats],
+        per-ray additional-input gradients into d_add [n / spr, add_dim]."""
+        net, desc = ctx.net, ctx.desc
+        if ctx.rows_grad:        # encoded rows = [positions (+ additional) | ... | directions]
+            d_pa, d_dir = _extra_input_grads(net, desc, dy, n, True, True)
+            d_x_rows.zero_()
+            d_x_rows[:, :d_pa.shape[1]] = d_pa
+            if d_dir is not None:
+                d_x_rows[:, ctx.row_floats - d_dir.shape[1]:] += d_dir
+        elif ctx.add_grad:       # per-ray constants: sum the per-sample contributions of the ray
+            d_pa, _ = _extra_input_grads(net, desc, dy, n, True, False)
+            a0 = 0 if desc.add_first else 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
+            d_add.copy_(d_pa[:, a0:a0 + desc.add_dim].reshape(-1, ctx.spr, desc.add_dim).sum(1))
 
     @staticmethod
     def backward(ctx, d_raw):
         lib = _lib.load()
-        net, desc, n = ctx.net, ctx.desc, ctx.n
+        net, desc, n, ns = ctx.net, ctx.desc, ctx.n, ctx.ns
         dev = d_raw.device
         d_raw = d_raw.contiguous().float()
-        ns = ctx.ns      # split-bf16 dgrad and wide wgrad jobs when the forward ran in that mode
-        if ns and ctx.input_grad and _wide_encoders(desc):
-            ns = 0       # input gradients through encoders with identity columns / more frequencies: fp32 dgrad variant only
-        packed_t = net.packed_weights_t_bf16(desc, ns, ctx.input_grad) if ns else net.packed_weights_t(desc, ctx.input_grad)
-        dy = torch.empty(ctx.sizes[0], device=dev, dtype=torch.float32)
-        gpart = torch.empty(ctx.sizes[1], device=dev, dtype=torch.float32)
         flat = net._take_grad_sink(lib.snerf_mlp_param_floats(desc), dev)
-        d_x = d_d = None
+        d_x = d_d = d_add = None
+        spr = ctx.spr
         if ctx.input_grad:
-            x, d, per_sample, spr = ctx.xd
+            x, d, per_sample, _ = ctx.xd
             d_x = torch.empty((n, 3), device=dev, dtype=torch.float32)
             d_d = torch.zeros((n, 3), device=dev, dtype=torch.float32)
-            with torch.cuda.device(dev), _lib.timed(f"mlp_bwd_inputs[n={n}]"):
-                if ns:
-                    check(lib.snerf_mlp_bwd_inputs_bf16_f32(desc, ptr(packed_t), ns, ptr(ctx.act), ptr(d_raw), ptr(x), ptr(d),
-                                                            per_sample, spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x),
-                                                            ptr(d_d), current_stream()), "snerf_mlp_bwd_inputs_bf16_f32")
+        if ctx.rows_grad:
+            d_x = torch.empty((n, ctx.row_floats), device=dev, dtype=torch.float32)
+        if ctx.add_grad:
+            d_add = torch.empty((n // spr, desc.add_dim), device=dev, dtype=torch.float32)
+
+        if not ctx.block:        # everything was saved by the forward: one pass
+            if ctx.input_grad:
+                dy = _launch_backward(net, desc, ns, ctx.act, d_raw, n, ctx.sizes, flat, True, x, d, per_sample, spr, d_x, d_d)
+            else:
+                dy = _launch_backward(net, desc, ns, ctx.act, d_raw, n, ctx.sizes, flat, False)
+            ctx.act = None
+            _FusedMlpFn._input_grads_from_dy(ctx, dy, n, d_x if ctx.rows_grad else None, d_add)
+        else:                    # blocks of whole rays: recompute the layer inputs, back-propagate, accumulate
+            xin, din, addin = ctx.inputs
+            per_sample = ctx.per_sample
+            tmp = None
+            for s0 in range(0, n, ctx.block):
+                m = min(ctx.block, n - s0)
+                sizes = _train_sizes(desc, m)
+                act = torch.empty(sizes[0], device=dev, dtype=torch.float32)
+                raw_b = torch.empty((m, 4), device=dev, dtype=torch.float32)
+                xb = xin[s0:s0 + m]
+                if per_sample == _ENCODED_ROWS:
+                    db = ab = None
                 else:
-                    check(lib.snerf_mlp_bwd_inputs_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), ptr(x), ptr(d),
-                                                       per_sample, spr, n, ptr(dy), ptr(gpart), ptr(flat), ptr(d_x),
-                                                       ptr(d_d), current_stream()), "snerf_mlp_bwd_inputs_f32")
+                    db = din[s0:s0 + m] if per_sample else din[s0 // spr:(s0 + m) // spr]
+                    ab = None if addin is None else addin[s0 // spr:(s0 + m) // spr]
+                _launch_forward(net, desc, ns, xb, db, per_sample, spr, ab, raw_b, act)
+                if s0 == 0:
+                    target = flat
+                else:
+                    if tmp is None:
+                        tmp = torch.empty_like(flat)
+                    target = tmp
+                if ctx.input_grad:
+                    dy = _launch_backward(net, desc, ns, act, d_raw[s0:s0 + m], m, sizes, target, True, xb, db, per_sample,
+                                          spr, d_x[s0:s0 + m], d_d[s0:s0 + m])
+                else:
+                    dy = _launch_backward(net, desc, ns, act, d_raw[s0:s0 + m], m, sizes, target, False)
+                if s0:
+                    flat.add_(tmp)
+                _FusedMlpFn._input_grads_from_dy(ctx, dy, m, d_x[s0:s0 + m] if ctx.rows_grad else None,
+                                                 None if d_add is None else d_add[s0 // spr:(s0 + m) // spr])
+                del act, dy
+            ctx.inputs = None
+        if ctx.input_grad:
             if not per_sample:       # one direction per ray: sum the per-sample contributions
                 d_d = d_d.view(-1, spr, 3).sum(1)
             ctx.xd = None
-        else:
-            with torch.cuda.device(dev), _lib.timed(f"mlp_bwd[n={n}]"):
-                if ns:
-                    check(lib.snerf_mlp_bwd_bf16_f32(desc, ptr(packed_t), ns, ptr(ctx.act), ptr(d_raw), n, ptr(dy),
-                                                     ptr(gpart), ptr(flat), current_stream()), "snerf_mlp_bwd_bf16_f32")
-                else:
-                    check(lib.snerf_mlp_bwd_f32(desc, ptr(packed_t), ptr(ctx.act), ptr(d_raw), n, ptr(dy), ptr(gpart),
-                                                ptr(flat), current_stream()), "snerf_mlp_bwd_f32")
-        ctx.act = None
-        d_add = None
-        if ctx.rows_grad:        # encoded rows = [positions (+ additional) | ... | directions]
-            d_pa, d_dir = _extra_input_grads(net, desc, dy, n, True, True)
-            d_x = torch.zeros((n, ctx.row_floats), device=dev, dtype=torch.float32)
-            d_x[:, :d_pa.shape[1]] = d_pa
-            if d_dir is not None:
-                d_x[:, ctx.row_floats - d_dir.shape[1]:] += d_dir
-        elif ctx.add_grad:       # per-ray constants: sum the per-sample contributions of the ray
-            d_pa, _ = _extra_input_grads(net, desc, dy, n, True, False)
-            a0 = 0 if desc.add_first else 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
-            d_add = d_pa[:, a0:a0 + desc.add_dim].reshape(-1, ctx.spr, desc.add_dim).sum(1)
         return (None, None, d_x, d_d, None, None, d_add) + tuple(_grads_from_flat(flat, ctx.shapes))
 
 
@@ -312,6 +427,10 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         # (v_mfma_f32_16x16x4_f32) or split-bf16 "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5
         # relative); activations, gradients, the narrow wgrad jobs and the reductions are fp32 in every mode
         self.precision = os.environ.get("SNERF_PRECISION", "fp32")
+        # training memory bound: saved layer inputs + d Y of ONE forward call above this many bytes are not kept but
+        # recomputed block by block in the backward (_FusedMlpFn).  Default: 64 GB of the 288 GB per call - a 4096-ray step
+        # (22 GB) keeps everything, a 256x256 frame (357 GB) trains in six blocks.  0 = never recompute.
+        self.activation_budget_bytes = int(float(os.environ.get("SNERF_TRAIN_ACT_GB", "64")) * (1 << 30))
 
     # ------------------------------------------------------------------ parameter plumbing
     def _ordered_params(self):

@@ -35,6 +35,7 @@ class RayGenerator:
         self.device = torch.device(device)
         poses = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(-1, 4, 4))
         self.n_frames = poses.shape[0]
+        self.frame_ids = list(range(self.n_frames))     # global frame numbers (for_rank: this rank's shard)
         self.poses = torch.from_numpy(poses).to(self.device)
         lower, span = coarse_bin_tables(near, far, number_samples)
         self.lower = torch.from_numpy(np.ascontiguousarray(lower)).to(self.device)
@@ -42,6 +43,21 @@ class RayGenerator:
         self.images = None
         if images is not None:
             self.images = torch.as_tensor(images, dtype=torch.float32, device=self.device).reshape(-1, 3).contiguous()
+
+    @classmethod
+    def for_rank(cls, poses, h, w, camera_angle_x, near, far, number_samples, device, images=None, world=None, rank=None):
+        """This rank's shard of a data set, by image: frames rank, rank + world, ... of `poses` / `images`
+        (host arrays) - only those are moved to the device.  `frame_ids` records which global frames they are."""
+        from . import dist as sdist
+        if world is None:
+            world, rank = sdist.world_rank()
+        ids = sdist.shard_frame_indices(len(poses), world, rank)
+        poses = np.asarray(poses, np.float64).reshape(-1, 4, 4)[ids]
+        if images is not None:
+            images = np.asarray(images)[ids]
+        gen = cls(poses, h, w, camera_angle_x, near, far, number_samples, device, images)
+        gen.frame_ids = ids
+        return gen
 
     @property
     def n_rays(self):

@@ -24,24 +24,26 @@ from . import io as sio
 
 def flatten_parameters_(models):
     """Moves every parameter of `models` into ONE contiguous fp32 buffer (values kept; `p.data` becomes a view of it)
-    and returns (flat_params, flat_grads, segments) with segments = [(model, offset, numel of its kernel-ordered
-    parameters)].  Per model the kernel-ordered parameters (`_ordered_params()` / `_params()`: the C-ABI's params_flat
-    order) come first, so a net packs its weight streams from its segment without a torch.cat
-    (nets.flat_parameter_vector) and the backward kernels can write its gradients into the matching segment of
-    `flat_grads` (set_grad_sink)."""
-    order, segments, seen = [], [], set()
+    and returns (flat_params, flat_grads, segments, order) with segments = [(model, offset, numel of its kernel-ordered
+    parameters)] and order = the parameters in buffer order.  Per model the kernel-ordered parameters
+    (`_ordered_params()` / `_params()`: the C-ABI's params_flat order) come first, so a net packs its weight streams from
+    its segment without a torch.cat (nets.flat_parameter_vector) and the backward kernels can write its gradients into the
+    matching segment of `flat_grads` (set_grad_sink).  A model listed twice, or one whose kernel-ordered parameters are
+    shared with an earlier model, gets no segment (its gradients then take the copying path of sync_gradients)."""
+    order, segments, seen, with_segment = [], [], set(), set()
     for m in models:
         first = m._ordered_params() if hasattr(m, "_ordered_params") else (m._params() if hasattr(m, "_params") else [])
         off = sum(p.numel() for p in order)
         own = [p for p in list(first) + list(m.parameters()) if not (id(p) in seen or seen.add(id(p)))]
         order += own
-        if first and all(a is b for a, b in zip(first, own)):
+        if first and id(m) not in with_segment and len(own) >= len(first) and all(a is b for a, b in zip(first, own)):
             segments.append((m, off, sum(p.numel() for p in first)))
+            with_segment.add(id(m))
     if not order:
-        return None, None, []
+        return None, None, [], []
     dev = order[0].device
     if any(p.device != dev or p.dtype != torch.float32 for p in order):
-        return None, None, []          # mixed devices / dtypes: keep the parameters where they are
+        return None, None, [], order   # mixed devices / dtypes: keep the parameters where they are
     flat = torch.empty(sum(p.numel() for p in order), dtype=torch.float32, device=dev)
     off = 0
     with torch.no_grad():
@@ -50,7 +52,7 @@ def flatten_parameters_(models):
             v.copy_(p.data)
             p.data = v
             off += p.numel()
-    return flat, torch.zeros_like(flat), segments
+    return flat, torch.zeros_like(flat), segments, order
 
 
 class DataParallelTrainer:
@@ -62,13 +64,14 @@ class DataParallelTrainer:
         self.world, self.rank = sdist.world_rank()
         # one flat parameter buffer and one flat gradient buffer for all nets (what is all-reduced is the flat
         # gradient the backward kernels wrote)
-        self._flat_p, self._flat_g, self._segments = flatten_parameters_(self.models)
-        seen = set()
-        self.params = [p for m in self.models for p in m.parameters() if not (id(p) in seen or seen.add(id(p)))]
+        self._flat_p, self._flat_g, self._segments, order = flatten_parameters_(self.models)
+        # the optimiser's parameter list IS the buffer order (kernel-ordered parameters of a model first), so that the
+        # gradient views below line up with the sinks whatever a model's registration order is
+        self.params = order
         self._views = None
         if self._flat_g is not None:
             off, self._views = 0, []
-            for p in self.params:       # same order as flatten_parameters_ laid them out
+            for p in self.params:
                 self._views.append(self._flat_g[off:off + p.numel()].view(p.shape))
                 off += p.numel()
         # every rank must start from the same replica (DDP broadcasts at construction; so does this)
@@ -104,7 +107,13 @@ class DataParallelTrainer:
         """Mean over ranks of all parameter gradients through ONE flat fp32 buffer (one collective).  The buffer covers
         every parameter on every rank - a parameter without a gradient on this rank contributes zeros - so the
         collective has the same size everywhere.  Gradients the backward kernels already wrote into the buffer (the
-        grad sinks) are not copied; afterwards every p.grad is a view of the buffer."""
+        grad sinks) are not copied; afterwards every p.grad is a view of the buffer.
+
+        Like torch's DistributedDataParallel, a parameter that took part in no rank's step (the fine net with
+        run_fine = 0, estimator heads) comes out with a ZERO gradient rather than None when world > 1: Adam then still
+        decays its moments (and applies weight_decay), whereas a single process skips it.  The reference has no multi-GPU
+        path to compare with; the multi-rank path keeps the collective's shape fixed instead of exchanging a has-grad
+        mask (which would put a device -> host read into every step)."""
         if self.world == 1:
             return
         if self._flat_g is None:       # parameters could not be flattened: per-tensor fallback, fixed list, zeros for None
@@ -223,7 +232,9 @@ class DataParallelTrainer:
 class RayBatchLoader:
     """The shuffled DataLoader over RaysFromImagesDataset (train.py:96-100) with the rays generated on the device
     (raygen.RayGenerator): `iterations` batches of `batch_size` uniformly drawn rays per epoch; each rank draws from its
-    own generator seed (base + rank), so ranks see different rays."""
+    own generator seed (base + rank).  Data-parallel runs shard the data set BY IMAGE (1200 images -> 150 per
+    GPU): build this rank's generator with RayGenerator.for_rank(...), which keeps only frames rank, rank + world, ...
+    on the device - the union over ranks covers every frame exactly once and no image is replicated."""
 
     def __init__(self, ray_generator, batch_size: int, iterations: int, seed: int = 0):
         self.gen, self.batch_size, self.iterations = ray_generator, int(batch_size), int(iterations)

@@ -167,9 +167,64 @@ def test_flat_parameter_vector_is_zero_copy_after_flattening():
     before = [p.detach().clone() for p in net._ordered_params()]
     v0 = flat_parameter_vector(net._ordered_params())
     assert v0.data_ptr() != net._ordered_params()[0].data_ptr()          # separate tensors: a torch.cat copy
-    flat, gflat, segs = flatten_parameters_([net])
+    flat, gflat, segs, order = flatten_parameters_([net])
+    assert [id(p) for p in order] == [id(p) for p in net._ordered_params()]
     v1 = flat_parameter_vector(net._ordered_params())
     assert v1.data_ptr() == flat.data_ptr() == net._ordered_params()[0].data_ptr() and torch.equal(v0, v1)
     assert all(torch.equal(a, b) for a, b in zip(before, net._ordered_params()))
     assert segs == [(net, 0, v1.numel())] and gflat.shape == flat.shape
     assert list(net.state_dict().keys())[0] == "positions_pose_input.weight"   # the checkpoint contract is untouched
+
+
+def test_flattened_buffer_order_drives_the_optimiser_and_the_gradient_views():
+    """the gradient views must follow the buffer order (kernel-ordered parameters first), not
+    m.parameters() order; a net listed twice gets one segment; a model whose kernel order differs from its registration
+    order still lines up."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.trainer import DataParallelTrainer, flatten_parameters_
+
+    class Reordered(torch.nn.Module):          # registration order (b, a) != kernel order (a, b)
+        def __init__(self):
+            super().__init__()
+            self.b = torch.nn.Linear(3, 2)
+            self.a = torch.nn.Linear(2, 3)
+
+        def _ordered_params(self):
+            return [self.a.weight, self.a.bias, self.b.weight, self.b.bias]
+
+    m = Reordered()
+    flat, gflat, segs, order = flatten_parameters_([m])
+    assert [id(p) for p in order] == [id(p) for p in m._ordered_params()] and segs == [(m, 0, flat.numel())]
+    tr = DataParallelTrainer(None, [m], fused=False)
+    assert [id(p) for p in tr.params] == [id(p) for p in m._ordered_params()]
+    off = 0
+    for p, v in zip(tr.params, tr._views):     # view i is exactly parameter i's slice of the flat gradient buffer
+        assert v.shape == p.shape and v.data_ptr() == tr._flat_g.data_ptr() + 4 * off
+        assert p.data_ptr() == tr._flat_p.data_ptr() + 4 * off
+        off += p.numel()
+    net = RenderRayNet(4, 128, 60, 24, skips=[2])
+    flat, gflat, segs, order = flatten_parameters_([net, net])       # coarse is fine
+    assert len(segs) == 1 and segs[0][2] == flat.numel() == sum(p.numel() for p in net.parameters())
+
+
+def test_frames_are_sharded_by_image_across_ranks():
+    """the data set is sharded by image - the union over ranks covers every frame exactly once, no frame is
+    held twice, counts differ by at most one; RayGenerator.for_rank moves only this rank's frames."""
+    from smpl_nerf_amd import dist as sdist
+    from smpl_nerf_amd.raygen import RayGenerator
+    for n_frames, world in ((1200, 8), (10, 4), (7, 8), (1, 2)):
+        shards = [sdist.shard_frame_indices(n_frames, world, r) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(n_frames))
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    assert len(sdist.shard_frame_indices(1200, 8, 3)) == 150
+    poses = np.tile(np.eye(4)[None], (10, 1, 1))
+    poses[:, 0, 3] = np.arange(10)
+    images = np.zeros((10, 4, 4, 3), np.float32) + np.arange(10, dtype=np.float32)[:, None, None, None]
+    seen = []
+    for r in range(4):
+        g = RayGenerator.for_rank(poses, 4, 4, np.pi / 3, 1.0, 4.0, 8, "cpu", images=images, world=4, rank=r)
+        assert g.n_frames == len(g.frame_ids) and g.images.shape == (g.n_frames * 16, 3)
+        assert [float(v) for v in g.poses[:, 0, 3]] == [float(i) for i in g.frame_ids]      # the right poses ...
+        assert [float(v) for v in g.images.view(g.n_frames, 16, 3)[:, 0, 0]] == [float(i) for i in g.frame_ids]  # ... and images
+        seen += g.frame_ids
+    assert sorted(seen) == list(range(10))

@@ -70,3 +70,17 @@ def test_install_rebinds_the_reference_modules():
         for k in set(sys.modules) - before:               # the stand-ins and whatever the reference pulled in
             if k.split(".")[0] in ("cv2", "imageio", "trimesh", "camera", "render", "make_golden") or k == "torch.utils.tensorboard":
                 sys.modules.pop(k, None)
+
+
+def test_install_normalises_the_root(tmp_path):
+    """a symlinked root matches the (absolute, resolved) module paths; a sibling directory whose name merely
+    starts with the root's does not; a missing directory is an error."""
+    from smpl_nerf_amd import dropin
+    link = tmp_path / "ref_link"
+    os.symlink(REF, link)
+    root = dropin._norm_root(str(link))
+    assert root == os.path.join(os.path.realpath(REF), "")
+    assert dropin._under(os.path.join(REF, "utils.py"), root)
+    assert not dropin._under(os.path.realpath(REF) + "2/utils.py", root)
+    with pytest.raises(FileNotFoundError):
+        dropin.install(str(tmp_path / "nope"))

@@ -61,7 +61,7 @@ def test_composite_backward(dev, N, wb, mode):
     raw = T(g3[f"raw_N{N}"], dev).requires_grad_(True)
     d = T(g3[f"dray_N{N}"], dev)[:, None, :].expand(B, N, 3) if mode == "ray" else T(g3[f"dsmp_N{N}"], dev)
     rgb, w, a = ops.composite(raw, T(g3[f"z_N{N}"], dev), d, bool(wb))
-    assert not w.requires_grad and not a.requires_grad
+    assert w.requires_grad and a.requires_grad      # all three outputs carry gradient, like utils.py:178-191
     (rgb * T(g7[f"c_gout_N{N}"], dev)).sum().backward()
     close(raw.grad.cpu().numpy(), g7[f"c_draw_N{N}_wb{wb}_{mode}"], 2e-4, 2e-6)
 

@@ -72,5 +72,31 @@ def main(sq, fetch, write, tsq=None, tfetch=None, twrite=None):
     print(json.dumps(out, indent=1))
 
 
+SMPL_KERNELS = {"warp_fwd": "warp_fwd_resident_kernel<256, 16, false>", "warp_fwd_train": "warp_fwd_resident_kernel<256, 8, true>",
+                "warp_bwd_dgrad": "warp_bwd_light_kernel", "render_fp32_per_sample_dirs": "mlp_fwd_kernel<256, 8, false, false>",
+                "fwd_train_fp32": "mlp_fwd_kernel<256, 8, false, true>", "dgrad_fp32_input_grad": "mlp_bwd_kernel<256, 8, true",
+                "wgrad_fp32_wide": "mlp_wgrad_kernel(", "wgrad_fp32_narrow": "mlp_wgrad_narrow_kernel",
+                "wgrad_fp32_direct": "mlp_wgrad_direct_kernel"}
+
+
+def generic(sq, fetch, write, kernels, command):
+    """Per-kernel rows (every distinct grid separately) of one workload: duration, clock, MFMA-pipe busy, HBM bytes."""
+    out = {"command": command, "note": "see the main summary's note for units and corrections", "kernels": {}}
+    for tag, name in kernels.items():
+        a, f, w = (summarise(name, [d]) for d in (sq, fetch, write))
+        for key, e in a.items():
+            out["kernels"][f"{tag} grid={key.split('grid=')[1]}"] = {
+                "kernel": "snerf::" + name, "duration_ms": e["avg_seconds"] * 1e3, "effective_clock_GHz": e["effective_clock_ghz"],
+                "mfma_pipe_busy_frac": e["mfma_busy_frac"], "wave_cycles_parked_frac": e.get("sq_wait_any_per_wave_cycle"),
+                "FETCH_SIZE_KB": f.get(key, {}).get("counters", {}).get("FETCH_SIZE"),
+                "WRITE_SIZE_KB": w.get(key, {}).get("counters", {}).get("WRITE_SIZE")}
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:7])
+    if sys.argv[1] == "--smpl-nerf":
+        generic(*sys.argv[2:5], SMPL_KERNELS,
+                "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --workload smpl_nerf --steps 3 --warmup 1 "
+                "--cpu-rays 0 --train-steps 3 --no-pmc --no-alt --points= (three separate passes: SQ/GRBM, FETCH_SIZE, WRITE_SIZE)")
+    else:
+        main(*sys.argv[1:7])

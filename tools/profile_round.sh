@@ -11,11 +11,17 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
 # (a) render only: every dispatch of a render kernel is one of the bench's frame launches (12 steps x {coarse, fine})
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-pmc --train-rays 0 > $OUT/bench_under_rocprof.json.log 2> $OUT/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-pmc --train-rays 0 --points= > $OUT/bench_under_rocprof.json.log 2> $OUT/trace.err
 # (b) the training section (all precisions) behind a one-step render
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --cpu-rays 0 > $OUT/train_under_rocprof.json.log 2> $OUT/trace_train.err
-RENDER="--steps 3 --warmup 1 --cpu-rays 0 --train-rays 0 --no-pmc"
-TRAIN="--steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --cpu-rays 0 --points= > $OUT/train_under_rocprof.json.log 2> $OUT/trace_train.err
+# (c) smpl_nerf: render + training rows of the warp kernels (warp_fwd_resident_kernel, warp_bwd_light_kernel) and the
+#     INPUT_GRAD dgrad variants; fp32 only, no CPU leg
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_smpl -- python $ROOT/bench.py --workload smpl_nerf --steps 10 --warmup 2 --no-pmc --no-alt --cpu-rays 0 --train-steps 10 --points= > $OUT/smpl_nerf_under_rocprof.json.log 2> $OUT/trace_smpl.err
+timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmcs_sq -- python $ROOT/bench.py --workload smpl_nerf --steps 3 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --no-alt --points= > $OUT/pmcs_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcs_fetch -- python $ROOT/bench.py --workload smpl_nerf --steps 3 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --no-alt --points= > $OUT/pmcs_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcs_write -- python $ROOT/bench.py --workload smpl_nerf --steps 3 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --no-alt --points= > $OUT/pmcs_write.log 2>&1
+RENDER="--steps 3 --warmup 1 --cpu-rays 0 --train-rays 0 --no-pmc --points="
+TRAIN="--steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --points="
 timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py $RENDER > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py $RENDER > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py $RENDER > $OUT/pmc_write.log 2>&1
@@ -24,8 +30,10 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmct_fetch --
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmct_write -- python $ROOT/bench.py $TRAIN > $OUT/pmct_write.log 2>&1
 cd $ROOT
 python tools/make_pmc_profile.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
+python tools/make_pmc_profile.py --smpl-nerf $OUT/pmcs_sq $OUT/pmcs_fetch $OUT/pmcs_write > $OUT/pmc_summary_smpl_nerf.json 2> $OUT/pmc_summary_smpl.err
+find $OUT/trace_smpl -name "*kernel_stats.csv" -exec cp {} $OUT/smpl_nerf_kernel_stats.csv \;
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 find $OUT/trace_train -name "*kernel_stats.csv" -exec cp {} $OUT/train_kernel_stats.csv \;
 # keep what travels back small: the raw per-dispatch counter CSVs are reduced above
-rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write
+rm -rf $OUT/trace $OUT/trace_train $OUT/trace_smpl $OUT/pmcs_sq $OUT/pmcs_fetch $OUT/pmcs_write $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write
 ls -la $OUT
