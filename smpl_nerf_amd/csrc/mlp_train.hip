@@ -18,9 +18,20 @@
 //                                order to the reference's [out, in] weight layout
 //
 // All MFMA work is v_mfma_f32_16x16x4_f32 (exact fp32), like the forward.
+#include <type_traits>
+
 #include "mlp_train_device.h"
 
 namespace snerf {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // transposed weight stream
@@ -270,7 +281,7 @@ struct WgradFold {
     const float *src;  // this wave's third piece per stage (extra X row `wave` < ex, or the extra dY row for wave 4), or null
 };
 
-template <int TI, int TJ>
+template <int TI, int TJ, bool FX = false, bool FY = false>
 __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const TrainLayout &L, const WgradArgs &A, float *ring,
                                            int l, int kb0, int jb, int n_rows_y, int n_rows_x, bool bias_job,
                                            const float *const (&row_src)[2], const WgradFold &F, int wave, int lane) {
@@ -284,9 +295,10 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
     const int64_t begin = (int64_t)blockIdx.y * A.chunk;
     const int64_t end = min(n, begin + A.chunk);
     const int nstages = begin < end ? (int)((end - begin + WL_STAGE - 1) / WL_STAGE) : 0;
-    const bool has3 = F.src != nullptr;
-    // folded tiles of this wave: (dY rows TI*bi .., extra X row bj) and (extra dY row, X row TJ*bj + bi)
-    const bool fx = active && bj < F.ex, fy = active && F.ey_layer >= 0 && bi < TJ && TJ * bj + bi < n_rows_x;
+    // folded tiles of this wave (compile-time variants: the plain jobs keep their instruction stream):
+    // (dY rows TI*bi .., extra X row bj) and (extra dY row, X row TJ*bj + bi)
+    const bool has3 = (FX || FY) && F.src != nullptr;
+    const bool fx = FX && active && bj < F.ex, fy = FY && active && bi < TJ && TJ * bj + bi < n_rows_x;
 
     auto issue = [&](int stage, int slot) {
         // lane covers 16 B: features 4*(lane&3).. of sample (lane>>2) of the stage; clamped at the end of the buffer
@@ -296,7 +308,7 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(row_src[q] + smp * 16 + (lane & 3) * 4),
                 (__attribute__((address_space(3))) void *)(ring + slot * WL_SLOT_FLOATS + (2 * wave + q) * WL_ROW_FLOATS), 16, 0, 0);
-        if (has3)   // wave-uniform: the folded rows are brought by waves 0 .. 4
+        if ((FX || FY) && has3)   // wave-uniform: the folded rows are brought by waves 0 .. 4
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(F.src + smp * 16 + (lane & 3) * 4),
                 (__attribute__((address_space(3))) void *)(ring + slot * WL_SLOT_FLOATS + (WL_XROW0 + wave) * WL_ROW_FLOATS), 16, 0, 0);
@@ -318,7 +330,7 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
     // stage st lives in slot st % WL_SLOTS.  A wave issues exactly two (three with a folded row) pieces per stage, so
     // `vmcnt(2k)` (`vmcnt(3k)`) leaves its k newest stages in flight.
     auto wait_landed = [&](int k) {  // k = stages allowed to stay in flight, 0 .. WL_SLOTS - 2
-        if (has3) {
+        if ((FX || FY) && has3) {
             if (k >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (k == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -326,6 +338,48 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
             if (k >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (k == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    // one stage (16 samples = 4 k-steps) of this wave's tiles.  MASKED: tiles past the edge of the job run with a = 0 and
+    // are not stored (their LDS rows hold finite filler data), samples past `end` contribute a = 0.
+    auto stage_body = [&](auto masked_c, auto bias_c, int slot, int64_t s0) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value, BIAS = decltype(bias_c)::value;
+        const float *ya = ring + slot * WL_SLOT_FLOATS + (TI * bi) * WL_ROW_FLOATS + lane;
+        const float *xb = ring + slot * WL_SLOT_FLOATS + (16 + TJ * bj) * WL_ROW_FLOATS + lane;
+#pragma unroll
+        for (int step = 0; step < WL_STAGE / 4; ++step) {
+            bool ok = true;
+            if constexpr (MASKED) ok = s0 + 4 * step + kslot < end;
+            float a[TI], b[TJ];
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const float va = ya[t * WL_ROW_FLOATS + 64 * step];
+                if constexpr (MASKED) a[t] = (t < n_ti && ok) ? va : 0.f;
+                else a[t] = va;
+            }
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) b[t] = xb[t * WL_ROW_FLOATS + 64 * step];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                if constexpr (BIAS) bsum[i] += a[i];
+            }
+            if (FX && fx) {   // wave-uniform: this wave's dY rows x folded X row bj
+                const float bx = ring[slot * WL_SLOT_FLOATS + (WL_XROW0 + bj) * WL_ROW_FLOATS + lane + 64 * step];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) accx[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bx, accx[i], 0, 0, 0);
+            }
+            if (FY && fy) {   // folded dY row x this wave's X row bi (read again: cheaper than selecting among b[])
+                const float va = ring[slot * WL_SLOT_FLOATS + WL_YROW0 * WL_ROW_FLOATS + lane + 64 * step];
+                const float ay = (!MASKED || ok) ? va : 0.f;
+                const float by = xb[bi * WL_ROW_FLOATS + 64 * step];
+                accy = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, by, accy, 0, 0, 0);
+                if constexpr (BIAS) ysum += ay;
+            }
+            // keep the k-steps apart: without the masks nothing stops the scheduler from hoisting the LDS reads of all four
+            // steps to the top (32 more live registers: spills at the 128 the 16-wave workgroup allows)
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     static_assert(WL_SLOTS == 4, "wait_landed covers k <= 2");
@@ -336,58 +390,33 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
         wait_landed(min(nstages, WL_SLOTS - 1) - 1);
         __builtin_amdgcn_s_barrier();
     }
+    // The matrix pipe does not co-issue with the vector ALU in fp32 (SQ_VALU_MFMA_COEXEC_CYCLES = 0): every vector
+    // instruction between two MFMAs is matrix time lost (r03: 0.89 per MFMA here = 11 % of the kernel).  So the common
+    // stages - all TI tiles real, all 16 samples inside the chunk - run without the per-value masks, and only the four waves
+    // that own the bias sums add them up; the masked variant serves the last stage of the buffer and the edge waves of
+    // odd-shaped jobs.  One loop per variant (a loop that chooses per stage makes the register allocator give up the
+    // in-place accumulators: 500 spilled registers).
     int slot = 0;
-    for (int st = 0; st < nstages; ++st) {
-        // the slot of stage st-1 was freed by the barrier that ended the previous iteration (st = 0: the one slot the
-        // prologue left empty)
-        if (st + WL_SLOTS - 1 <= nstages - 1) issue(st + WL_SLOTS - 1, slot == 0 ? WL_SLOTS - 1 : slot - 1);
-        if (active) {
-            const float *ya = ring + slot * WL_SLOT_FLOATS + (TI * bi) * WL_ROW_FLOATS + lane;
-            const float *xb = ring + slot * WL_SLOT_FLOATS + (16 + TJ * bj) * WL_ROW_FLOATS + lane;
-            const int64_t s0 = begin + (int64_t)st * WL_STAGE;
-            // branch-free: tiles past the edge of the job run with a = 0 and are not stored; their LDS rows hold
-            // finite filler data
-#pragma unroll
-            for (int step = 0; step < WL_STAGE / 4; ++step) {
-                const bool ok = s0 + 4 * step + kslot < end;  // masked samples contribute a = 0 (b is finite data)
-                float a[TI], b[TJ];
-#pragma unroll
-                for (int t = 0; t < TI; ++t) {
-                    const float va = ya[t * WL_ROW_FLOATS + 64 * step];
-                    a[t] = (t < n_ti && ok) ? va : 0.f;
-                }
-#pragma unroll
-                for (int t = 0; t < TJ; ++t) b[t] = xb[t * WL_ROW_FLOATS + 64 * step];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                    bsum[i] += a[i];
-                }
-                if (fx) {   // wave-uniform: this wave's dY rows x folded X row bj
-                    const float bx = ring[slot * WL_SLOT_FLOATS + (WL_XROW0 + bj) * WL_ROW_FLOATS + lane + 64 * step];
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) accx[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bx, accx[i], 0, 0, 0);
-                }
-                if (fy) {   // folded dY row x this wave's X row bi
-                    const float va = ring[slot * WL_SLOT_FLOATS + WL_YROW0 * WL_ROW_FLOATS + lane + 64 * step];
-                    const float ay = ok ? va : 0.f;
-                    float by = b[0];
-#pragma unroll
-                    for (int t = 1; t < TJ; ++t) by = (bi == t) ? b[t] : by;
-                    accy = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, by, accy, 0, 0, 0);
-                    ysum += ay;
-                }
+    auto run = [&](auto masked_c, auto bias_c, int st_begin, int st_end) __attribute__((always_inline)) {
+        for (int st = st_begin; st < st_end; ++st) {
+            // the slot of stage st-1 was freed by the barrier that ended the previous iteration (st = 0: the one slot the
+            // prologue left empty)
+            if (st + WL_SLOTS - 1 <= nstages - 1) issue(st + WL_SLOTS - 1, slot == 0 ? WL_SLOTS - 1 : slot - 1);
+            if (active) stage_body(masked_c, bias_c, slot, begin + (int64_t)st * WL_STAGE);
+            if (st + 1 < nstages) {
+                // stage st+1 landed (this wave's pieces); the stages issued after it may stay in flight; everyone is done
+                // reading `slot`
+                wait_landed(min(st + WL_SLOTS - 1, nstages - 1) - (st + 1));
+                __builtin_amdgcn_s_barrier();
             }
+            slot = slot == WL_SLOTS - 1 ? 0 : slot + 1;
         }
-        if (st + 1 < nstages) {
-            // stage st+1 landed (this wave's pieces); the stages issued after it may stay in flight; everyone is done
-            // reading `slot`
-            wait_landed(min(st + WL_SLOTS - 1, nstages - 1) - (st + 1));
-            __builtin_amdgcn_s_barrier();
-        }
-        slot = slot == WL_SLOTS - 1 ? 0 : slot + 1;
-    }
+    };
+    // stages [0, nfast) lie inside the chunk with all their samples
+    const int nfast = (!active || n_ti == TI) ? (int)((end - begin) / WL_STAGE) : 0;
+    if (want_bias) run(std::false_type{}, std::true_type{}, 0, nfast);
+    else run(std::false_type{}, std::false_type{}, 0, nfast);
+    run(std::true_type{}, std::true_type{}, nfast, nstages);
     if (!active) return;
     // ---- write the partial of this (block, chunk) ---------------------------------------------------
     float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
@@ -406,10 +435,10 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
             v += __shfl_xor(v, 32, 64);
             if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (TI * bi + i) * 16 + lane] = v;
         }
-        if (fx)   // folded segment of the same layer: tile column ex_tj0 + bj
+        if (FX && fx)   // folded segment of the same layer: tile column ex_tj0 + bj
             *reinterpret_cast<f4 *>(part + ((int64_t)((TI * bi + i) * Ly.nkb + F.ex_tj0 + bj) * 64 + lane) * 4) = accx[i];
     }
-    if (fy) {     // the folded layer's (one output tile) partial: tile column = this wave's X row
+    if (FY && fy) {     // the folded layer's (one output tile) partial: tile column = this wave's X row
         const Layer &Le = P.layer[F.ey_layer];
         float *pe = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[F.ey_layer];
         const int tj = TJ * bj + bi;
@@ -468,7 +497,7 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     // ---- what rides with this job (first group of the layer's first wide segment only) ------------------------------
     WgradFold F{0, 0, -1, nullptr};
     if (A.fold && jb == 0 && s == wgrad_first_wide_seg(Ly)) {
-        const int xs = wgrad_fold_xseg(P, l);
+        const int xs = wgrad_fold_xseg(P, l, A.fold);
         if (xs >= 0) {
             F.ex = Ly.seg[xs].nkb;
             F.ex_tj0 = 0;
@@ -482,6 +511,19 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     }
     // wave block shape: the job's <=16 x <=16 tiles are cut so that (up to) all 16 waves own a block
     const int ti = n_rows_y > 8 ? 4 : (n_rows_y > 4 ? 2 : 1), tj = n_rows_x > 8 ? 4 : (n_rows_x > 4 ? 2 : 1);
+    // the folding variants (mlp_train_device.h guarantees these shapes: 16 or 8 output tiles, 16 input k-blocks)
+    if (F.ex > 0 || F.ey_layer >= 0) {
+        const bool x = F.ex > 0, y = F.ey_layer >= 0;
+        if (ti == 4 && tj == 4 && x && !y)
+            return wgrad_wave<4, 4, true, false>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
+        if (ti == 2 && tj == 4 && x && y)
+            return wgrad_wave<2, 4, true, true>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
+        if (ti == 2 && tj == 4 && !x && y)
+            return wgrad_wave<2, 4, false, true>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
+        if (ti == 2 && tj == 4 && x && !y)
+            return wgrad_wave<2, 4, true, false>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
+        __builtin_trap();   // unreachable: wgrad_kind only folds into these shapes
+    }
 #define SNERF_WG_CASE(TI_, TJ_)                                                                                       \
     if (ti == TI_ && tj == TJ_)                                                                                       \
         return wgrad_wave<TI_, TJ_>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
@@ -497,89 +539,121 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
 #undef SNERF_WG_CASE
 }
 
-// The narrow (layer, segment) pairs: one wave per workgroup owns a <= 4x4-tile block of dW and one chunk of samples;
-// operands go straight from L2/HBM into MFMA registers (4 samples x 16 features = one 256 B access per tile-row),
-// WG_PREFETCH k-steps in flight; no LDS, no barrier - occupancy bound by VGPRs only.
-constexpr int WG_THREADS = 64;
-constexpr int WG_PREFETCH = 4;  // k-steps (4 samples each) of operands in flight per wave
+// The narrow (layer, segment) pairs: a workgroup owns a <= 4x4-tile block of dW and one chunk of samples; operands go
+// straight from L2/HBM into MFMA registers (4 samples x 16 features = one 256 B access per tile-row), WG_PREFETCH k-steps
+// in flight per wave; no LDS in the loop, no barrier.
+// r03: the chunk is split over the WG_WAVES waves of the workgroup (quarter chunks, summed through LDS at the end): the
+// single-wave version put 1792 unequal waves on 1024 SIMDs - the launch lasted as long as the SIMDs that drew two long
+// jobs (42 % matrix-pipe busy); 7168 quarter waves balance.  And the loop is free of per-value vector work (tile / sample
+// masks, 64-bit address arithmetic: 3.2 vector instructions per MFMA before, and fp32 MFMAs do not co-issue with the vector
+// ALU): full k-steps run unmasked from wave-uniform row bases + one running 32-bit lane offset; masks only in the tail.
+constexpr int WG_WAVES = 4, WG_THREADS = WG_WAVES * 64;
 
-__global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_direct_kernel(Plan P, TrainLayout L, WgradArgs A) {
-    const int lane = threadIdx.x;
-    // ---- decode the job: (narrow layer, segment, 4x4-tile block) -------------------------------------
-    int job = blockIdx.x, l = 0, s = 0, kb0 = 0, nbj = 1;
-    for (l = 0; l < P.nlayers; ++l) {
-        bool found = false;
-        kb0 = 0;
-        for (s = 0; s < P.layer[l].nseg; ++s) {
-            nbj = (P.layer[l].seg[s].nkb + 3) / 4;
-            const int cnt = wgrad_kind(P, l, s, A.fold != 0) == 2 ? ((P.layer[l].t_out + 3) / 4) * nbj : 0;
-            if (job < cnt) { found = true; break; }
-            job -= cnt;
-            kb0 += P.layer[l].seg[s].nkb;
-        }
-        if (found) break;
+// buffer resource over this wave's segment of one tile-row: wave-uniform base in SGPRs, so a load is `buffer_load_dword v,
+// voff, s[rsrc] offen offset:imm` - no per-load 64-bit vector address arithmetic (the flat form cost 8 x v_lshl_add_u64 per
+// k-step) - and the hardware range check (offset >= num_records returns 0) IS the sample mask: k-steps and lanes past the
+// end of the segment read zeros, so the loop needs neither a tail nor a per-value select.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float *base, int bytes) {
+    // the base IS wave-uniform; say so, or the resource lands in vector registers and every load becomes a waterfall loop
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+template <int IMM>
+__device__ __forceinline__ float row_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + IMM, 0, 0));
+}
+
+template <int WG_PREFETCH, bool FULL>   // FULL: all 4 x 4 tiles of the block are real
+__device__ __forceinline__ void wgrad_direct_wave(const float *const (&ya)[4], const float *const (&xb)[4], int n_ti, int n_tj,
+                                                  int64_t wb, int64_t we, int lane, f4 (&acc)[4][4], float (&bsum)[4]) {
+    const int bytes = (int)(we - wb) * 64;               // this wave's samples of a tile-row (a quarter chunk: far below 2 GB)
+    __amdgpu_buffer_rsrc_t ry[4], rx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ry[t] = row_rsrc(ya[t], bytes);
+        rx[t] = row_rsrc(xb[t], bytes);
     }
-    const Layer &Ly = P.layer[l];
-    const int bi = job / nbj, bj = job - bi * nbj;
-    const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
-    const int64_t n = A.n;
-    // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: base + s0*16 + lane
-    const float *dyp = A.dy + ((int64_t)(L.dy[l] + 4 * bi) * n) * 16 + lane;
-    const float *xp = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj) * n) * 16 + lane;
-    int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
-    while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
-    const bool want_bias = (s == first_seg && bj == 0);
-    const int kslot = lane >> 4;
+    // lane (i = lane&15, kslot = lane>>4) reads feature i of sample s0 + kslot: byte offset (s0 - wb)*64 + lane*4 from the
+    // row base; k-step p of a group sits IMM = 256 p bytes further
+    auto load_ab = [&](auto imm_c, unsigned voff, float (&a)[4], float (&b)[4]) __attribute__((always_inline)) {
+        constexpr int IMM = decltype(imm_c)::value;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = (FULL || t < n_ti) ? row_load<IMM>(ry[t], voff) : 0.f;
+            b[t] = (FULL || t < n_tj) ? row_load<IMM>(rx[t], voff) : 0.f;
+        }
+    };
+    // software pipeline over groups of WG_PREFETCH k-steps (4 samples each), one group ahead; ONE loop (more than one loop
+    // that updates `acc` costs the in-place accumulators), the prefetch of the group behind the last one reads zeros
+    const int ngroups = ((int)(we - wb) + 4 * WG_PREFETCH - 1) / (4 * WG_PREFETCH);
+    unsigned voff = (unsigned)lane * 4u;
+    float ra[WG_PREFETCH][4], rb[WG_PREFETCH][4];
+    static_for<0, WG_PREFETCH>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        load_ab(std::integral_constant<int, 256 * p>{}, voff, ra[p], rb[p]);
+    });
+    for (int g = 0; g < ngroups; ++g) {
+        voff += 256u * WG_PREFETCH;
+        static_for<0, WG_PREFETCH>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            float a0[4], b0[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a0[t] = ra[p][t];
+                b0[t] = rb[p][t];
+            }
+            load_ab(std::integral_constant<int, 256 * p>{}, voff, ra[p], rb[p]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (FULL || i < n_ti) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (FULL || j < n_tj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                    bsum[i] += a0[i];   // (unconditional: the four adds cost less than a second loop variant)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one k-step at a time: hoisting all 32 loads of a group spills
+        });
+    }
+}
 
-    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
-    const int64_t end = min(n, begin + A.chunk);
-
+// everything behind the job decode, one instantiation per FULL (the accumulators of the two variants never meet)
+template <int WG_PREFETCH, bool FULL>
+__device__ __forceinline__ void wgrad_direct_block(const Layer &Ly, const TrainLayout &L, const WgradArgs &A, float *s_acc,
+                                                   const float *const (&ya)[4], const float *const (&xb)[4], int l, int kb0,
+                                                   int bi, int bj, int n_ti, int n_tj, int64_t wb, int64_t we, bool want_bias,
+                                                   int wave, int lane) {
     f4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    wgrad_direct_wave<WG_PREFETCH, FULL>(ya, xb, n_ti, n_tj, wb, we, lane, acc, bsum);
 
-    auto load_ab = [&](int64_t s0, float (&a)[4], float (&b)[4]) {
-        const bool ok = s0 + kslot < end;
-        const int64_t off = ok ? s0 * 16 : 0;  // masked lanes read sample 0 of the tile-row (finite data) and a = 0
+    // ---- sum the waves' quarters in a fixed order (wave 0 + 1 + 2 + 3) ------------------------------------------
+    constexpr int PER_WAVE = 16 * 256 + 4 * 64;
+    if (wave > 0) {
+        float *dst = s_acc + (wave - 1) * PER_WAVE;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = (t < n_ti && ok) ? dyp[(int64_t)t * n * 16 + off] : 0.f;
-            b[t] = (t < n_tj) ? xp[(int64_t)t * n * 16 + off] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f4 *>(dst + ((i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+            dst[16 * 256 + i * 64 + lane] = bsum[i];
         }
-    };
-    // software pipeline: WG_PREFETCH k-steps of operands in flight (register ring, statically indexed)
-    float ra[WG_PREFETCH][4], rb[WG_PREFETCH][4];
-#pragma unroll
-    for (int p = 0; p < WG_PREFETCH; ++p) {
-        const int64_t sp = begin + 4 * p;
-        if (sp < end) load_ab(sp, ra[p], rb[p]);
     }
-    for (int64_t s0 = begin; s0 < end; s0 += 4 * WG_PREFETCH) {
+    __syncthreads();
+    if (wave > 0) return;
 #pragma unroll
-        for (int p = 0; p < WG_PREFETCH; ++p) {
-            const int64_t sc = s0 + 4 * p;
-            if (sc < end) {  // wave-uniform
-                float a0[4], b0[4];
+    for (int w = 0; w < WG_WAVES - 1; ++w) {
+        const float *src = s_acc + w * PER_WAVE;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a0[t] = ra[p][t];
-                    b0[t] = rb[p][t];
-                }
-                const int64_t sn = sc + 4 * WG_PREFETCH;
-                if (sn < end) load_ab(sn, ra[p], rb[p]);
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < n_ti) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < n_tj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
-                        bsum[i] += a0[i];
-                    }
-                }
-            }
+            for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f4 *>(src + ((i * 4 + j) * 64 + lane) * 4);
+            bsum[i] += src[16 * 256 + i * 64 + lane];
         }
     }
     // ---- write the partial of this (block, chunk) ---------------------------------------------------
@@ -600,6 +674,51 @@ __global__ __launch_bounds__(WG_THREADS) void mlp_wgrad_direct_kernel(Plan P, Tr
             if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
         }
     }
+}
+
+template <int WG_PREFETCH>
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_wgrad_direct_kernel(Plan P, TrainLayout L, WgradArgs A) {
+    __shared__ __attribute__((aligned(16))) float s_acc[(WG_WAVES - 1) * (16 * 256 + 4 * 64)];   // 3 x (16 tiles + 4 bias sums)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ---- decode the job: (narrow layer, segment, 4x4-tile block) -------------------------------------
+    int job = blockIdx.x, l = 0, s = 0, kb0 = 0, nbj = 1;
+    for (l = 0; l < P.nlayers; ++l) {
+        bool found = false;
+        kb0 = 0;
+        for (s = 0; s < P.layer[l].nseg; ++s) {
+            nbj = (P.layer[l].seg[s].nkb + 3) / 4;
+            const int cnt = wgrad_kind(P, l, s, A.fold) == 2 ? ((P.layer[l].t_out + 3) / 4) * nbj : 0;
+            if (job < cnt) { found = true; break; }
+            job -= cnt;
+            kb0 += P.layer[l].seg[s].nkb;
+        }
+        if (found) break;
+    }
+    const Layer &Ly = P.layer[l];
+    const int bi = job / nbj, bj = job - bi * nbj;
+    const int n_ti = min(4, Ly.t_out - 4 * bi), n_tj = min(4, Ly.seg[s].nkb - 4 * bj);
+    const int64_t n = A.n;
+    int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
+    while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
+    const bool want_bias = (s == first_seg && bj == 0);
+
+    // this wave's quarter of the chunk (multiples of 4 samples)
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+    const int64_t sub = begin < end ? ((end - begin + 4 * WG_WAVES - 1) / (4 * WG_WAVES)) * 4 : 0;
+    const int64_t wb = min(end, begin + wave * sub), we = min(end, wb + sub);
+    // wave-uniform row bases at sample wb (rows the block does not have alias row 0: never read)
+    const float *ya[4], *xb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ya[t] = A.dy + ((int64_t)(L.dy[l] + 4 * bi + (t < n_ti ? t : 0)) * n + wb) * 16;
+        xb[t] = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj + (t < n_tj ? t : 0)) * n + wb) * 16;
+    }
+    if (n_ti == 4 && n_tj == 4)
+        wgrad_direct_block<WG_PREFETCH, true>(Ly, L, A, s_acc, ya, xb, l, kb0, bi, bj, n_ti, n_tj, wb, we, want_bias, wave, lane);
+    else
+        wgrad_direct_block<WG_PREFETCH, false>(Ly, L, A, s_acc, ya, xb, l, kb0, bi, bj, n_ti, n_tj, wb, we, want_bias, wave, lane);
 }
 
 // sum over the G partials and scatter slot order -> state_dict order
@@ -631,7 +750,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
     }
     if (dst < 0) return;
     // the bias sums of a layer ride with its first non-empty segment; a folded pair was written by the wide job's chunks
-    const int G = (seg < Ly.nseg && wgrad_kind(P, l, seg, fold != 0) != 2) ? G_wide : G_narrow;
+    const int G = (seg < Ly.nseg && wgrad_kind(P, l, seg, fold) != 2) ? G_wide : G_narrow;
     float sum = 0.f;
     for (int c = 0; c < G; ++c) sum += part[(int64_t)c * L.gp_floats + e];
     flat_grad[dst] = sum;
@@ -667,7 +786,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     W.xstat = reinterpret_cast<const int *>(act + (int64_t)L.act_rows * n * 16);   // (f16x3 wide jobs only)
     W.ystat = reinterpret_cast<const int *>(dy + (int64_t)L.dy_rows * n * 16);
     W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
-    W.fold = (!wide_nsplit && tuning().wgrad_fold) ? 1 : 0;   // the split-precision wide kernels do not carry folded tiles
+    W.fold = wide_nsplit ? 0 : tuning().wgrad_fold;   // the split-precision wide kernels do not carry folded tiles
     static LdsRaised raised;   // per device
     int rc;
     if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_kernel), WL_LDS_BYTES, raised, "wgrad"))) return rc;
@@ -679,14 +798,15 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             if ((rc = check_launch("wgrad"))) return rc;
         }
     }
-    if (const int jobs = wgrad_direct_jobs(P, W.fold != 0)) {
+    if (const int jobs = wgrad_direct_jobs(P, W.fold)) {
         W.chunk = (((n + G_narrow - 1) / G_narrow) + 15) / 16 * 16;
         // f16x3 step: the narrow jobs with two fp16 parts as well (SNERF_WGRAD_NARROW_F16=0: fp32 MFMA)
         const bool narrow_f16 = tuning().wgrad_narrow_f16;
         if (wide_nsplit == SNERF_SPLIT_F16X3 && narrow_f16) {
             if ((rc = launch_wgrad_direct_f16(P, L, W, jobs, G_narrow, s))) return rc;
         } else {
-            hipLaunchKernelGGL(mlp_wgrad_direct_kernel, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, P, L, W);
+            // 4 k-steps of operands in flight per wave (measured r03: 2 / 3 / 4 / 6 -> 0.61 / 0.58 / 0.56 / 0.57 ms per launch)
+            hipLaunchKernelGGL(mlp_wgrad_direct_kernel<4>, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, P, L, W);
             if ((rc = check_launch("wgrad_direct"))) return rc;
         }
     }

@@ -70,7 +70,7 @@ struct WgradArgs {
     int64_t n;
     int64_t chunk;  // samples per K-split, multiple of 16
     const int *xstat, *ystat;  // f16x3 wide wgrad: exponents of the largest |X| entering / |dY| leaving forward layer l
-    int fold;                  // fp32 step: narrow pairs that share an operand with a wide job ride with it (wgrad_kind)
+    int fold;                  // fp32 step: narrow pairs that share an operand with a wide job ride with it (wgrad_kind): level
 };
 
 
@@ -95,9 +95,15 @@ __host__ __device__ inline int wgrad_first_wide_seg(const Layer &Ly) {
         if (wgrad_wide(Ly, s)) return s;
     return -1;
 }
-__host__ __device__ inline int wgrad_fold_xseg(const Plan &P, int l) {   // folded segment of layer l, or -1
+// fold level 1: only directional_input's job (8 output tiles = half the MFMAs of a 256 x 256 job for the same operand
+// traffic) carries folded tiles; level 2: the 16-tile skip layers carry their position-encoding columns too (+25 % MFMAs in
+// that one job: measured SLOWER - it breaks the whole-rounds schedule of 9 equal jobs x 113 chunks on 256 CUs)
+__host__ __device__ inline int wgrad_fold_xseg(const Plan &P, int l, int fold = 2) {   // folded segment of layer l, or -1
     const Layer &Ly = P.layer[l];
     if (wgrad_first_wide_seg(Ly) < 0) return -1;
+    // the kernel variants that carry folded tiles: 16 output tiles (4 x 4 per wave) - and 8 (2 x 4) for directional_input
+    const bool din = Ly.t_out == 8 && l == P.n_hidden + 3 && P.nlayers == P.n_hidden + 6;
+    if (!((Ly.t_out == 16 && fold >= 2) || din)) return -1;
     for (int s = 0; s < Ly.nseg; ++s)
         if (!wgrad_wide(Ly, s) && Ly.seg[s].nkb >= 1 && Ly.seg[s].nkb <= 4) return s;
     return -1;
@@ -110,10 +116,10 @@ __host__ __device__ inline bool wgrad_fold_sigma(const Plan &P) {
            Ld.t_out == 8;
 }
 // how the pair (layer l, segment s) is computed: 0 = wide job, 1 = rides with a wide job, 2 = direct narrow job
-__host__ __device__ inline int wgrad_kind(const Plan &P, int l, int s, bool fold) {
+__host__ __device__ inline int wgrad_kind(const Plan &P, int l, int s, int fold) {
     if (wgrad_wide(P.layer[l], s)) return 0;
     if (fold) {
-        if (wgrad_fold_xseg(P, l) == s) return 1;
+        if (wgrad_fold_xseg(P, l, fold) == s) return 1;
         if (l == P.n_hidden + 2 && wgrad_fold_sigma(P)) return 1;
     }
     return 2;
@@ -125,7 +131,7 @@ __host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups
             if (wgrad_wide(P.layer[l], s)) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
     return jobs;
 }
-__host__ __device__ inline int wgrad_direct_jobs(const Plan &P, bool fold = false) {  // narrow jobs: 4x4-tile blocks
+__host__ __device__ inline int wgrad_direct_jobs(const Plan &P, int fold = 0) {  // narrow jobs: 4x4-tile blocks
     int jobs = 0;
     for (int l = 0; l < P.nlayers; ++l)
         for (int s = 0; s < P.layer[l].nseg; ++s)

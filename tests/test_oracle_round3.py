@@ -73,3 +73,17 @@ def test_raw2outputs_full_backward_of_the_torch_reference(N, wb, mode):
     for got, ref in ((raw.grad, g[f"c_draw_{key}"]), (z.grad, g[f"c_dz_{key}"]), (d0.grad, g[f"c_ddir_{key}"])):
         got = np.zeros_like(ref) if got is None else got.numpy()
         close(got, ref, 1e-4, 1e-6 * max(np.abs(ref).max(), 1e-12))
+
+
+def test_training_restatement_reproduces_the_reference_curve_prefix():
+    """oracle/torch_cpu_path.train_step (the timing stand-in of bench.py's train.cpu_baseline) against the first steps of the
+    reference's own 200-step run (g15_train200.npz): same batches, bit-identical losses."""
+    from oracle import torch_cpu_path as Tc
+    g = load_golden("g15_train200.npz")
+    pc, pf = syn.make_scene_nets(101)
+    state = Tc.TrainState([pc, pf], lr=float(g["lr"][0]))
+    data = syn.frame_batch(128, 128, seed=7)
+    for i in range(3):
+        batch = [torch.from_numpy(np.ascontiguousarray(a[g["idx"][i]])) for a in data]
+        loss = Tc.train_step(state, batch)
+        assert loss == g["losses"][i], (i, loss, g["losses"][i])
