@@ -38,9 +38,8 @@
  *       SNERF_WGRAD_F16=0                 f16x3 steps: three bf16 parts for the wide weight-gradient GEMMs
  *       SNERF_WGRAD_NARROW_F16=0          f16x3 steps: narrow weight-gradient jobs in fp32
  *       SNERF_WGRAD_F16_SPLIT_PER_WAVE=1  f16x3 wide weight-gradient GEMMs: every wave converts its own operands
- *       SNERF_WGRAD_FOLD=0 | 2            fp32 steps: 0 = every narrow weight-gradient pair as its own job; default 1 = the sigma
- *                                         head and the direction-encoding columns ride with directional_input's wide job;
- *                                         2 = the position-encoding columns of skip layers ride with theirs too (slower)
+ *       SNERF_WGRAD_FOLD=0                fp32 steps: every narrow weight-gradient pair as its own job (default: the sigma head
+ *                                         and the direction-encoding columns ride with directional_input's wide job)
  *     (smpl_nerf_amd/ reads one more, on the Python side only: SNERF_PRECISION = default arithmetic of new nets.)
  */
 #ifndef SMPLNERF_H

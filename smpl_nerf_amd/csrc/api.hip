@@ -66,7 +66,7 @@ const Tuning &tuning() {
         k.wgrad_narrow_f16 = flag("SNERF_WGRAD_NARROW_F16", true);
         k.wgrad_f16_split_per_wave = flag("SNERF_WGRAD_F16_SPLIT_PER_WAVE", false);
         const char *fo = getenv("SNERF_WGRAD_FOLD");
-        k.wgrad_fold = fo ? atoi(fo) : 1;
+        k.wgrad_fold = fo ? (atoi(fo) != 0 ? 1 : 0) : 1;
         return k;
     }();
     return t;

@@ -346,6 +346,47 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
         constexpr bool MASKED = decltype(masked_c)::value, BIAS = decltype(bias_c)::value;
         const float *ya = ring + slot * WL_SLOT_FLOATS + (TI * bi) * WL_ROW_FLOATS + lane;
         const float *xb = ring + slot * WL_SLOT_FLOATS + (16 + TJ * bj) * WL_ROW_FLOATS + lane;
+        if constexpr (!MASKED) {
+            // Unmasked stage: the operands of k-step s + 1 are read from LDS BEFORE the MFMAs of k-step s issue.  The four
+            // waves of a SIMD leave every barrier in lock-step and the round-robin matrix pipe keeps them there: with
+            // read -> wait -> 16 MFMAs per step all four sat in the LDS round trip at the same moment, every k-step.
+            float a[2][TI], b[2][TJ];
+            auto read = [&](int step, float (&av)[TI], float (&bv)[TJ]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int t = 0; t < TI; ++t) av[t] = ya[t * WL_ROW_FLOATS + 64 * step];
+#pragma unroll
+                for (int t = 0; t < TJ; ++t) bv[t] = xb[t * WL_ROW_FLOATS + 64 * step];
+            };
+            read(0, a[0], b[0]);
+#pragma unroll
+            for (int step = 0; step < WL_STAGE / 4; ++step) {
+                const int cur = step & 1;
+                if (step + 1 < WL_STAGE / 4) read(step + 1, a[cur ^ 1], b[cur ^ 1]);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                    if constexpr (BIAS) bsum[i] += a[cur][i];
+                }
+                if (FX && fx) {   // wave-uniform: this wave's dY rows x folded X row bj
+                    const float bx = ring[slot * WL_SLOT_FLOATS + (WL_XROW0 + bj) * WL_ROW_FLOATS + lane + 64 * step];
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) accx[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], bx, accx[i], 0, 0, 0);
+                }
+                if (FY && fy) {   // folded dY row x this wave's X row bi (read again: cheaper than selecting among b[])
+                    const float ay = ring[slot * WL_SLOT_FLOATS + WL_YROW0 * WL_ROW_FLOATS + lane + 64 * step];
+                    const float by = xb[bi * WL_ROW_FLOATS + 64 * step];
+                    accy = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, by, accy, 0, 0, 0);
+                    if constexpr (BIAS) ysum += ay;
+                }
+                // pin: the LDS reads of the next step first, then this step's MFMAs; nothing crosses the step boundary
+                __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ + TI + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int step = 0; step < WL_STAGE / 4; ++step) {
             bool ok = true;
@@ -514,8 +555,6 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     // the folding variants (mlp_train_device.h guarantees these shapes: 16 or 8 output tiles, 16 input k-blocks)
     if (F.ex > 0 || F.ey_layer >= 0) {
         const bool x = F.ex > 0, y = F.ey_layer >= 0;
-        if (ti == 4 && tj == 4 && x && !y)
-            return wgrad_wave<4, 4, true, false>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
         if (ti == 2 && tj == 4 && x && y)
             return wgrad_wave<2, 4, true, true>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
         if (ti == 2 && tj == 4 && !x && y)
@@ -750,6 +789,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
     }
     if (dst < 0) return;
     // the bias sums of a layer ride with its first non-empty segment; a folded pair was written by the wide job's chunks
+    // a folded pair was written by its carrier's (wide) workgroups
     const int G = (seg < Ly.nseg && wgrad_kind(P, l, seg, fold) != 2) ? G_wide : G_narrow;
     float sum = 0.f;
     for (int c = 0; c < G; ++c) sum += part[(int64_t)c * L.gp_floats + e];

@@ -70,7 +70,7 @@ struct WgradArgs {
     int64_t n;
     int64_t chunk;  // samples per K-split, multiple of 16
     const int *xstat, *ystat;  // f16x3 wide wgrad: exponents of the largest |X| entering / |dY| leaving forward layer l
-    int fold;                  // fp32 step: narrow pairs that share an operand with a wide job ride with it (wgrad_kind): level
+    int fold;                  // fp32 step: narrow pairs that share an operand with a wide job ride with it (wgrad_kind)
 };
 
 
@@ -83,27 +83,25 @@ struct WgradArgs {
 __host__ __device__ inline bool wgrad_wide(const Layer &Ly, int s) { return Ly.t_out >= 8 && Ly.seg[s].nkb >= 16; }
 // Folding (fp32 steps).  The narrow pairs are bound by HBM, not by the matrix pipe: a single-wave 4x4-tile job needs 2 KB of
 // operands per 16 MFMAs and the 20 narrow jobs of the default net move 8.7 KB per sample - while most of those bytes are
-// ALREADY staged in LDS by a wide job: the position-encoding columns of a skip layer and the direction-encoding columns of
-// directional_input contract the same d Y rows as the layer's 256-column job (only 4 / 2 more X tile-rows), and the sigma
-// head contracts the same X rows (`o`) as directional_input's job (one more d Y tile-row).  mlp_wgrad_kernel computes those
-// as extra accumulator tiles of the wide job: no extra d Y / X traffic beyond the few extra rows, no extra barrier, +3 % wide
-// MFMAs - and 10 of the 20 narrow jobs (4 KB per sample) disappear.
-//   xseg fold: one narrow segment (<= 4 k-blocks) of a layer that also has a wide segment -> extra X rows of that job
+// ALREADY staged in LDS by a wide job: the direction-encoding columns of directional_input contract the same d Y rows as
+// the layer's 256-column job (only 2 more X tile-rows), and the sigma head contracts the same X rows (`o`) as that job (one
+// more d Y tile-row).  mlp_wgrad_kernel computes those as extra accumulator tiles of that (half-length) job: no extra d Y / X
+// traffic beyond the few extra rows, no extra barrier - and 6 of the 20 narrow jobs (2 KB per sample) disappear.
+//   xseg fold: the narrow segment (<= 4 k-blocks) of directional_input, which also has a wide segment -> extra X rows
 //   sigma fold: the 1-row sigma head -> extra d Y row of directional_input's hidden-segment job (same X rows, same width)
 __host__ __device__ inline int wgrad_first_wide_seg(const Layer &Ly) {
     for (int s = 0; s < Ly.nseg; ++s)
         if (wgrad_wide(Ly, s)) return s;
     return -1;
 }
-// fold level 1: only directional_input's job (8 output tiles = half the MFMAs of a 256 x 256 job for the same operand
-// traffic) carries folded tiles; level 2: the 16-tile skip layers carry their position-encoding columns too (+25 % MFMAs in
-// that one job: measured SLOWER - it breaks the whole-rounds schedule of 9 equal jobs x 113 chunks on 256 CUs)
-__host__ __device__ inline int wgrad_fold_xseg(const Plan &P, int l, int fold = 2) {   // folded segment of layer l, or -1
+// Only directional_input's job (8 output tiles = half the MFMAs of a 256 x 256 job for the same operand traffic) carries
+// folded tiles.  (Measured r03: letting the 16-tile skip layers carry their position-encoding columns as well - +25 % MFMAs
+// in that one job - made the wide kernel 17 % SLOWER: it breaks the whole-rounds schedule of 9 equal jobs x 113 chunks on
+// 256 CUs.  Those columns stay direct jobs.)
+__host__ __device__ inline int wgrad_fold_xseg(const Plan &P, int l, int fold = 1) {   // folded segment of layer l, or -1
     const Layer &Ly = P.layer[l];
     if (wgrad_first_wide_seg(Ly) < 0) return -1;
-    // the kernel variants that carry folded tiles: 16 output tiles (4 x 4 per wave) - and 8 (2 x 4) for directional_input
-    const bool din = Ly.t_out == 8 && l == P.n_hidden + 3 && P.nlayers == P.n_hidden + 6;
-    if (!((Ly.t_out == 16 && fold >= 2) || din)) return -1;
+    if (!(Ly.t_out == 8 && l == P.n_hidden + 3 && P.nlayers == P.n_hidden + 6)) return -1;
     for (int s = 0; s < Ly.nseg; ++s)
         if (!wgrad_wide(Ly, s) && Ly.seg[s].nkb >= 1 && Ly.seg[s].nkb <= 4) return s;
     return -1;
@@ -115,6 +113,9 @@ __host__ __device__ inline bool wgrad_fold_sigma(const Plan &P) {
     return Ls.t_out == 1 && Ls.nseg == 1 && wgrad_first_wide_seg(Ld) == 0 && Ld.seg[0].nkb == Ls.seg[0].nkb && Ld.seg[0].nkb == 16 &&
            Ld.t_out == 8;
 }
+// (Measured r03: the 8-tile job - half the MFMAs of a 16-tile job per sample - lasts 0.7, not 0.5, of a 16-tile
+// workgroup; giving it double chunks to "equalise" made the launch 19 % slower.  Per stage a workgroup pays ~20 % of a
+// 16-tile stage that does not overlap with its MFMAs.)
 // how the pair (layer l, segment s) is computed: 0 = wide job, 1 = rides with a wide job, 2 = direct narrow job
 __host__ __device__ inline int wgrad_kind(const Plan &P, int l, int s, int fold) {
     if (wgrad_wide(P.layer[l], s)) return 0;

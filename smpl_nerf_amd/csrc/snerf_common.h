@@ -46,7 +46,7 @@ struct Tuning {
     bool wgrad_f16;                 // SNERF_WGRAD_F16                 (1)
     bool wgrad_narrow_f16;          // SNERF_WGRAD_NARROW_F16          (1)
     bool wgrad_f16_split_per_wave;  // SNERF_WGRAD_F16_SPLIT_PER_WAVE  (0)
-    int wgrad_fold;                 // SNERF_WGRAD_FOLD                (1; 0 = none, 2 = also into 16-tile layers)
+    int wgrad_fold;                 // SNERF_WGRAD_FOLD                (1)
 };
 const Tuning &tuning();
 

