@@ -270,6 +270,10 @@ constexpr int WL_ROW_FLOATS = WL_STAGE * 16;      // one tile-row of a stage: 1 
 constexpr int WL_XROW0 = 32, WL_YROW0 = 36;         // LDS rows of the folded operands: <= 4 extra X rows, one extra dY row
 constexpr int WL_SLOT_FLOATS = 37 * WL_ROW_FLOATS;  // 16 dY rows + 16 X rows + the folded rows (mlp_train_device.h)
 constexpr int WL_SLOTS = 4;                          // ring depth: up to WL_SLOTS - 2 stages in flight behind the one awaited
+// (Measured r03: 32-sample stages in a double buffer - half the barriers per MFMA - 4.79 instead of 4.65 ms per launch: the
+// ~20 % of a stage that does not overlap with the MFMAs is not the barrier.  The 8-tile job lasts 0.7 of a 16-tile one for
+// the same 32 KiB per stage, i.e. a stage cannot stream in faster than ~0.7 of a 16-tile stage's MFMA time: the kernel runs
+// close to what the tile-row reads (1 KiB pieces, 2 TB/s aggregate) allow.)
 constexpr int WL_LDS_BYTES = WL_SLOTS * WL_SLOT_FLOATS * 4;
 
 // the stage loop and the epilogue for one wave that owns TI x TJ accumulator tiles
@@ -814,6 +818,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
         if (n_cu < 1) return n_cu;
         const int jobs = wgrad_jobs(P);
         if (jobs > 0 && (int64_t)jobs * G > n_cu) {
+            // (fewer whole rounds = fewer partials for the reduce: measured r03, 4 / 3 / 2 / 1 rounds -> the same step time)
             const int rounds = (int)((int64_t)jobs * G / n_cu);
             G = min(G, max(1, rounds * n_cu / jobs));
         }

@@ -129,5 +129,26 @@ def main():
     MG.save("g14_ops_grads.npz", **g)
 
 
+def sample_pdf_grads():
+    """g16_sample_pdf_grad.npz: sample_pdf (utils.py:194-228) under autograd - the gradient w.r.t. bins and weights that the
+    reference's own autograd gives (fine_sampling detaches the result, sample_pdf itself does not)."""
+    U = MG._import_reference()[0]
+    torch.set_grad_enabled(True)
+    g4 = np.load(os.path.join(HERE, "g4_sampler.npz"))
+    rng = np.random.default_rng(424242)
+    z, w = g4["z"], g4["w"]
+    bins = t(.5 * (z[..., 1:] + z[..., :-1])).requires_grad_(True)
+    wi = t(np.ascontiguousarray(w[..., 1:-1])).requires_grad_(True)
+    out = U.sample_pdf(bins, wi, MG.Args(number_fine_samples=128))
+    gout = rng.normal(size=tuple(out.shape)).astype(F32)
+    (out * t(gout)).sum().backward()
+    MG.save("g16_sample_pdf_grad.npz", bins=bins.detach().numpy(), weights=wi.detach().numpy(), gout=gout,
+            samples=out.detach().numpy(), d_bins=bins.grad.numpy(), d_weights=wi.grad.numpy())
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-g16" in sys.argv:
+        sample_pdf_grads()
+    else:
+        main()
+        sample_pdf_grads()

@@ -28,6 +28,16 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmct_sq -- python $ROOT/bench.py $TRAIN > $OUT/pmct_sq.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmct_fetch -- python $ROOT/bench.py $TRAIN > $OUT/pmct_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmct_write -- python $ROOT/bench.py $TRAIN > $OUT/pmct_write.log 2>&1
+# (d) the multi-rank path at world 8 on this 1-GPU box: launcher, rendezvous, replica broadcast and the flat gradient all-reduce
+#     (gloo, ranks share the device - a dry run of the code path, not a scaling measurement)
+timeout 900 python $ROOT/bench.py --gpus 8 --steps 3 --warmup 1 --no-pmc --no-alt --cpu-rays 0 --points= --train-rays 512 --train-steps 3 > $OUT/bench_8ranks_1gpu_gloo.json.log 2> $OUT/bench_8ranks.err
+# (e) other workloads / operating points of the reference (one bench line each)
+timeout 600 python $ROOT/bench.py --coarse-only --no-pmc --no-alt --steps 20 > $OUT/bench_coarse_only.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py --workload smpl_nerf --no-pmc --steps 10 --cpu-rays 1024 --cpu-train-rays 256 > $OUT/bench_smpl_nerf.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py --workload smpl_nerf --res 256 --no-pmc --no-alt --steps 5 --cpu-rays 0 --points= > $OUT/bench_smpl_nerf_256.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py --workload append_vertices --res 256 --no-pmc --no-alt --steps 5 --cpu-rays 0 --points= > $OUT/bench_append_vertices_256.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py --workload append_smpl_params --no-pmc --no-alt --steps 10 --cpu-rays 0 --points= > $OUT/bench_append_smpl_params.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py > $OUT/bench_default.json.log 2>/dev/null
 cd $ROOT
 python tools/make_pmc_profile.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
 python tools/make_pmc_profile.py --smpl-nerf $OUT/pmcs_sq $OUT/pmcs_fetch $OUT/pmcs_write > $OUT/pmc_summary_smpl_nerf.json 2> $OUT/pmc_summary_smpl.err
