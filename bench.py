@@ -543,11 +543,16 @@ def main():
     if a.train_rays > 0 and run_fine:
         try:
             train = train_section(a.precision, a.workload, data, min(a.train_rays, rays), a.train_steps, world, rank, dev)
-            if a.points and "2048" in [v.strip() for v in a.points.split(",")] and a.train_rays != 2048 and rays >= 2048:
-                t = train_section(a.precision, a.workload, data, 2048, a.train_steps, world, rank, dev)
-                train["operating_point_2048_rays"] = {k: t[k] for k in (
-                    "value", "rays_per_step_per_gpu", "ms_per_step", "host_enqueue_ms_per_step", "c_abi_calls_per_step",
-                    "mlp_kernels_ms_per_step", "mlp_roofline_frac", "peak_allocated_bytes")}
+            if a.points and world == 1:   # the reference's own batch sizes (config_parser.py:53, README quickstart)
+                pts = []
+                for n in sorted({int(v) for v in a.points.split(",") if v.strip()}):
+                    if n == min(a.train_rays, rays) or n > rays:
+                        continue
+                    t = train_section(a.precision, a.workload, data, n, a.train_steps, world, rank, dev)
+                    pts.append({k: t[k] for k in ("value", "rays_per_step_per_gpu", "ms_per_step", "host_enqueue_ms_per_step",
+                                                   "c_abi_calls_per_step", "mlp_kernels_ms_per_step", "mlp_roofline_frac",
+                                                   "peak_allocated_bytes")})
+                train["operating_points"] = pts
             if not a.no_alt:
                 train_alt = {}
                 for prec in ("bf16x6", "f16x3", "fp32"):

@@ -40,7 +40,8 @@
  *       SNERF_WGRAD_F16_SPLIT_PER_WAVE=1  f16x3 wide weight-gradient GEMMs: every wave converts its own operands
  *       SNERF_WGRAD_FOLD=0                fp32 steps: every narrow weight-gradient pair as its own job (default: the sigma head
  *                                         and the direction-encoding columns ride with directional_input's wide job)
- *     (smpl_nerf_amd/ reads one more, on the Python side only: SNERF_PRECISION = default arithmetic of new nets.)
+ *     (smpl_nerf_amd/ reads two more, on the Python side only: SNERF_PRECISION = default arithmetic of new nets;
+ *     SNERF_TRAIN_ACT_GB = default activation budget of a training forward call, 64.)
  */
 #ifndef SMPLNERF_H
 #define SMPLNERF_H

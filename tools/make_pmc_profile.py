@@ -15,7 +15,7 @@ KERNELS = {"fp32": "mlp_fwd_kernel<256, 8, false, false>", "f16x3": "mlp_fwd_bf1
            "bf16x6": "mlp_fwd_bf16_kernel<256, 8, 3, false, 0>", "bf16x3": "mlp_fwd_bf16_kernel<256, 8, 2, false, 0>"}
 TRAIN_KERNELS = {"fwd_train_f16x3": "mlp_fwd_bf16_kernel<256, 8, 2, true, 1>", "fwd_train_bf16x6": "mlp_fwd_bf16_kernel<256, 8, 3, true, 0>", "dgrad_f16x3": "mlp_bwd_bf16_kernel<256, 8, 2, false, 1>", "dgrad_bf16x6": "mlp_bwd_bf16_kernel<256, 8, 3, false, 0>",
                  "wgrad_f16x3_wide": "mlp_wgrad_f16_kernel", "wgrad_bf16x6_wide": "mlp_wgrad_bf16_kernel<3, 0>", "wgrad_fp32_wide": "mlp_wgrad_kernel(", "wgrad_f16x3_narrow": "mlp_wgrad_direct_f16_kernel", "wgrad_fp32_narrow": "mlp_wgrad_direct_kernel", "fwd_train_fp32": "mlp_fwd_kernel<256, 8, false, true>",
-                 "dgrad_fp32": "mlp_bwd_kernel<256, 8, false>"}
+                 "dgrad_fp32": "mlp_bwd_kernel<256, 8, false"}
 ALG_BYTES = {1048576: 1048576 * (12 + 16) + 16384 * 12, 3145728: 3145728 * (12 + 16) + 16384 * 12}  # x, raw, dirs
 
 
