@@ -73,6 +73,16 @@ WORKLOADS = {
 
 
 # ---------------------------------------------------------------------------------------------------- launch
+def _flush_c_stdio():
+    """RCCL prints its version banner to the C library's stdout at the first collective; redirected to a pipe that stream is
+    block-buffered and would surface at process exit - AFTER the JSON line.  Flush it where it was written."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -398,6 +408,12 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a.gpus))
 
+    # stdout carries the ONE JSON line and nothing else: everything any library writes to file descriptor 1 from here on
+    # (RCCL prints a version banner through the C library's stdout at its first collective) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -412,9 +428,13 @@ def main():
     dev = torch.device("cuda", local_rank % ndev)   # one rank per GPU; the modulo only matters for dry runs of the
     torch.cuda.set_device(dev)                       # multi-rank path on fewer GPUs than ranks
     backend = None
-    if world > 1:
+    # SNERF_BENCH_FORCE_GROUP=1: form the process group at world size 1 too - the only way to take the RCCL branch of this
+    # script (init with device_id, device barrier, max over ranks on the device) on a 1-GPU box
+    grouped = world > 1 or bool(os.environ.get("SNERF_BENCH_FORCE_GROUP"))
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         backend = os.environ.get("SNERF_DIST_BACKEND", "nccl" if ndev >= world else "gloo")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -449,6 +469,7 @@ def main():
             out = pipe(data)
         barrier(dev)
         torch.cuda.synchronize()
+        _flush_c_stdio()       # (the barrier above was the group's first collective)
         with _lib.profile() as prof:
             t0 = time.perf_counter()
             for _ in range(a.steps):
@@ -649,8 +670,9 @@ def main():
                                                            info["cores"], TRAIN_LR)
             line["rgb_fine_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[1][:n].cpu().numpy() - ref[1])))
             line["rgb_coarse_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[0][:n].cpu().numpy() - ref[0])))
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        _flush_c_stdio()
+        print(json.dumps(line), file=json_out, flush=True)
+    if grouped:
         import torch.distributed as dist
         dist.destroy_process_group()
 

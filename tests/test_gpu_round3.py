@@ -465,3 +465,63 @@ def test_sample_pdf_is_differentiable(dev):
         assert rows.mean() >= 0.9, (rows.mean(), np.abs(got - ref).max())
     with torch.no_grad():
         np.testing.assert_array_equal(ops.sample_pdf(bins, w, O.Args(number_fine_samples=128, strict_cumsum=1)).cpu().numpy(), g["samples"])
+
+
+# ------------------------------------------------------------------------------------------ RCCL on the GPU box
+def _rccl_worker(port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dv = torch.device("cuda", 0)
+    torch.cuda.set_device(dv)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dv)      # what bench.py / the trainer do on an 8-GPU node
+    try:
+        from smpl_nerf_amd import dist as sd
+        flat = torch.arange(1220872, device=dv, dtype=torch.float32)          # the nerf gradient buffer's size
+        ref = flat.clone()
+        sd.allreduce_mean_(flat)                                              # RCCL all-reduce on the compute stream
+        sd.broadcast_(flat, 0)
+        sd.barrier(dv)                                                        # barrier(device_ids=[...]) as in bench.py
+        t = sd.max_over_ranks(1.25, dv)
+        rows = sd.gather_rows(torch.ones((5, 3), device=dv), 5)
+        torch.cuda.synchronize()
+        q.put((bool(torch.equal(flat, ref)), t, tuple(rows.shape), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_of_the_path_run_on_this_gpu():
+    """N > 1 cannot run on a 1-GPU box, but RCCL can: a world-size-1 "nccl" group through every collective the path uses
+    (flat-buffer all-reduce, replica broadcast, device barrier, max over ranks, row gather) - initialisation, stream
+    semantics and the dmabuf IPC setting of this image are exercised for real, only the xGMI transport is not."""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    same, t, shape, backend = q.get()
+    assert same and t == 1.25 and shape == (5, 3) and backend == "nccl"
+
+
+def test_bench_takes_its_rccl_branch_at_world_size_one():
+    """bench.py with SNERF_BENCH_FORCE_GROUP=1: process group on "nccl" (= RCCL) with device_id, device barrier and
+    max-over-ranks on the device - the branch the driver's 8-GPU run takes, here with one rank."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SNERF_BENCH_FORCE_GROUP="1", SNERF_DIST_BACKEND="nccl")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-rays", "0",
+                        "--train-rays", "512", "--train-steps", "2", "--no-alt", "--no-pmc", "--points="],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and "nccl" in line["config"]["parallelism"] and line["value"] > 5e7
+    assert line["train"]["value"] > 1e7
