@@ -1,0 +1,127 @@
+// Micro-benchmark: cycles per v_mfma_f32_16x16x4_f32 in the k-block pattern of the fused kernels (two accumulators alternating,
+// two ds_read_b128 of the next tile pair per 8 MFMAs), with and without the LDS reads, 1 or 2 waves per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_lds.hip -o /tmp/mfma_lds && /tmp/mfma_lds
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// 0: MFMA only; 1: + 2 ds_read_b128 per 8 MFMAs (operands used); 2: ds_reads issued but MFMA operands constant;
+// 3: as 1 + a workgroup barrier every 128 MFMAs per wave (the slab hand-over); 4: as 3 + 33 KiB of LDS-DMA per period behind
+// the period's first k-block (the slab refill); 5: as 3 + the register-staged refill (global loads -> ds_write before the barrier)
+template <int MODE>
+__global__ __launch_bounds__(512) void k(float *out, long long *cyc, int iters, const float *src) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = (float)(i & 7) * 1e-3f;
+    __syncthreads();
+    f4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    f4 b = f4{1.f, 0.5f, 0.25f, 0.125f};
+    const f4 *ap = reinterpret_cast<const f4 *>(lds) + lane;
+    f4 a0 = ap[0], a1 = ap[64];
+    long long t0 = __builtin_readcyclecounter();
+    f4 st[5];
+    const f4 *gsrc = reinterpret_cast<const f4 *>(src) + threadIdx.x;
+    if (MODE == 5) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st[q] = gsrc[q * 512];
+    }
+    for (int it = 0; it < iters; ++it) {
+        if (MODE >= 3 && (it & 1) == 0 && it) {
+            if (MODE == 5) {   // register-staged hand-over: staged slab -> LDS, next global loads, barrier
+                f4 *d = reinterpret_cast<f4 *>(lds + 8192 + ((it >> 1) % 2) * 8448) + threadIdx.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[q * 512] = st[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st[q] = gsrc[q * 512 + ((it >> 1) & 63) * 2112];
+            }
+            if (MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int to = 0; to < 16; to += 2) {
+            f4 n0 = a0, n1 = a1;
+            if (MODE >= 1) {
+                n0 = ap[((to + 2) & 15) * 64];
+                n1 = ap[((to + 3) & 15) * 64];
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(MODE == 2 ? b[r] : a0[r], b[r], acc[to], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(MODE == 2 ? b[r] : a1[r], b[r], acc[to + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 2) { asm volatile("" ::"v"(n0), "v"(n1)); }
+            a0 = n0;
+            a1 = n1;
+            if (MODE == 4 && to == 14 && (it & 1) == 0) {   // the refill of this period, behind its first k-block
+                const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                const char *g = reinterpret_cast<const char *>(src) + lane * 16 + (size_t)((it >> 1) & 63) * 33792;
+                char *dst = reinterpret_cast<char *>(lds + 8192 + ((it >> 1) % 2) * 8448);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (q * 512 + wave * 64) * 16),
+                                                     (__attribute__((address_space(3))) void *)(dst + (q * 512 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char *name, int threads) {
+    float *out;
+    long long *cyc, h[8 * 256];
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&cyc, sizeof(h));
+    const int iters = 20000;
+    const int lds_bytes = 32768 + 2 * 33792;
+    static float *src = nullptr;
+    if (!src) {
+        hipMalloc(&src, 64 * 33792 + 65536);
+        hipMemset(src, 0, 64 * 33792 + 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    }
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    const int waves = threads / 64;
+    double mean = 0;
+    for (int i = 0; i < 256 * waves; ++i) mean += (double)h[i];
+    mean /= 256 * waves;
+    const double per_mfma_wave = mean / (iters * 64.0);
+    const double tflops = 256.0 * waves * iters * 64.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    printf("%-46s waves/SIMD %d: %.2f s_memtime ticks per MFMA per wave; wall %.3f ms = %.1f TFLOP/s (%.3f of 157.3)\n", name,
+           waves / 4, per_mfma_wave, ms, tflops, tflops / 157.3);
+    hipFree(out);
+    hipFree(cyc);
+}
+int main() {
+    run<0>("MFMA only", 256);
+    run<0>("MFMA only", 512);
+    run<1>("+ 2 ds_read_b128 per 8 MFMAs (used)", 256);
+    run<1>("+ 2 ds_read_b128 per 8 MFMAs (used)", 512);
+    run<2>("+ 2 ds_read_b128 per 8 MFMAs (results unused)", 512);
+    run<3>("+ barrier every 128 MFMAs per wave", 512);
+    run<4>("+ barrier + 33 KiB LDS-DMA refill per period", 512);
+    run<5>("+ barrier + register-staged refill per period", 512);
+    return 0;
+}
