@@ -77,6 +77,82 @@ __global__ __launch_bounds__(512) void k(float *out, long long *cyc, int iters, 
     if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// The split-precision pattern: v_mfma_f32_16x16x32_bf16 (16 cycles), one ds_read_b128 per MFMA (a 1 KiB A part per product),
+// PRODUCTS products per output tile, 16 tiles per k-block = one slab of PARTS x 16 KiB per period.
+// MODE 0: MFMA + LDS reads; 1: + barrier per slab; 2: + the slab refill by LDS-DMA, issued by alternating halves (as shipped)
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+template <int MODE, int PARTS, int PRODUCTS>
+__global__ __launch_bounds__(512) void kb(float *out, long long *cyc, int iters, const float *src) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < PARTS * 4096; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    f4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    bf8 b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = (__bf16)1.0f;
+    const bf8 *ap = reinterpret_cast<const bf8 *>(lds) + lane;
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE >= 1 && it) {
+            if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (MODE == 2 && ((wave >= 4) == ((it & 1) != 0))) {   // this half's turn: the whole slab, PARTS * 4 pieces per wave
+                const char *g = reinterpret_cast<const char *>(src) + lane * 16 + (size_t)(it & 31) * PARTS * 16384;
+                char *dst = reinterpret_cast<char *>(lds) + PARTS * 16384 * (1 + (it & 1));
+#pragma unroll
+                for (int q = 0; q < PARTS * 4; ++q)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + ((wave & 3) * PARTS * 4 + q) * 1024),
+                                                     (__attribute__((address_space(3))) void *)(dst + ((wave & 3) * PARTS * 4 + q) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int to = 0; to < 16; ++to) {
+            bf8 a[PARTS];
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) a[p] = ap[(to * PARTS + p) * 64];
+#pragma unroll
+            for (int t = 0; t < PRODUCTS; ++t) acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t % PARTS], b, acc[to], 0, 0, 0);
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+template <int MODE, int PARTS, int PRODUCTS>
+void runb(const char *name) {
+    float *out, *src;
+    long long *cyc;
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&cyc, 8 * 256 * 8);
+    hipMalloc(&src, 32 * PARTS * 16384 + 65536);
+    hipMemset(src, 0, 32 * PARTS * 16384 + 65536);
+    const int iters = 20000, lds_bytes = 3 * PARTS * 16384;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kb<MODE, PARTS, PRODUCTS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kb<MODE, PARTS, PRODUCTS>), dim3(256), dim3(512), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((kb<MODE, PARTS, PRODUCTS>), dim3(256), dim3(512), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tflops = 256.0 * 8 * iters * 16.0 * PRODUCTS * 16384.0 / (ms * 1e-3) / 1e12;
+    printf("bf16 16x16x32, %d parts / %d products, %-40s wall %.3f ms = %.0f TFLOP/s of products (%.3f of 2500)\n", PARTS, PRODUCTS, name, ms,
+           tflops, tflops / 2500.0);
+    hipFree(out);
+    hipFree(cyc);
+    hipFree(src);
+}
+
 template <int MODE>
 void run(const char *name, int threads) {
     float *out;
@@ -123,5 +199,11 @@ int main() {
     run<3>("+ barrier every 128 MFMAs per wave", 512);
     run<4>("+ barrier + 33 KiB LDS-DMA refill per period", 512);
     run<5>("+ barrier + register-staged refill per period", 512);
+    runb<0, 3, 6>("MFMA + one ds_read_b128 per product");
+    runb<1, 3, 6>("+ barrier per slab");
+    runb<2, 3, 6>("+ 48 KiB LDS-DMA refill per slab (halves alternate)");
+    runb<0, 2, 3>("MFMA + one ds_read_b128 per product");
+    runb<1, 2, 3>("+ barrier per slab");
+    runb<2, 2, 3>("+ 32 KiB LDS-DMA refill per slab (halves alternate)");
     return 0;
 }
