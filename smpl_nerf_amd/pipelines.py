@@ -194,13 +194,16 @@ class SmplNerfPipeline(NerfPipeline):
 
 
     def render_rays(self, data):
-        """forward(data) for inference through the single C-ABI call snerf_render_rays_smpl_f32 (run_fine = 1 only)."""
+        """forward(data) for inference through the single C-ABI call snerf_render_rays_smpl_f32.  The one-call entry covers
+        the full coarse + fine march with the encoded pose; run_fine = 0 and human_pose_encoding = 0 (three launches instead
+        of eight) go through forward() under no_grad - the same kernels, the same results."""
         from . import _lib
         from ._lib import check, ptr, current_stream
         ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
         args = self.args
         if not args.human_pose_encoding or not args.run_fine:
-            raise NotImplementedError("SmplNerfPipeline.render_rays: human_pose_encoding = 1 and run_fine = 1 only")
+            with torch.no_grad():
+                return self.forward(data)
         B, Nc = z_vals.shape
         Nf = int(args.number_fine_samples)
         N = Nc + Nf

@@ -525,3 +525,24 @@ def test_bench_takes_its_rccl_branch_at_world_size_one():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and "nccl" in line["config"]["parallelism"] and line["value"] > 5e7
     assert line["train"]["value"] > 1e7
+
+
+def test_smpl_render_rays_covers_the_modes_without_a_one_call_entry(dev):
+    """SmplNerfPipeline.render_rays with run_fine = 0 (and with human_pose_encoding = 0) - the modes the one-call C entry
+    does not cover - returns what forward() returns, under no_grad, instead of raising."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import SmplNerfPipeline
+    g = load_golden("g12_smpl_raw_pose.npz")
+    pc, pf = syn.make_scene_nets(101)
+    pw = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("warp_param/")}
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    d = [T(a[g["sub"]], dev) for a in data[:4]] + [T(g["goal_pose"], dev), T(data[4][g["sub"]], dev)]
+    pipe = SmplNerfPipeline(_net(dev, pc), _net(dev, pf), _warp(dev, pw, 3, 2), O.Args(run_fine=0, human_pose_encoding=0),
+                            PositionalEncoder(10, 0), PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+    out = pipe.render_rays(d)
+    with torch.no_grad():
+        ref = pipe(d)
+    assert len(out) == 6 and all(not o.requires_grad for o in out)
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+    close(out[0].cpu().numpy(), g["rgb_wb0"], 0, 1e-4)
