@@ -140,6 +140,7 @@ def test_training_forward_relu_sign_masks(dev, prec, kw):
     n = 1000                                                               # ragged against the 128-sample tile
     pts, dirs = rng.uniform(-2, 2, (n, 1, 3)).astype(F32), rng.normal(size=(n, 3)).astype(F32)
     net = make_net(dev, params, precision=prec, **kw)
+    net.activation_budget_bytes = 1 << 40          # the stored form (the block-wise backward keeps no activation buffer)
     raw = net.forward_fused(T(pts, dev), T(dirs, dev), 1, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
     act = raw.grad_fn.act.cpu().numpy()
     rows = act.size // (n * 16)

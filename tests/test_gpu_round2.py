@@ -435,6 +435,7 @@ def test_relu_mask_flips_are_counted_and_everything_else_is_tight(dev, prec):
     dray = rng.normal(size=(B, 3)).astype(F32)
     gout = rng.normal(size=(n, 4)).astype(F32)
     net = _net(dev, params, precision=prec)
+    net.activation_budget_bytes = 1 << 40          # the stored form: the activation buffer is read below
     raw = net.forward_fused(T(pts, dev), T(dray, dev), Ns, *_encoders())
     masks = _relu_masks_from_act(N(raw.grad_fn.act), n)
     # torch reference activations

@@ -546,3 +546,26 @@ def test_smpl_render_rays_covers_the_modes_without_a_one_call_entry(dev):
     for a, b in zip(ref, out):
         assert torch.equal(a, b)
     close(out[0].cpu().numpy(), g["rgb_wb0"], 0, 1e-4)
+
+
+def test_block_wise_backward_of_encoded_rows(dev):
+    """RenderRayNet.forward(x_enc) under a small activation budget: the encoded rows' gradient and the parameter gradients of
+    the block-wise backward equal the stored form's."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    g2, g7 = load_golden("g2_mlp.npz"), load_golden("g7_grads.npz")
+    params = syn.make_render_ray_net_params(11, 30.0, 10.0, skips=(4,))
+    res = {}
+    for budget in (0, 1 << 20):        # 1 MB: ~49 rows per block of the 160
+        net = RenderRayNet(8, 256, 60, 24, skips=[4])
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        net = net.to(dev)
+        net.activation_budget_bytes = budget
+        x = T(g2["inputs"], dev).requires_grad_(True)
+        raw = net(x)
+        (raw * T(g7["m_gout"], dev)).sum().backward()
+        res[budget] = (raw.detach().clone(), x.grad.clone(), _grads((net,)))
+    assert torch.equal(res[0][0], res[1 << 20][0])
+    _assert_grads_close([res[1 << 20][1]] + res[1 << 20][2], [res[0][1]] + res[0][2], 2e-5)
+    for k, p in zip([k for k, _ in net.named_parameters()], res[1 << 20][2]):
+        ref = g7[f"m_skip4/{k}"]
+        close(R.digest(p), ref, 5e-4, 5e-5 * max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel())))
