@@ -81,7 +81,20 @@ __global__ __launch_bounds__(512) void k(float *out, long long *cyc, int iters, 
 // PRODUCTS products per output tile, 16 tiles per k-block = one slab of PARTS x 16 KiB per period.
 // MODE 0: MFMA + LDS reads; 1: + barrier per slab; 2: + the slab refill by LDS-DMA, issued by alternating halves (as shipped)
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-template <int MODE, int PARTS, int PRODUCTS>
+template <int PARTS>
+__device__ inline void split_parts(const float (&v)[8], bf8 (&b)[PARTS]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float r = v[e];
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) {
+            const __bf16 h = (__bf16)r;
+            b[p][e] = h;
+            r -= (float)h;
+        }
+    }
+}
+template <int MODE, int PARTS, int PRODUCTS, bool SPLIT = false>
 __global__ __launch_bounds__(512) void kb(float *out, long long *cyc, int iters, const float *src) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -91,12 +104,22 @@ __global__ __launch_bounds__(512) void kb(float *out, long long *cyc, int iters,
     f4 acc[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-    bf8 b;
+    bf8 b[PARTS];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) b[e] = (__bf16)1.0f;
+    for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[p][e] = (__bf16)1.0f;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 1.0f + 1e-3f * (float)(lane + e);
     const bf8 *ap = reinterpret_cast<const bf8 *>(lds) + lane;
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
+        if (SPLIT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
+            split_parts<PARTS>(v, b);
+        }
         if (MODE >= 1 && it) {
             if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -115,7 +138,7 @@ __global__ __launch_bounds__(512) void kb(float *out, long long *cyc, int iters,
 #pragma unroll
             for (int p = 0; p < PARTS; ++p) a[p] = ap[(to * PARTS + p) * 64];
 #pragma unroll
-            for (int t = 0; t < PRODUCTS; ++t) acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t % PARTS], b, acc[to], 0, 0, 0);
+            for (int t = 0; t < PRODUCTS; ++t) acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t % PARTS], b[(t / PARTS + t) % PARTS], acc[to], 0, 0, 0);
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -125,7 +148,7 @@ __global__ __launch_bounds__(512) void kb(float *out, long long *cyc, int iters,
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
-template <int MODE, int PARTS, int PRODUCTS>
+template <int MODE, int PARTS, int PRODUCTS, bool SPLIT = false>
 void runb(const char *name) {
     float *out, *src;
     long long *cyc;
@@ -134,20 +157,122 @@ void runb(const char *name) {
     hipMalloc(&src, 32 * PARTS * 16384 + 65536);
     hipMemset(src, 0, 32 * PARTS * 16384 + 65536);
     const int iters = 20000, lds_bytes = 3 * PARTS * 16384;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(kb<MODE, PARTS, PRODUCTS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kb<MODE, PARTS, PRODUCTS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((kb<MODE, PARTS, PRODUCTS>), dim3(256), dim3(512), lds_bytes, 0, out, cyc, iters, src);
+    hipLaunchKernelGGL((kb<MODE, PARTS, PRODUCTS, SPLIT>), dim3(256), dim3(512), lds_bytes, 0, out, cyc, iters, src);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((kb<MODE, PARTS, PRODUCTS>), dim3(256), dim3(512), lds_bytes, 0, out, cyc, iters, src);
+    hipLaunchKernelGGL((kb<MODE, PARTS, PRODUCTS, SPLIT>), dim3(256), dim3(512), lds_bytes, 0, out, cyc, iters, src);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     const double tflops = 256.0 * 8 * iters * 16.0 * PRODUCTS * 16384.0 / (ms * 1e-3) / 1e12;
-    printf("bf16 16x16x32, %d parts / %d products, %-40s wall %.3f ms = %.0f TFLOP/s of products (%.3f of 2500)\n", PARTS, PRODUCTS, name, ms,
-           tflops, tflops / 2500.0);
+    printf("bf16 16x16x32, %d parts / %d products%s, %-40s wall %.3f ms = %.0f TFLOP/s of products (%.3f of 2500)\n", PARTS, PRODUCTS,
+           SPLIT ? " + VALU split" : "", name, ms, tflops, tflops / 2500.0);
+    hipFree(out);
+    hipFree(cyc);
+    hipFree(src);
+}
+
+// The same slab stream with 32 samples per wave: v_mfma_f32_32x32x16_bf16 (32 cycles), ONE wave per SIMD (4 waves, 128 samples per
+// workgroup as shipped; 8 accumulator tiles of 16 registers).  A slab = one 32-wide k-block x 256 outputs x PARTS = 8 output tiles
+// x 2 k-halves x PARTS A pieces of 1 KiB, each read once per wave (half the LDS bytes per FLOP of the 16-sample form).
+// MODE as kb; the refill is issued by all four waves every slab (there is no other half to alternate with).
+// SPLIT: the operand split of the k-block's B values is done on the VALU inside the loop (16 values per lane here, 8 in kb).
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int MODE, int PARTS, int PRODUCTS, bool SPLIT>
+__global__ __launch_bounds__(256) void kc(float *out, long long *cyc, int iters, const float *src) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < PARTS * 4096; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    f16v acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    bf8 b[2][PARTS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[h][p][e] = (__bf16)1.0f;
+    float v[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[h][e] = 1.0f + 1e-3f * (float)(lane + e + h);
+    const bf8 *ap = reinterpret_cast<const bf8 *>(lds) + lane;
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE >= 1 && it) {
+            if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (MODE == 2) {
+                const char *g = reinterpret_cast<const char *>(src) + lane * 16 + (size_t)(it & 31) * PARTS * 16384;
+                char *dst = reinterpret_cast<char *>(lds) + PARTS * 16384 * (1 + (it & 1));
+#pragma unroll
+                for (int q = 0; q < PARTS * 4; ++q)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (wave * PARTS * 4 + q) * 1024),
+                                                     (__attribute__((address_space(3))) void *)(dst + (wave * PARTS * 4 + q) * 1024), 16, 0, 0);
+            }
+        }
+        if (SPLIT) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[h][e]));
+                split_parts<PARTS>(v[h], b[h]);
+            }
+        }
+#pragma unroll
+        for (int to = 0; to < 8; ++to)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf8 a[PARTS];
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p) a[p] = ap[((to * 2 + h) * PARTS + p) * 64];
+#pragma unroll
+                for (int t = 0; t < PRODUCTS; ++t)
+                    acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t % PARTS], b[h][(t / PARTS + t) % PARTS], acc[to], 0, 0, 0);
+            }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[t][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+template <int MODE, int PARTS, int PRODUCTS, bool SPLIT>
+void runc(const char *name) {
+    float *out, *src;
+    long long *cyc;
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&cyc, 8 * 256 * 8);
+    hipMalloc(&src, 32 * PARTS * 16384 + 65536);
+    hipMemset(src, 0, 32 * PARTS * 16384 + 65536);
+    const int iters = 20000, lds_bytes = 3 * PARTS * 16384;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kc<MODE, PARTS, PRODUCTS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kc<MODE, PARTS, PRODUCTS, SPLIT>), dim3(256), dim3(256), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((kc<MODE, PARTS, PRODUCTS, SPLIT>), dim3(256), dim3(256), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tflops = 256.0 * 4 * iters * 16.0 * PRODUCTS * 32768.0 / (ms * 1e-3) / 1e12;
+    printf("bf16 32x32x16, %d parts / %d products%s, %-40s wall %.3f ms = %.0f TFLOP/s of products (%.3f of 2500)\n", PARTS, PRODUCTS,
+           SPLIT ? " + VALU split" : "", name, ms, tflops, tflops / 2500.0);
     hipFree(out);
     hipFree(cyc);
     hipFree(src);
@@ -205,5 +330,15 @@ int main() {
     runb<0, 2, 3>("MFMA + one ds_read_b128 per product");
     runb<1, 2, 3>("+ barrier per slab");
     runb<2, 2, 3>("+ 32 KiB LDS-DMA refill per slab (halves alternate)");
+    runb<2, 3, 6, true>("+ 48 KiB LDS-DMA refill per slab (halves alternate)");
+    runb<2, 2, 3, true>("+ 32 KiB LDS-DMA refill per slab (halves alternate)");
+    runc<0, 3, 6, false>("MFMA + one ds_read_b128 per 2 products");
+    runc<1, 3, 6, false>("+ barrier per slab");
+    runc<2, 3, 6, false>("+ 48 KiB LDS-DMA refill per slab (all 4 waves)");
+    runc<2, 3, 6, true>("+ 48 KiB LDS-DMA refill per slab (all 4 waves)");
+    runc<0, 2, 3, false>("MFMA + one ds_read_b128 per 1.5 products");
+    runc<1, 2, 3, false>("+ barrier per slab");
+    runc<2, 2, 3, false>("+ 32 KiB LDS-DMA refill per slab (all 4 waves)");
+    runc<2, 2, 3, true>("+ 32 KiB LDS-DMA refill per slab (all 4 waves)");
     return 0;
 }
