@@ -71,11 +71,10 @@ __global__ __launch_bounds__(CP_THREADS) void composite_fwd_kernel(
         const float a = ok ? __fsub_rn(1.0f, expf(__fmul_rn(-fmaxf(sig, 0.f), dist))) : 0.f;
         const float om = ok ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
         // inclusive fp64 prefix product over the chunk, shifted to exclusive
-        const double incl = wave_scan_mul((double)om, lane);
-        double excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0;
+        const double incl = wave_scan_mul((double)om);
+        const double excl = wave_shift_up1(incl, 1.0);
         const float T = (float)(carry * excl);
-        carry *= __shfl(incl, 63, 64);
+        carry *= wave_last(incl);
         const float w = __fmul_rn(a, T);
         if (ok) {
             if (w_out) w_out[base + i] = w;
@@ -170,8 +169,8 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
             float a, dist, sig, ex;
             sample(i, r, a, om, dist, sig, ex);
         }
-        const double incl = wave_scan_mul((double)om, lane);
-        carry *= __shfl(incl, 63, 64);
+        const double incl = wave_scan_mul((double)om);
+        carry *= wave_last(incl);
     }
     const float gsum = white_bg ? (gr + gg + gb) : 0.f;
     // reverse sweep
@@ -184,9 +183,8 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         float a = 0.f, om = 1.0f, dist = 0.f, sig = 0.f, ex = 1.0f;
         if (ok) sample(i, r, a, om, dist, sig, ex);
-        const double incl = wave_scan_mul((double)om, lane);
-        double excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0;
+        const double incl = wave_scan_mul((double)om);
+        const double excl = wave_shift_up1(incl, 1.0);
         const float T = (float)(s_carry[wave][c] * excl);
         const float w = a * T;
         const float cr = sigmoidf_ref(r.x), cg = sigmoidf_ref(r.y), cb = sigmoidf_ref(r.z);
@@ -224,9 +222,9 @@ __global__ __launch_bounds__(CP_THREADS) void composite_bwd_kernel(
             }
         }
         if (d_z) {   // d z_i = e_{i-1} - e_i
-            const float e_last = __shfl(e, 63, 64);
+            const float e_last = wave_last(e);
             if (lane == 0 && c + 1 < nchunk) d_z[base + (c + 1) * WAVE] = z_pend + e_last;
-            float prev = __shfl_up(e, 1, 64);
+            const float prev = wave_shift_up1(e, 0.f);
             if (lane == 0) {
                 z_pend = -e;
                 if (c == 0) d_z[base] = -e;

@@ -27,35 +27,46 @@ namespace snerf {
 constexpr int SP_THREADS = 256;
 constexpr int SP_WAVES = SP_THREADS / WAVE;
 
-__device__ __forceinline__ int count_le(const float *__restrict__ row, int n, float v) {  // #{k: row[k] <= v}
-    int lo = 0, len = n;
-    while (len > 0) {
-        int half = len >> 1;
-        bool go = row[lo + half] <= v;
-        lo = go ? lo + half + 1 : lo;
-        len = go ? len - half - 1 : half;
+// #{k: row[k] <= v} (LE) / #{k: row[k] < v} of an ascending row of n: branch-free bisection over power-of-two steps, the same
+// trip count in every lane.  N > 0: n is the compile-time constant N - a row of 2^k - 1 entries needs no range check at all, a
+// row of 2^k entries one extra comparison with its last entry, and every read gets an immediate offset.
+__device__ __forceinline__ int pow2_floor(int n) { return 1 << (31 - __builtin_clz(n)); }
+template <int N, bool LE>
+__device__ __forceinline__ int count_below(const float *__restrict__ row, int n, float v) {
+    if constexpr (N > 0 && (N & (N + 1)) == 0) {            // N = 2^k - 1
+        int pos = 0;
+#pragma unroll
+        for (int step = (N + 1) >> 1; step > 0; step >>= 1) {
+            const float r = row[pos + step - 1];
+            pos += (LE ? r <= v : r < v) ? step : 0;
+        }
+        return pos;
+    } else if constexpr (N > 1 && (N & (N - 1)) == 0) {     // N = 2^k
+        const float last = row[N - 1];
+        const int head = count_below<N - 1, LE>(row, N - 1, v);
+        return (LE ? last <= v : last < v) ? N : head;
+    } else {
+        int pos = 0;
+        for (int step = pow2_floor(n); step > 0; step >>= 1) {
+            const int p = pos + step;
+            const float r = row[min(p, n) - 1];
+            pos = (p <= n && (LE ? r <= v : r < v)) ? p : pos;
+        }
+        return pos;
     }
-    return lo;
 }
-__device__ __forceinline__ int count_lt(const float *__restrict__ row, int n, float v) {  // #{k: row[k] < v}
-    int lo = 0, len = n;
-    while (len > 0) {
-        int half = len >> 1;
-        bool go = row[lo + half] < v;
-        lo = go ? lo + half + 1 : lo;
-        len = go ? len - half - 1 : half;
-    }
-    return lo;
-}
+__host__ __device__ inline int sp_round4(int n) { return (n + 3) & ~3; }
 
 // DIRECT = the literal sample_pdf(bins, weights) calling convention (utils.py:194): `z` holds the
 // bins [B, Nc-1] and `weights` the interior weights [B, Nc-2]; no merge, no points.
-template <bool DIRECT>
+// NC, NF > 0: the sample counts as compile-time constants (the launcher picks the 64 + 128 instance for the pipeline's shape).
+template <bool DIRECT, int NC, int NF>
 __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
     const float *__restrict__ z, const float *__restrict__ weights, const float *__restrict__ u,
-    const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ tot_in, int64_t B, int Nc, int Nf,
+    const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ tot_in, int64_t B, int Nc_arg, int Nf_arg,
     int64_t *__restrict__ inds_out, float *__restrict__ zs_out, float *__restrict__ zf_out,
     float *__restrict__ pts_out) {
+    const int Nc = NC > 0 ? NC : Nc_arg, Nf = NF > 0 ? NF : Nf_arg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -64,12 +75,13 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
     const int Nb = Nc - 1;           // number of bins == len(cdf)
     const int M = Nc - 2;            // number of interior weights
     const int Nt = Nc + Nf;
-    const int per_wave = Nc + 2 * Nb + Nf + Nt;
+    const int n_in = sp_round4(Nc + 2 * Nb + Nf);      // the arrays below s_out; s_out and every wave's base are 16-byte aligned
+    const int per_wave = n_in + sp_round4(Nt);
     float *s_z = smem + wave * per_wave;  // [Nc]
     float *s_bins = s_z + Nc;             // [Nb]
     float *s_cdf = s_bins + Nb;           // [Nb]
     float *s_zs = s_cdf + Nb;             // [Nf]
-    float *s_out = s_zs + Nf;             // [Nt]
+    float *s_out = s_z + n_in;            // [Nt]
 
     const float *zr = z + ray * (DIRECT ? Nb : Nc);
     const float *wr = DIRECT ? weights + ray * M - 1 : weights + ray * Nc;  // wr[k+1] = k-th interior weight
@@ -104,9 +116,9 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
         const int k = c0 + lane;  // interior weight index 0..M-1  <->  weights[k+1]
         double p = 0.0;
         if (k < M) p = (double)__fdiv_rn(__fadd_rn(wr[k + 1], 1e-5f), tot);
-        const double incl = wave_scan_add(p, lane) + carry;
+        const double incl = wave_scan_add(p) + carry;
         if (k < M) s_cdf[k + 1] = (float)incl;
-        carry = __shfl(incl, 63, 64);
+        carry = wave_last(incl);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
     // ---- invert the cdf for every u ----------------------------------------------------------------
     for (int f = lane; f < Nf; f += WAVE) {
         const float uf = u[f];
-        const int ind = count_le(s_cdf, Nb, uf);                    // searchsorted(cdf, u, 'right')
+        const int ind = count_below<(NC > 0 ? NC - 1 : 0), true>(s_cdf, Nb, uf);                    // searchsorted(cdf, u, 'right')
         const int below = max(0, ind - 1);
         const int above = min(Nb - 1, ind);
         const float c0v = s_cdf[below], c1v = s_cdf[above];
@@ -138,11 +150,11 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
     if (fast) {
         for (int i = lane; i < Nc; i += WAVE) {
             const float v = s_z[i];
-            s_out[i + count_lt(s_zs, Nf, v)] = v;
+            s_out[i + count_below<NF, false>(s_zs, Nf, v)] = v;
         }
         for (int f = lane; f < Nf; f += WAVE) {
             const float v = s_zs[f];
-            s_out[f + count_le(s_z, Nc, v)] = v;
+            s_out[f + count_below<NC, true>(s_z, Nc, v)] = v;
         }
     } else {
         // exact stable rank sort of cat(z, samples); NaNs (never produced by the pipeline) sort last
@@ -161,18 +173,46 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     // ---- stores: z_fine and pts = o + d * z (mul then add, as the reference's eager ops) ------------------
-    if (zf_out)
-        for (int e = lane; e < Nt; e += WAVE) zf_out[ray * Nt + e] = s_out[e];
+    // Rows of a multiple of four samples go out as 16-byte vectors: z_fine straight from s_out, the points through a
+    // 64-sample staging area laid over the arrays that are dead by now (one sample per lane -> 3 floats at stride 3,
+    // conflict-free; then 48 lanes copy 768 contiguous bytes).  Other shapes take the dword path.
+    const bool vec = (Nt & 3) == 0 && n_in >= 3 * WAVE && ((reinterpret_cast<uintptr_t>(zf_out) | reinterpret_cast<uintptr_t>(pts_out)) & 15) == 0;
+    if (zf_out) {
+        if (vec) {
+            for (int q = lane; q < (Nt >> 2); q += WAVE)
+                reinterpret_cast<float4 *>(zf_out + ray * Nt)[q] = reinterpret_cast<const float4 *>(s_out)[q];
+        } else {
+            for (int e = lane; e < Nt; e += WAVE) zf_out[ray * Nt + e] = s_out[e];
+        }
+    }
     if (pts_out) {
         const float ox = o[ray * 3 + 0], oy = o[ray * 3 + 1], oz = o[ray * 3 + 2];
         const float dx = d[ray * 3 + 0], dy = d[ray * 3 + 1], dz = d[ray * 3 + 2];
         float *pr = pts_out + ray * Nt * 3;
-        for (int e = lane; e < 3 * Nt; e += WAVE) {  // coalesced over the flattened [Nt,3] row
-            const int s = e / 3, ch = e - 3 * s;
-            const float zv = s_out[s];
-            const float ov = ch == 0 ? ox : (ch == 1 ? oy : oz);
-            const float dv = ch == 0 ? dx : (ch == 1 ? dy : dz);
-            pr[e] = __fadd_rn(ov, __fmul_rn(dv, zv));
+        if (vec) {
+            float *stage = s_z;
+            for (int c0 = 0; c0 < Nt; c0 += WAVE) {
+                if (c0 + lane < Nt) {
+                    const float zv = s_out[c0 + lane];
+                    stage[3 * lane + 0] = __fadd_rn(ox, __fmul_rn(dx, zv));
+                    stage[3 * lane + 1] = __fadd_rn(oy, __fmul_rn(dy, zv));
+                    stage[3 * lane + 2] = __fadd_rn(oz, __fmul_rn(dz, zv));
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const int nvec = (3 * min(WAVE, Nt - c0)) >> 2;
+                if (lane < nvec) reinterpret_cast<float4 *>(pr + 3 * c0)[lane] = reinterpret_cast<const float4 *>(stage)[lane];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        } else {
+            for (int e = lane; e < 3 * Nt; e += WAVE) {  // coalesced over the flattened [Nt,3] row
+                const int s = e / 3, ch = e - 3 * s;
+                const float zv = s_out[s];
+                const float ov = ch == 0 ? ox : (ch == 1 ? oy : oz);
+                const float dv = ch == 0 ? dx : (ch == 1 ? dy : dz);
+                pr[e] = __fadd_rn(ov, __fmul_rn(dv, zv));
+            }
         }
     }
 }
@@ -223,22 +263,25 @@ static int snerf::launch_sample_pdf(bool direct, const float *z, const float *we
     if (B == 0) return SNERF_OK;
     if (!z || !weights || !u) return fail(SNERF_E_BADARG, "sample_pdf: z/weights/u is null");
     if (pts && (!o || !d)) return fail(SNERF_E_BADARG, "sample_pdf: pts requested but o/d is null");
-    const int per_wave = Nc + 2 * (Nc - 1) + Nf + (Nc + Nf);
-    const size_t lds = (size_t)SP_WAVES * per_wave * sizeof(float);  // <= 4 * 6142 * 4 = 96 KiB
+    const int per_wave = sp_round4(Nc + 2 * (Nc - 1) + Nf) + sp_round4(Nc + Nf);
+    const size_t lds = (size_t)SP_WAVES * per_wave * sizeof(float);  // <= 4 * 6144 * 4 = 96 KiB
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sample_pdf_kernel<false>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sample_pdf_kernel<false, 0, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(sample_pdf_kernel<true>),
+            hipFuncSetAttribute(reinterpret_cast<const void *>(sample_pdf_kernel<true, 0, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
             return fail(SNERF_E_LAUNCH, "sample_pdf: cannot raise dynamic LDS limit");
     }
     const int64_t grid = (B + SP_WAVES - 1) / SP_WAVES;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "sample_pdf: B too large");
     if (direct)
-        hipLaunchKernelGGL(sample_pdf_kernel<true>, dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
+        hipLaunchKernelGGL((sample_pdf_kernel<true, 0, 0>), dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
+                           weights, u, o, d, tot, B, Nc, Nf, inds, z_samples, z_fine, pts);
+    else if (Nc == 64 && Nf == 128)
+        hipLaunchKernelGGL((sample_pdf_kernel<false, 64, 128>), dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
                            weights, u, o, d, tot, B, Nc, Nf, inds, z_samples, z_fine, pts);
     else
-        hipLaunchKernelGGL(sample_pdf_kernel<false>, dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
+        hipLaunchKernelGGL((sample_pdf_kernel<false, 0, 0>), dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
                            weights, u, o, d, tot, B, Nc, Nf, inds, z_samples, z_fine, pts);
     return check_launch("sample_pdf");
 }

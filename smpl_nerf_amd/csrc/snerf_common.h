@@ -57,32 +57,52 @@ constexpr int WAVE = 64;
 // ---- wave-level primitives (64-wide wavefronts) ------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// Wavefront scans and sums on the DPP network (row_shr within rows of 16 lanes, row_bcast:15 / :31 across rows - the GFX9
+// sequence): one VALU move per 32 bits and step instead of a ds_bpermute with its index arithmetic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double identity, double v) {
+    const long long o = __builtin_bit_cast(long long, identity), x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)x, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// inclusive prefix sum / product over the 64 lanes (lanes without a source take the identity)
+template <class T>
+__device__ __forceinline__ T wave_scan_add(T v, int /*lane*/ = 0) {
+    v += dpp_take<0x111, 0xf>(T(0), v);   // row_shr:1
+    v += dpp_take<0x112, 0xf>(T(0), v);   // row_shr:2
+    v += dpp_take<0x114, 0xf>(T(0), v);   // row_shr:4
+    v += dpp_take<0x118, 0xf>(T(0), v);   // row_shr:8
+    v += dpp_take<0x142, 0xa>(T(0), v);   // row_bcast:15 -> rows 1, 3
+    v += dpp_take<0x143, 0xc>(T(0), v);   // row_bcast:31 -> rows 2, 3
     return v;
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+template <class T>
+__device__ __forceinline__ T wave_scan_mul(T v, int /*lane*/ = 0) {
+    v *= dpp_take<0x111, 0xf>(T(1), v);
+    v *= dpp_take<0x112, 0xf>(T(1), v);
+    v *= dpp_take<0x114, 0xf>(T(1), v);
+    v *= dpp_take<0x118, 0xf>(T(1), v);
+    v *= dpp_take<0x142, 0xa>(T(1), v);
+    v *= dpp_take<0x143, 0xc>(T(1), v);
     return v;
 }
-// inclusive prefix product / sum over the 64 lanes in fp64
-__device__ __forceinline__ double wave_scan_mul(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double t = __shfl_up(v, off, 64);
-        if (lane >= off) v *= t;
-    }
-    return v;
+__device__ __forceinline__ float wave_last(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ double wave_last(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ double wave_scan_add(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
+// lane i <- lane i-1 (wave_shr:1); lane 0 takes `first`
+template <class T>
+__device__ __forceinline__ T wave_shift_up1(T v, T first) { return dpp_take<0x138, 0xf>(first, v); }
+// the sum over the 64 lanes, in every lane (a scan whose last lane is broadcast through an SGPR)
+__device__ __forceinline__ float wave_sum(float v) { return wave_last(wave_scan_add(v)); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_last(wave_scan_add(v)); }
 
 }  // namespace snerf
