@@ -46,9 +46,14 @@ struct FwdArgs {
     int64_t n_tiles;   // sample tiles (NWAVES x 16 samples)
 };
 
+#ifndef SNERF_EXP_NOSTORE
+#define SNERF_EXP_NOSTORE 0
+#endif
 // one tile (16 features of this lane's sample) <-> the tile-row-major activation buffer
 __device__ __forceinline__ void store_tile(float *buf, int row, int64_t n, int64_t sample, int g, f4 v) {
+#if SNERF_EXP_NOSTORE != 1   // (diagnostic build: the training forward without its activation stores - DESIGN 6)
     __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(buf + ((int64_t)row * n + sample) * 16 + 4 * g));
+#endif
 }
 template <int N>
 __device__ __forceinline__ void store_tiles(float *buf, int row0, int64_t n, int64_t sample, int g, const f4 (&tiles)[N]) {
@@ -80,7 +85,11 @@ __device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, in
         }
     // the address is formed here, not hoisted to the top of the tile (where it would cost two registers per layer)
     asm volatile("" : "+v"(sample));
+#if SNERF_EXP_NOSTORE != 2   // (diagnostic build: without the sign-mask stores)
     *mask_ptr(buf, mask_row, idx, n, sample, g) = uint2{w[0], w[1]};
+#else
+    asm volatile("" ::"v"(w[0]), "v"(w[1]));
+#endif
 }
 
 // The 3-slot ring (99 KiB) is dynamic LDS: a launch gets 64 KiB unless the limit is raised per kernel once.

@@ -590,6 +590,9 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
 // jobs (42 % matrix-pipe busy); 7168 quarter waves balance.  And the loop is free of per-value vector work (tile / sample
 // masks, 64-bit address arithmetic: 3.2 vector instructions per MFMA before, and fp32 MFMAs do not co-issue with the vector
 // ALU): full k-steps run unmasked from wave-uniform row bases + one running 32-bit lane offset; masks only in the tail.
+#ifndef WGD_EXP
+#define WGD_EXP 0
+#endif
 constexpr int WG_WAVES = 4, WG_THREADS = WG_WAVES * 64;
 
 // buffer resource over this wave's segment of one tile-row: wave-uniform base in SGPRs, so a load is `buffer_load_dword v,
@@ -647,7 +650,13 @@ __device__ __forceinline__ void wgrad_direct_wave(const float *const (&ya)[4], c
                 a0[t] = ra[p][t];
                 b0[t] = rb[p][t];
             }
+#if WGD_EXP != 1
             load_ab(std::integral_constant<int, 256 * p>{}, voff, ra[p], rb[p]);
+#endif
+#if WGD_EXP == 2
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(a0[t]), "v"(b0[t]));
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (FULL || i < n_ti) {
@@ -657,6 +666,7 @@ __device__ __forceinline__ void wgrad_direct_wave(const float *const (&ya)[4], c
                     bsum[i] += a0[i];   // (unconditional: the four adds cost less than a second loop variant)
                 }
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);   // one k-step at a time: hoisting all 32 loads of a group spills
         });
     }

@@ -278,6 +278,95 @@ void runc(const char *name) {
     hipFree(src);
 }
 
+// The fp32 k-block pattern with CG 16-sample column groups per wave and ONE wave per SIMD (4 waves, CG x 64 samples per
+// workgroup): every A tile read from LDS feeds CG MFMAs, and a 33 KiB slab lasts CG x 128 MFMAs per wave.
+// MODE 1: MFMA + A reads; 3: + barrier per slab; 4: + the slab refill by LDS-DMA
+template <int MODE, int CG>
+__global__ __launch_bounds__(256) void k3(float *out, long long *cyc, int iters, const float *src) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = (float)(i & 7) * 1e-3f;
+    __syncthreads();
+    f4 acc[CG][16];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[c][t] = f4{0.f, 0.f, 0.f, 0.f};
+    f4 b[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) b[c] = f4{1.f + c, 0.5f, 0.25f, 0.125f};
+    const f4 *ap = reinterpret_cast<const f4 *>(lds) + lane;
+    f4 a0 = ap[0], a1 = ap[64];
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE >= 3 && (it & 1) == 0 && it) {
+            if (MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int to = 0; to < 16; to += 2) {
+            f4 n0 = ap[((to + 2) & 15) * 64], n1 = ap[((to + 3) & 15) * 64];
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    acc[c][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], b[c][r], acc[c][to], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    acc[c][to + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], b[c][r], acc[c][to + 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
+            if (MODE == 4 && (it & 1) == 0 && (to & 1) == 0) {   // the refill of this period: one piece per wave behind each tile pair
+                const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                const int q = to >> 1;                             // 8 rounds x 4 waves = 32 pieces of 1 KiB (+ the bias piece: wave 0, round 0)
+                const char *g = reinterpret_cast<const char *>(src) + lane * 16 + (size_t)((it >> 1) & 63) * 33792;
+                char *dst = reinterpret_cast<char *>(lds + 8192 + ((it >> 1) % 2) * 8448);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (q * 4 + wave) * 1024),
+                                                 (__attribute__((address_space(3))) void *)(dst + (q * 4 + wave) * 1024), 16, 0, 0);
+            }
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += acc[c][t][0] + acc[c][t][1] + acc[c][t][2] + acc[c][t][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+template <int MODE, int CG>
+void run3(const char *name) {
+    float *out, *src;
+    long long *cyc;
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&cyc, 8 * 256 * 8);
+    hipMalloc(&src, 64 * 33792 + 65536);
+    hipMemset(src, 0, 64 * 33792 + 65536);
+    const int iters = 8000, lds_bytes = 32768 + 2 * 33792;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k3<MODE, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((k3<MODE, CG>), dim3(256), dim3(256), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k3<MODE, CG>), dim3(256), dim3(256), lds_bytes, 0, out, cyc, iters, src);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tflops = 256.0 * 4 * iters * 64.0 * CG * 2048.0 / (ms * 1e-3) / 1e12;
+    printf("fp32 16x16x4, %d column groups per wave, 1 wave/SIMD, %-44s wall %.3f ms = %.1f TFLOP/s (%.3f of 157.3)\n", CG, name, ms, tflops,
+           tflops / 157.3);
+    hipFree(out);
+    hipFree(cyc);
+    hipFree(src);
+}
+
 template <int MODE>
 void run(const char *name, int threads) {
     float *out;
@@ -324,6 +413,15 @@ int main() {
     run<3>("+ barrier every 128 MFMAs per wave", 512);
     run<4>("+ barrier + 33 KiB LDS-DMA refill per period", 512);
     run<5>("+ barrier + register-staged refill per period", 512);
+    run3<1, 1>("MFMA + A reads");
+    run3<3, 1>("+ barrier per slab");
+    run3<4, 1>("+ barrier + 33 KiB LDS-DMA refill per slab");
+    run3<1, 2>("MFMA + A reads");
+    run3<3, 2>("+ barrier per slab");
+    run3<4, 2>("+ barrier + 33 KiB LDS-DMA refill per slab");
+    run3<1, 3>("MFMA + A reads");
+    run3<3, 3>("+ barrier per slab");
+    run3<4, 3>("+ barrier + 33 KiB LDS-DMA refill per slab");
     runb<0, 3, 6>("MFMA + one ds_read_b128 per product");
     runb<1, 3, 6>("+ barrier per slab");
     runb<2, 3, 6>("+ 48 KiB LDS-DMA refill per slab (halves alternate)");
