@@ -611,6 +611,9 @@ __device__ __forceinline__ float row_load(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + IMM, 0, 0));
 }
 
+// (Measured r03: a third instantiation with the rgb head's 1 x 4 tiles as compile-time counts - its loop then has no
+// predicates and no scratch traffic - made the launch SLOWER, 0.565 -> 0.587 ms: the kernel is bound by its operand stream,
+// and the two rgb blocks per chunk are not its tail.)
 template <int WG_PREFETCH, bool FULL>   // FULL: all 4 x 4 tiles of the block are real
 __device__ __forceinline__ void wgrad_direct_wave(const float *const (&ya)[4], const float *const (&xb)[4], int n_ti, int n_tj,
                                                   int64_t wb, int64_t we, int lane, f4 (&acc)[4][4], float (&bsum)[4]) {
