@@ -569,3 +569,41 @@ def test_block_wise_backward_of_encoded_rows(dev):
     for k, p in zip([k for k, _ in net.named_parameters()], res[1 << 20][2]):
         ref = g7[f"m_skip4/{k}"]
         close(R.digest(p), ref, 5e-4, 5e-5 * max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel())))
+
+
+# ------------------------------------------------------------------------------------------ sampler store paths (r03)
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (64, 64), (33, 31), (16, 16), (8, 4), (100, 92)])
+def test_sample_pdf_store_paths_agree(dev, Nc, Nf):
+    """sample_pdf_kernel writes rows of a multiple of four samples as 16-byte vectors (the points through an LDS staging
+    area) and everything else dword by dword; the 64 + 128 shape runs a compile-time-sized instance.  Every path must give
+    the same bits: outputs at 16-byte-aligned addresses against outputs one float off alignment (which forces the dword
+    path), for shapes on both sides of each condition, and both against the numpy oracle's z_fine / points."""
+    from smpl_nerf_amd import _lib
+    from smpl_nerf_amd.ops import ptr, current_stream, check, uniform_u
+    rng = np.random.default_rng(100 * Nc + Nf)
+    B = 257
+    z = np.sort(rng.uniform(1, 4, (B, Nc)).astype(F32), axis=-1)
+    w = (rng.uniform(0, 1, (B, Nc)) ** 4).astype(F32)
+    o, d = rng.normal(size=(B, 3)).astype(F32), rng.normal(size=(B, 3)).astype(F32)
+    tz, tw, to, td = T(z, dev), T(w, dev), T(o, dev), T(d, dev)
+    u = uniform_u(Nf, dev)
+    Nt = Nc + Nf
+    lib = _lib.load()
+    outs = []
+    for off in (0, 1):
+        zf_buf = torch.full((B * Nt + 4,), float("nan"), device=dev)
+        pts_buf = torch.full((B * Nt * 3 + 4,), float("nan"), device=dev)
+        zf, pts = zf_buf[off:off + B * Nt], pts_buf[off:off + B * Nt * 3]
+        assert zf.data_ptr() % 16 == 4 * off and pts.data_ptr() % 16 == 4 * off
+        with torch.cuda.device(dev):
+            check(lib.snerf_sample_pdf_f32(ptr(tz), ptr(tw), ptr(u), ptr(to), ptr(td), B, Nc, Nf, None, None, ptr(zf), ptr(pts),
+                                           current_stream()), "snerf_sample_pdf_f32")
+        torch.cuda.synchronize()
+        assert torch.isnan(zf_buf[:off]).all() and torch.isnan(zf_buf[off + B * Nt:]).all()        # nothing outside the rows
+        assert torch.isnan(pts_buf[:off]).all() and torch.isnan(pts_buf[off + B * Nt * 3:]).all()
+        outs.append((zf.cpu().numpy().reshape(B, Nt), pts.cpu().numpy().reshape(B, Nt, 3)))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    z_ref, pts_ref = O.fine_sampling(o, d, z, w, Nf, u=u.cpu().numpy())
+    np.testing.assert_array_equal(outs[0][0], z_ref)
+    np.testing.assert_array_equal(outs[0][1], pts_ref)
