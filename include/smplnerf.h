@@ -31,6 +31,8 @@
  *     a release build can ignore them.  (unset = default)
  *       SNERF_FWD_PERSISTENT=0            fp32 render kernel: one workgroup per 128-sample tile instead of one per CU
  *       SNERF_FWD_WAVES=4                 fp32 kernels: two 4-wave workgroups per CU instead of one 8-wave workgroup
+ *       SNERF_FWD_SMALL_TILES=0           fp32 forward: 128-sample tiles also for calls of <= 64 x CUs samples (default: 64-sample
+ *                                         tiles there - half the latency of a small call)
  *       SNERF_BF16_PERSISTENT=0           split-precision forward / dgrad: one workgroup per tile
  *       SNERF_WARP_RESIDENT=0             warp net: slab-streaming kernel instead of the LDS-resident one
  *       SNERF_WARP_BWD_RING=1             warp backward: slab-ring dgrad instead of the ring-free one

@@ -58,6 +58,7 @@ const Tuning &tuning() {
         k.fwd_persistent = flag("SNERF_FWD_PERSISTENT", true);
         const char *w = getenv("SNERF_FWD_WAVES");
         k.fwd_waves = (w && atoi(w) == 4) ? 4 : 8;
+        k.fwd_small_tiles = flag("SNERF_FWD_SMALL_TILES", true);
         k.bf16_persistent = flag("SNERF_BF16_PERSISTENT", true);
         k.warp_resident = flag("SNERF_WARP_RESIDENT", true);
         k.warp_bwd_ring = flag("SNERF_WARP_BWD_RING", false);

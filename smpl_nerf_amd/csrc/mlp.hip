@@ -305,6 +305,12 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // peak on the 128x128 frame); SNERF_FWD_WAVES=4 selects two independent 4-wave workgroups per CU instead
     // (83.1 %; twice the L2->LDS weight traffic).  Tuning knob, read once.
     if (tuning().fwd_waves == 4) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
+    // Small calls (the README's 64-ray batches: 4096 + 12 288 samples): while 64-sample tiles still fit one round of the chip,
+    // the 4-wave form finishes in half the time of a 128-sample tile's pass through the weight stream - a call of up to
+    // 64 x CUs samples is one tile's latency, not throughput (same per-sample arithmetic: bit-identical results).
+    const int n_cu = device_cu_count("mlp_fwd");
+    if (n_cu < 1) return n_cu;
+    if (tuning().fwd_small_tiles && A.n <= (int64_t)64 * n_cu) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
     return launch_fwd_nw<FWD_WAVES, ENCODED, TRAIN>(P, A, s);
 }
 

@@ -39,6 +39,7 @@ int raise_dynamic_lds(const void *kernel, int bytes, LdsRaised &state, const cha
 struct Tuning {
     bool fwd_persistent;            // SNERF_FWD_PERSISTENT            (default 1)
     int fwd_waves;                  // SNERF_FWD_WAVES                 (8; 4 = two 4-wave workgroups per CU)
+    bool fwd_small_tiles;           // SNERF_FWD_SMALL_TILES=0         fp32 forward: no 64-sample tiles for calls of <= 64 x CUs samples
     bool bf16_persistent;           // SNERF_BF16_PERSISTENT           (1)
     bool warp_resident;             // SNERF_WARP_RESIDENT             (1)
     bool warp_bwd_ring;             // SNERF_WARP_BWD_RING             (0)

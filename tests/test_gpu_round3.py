@@ -607,3 +607,36 @@ def test_sample_pdf_store_paths_agree(dev, Nc, Nf):
     z_ref, pts_ref = O.fine_sampling(o, d, z, w, Nf, u=u.cpu().numpy())
     np.testing.assert_array_equal(outs[0][0], z_ref)
     np.testing.assert_array_equal(outs[0][1], pts_ref)
+
+
+# ------------------------------------------------------------------------------------------ small calls (r03)
+@pytest.mark.parametrize("rays", [1, 64, 200])
+def test_small_calls_use_64_sample_tiles_and_equal_the_large_call(dev, rays):
+    """Calls of <= 64 x CUs samples run the 4-wave (64-sample-tile) form of the fp32 forward (csrc/mlp.hip: launch_fwd) -
+    half the latency at the README's 64-ray batches.  Same per-sample arithmetic: the rows of a small call equal the same
+    rows evaluated inside a frame-sized call bit for bit, in inference and in the training forward (whose gradients then
+    match to summation order)."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(rays)
+    pc, _ = syn.make_scene_nets(101)
+    Ns, big = 64, 1024
+    pts = rng.uniform(-2, 2, (big, Ns, 3)).astype(F32)
+    dirs = rng.normal(size=(big, 3)).astype(F32)
+    pe, de = PositionalEncoder(10, 0), PositionalEncoder(4, 0)
+    net = _net(dev, pc)
+    with torch.no_grad():
+        full = net.forward_fused(T(pts, dev), T(dirs, dev), Ns, pe, de)                    # 65 536 samples: 128-sample tiles
+        small = net.forward_fused(T(pts[:rays], dev), T(dirs[:rays], dev), Ns, pe, de)     # <= 12 800 samples: 64-sample tiles
+    assert torch.equal(small.reshape(-1, 4), full.reshape(-1, 4)[:rays * Ns])
+    gout = T(rng.normal(size=(rays * Ns, 4)).astype(F32), dev)
+    grads = []
+    for n_rays in (rays, big):
+        net.zero_grad(set_to_none=True)
+        raw = net.forward_fused(T(pts[:n_rays], dev), T(dirs[:n_rays], dev), Ns, pe, de).reshape(-1, 4)
+        (raw[:rays * Ns] * gout).sum().backward()
+        grads.append([p.grad.clone() for p in net.parameters()])
+        if n_rays == rays:
+            assert torch.equal(raw.detach(), full.reshape(-1, 4)[:rays * Ns])
+    for a, b in zip(*grads):
+        scale = max(b.abs().max().item(), 1e-20)
+        assert (a - b).abs().max().item() <= 2e-5 * scale
