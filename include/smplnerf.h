@@ -169,7 +169,9 @@ int snerf_sample_pdf_bins_f32(const float *bins, const float *weights, const flo
  * encoding (train.py:154-159). */
 typedef struct snerf_mlp_desc {
     int32_t n_layers;     /* 8 */
-    int32_t width;        /* 256 (or 128) */
+    int32_t width;        /* 2 .. 256 (--netwidth, config_parser.py:20).  The kernels are built for trunks of 256 and 128
+                             features; any other width runs zero-padded inside the next larger one (same results, the
+                             cost of that kernel).  The split-precision entry points take 256 only. */
     int32_t pos_freqs;    /* 10 */
     int32_t pos_identity; /* 0 */
     int32_t dir_freqs;    /* 4 */
@@ -295,7 +297,7 @@ int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float *packed, c
  * Mirrors WarpFieldNet.__init__ (models/warp_field_net.py:8-15): linear1 [width, positions_dim+pose_dim],
  * linear2 [3, width]; positions_dim is expressed through the position encoder. */
 typedef struct snerf_warp_desc {
-    int32_t width;        /* 256 */
+    int32_t width;        /* 1 .. 256 (--netwidth_warp); other widths than 256 / 128 run zero-padded; split precision: 256 */
     int32_t pos_freqs;    /* 10 */
     int32_t pos_identity; /* 0 */
     int32_t pose_dim;     /* 40 = encoded pose of the two joints (models/smpl_nerf_pipeline.py:28-30) */

@@ -108,12 +108,17 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
     why = "";
     P.kw = kw;
     if (d.n_layers < 2 || d.n_layers > 16) { why = "n_layers must be in [2,16]"; return -1; }
-    if (d.width != 256 && d.width != 128) { why = "width must be 256 or 128"; return -1; }
+    if (d.width < 2 || d.width > 256) { why = "width must be in [2, 256]"; return -1; }
     if (d.pos_freqs < 0 || d.pos_freqs > 16 || d.dir_freqs < 0 || d.dir_freqs > 16) { why = "bad encoder frequencies"; return -1; }
     if (d.add_dim < 0 || d.add_dim > 4096) { why = "bad add_dim"; return -1; }
+    // W / WD: the layer widths of the parameters (RenderRayNet: width and width // 2).  The kernels exist for trunks of 128 and
+    // 256 features: any other width runs embedded in the next larger one - the extra output rows and input slots of every
+    // layer are zero padding like the rows 3 .. 15 of the rgb head (their activations are relu(0) = 0, nothing reads them,
+    // no gradient is scattered from them), so the results are those of the unpadded network.
     const int W = d.width, WD = W / 2;
+    const int WK = W <= 128 ? 128 : 256, WDK = WK / 2;
     const int pid = d.pos_identity ? 1 : 0, did = d.dir_identity ? 1 : 0;
-    P.width = W;
+    P.width = WK;
     P.n_hidden = d.n_layers - 1;
     P.pos_dim = 3 * (pid + 2 * d.pos_freqs);
     P.dir_dim = 3 * (did + 2 * d.dir_freqs);
@@ -126,15 +131,16 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
     const int pin = P.pos_dim + P.add_dim;
     int nl = 0, slab = 0;
     int64_t off = 0;
-    auto add_layer = [&](int n_out, bool hidden, int hidden_cols, int extra /*0 none, 1 pos(+add), 2 dir*/) {
+    // n_out / hidden_cols: sizes in the parameters; n_out_k / hidden_k: the (padded) sizes the kernel walks
+    auto add_layer = [&](int n_out, int n_out_k, bool hidden, int hidden_cols, int hidden_k, int extra /*0 none, 1 pos(+add), 2 dir*/) {
         Layer &Ly = P.layer[nl++];
         Ly.n_out = n_out;
-        Ly.t_out = (n_out + 15) / 16;
+        Ly.t_out = (n_out_k + 15) / 16;
         Ly.nseg = 0;
         int col = 0;
         if (hidden) {
             Seg &s = Ly.seg[Ly.nseg++];
-            s = Seg{SEG_HIDDEN, col, hidden_cols, hidden_cols / kw, 0, 0};
+            s = Seg{SEG_HIDDEN, col, hidden_cols, hidden_k / kw, 0, 0};
             col += hidden_cols;
         }
         if (extra == 1) {
@@ -168,14 +174,14 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
         Ly.b_off = off;
         off += Ly.n_out;
     };
-    add_layer(W, false, 0, 1);                                   // positions_pose_input   (:19)
+    add_layer(W, WK, false, 0, 0, 1);                            // positions_pose_input   (:19)
     for (int i = 0; i < d.n_layers - 1; ++i)                     // positional_net[i]      (:21-25)
-        add_layer(W, true, W, ((d.skip_mask >> i) & 1u) ? 1 : 0);
-    add_layer(W, true, W, 0);                                    // additional_linear_layer (:27)
-    add_layer(1, true, W, 0);                                    // sigma_out_layer        (:28)
-    add_layer(WD, true, W, d.use_dir ? 2 : 0);                   // directional_input      (:31-34)
-    add_layer(WD, true, WD, 0);                                  // directional_net[0]     (:38-39)
-    add_layer(3, true, WD, 0);                                   // rgb_out_layer          (:40)
+        add_layer(W, WK, true, W, WK, ((d.skip_mask >> i) & 1u) ? 1 : 0);
+    add_layer(W, WK, true, W, WK, 0);                            // additional_linear_layer (:27)
+    add_layer(1, 1, true, W, WK, 0);                             // sigma_out_layer        (:28)
+    add_layer(WD, WDK, true, W, WK, d.use_dir ? 2 : 0);          // directional_input      (:31-34)
+    add_layer(WD, WDK, true, WD, WDK, 0);                        // directional_net[0]     (:38-39)
+    add_layer(3, 3, true, WD, WDK, 0);                           // rgb_out_layer          (:40)
     (void)pin;
     P.nlayers = nl;
     P.total_slabs = slab;
@@ -366,11 +372,12 @@ inline int wgrad_chunks(int64_t n) {
 // kw = 16: fp32 stream (warp.hip); kw = 32: split-bf16 stream (warp_bf16.hip, width 256 only)
 inline int make_warp_plan(const snerf_warp_desc &d, Plan &P, const char *&why, int kw = 16) {
     why = "";
-    if (d.width != 256 && d.width != 128) { why = "width must be 256 or 128"; return -1; }
+    if (d.width < 1 || d.width > 256) { why = "width must be in [1, 256]"; return -1; }
     if (d.pos_freqs < 0 || d.pos_freqs > 16) { why = "bad encoder frequencies"; return -1; }
     if (d.pose_dim < 0 || d.pose_dim > 4096) { why = "bad pose_dim"; return -1; }
     const int pid = d.pos_identity ? 1 : 0;
-    P.width = d.width;
+    const int WK = d.width <= 128 ? 128 : 256;   // other widths run zero-padded inside the next kernel width (make_plan)
+    P.width = WK;
     P.kw = kw;
     P.n_hidden = 0;
     P.pos_dim = 3 * (pid + 2 * d.pos_freqs);
@@ -382,7 +389,7 @@ inline int make_warp_plan(const snerf_warp_desc &d, Plan &P, const char *&why, i
     P.add_nkb = (d.pose_dim + kw - 1) / kw;
     Layer &L0 = P.layer[0];
     L0.n_out = d.width;
-    L0.t_out = d.width / 16;
+    L0.t_out = WK / 16;
     L0.nseg = 0;
     int col = 0;
     L0.seg[L0.nseg++] = Seg{SEG_PE, col, P.pos_dim, P.pos_nkb, d.pos_freqs, pid};
@@ -405,9 +412,9 @@ inline int make_warp_plan(const snerf_warp_desc &d, Plan &P, const char *&why, i
     L1.n_out = 3;
     L1.t_out = 1;
     L1.nseg = 1;
-    L1.seg[0] = Seg{SEG_HIDDEN, 0, d.width, d.width / kw, 0, 0};
+    L1.seg[0] = Seg{SEG_HIDDEN, 0, d.width, WK / kw, 0, 0};
     L1.n_in = d.width;
-    L1.nkb = d.width / kw;
+    L1.nkb = WK / kw;
     L1.first_slab = L0.nslab;
     L1.nslab = (L1.nkb + slab_tiles(kw) - 1) / slab_tiles(kw);
     L1.w_off = L0.b_off + L0.n_out;

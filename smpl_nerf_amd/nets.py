@@ -671,9 +671,9 @@ class _WarpFn(torch.autograd.Function):
         ctx.act = None
         d_pose = None
         if ctx.pose_grad:      # d h [n, width] (tile-rows 0 .. T-1 of dy) contracted with linear1's pose columns, summed per ray
-            T = desc.width // 16
+            T = (desc.width + 15) // 16      # (a width that is not a kernel width runs zero-padded: the first tiles hold it)
             with torch.no_grad():
-                dh = dy[:T * n * 16].view(T, n, 16).permute(1, 0, 2).reshape(n, T * 16)
+                dh = dy[:T * n * 16].view(T, n, 16).permute(1, 0, 2).reshape(n, T * 16)[:, :desc.width]
                 pos_dim = 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
                 d_pose = (dh @ net.linear1.weight[:, pos_dim:]).view(-1, ctx.spr, desc.pose_dim).sum(1)
         return (None, None, None, d_pose, None, None) + tuple(_grads_from_flat(flat, ctx.shapes))

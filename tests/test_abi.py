@@ -54,7 +54,11 @@ def test_mlp_descriptor_arithmetic(lib):
     assert lib.snerf_mlp_param_floats(d0) == 595076       # skips=[]
     # 77 slabs of 33 KiB (32 A tiles + bias) + 3 pad slabs (mlp_plan.h)
     assert lib.snerf_mlp_packed_floats(d) == (77 + 3) * 8448
-    bad = _lib.MlpDesc(8, 200, 10, 0, 4, 0, 0, 0, 1)
+    # any width up to 256 (other widths than 128 / 256 run zero-padded): the parameter count is RenderRayNet's own
+    w200 = _lib.MlpDesc(8, 200, 10, 0, 4, 0, 0, 0, 1)
+    assert lib.snerf_mlp_param_floats(w200) == (200 * 61 + 7 * 200 * 201 + 200 * 201 + 201 + 100 * 225 + 100 * 101 + 3 * 101)
+    assert lib.snerf_mlp_packed_floats(w200) == lib.snerf_mlp_packed_floats(d0)       # the stream of the 256-wide kernel
+    bad = _lib.MlpDesc(8, 320, 10, 0, 4, 0, 0, 0, 1)
     assert lib.snerf_mlp_param_floats(bad) < 0
     assert lib.snerf_mlp_pack_f32(d, None, None, None) == -1
 

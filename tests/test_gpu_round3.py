@@ -640,3 +640,66 @@ def test_small_calls_use_64_sample_tiles_and_equal_the_large_call(dev, rays):
     for a, b in zip(*grads):
         scale = max(b.abs().max().item(), 1e-20)
         assert (a - b).abs().max().item() <= 2e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------ any --netwidth (r03)
+@pytest.mark.parametrize("n_layers,width,skips", [(8, 64, (4,)), (4, 100, (1,)), (8, 200, (4,)), (3, 250, ()), (5, 30, (2,)),
+                                                  (2, 7, ())])
+def test_render_ray_net_of_any_width_up_to_256(dev, n_layers, width, skips):
+    """config_parser.py:20 `--netwidth` is free; the kernels exist for trunks of 128 and 256 features, other widths run
+    zero-padded inside the next larger one (csrc/mlp_plan.h: make_plan).  Output of the fused forward (positions +
+    directions), of forward(encoded rows), and every parameter gradient against the torch fp32 restatement of
+    models/render_ray_net.py:42-61 (pinned against the reference in test_grad_golden.py)."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(width)
+    kw = dict(n_layers=n_layers, width=width, skips=skips)
+    params = syn.make_render_ray_net_params(7 + width, 30.0, 10.0, **kw)
+    net = RenderRayNet(n_layers, width, 60, 24, skips=list(skips))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.to(dev)
+    n = 777
+    pts, dirs = rng.uniform(-2, 2, (n, 1, 3)).astype(F32), rng.normal(size=(n, 3)).astype(F32)
+    gout = rng.normal(size=(n, 4)).astype(F32)
+    dn = dirs / np.linalg.norm(dirs, axis=-1, keepdims=True)
+    x_enc = torch.cat([R.posenc(torch.from_numpy(pts[:, 0]), 10, 0), R.posenc(torch.from_numpy(dn.astype(F32)), 4, 0)], -1)
+    P = R.tparams(params)
+    ref = R.render_ray_net(P, x_enc, n_layers=n_layers, skips=skips)
+    (ref * torch.from_numpy(gout)).sum().backward()
+    tol = 2e-5 * max(1.0, ref.detach().abs().max().item())
+    with torch.no_grad():
+        raw = net.forward_fused(T(pts, dev), T(dirs, dev), 1, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        close(raw.cpu().numpy(), ref.detach().numpy(), 0, 5 * tol)       # (the kernel encodes and normalises itself)
+        close(net(x_enc.to(dev)).cpu().numpy(), ref.detach().numpy(), 0, tol)
+    raw = net(x_enc.to(dev))
+    (raw * T(gout, dev)).sum().backward()
+    for k, p in net.named_parameters():
+        g = P[k].grad.numpy()
+        assert p.grad is not None and p.grad.shape == p.shape
+        close(p.grad.cpu().numpy(), g, 5e-4, 5e-5 * np.abs(g).max())
+
+
+@pytest.mark.parametrize("width", [64, 100, 200])
+def test_warp_field_net_of_any_width_up_to_256(dev, width):
+    """`--netwidth_warp` likewise (config_parser.py:30): WarpFieldNet.forward(rows) and its gradients against torch."""
+    rng = np.random.default_rng(width)
+    params = syn.make_warp_field_params(5 + width, width=width)
+    from smpl_nerf_amd.nets import WarpFieldNet
+    net = WarpFieldNet(8, width, 60, 40)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.to(dev).train()
+    x = rng.uniform(-1, 1, (300, 100)).astype(F32)
+    gout = rng.normal(size=(300, 3)).astype(F32)
+    P = R.tparams(params)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(xt, P["linear1.weight"], P["linear1.bias"])),
+                                     P["linear2.weight"], P["linear2.bias"])
+    (ref * torch.from_numpy(gout)).sum().backward()
+    xg = T(x, dev).requires_grad_(True)
+    out = net(xg)
+    close(out.detach().cpu().numpy(), ref.detach().numpy(), 1e-5, 1e-6)
+    (out * T(gout, dev)).sum().backward()
+    close(xg.grad.cpu().numpy(), xt.grad.numpy(), 1e-4, 1e-5)
+    for k, p in net.named_parameters():
+        g = P[k].grad.numpy()
+        close(p.grad.cpu().numpy(), g, 2e-4, 2e-5 * np.abs(g).max())
