@@ -107,7 +107,7 @@ __host__ __device__ inline int pe_slot_col32(int L, int ident, int kb, int g, in
 inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw = 16) {
     why = "";
     P.kw = kw;
-    if (d.n_layers < 2 || d.n_layers > 16) { why = "n_layers must be in [2,16]"; return -1; }
+    if (d.n_layers < 1 || d.n_layers > 16) { why = "n_layers must be in [1,16]"; return -1; }
     if (d.width < 2 || d.width > 256) { why = "width must be in [2, 256]"; return -1; }
     if (d.pos_freqs < 0 || d.pos_freqs > 16 || d.dir_freqs < 0 || d.dir_freqs > 16) { why = "bad encoder frequencies"; return -1; }
     if (d.add_dim < 0 || d.add_dim > 4096) { why = "bad add_dim"; return -1; }
