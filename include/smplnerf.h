@@ -169,7 +169,7 @@ int snerf_sample_pdf_bins_f32(const float *bins, const float *weights, const flo
  * encoding (train.py:154-159). */
 typedef struct snerf_mlp_desc {
     int32_t n_layers;     /* 8 */
-    int32_t width;        /* 2 .. 256 (--netwidth, config_parser.py:20).  The kernels are built for trunks of 256 and 128
+    int32_t width;        /* 2 .. 256 (--netwidth, config_parser.py:20).  The kernels are built for trunks of 256, 128 and 64
                              features; any other width runs zero-padded inside the next larger one (same results, the
                              cost of that kernel).  The split-precision entry points take 256 only. */
     int32_t pos_freqs;    /* 10 */

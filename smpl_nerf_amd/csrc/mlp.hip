@@ -294,8 +294,10 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
     const int64_t grid = (!TRAIN && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
     if (P.width == 256)
         SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
-    else
+    else if (P.width == 128)
         SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+    else
+        SNERF_LAUNCH_RING((mlp_fwd_kernel<64, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     return check_launch("mlp_fwd");
 }
 

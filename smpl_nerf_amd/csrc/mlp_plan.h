@@ -111,12 +111,12 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
     if (d.width < 2 || d.width > 256) { why = "width must be in [2, 256]"; return -1; }
     if (d.pos_freqs < 0 || d.pos_freqs > 16 || d.dir_freqs < 0 || d.dir_freqs > 16) { why = "bad encoder frequencies"; return -1; }
     if (d.add_dim < 0 || d.add_dim > 4096) { why = "bad add_dim"; return -1; }
-    // W / WD: the layer widths of the parameters (RenderRayNet: width and width // 2).  The kernels exist for trunks of 128 and
+    // W / WD: the layer widths of the parameters (RenderRayNet: width and width // 2).  The kernels exist for trunks of 64, 128 and
     // 256 features: any other width runs embedded in the next larger one - the extra output rows and input slots of every
     // layer are zero padding like the rows 3 .. 15 of the rgb head (their activations are relu(0) = 0, nothing reads them,
     // no gradient is scattered from them), so the results are those of the unpadded network.
     const int W = d.width, WD = W / 2;
-    const int WK = W <= 128 ? 128 : 256, WDK = WK / 2;
+    const int WK = W <= 64 ? 64 : W <= 128 ? 128 : 256, WDK = WK / 2;
     const int pid = d.pos_identity ? 1 : 0, did = d.dir_identity ? 1 : 0;
     P.width = WK;
     P.n_hidden = d.n_layers - 1;

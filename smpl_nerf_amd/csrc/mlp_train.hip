@@ -950,10 +950,14 @@ static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const f
         if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
         else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
         else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-    } else {
+    } else if (P.width == 128) {
         if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
         else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
         else SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+    } else {
+        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        else SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
     }
     int rc = check_launch("mlp_bwd(dgrad)");
     if (rc) return rc;
