@@ -105,8 +105,8 @@ static void check_plan(const snerf_mlp_desc &d, int kw) {
 }
 
 int main() {
-    for (int n_layers : {2, 3, 8, 16})
-        for (int width = 128; width <= 256; width += 128)
+    for (int n_layers : {1, 2, 3, 8, 16})
+        for (int width : {2, 7, 30, 64, 100, 128, 200, 250, 256})   // other widths than 64 / 128 / 256 run zero-padded (make_plan)
             for (int pL : {0, 4, 10, 16})
                 for (int pid = 0; pid < 2; ++pid)
                     for (int dL : {0, 4, 16})
@@ -120,7 +120,7 @@ int main() {
                                                              use_dir, add_first};
                                             check_plan(d, kw);
                                         }
-    for (int width = 128; width <= 256; width += 128)
+    for (int width : {1, 64, 100, 128, 200, 256})
         for (int pL = 0; pL <= 16; ++pL)
             for (int pid = 0; pid < 2; ++pid)
                 for (int pose : {0, 2, 40, 69, 100})
