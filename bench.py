@@ -57,6 +57,7 @@ COARSE_ONLY = ("nerf {r}x{r} frame per GPU, coarse-only 64 samples/ray, run_fine
                "render (BASELINE configs[0], the reference's CPU-runnable case)")
 WARP_FLOP_PER_EVAL = 2 * (256 * 100 + 3 * 256)      # WarpFieldNet 100 -> 256 -> 3: 52 736 FLOP (SURVEY.md 8d / BASELINE.md 3)
 WARP_FLOP_PADDED = 2 * (256 * 112 + 16 * 256)       # as executed: 7 k-blocks of 16 input slots, the 3-wide head in a 16-wide tile
+WARP_FLOP_FOLDED = 2 * (256 * 64 + 16 * 256)        # fp32 inference: the 3 pose k-blocks are one 256-vector per ray (csrc/warp.hip)
 WORKLOADS = {
     "nerf": "nerf {r}x{r} frame per GPU, coarse+fine 64+128 samples/ray, run_fine=1, netdepth 8, width 256, skips [4], "
             "forward render (BASELINE configs[1])",
@@ -649,12 +650,16 @@ def main():
             wupl = a.steps * evals_per_step / wcalls
             wtf = WARP_FLOP_PER_EVAL * wupl / (wms / wcalls * 1e-3) / 1e12
             wpeak = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
+            # what the matrix pipe executes per sample: the fp32 inference kernel folds the per-ray pose columns (unless
+            # SNERF_WARP_FOLD=0), the split-precision kernel runs all 7 k-blocks
+            folded = a.precision == "fp32" and os.environ.get("SNERF_WARP_FOLD", "1") != "0"
+            wexec = WARP_FLOP_FOLDED if folded else WARP_FLOP_PADDED
             line["warp_roofline"] = {
                 "bound": "mfma", "kernel": "snerf::warp_fwd_resident_kernel<256, 16, false>" if a.precision == "fp32"
                 else "snerf::warp_fwd_bf16_kernel<256, 8>", "achieved": wtf, "peak": wpeak, "unit": "TFLOP/s",
                 "frac": wtf / wpeak, "avg_launch_ms": wms / wcalls, "launches": wcalls, "flop_per_unit": WARP_FLOP_PER_EVAL,
-                "units_per_launch": wupl, "frac_on_padded_flops_as_executed": wtf / wpeak * WARP_FLOP_PADDED / WARP_FLOP_PER_EVAL,
-                "padded_flop_per_unit": WARP_FLOP_PADDED}
+                "units_per_launch": wupl, "frac_on_padded_flops_as_executed": wtf / wpeak * wexec / WARP_FLOP_PER_EVAL,
+                "padded_flop_per_unit": wexec, "pose_columns_folded_per_ray": bool(folded)}
         if points:
             line["operating_points_render"] = points
         if train is not None:

@@ -114,6 +114,37 @@ __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_kernel(WarpArgs A) {
 // layers and tiles.  Used whenever the net fits (warp_resident_bytes <= 160 KiB - what the hardware has).
 __host__ __device__ inline int warp_resident_bytes(int T, int nkb0) { return (T * nkb0 + T + 2) * 1024; }
 
+// The pose encoding is a per-RAY constant (SmplNerfPipeline expands goal_pose over the samples, models/smpl_nerf_pipeline.py:
+// 40-45): its columns of linear1 contribute the same 256-vector to all 64 / 192 samples of a ray.  For inference that
+// vector is evaluated once per ray - ray_bias[ray][o] = linear1.bias[o] + sum_c linear1[o, pos_dim + c] * pose_enc[ray][c],
+// read from the packed stream (A tile (kb, to), lane m + 16 g, value r  <->  W[16 to + m][16 kb + 4 g + r]) - and the
+// resident kernel starts its accumulators from it instead of running the pose k-blocks per sample (3 of the 7 k-blocks
+// of the default net: 37 % of the kernel's MFMAs).  One thread per (ray, output feature).
+__global__ __launch_bounds__(256) void warp_ray_bias_kernel(const float *__restrict__ packed, const float *__restrict__ add,
+                                                            int64_t n_rays, int add_dim, int pos_nkb, int add_nkb, int T,
+                                                            float *__restrict__ out) {
+    const int width = T * 16;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_rays * width) return;
+    const int64_t ray = e / width;
+    const int o = (int)(e - ray * width), to = o >> 4, m = o & 15;
+    const float *a = add + ray * add_dim;
+    float sum = packed[SLAB_A_FLOATS + o];   // linear1.bias (aux block of the first slab)
+    for (int kb = 0; kb < add_nkb; ++kb) {
+        const int t = (pos_nkb + kb) * T + to;
+        const float *tile = packed + (int64_t)(t / SLAB_TILES) * SLAB_FLOATS + (t % SLAB_TILES) * 256;
+        for (int g = 0; g < 4; ++g) {
+            const f4 w = *reinterpret_cast<const f4 *>(tile + (m + 16 * g) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * kb + 4 * g + r;
+                if (c < add_dim) sum += w[r] * a[c];
+            }
+        }
+    }
+    out[e] = sum;
+}
+
 template <int WIDTH, int NWAVES, bool TRAIN>
 __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_resident_kernel(WarpArgs A) {
     constexpr int NT = NWAVES * 64;
@@ -158,18 +189,24 @@ __global__ __launch_bounds__(NWAVES * 64) void warp_fwd_resident_kernel(WarpArgs
         }
         c.add = A.add_dim ? A.add + ray * A.add_dim : nullptr;
         f4 in[T], acc[T];
-        {
+        const bool folded = !TRAIN && A.ray_bias;   // the pose columns arrive as this ray's accumulator start
+        if (folded) {
+            const f4 *rb = reinterpret_cast<const f4 *>(A.ray_bias + ray * WIDTH) + (lane >> 4);
+#pragma unroll
+            for (int to = 0; to < T; ++to) acc[to] = rb[to * 4];
+        } else {
             const f4 *aux = reinterpret_cast<const f4 *>(b1) + (lane >> 4);
 #pragma unroll
             for (int to = 0; to < T; ++to) acc[to] = aux[to * 4];
         }
-        for (int kb = 0; kb < nkb0; ++kb) {
+        const int nkb_run = folded ? A.pos_nkb : nkb0;
+        for (int kb = 0; kb < nkb_run; ++kb) {
             f4 b;
             if (kb < A.pos_nkb) b = pe_operand<false>(c, false, A.pos_L, A.pos_id, kb, 0);
             else b = add_operand(c, A.add_dim, kb - A.pos_nkb);
             if (TRAIN && valid) store_tile(A.act, kb, A.n, sample, c.g, b);
             const float *cur = w1 + kb * (T * 256);
-            kblock<T>(cur, kb + 1 < nkb0 ? cur + T * 256 : w2, b, acc, pa0, pa1, lane);
+            kblock<T>(cur, kb + 1 < nkb_run ? cur + T * 256 : w2, b, acc, pa0, pa1, lane);
         }
         relu_into(in, acc);
         if (TRAIN && valid) store_tiles(A.act, nkb0, A.n, sample, c.g, in);
@@ -444,6 +481,20 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
             const int n_cu = device_cu_count("warp_fwd");
             if (n_cu < 1) return n_cu;
             const int64_t g = A.n_tiles < n_cu ? A.n_tiles : n_cu;
+            // inference with pose columns and at least one position k-block: the per-ray fold (warp_ray_bias_kernel); the
+            // table lives in a stream-ordered allocation for the duration of the two launches
+            float *ray_bias = nullptr;
+            if (!act && P.add_dim > 0 && P.pos_nkb > 0 && tuning().warp_fold && n % samples_per_ray == 0) {
+                const int64_t n_rays = n / samples_per_ray, floats = n_rays * P.width;
+                if (hipMallocAsync(reinterpret_cast<void **>(&ray_bias), (size_t)floats * sizeof(float), s) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ray_bias = nullptr;   // no memory for the table: the unfolded kernel needs none
+                } else {
+                    hipLaunchKernelGGL(warp_ray_bias_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, s, packed, pose_enc,
+                                       n_rays, P.add_dim, P.pos_nkb, P.add_nkb, T, ray_bias);
+                    A.ray_bias = ray_bias;
+                }
+            }
 #define SNERF_WARP_RES(W_, RW_, TR_)                                                                                      \
     do {                                                                                                                  \
         static LdsRaised raised; /* per device */                                                                         \
@@ -460,6 +511,7 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
                 else SNERF_WARP_RES(128, 16, false);
             }
 #undef SNERF_WARP_RES
+            if (ray_bias) (void)hipFreeAsync(ray_bias, s);
             return check_launch("warp_fwd(resident)");
         }
     }

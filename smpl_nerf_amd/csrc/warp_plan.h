@@ -17,6 +17,7 @@ struct WarpArgs {
     float *act;  // training: tile-row-major [pe | pose | h] (see warp_train_layout)
     int l1_slab;        // first slab of linear2 in the stream (resident kernel)
     int64_t n_tiles;    // sample tiles (resident kernel: persistent workgroups)
+    const float *ray_bias;   // resident inference kernel: [n/spr][WIDTH] = linear1.bias + linear1[:, pose columns] . pose_enc, or null
 };
 
 }  // namespace snerf

@@ -706,3 +706,33 @@ def test_warp_field_net_of_any_width_up_to_256(dev, width):
     for k, p in net.named_parameters():
         g = P[k].grad.numpy()
         close(p.grad.cpu().numpy(), g, 2e-4, 2e-5 * np.abs(g).max())
+
+
+# ------------------------------------------------------------------------------------------ warp net: per-ray pose fold (r03)
+@pytest.mark.parametrize("tag,pdim,qdim,pos_enc", [("enc", 60, 40, (10, 0)), ("raw", 3, 2, (0, 1))])
+def test_warp_inference_folds_the_pose_columns_per_ray(dev, tag, pdim, qdim, pos_enc):
+    """The pose encoding is a per-ray constant (models/smpl_nerf_pipeline.py:40-45), so the inference kernel adds its
+    columns of linear1 once per ray (csrc/warp.hip: warp_ray_bias_kernel) instead of per sample; the training forward does
+    not fold.  Both must give the reference's warp: compare inference (folded), training forward (unfolded) and the torch
+    evaluation of models/warp_field_net.py:17-21 on rays of 64 and of 7 samples (a wave's 16 samples then span 3 rays)."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(pdim)
+    params = syn.make_warp_field_params(31 + pdim, positions_dim=pdim, pose_dim=qdim, out_scale=0.3)
+    net = _warp(dev, params, pdim, qdim)
+    P = R.tparams(params, requires_grad=False)
+    pe = PositionalEncoder(*pos_enc)
+    for B, Ns in ((37, 64), (301, 7)):
+        x = rng.uniform(-1.5, 1.5, (B, Ns, 3)).astype(F32)
+        pose = rng.uniform(-1, 1, (B, qdim)).astype(F32)          # what the pipeline passes: the encoded (or raw) pose per ray
+        o = rng.normal(size=(B, 3)).astype(F32)
+        rows = torch.cat([R.posenc(torch.from_numpy(x), pos_enc[0], pos_enc[1]),
+                          torch.from_numpy(pose)[:, None, :].expand(B, Ns, qdim)], -1)
+        ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(rows, P["linear1.weight"], P["linear1.bias"])),
+                                         P["linear2.weight"], P["linear2.bias"]).numpy()
+        with torch.no_grad():
+            inf = net.forward_fused(T(x, dev), T(pose, dev), T(o, dev), Ns, pe)
+        trn = net.forward_fused(T(x, dev), T(pose, dev).requires_grad_(True), T(o, dev), Ns, pe)
+        for out in (inf, trn):
+            close(out[0].detach().cpu().numpy().reshape(B, Ns, 3), ref, 1e-5, 2e-6)
+        close(inf[0].cpu().numpy(), trn[0].detach().cpu().numpy(), 1e-5, 1e-6)
+        close(inf[1].cpu().numpy(), trn[1].detach().cpu().numpy(), 1e-6, 1e-6)       # warped points
