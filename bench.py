@@ -454,6 +454,12 @@ def main():
     # algorithmic FLOPs of one RenderRayNet evaluation of THIS workload (2 x weight elements the output depends on: the
     # additional-input columns of the pose-conditioned nets count, AppendVerticesNet's dead vertices_net branch does not)
     FLOP_PER_EVAL = 2 * sum(p.numel() for k, p in nets[0].named_parameters() if k.endswith("weight") and not k.startswith("vertices_net"))
+    # ... of which the fp32 inference kernel does not execute the additional-input columns per sample: they are per-ray
+    # constants, folded into one vector per ray and layer (csrc/mlp.hip: mlp_add_fold_kernel; SNERF_MLP_FOLD=0 turns it off)
+    d0 = nets[0].desc_for_rows() if hasattr(nets[0], "desc_for_rows") else None
+    add_cols = int(getattr(nets[0], "additional_input_dim", 0)) if d0 is None else int(d0.add_dim)
+    n_add_layers = 1 + sum(1 for i in range(nets[0].n_layers - 1) if i in nets[0].skips)
+    FOLDED_FLOP_PER_EVAL = 2 * add_cols * nets[0].width * n_add_layers if os.environ.get("SNERF_MLP_FOLD", "1") != "0" else 0
     # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
     frame_id = shard_frames(world, rank)
     data_np = frame_inputs(a.workload, a.res, frame_id)
@@ -528,6 +534,9 @@ def main():
              "unit": "TFLOP/s", "frac": alg / peak, "traffic": None, "avg_launch_ms": avg_ms, "launches": calls,
              "flop_per_unit": FLOP_PER_EVAL, "units_per_launch": units_per_launch}
         if prec == "fp32":
+            if FOLDED_FLOP_PER_EVAL:    # algorithmic FLOPs the kernel does not pay per sample (per-ray inputs folded)
+                r["flop_per_unit_executed_per_sample"] = FLOP_PER_EVAL - FOLDED_FLOP_PER_EVAL
+                r["frac_on_executed_flops"] = alg / peak * (FLOP_PER_EVAL - FOLDED_FLOP_PER_EVAL) / FLOP_PER_EVAL
             r["peak_note"] = "fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32: 157.3 TFLOP/s"
         else:
             r["peak_note"] = ("dense 16-bit MFMA peak 2500 TFLOP/s; `achieved` counts the network's own fp32 MACs "

@@ -36,6 +36,8 @@
  *       SNERF_BF16_PERSISTENT=0           split-precision forward / dgrad: one workgroup per tile
  *       SNERF_WARP_RESIDENT=0             warp net: slab-streaming kernel instead of the LDS-resident one
  *       SNERF_WARP_BWD_RING=1             warp backward: slab-ring dgrad instead of the ring-free one
+ *       SNERF_MLP_FOLD=0                  fp32 inference of nets with additional inputs: their columns as k-blocks per sample (default:
+ *                                         one vector per ray and layer - the additional inputs are per-ray constants)
  *       SNERF_WARP_FOLD=0                 warp inference: the pose columns of linear1 as k-blocks per sample (default: folded into
  *                                         one 256-vector per ray - the pose encoding is a per-ray constant)
  *       SNERF_WGRAD_BF16=0                split-precision steps: all weight-gradient GEMMs in fp32

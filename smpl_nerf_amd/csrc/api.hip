@@ -63,6 +63,7 @@ const Tuning &tuning() {
         k.warp_resident = flag("SNERF_WARP_RESIDENT", true);
         k.warp_bwd_ring = flag("SNERF_WARP_BWD_RING", false);
         k.warp_fold = flag("SNERF_WARP_FOLD", true);
+        k.mlp_fold = flag("SNERF_MLP_FOLD", true);
         k.wgrad_bf16 = flag("SNERF_WGRAD_BF16", true);
         k.wgrad_f16 = flag("SNERF_WGRAD_F16", true);
         k.wgrad_narrow_f16 = flag("SNERF_WGRAD_NARROW_F16", true);

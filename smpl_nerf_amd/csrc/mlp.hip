@@ -69,7 +69,11 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(Plan P, const float *__re
 }
 
 // TRAIN additionally stores every layer input (post-activation) for the backward kernels.
-template <int WIDTH, int NWAVES, bool ENCODED, bool TRAIN>
+// FOLD (inference, per-ray additional inputs): the additional columns of layer 0 and of the skip layers are per-RAY
+// constants (the pipelines expand one row per ray over its samples: models/append_smpl_params_pipeline.py,
+// append_to_nerf_pipeline.py, append_vertices_pipeline.py), so W_add . add is evaluated once per ray by
+// mlp_add_fold_kernel and added to the accumulators here; their k-blocks of the stream are skipped, not multiplied.
+template <int WIDTH, int NWAVES, bool ENCODED, bool TRAIN, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;   // tiles of the trunk
@@ -144,7 +148,19 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
             run.step(b, acc);
         }
     };
+    int fold_slot = 0;
     auto add_segment = [&](LayerRun<T, NT> &run, bool first) {
+        if (FOLD) {
+            for (int kb = 0; kb < A.add_nkb; ++kb) run.skip();
+            const f4 *row = reinterpret_cast<const f4 *>(A.fold + ((sc / A.spr) * A.fold_slots + fold_slot) * WIDTH) + c.g;
+#pragma unroll
+            for (int to = 0; to < T; ++to) {
+                const f4 v = row[to * 4];
+                acc[to][0] += v[0], acc[to][1] += v[1], acc[to][2] += v[2], acc[to][3] += v[3];
+            }
+            ++fold_slot;
+            return;
+        }
         for (int kb = 0; kb < A.add_nkb; ++kb) {
             f4 b;
             if (ENCODED) {
@@ -280,7 +296,44 @@ int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStrea
 
 constexpr int FWD_WAVES = 8;  // 128 samples per workgroup, one workgroup per CU (2 waves per SIMD)
 
-template <int NW, bool ENCODED, bool TRAIN>
+// FOLD pre-pass: out[(ray * slots + slot) * W + o] = sum_c W_l[o, additional column c] * add[ray][c], l = layer 0 and the
+// skip layers in order, read from the packed stream (A tile (kb, to) of a layer: lane m + 16 g, value r  <->
+// W[16 to + m][column of slot (kb, g, r)]).  One thread per (ray, slot, output feature); W = 16 * t_out of the trunk.
+__global__ __launch_bounds__(256) void mlp_add_fold_kernel(Plan P, const float *__restrict__ packed, const float *__restrict__ add,
+                                                           int64_t n_rays, int slots, float *__restrict__ out) {
+    const int W = P.layer[0].t_out * 16;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_rays * slots * W) return;
+    const int o = (int)(e % W), slot = (int)((e / W) % slots);
+    const int64_t ray = e / ((int64_t)W * slots);
+    int l = 0;   // the slot-th layer with an additional-input segment
+    for (int seen = 0; l < P.nlayers; ++l) {
+        bool has = false;
+        for (int sg = 0; sg < P.layer[l].nseg; ++sg) has = has || P.layer[l].seg[sg].type == SEG_ADD;
+        if (has && seen++ == slot) break;
+    }
+    const Layer &Ly = P.layer[l];
+    int kb0 = 0, sg = 0;
+    while (Ly.seg[sg].type != SEG_ADD) kb0 += Ly.seg[sg++].nkb;
+    const int to = o >> 4, m = o & 15, T = Ly.t_out;
+    const float *a = add + ray * P.add_dim;
+    float sum = 0.f;
+    for (int kb = 0; kb < Ly.seg[sg].nkb; ++kb) {
+        const int t = (kb0 + kb) * T + to;
+        const float *tile = packed + (int64_t)(Ly.first_slab + t / SLAB_TILES) * SLAB_FLOATS + (t % SLAB_TILES) * 256;
+        for (int g = 0; g < 4; ++g) {
+            const f4 w = *reinterpret_cast<const f4 *>(tile + (m + 16 * g) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * kb + 4 * g + r;
+                if (c < P.add_dim) sum += w[r] * a[c];
+            }
+        }
+    }
+    out[e] = sum;
+}
+
+template <int NW, bool ENCODED, bool TRAIN, bool FOLD = false>
 static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
     const int64_t tile = NW * 16;
     FwdArgs B = A;
@@ -293,12 +346,36 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
     const bool persistent = tuning().fwd_persistent;
     const int64_t grid = (!TRAIN && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
     if (P.width == 256)
-        SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN, FOLD>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     else if (P.width == 128)
-        SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN, FOLD>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     else
-        SNERF_LAUNCH_RING((mlp_fwd_kernel<64, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        SNERF_LAUNCH_RING((mlp_fwd_kernel<64, NW, ENCODED, TRAIN, FOLD>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     return check_launch("mlp_fwd");
+}
+
+// inference with per-ray additional inputs: pre-pass + FOLD kernel; the table lives in a stream-ordered allocation for the
+// duration of the two launches.  Returns 1 when the fold does not apply (the caller then runs the per-sample form).
+template <int NW>
+static int launch_fwd_folded(const Plan &P, const FwdArgs &A, hipStream_t s) {
+    if (!P.add_dim || !tuning().mlp_fold || A.n % A.spr != 0) return 1;
+    int slots = 0;
+    for (int l = 0; l < P.nlayers; ++l)
+        for (int sg = 0; sg < P.layer[l].nseg; ++sg) slots += P.layer[l].seg[sg].type == SEG_ADD ? 1 : 0;
+    const int64_t n_rays = A.n / A.spr, floats = n_rays * slots * P.width;
+    if (!slots || (floats + 255) / 256 > 0x7fffffffLL) return 1;
+    float *table = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&table), (size_t)floats * sizeof(float), s) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;   // no memory for the table: the per-sample form needs none
+    }
+    hipLaunchKernelGGL(mlp_add_fold_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, s, P, A.packed, A.add, n_rays, slots, table);
+    FwdArgs B = A;
+    B.fold = table;
+    B.fold_slots = slots;
+    const int rc = launch_fwd_nw<NW, false, false, true>(P, B, s);
+    (void)hipFreeAsync(table, s);
+    return rc;
 }
 
 template <bool ENCODED, bool TRAIN>
@@ -306,6 +383,10 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // 8 waves (128 samples) per workgroup = one workgroup per CU, 2 waves per SIMD (85.7 % of the fp32 MFMA
     // peak on the 128x128 frame); SNERF_FWD_WAVES=4 selects two independent 4-wave workgroups per CU instead
     // (83.1 %; twice the L2->LDS weight traffic).  Tuning knob, read once.
+    if (!ENCODED && !TRAIN && tuning().fwd_waves != 4) {   // per-ray additional inputs: the folded form (8-wave tiles)
+        const int rc = launch_fwd_folded<FWD_WAVES>(P, A, s);
+        if (rc != 1) return rc;
+    }
     if (tuning().fwd_waves == 4) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
     // Small calls (the README's 64-ray batches: 4096 + 12 288 samples): while 64-sample tiles still fit one round of the chip,
     // the 4-wave form finishes in half the time of a 128-sample tile's pass through the weight stream - a call of up to

@@ -38,6 +38,10 @@ struct FwdArgs {
     // training only: activation buffer in tile-row-major layout (mlp_plan.h TrainLayout)
     float *act;
     int act_pe, act_add, act_dpe, act_x1, act_o, act_h1, act_h2, act_mask;
+    // inference with per-ray additional inputs (FOLD instantiation): fold[(ray * fold_slots + slot) * WIDTH + o] =
+    // sum_c W_l[o, add columns] * add[ray][c] for layer 0 (slot 0) and the skip layers in order (mlp.hip: mlp_add_fold_kernel)
+    const float *fold;
+    int fold_slots;
     int act_rows;      // f16x3 training forward: the per-layer |X| exponents go behind this many tile-rows of `act`
     // split-bf16 training forward only: encoder / additional k-block counts of the 16-wide (fp32) plan, which
     // defines the activation layout the backward kernels read
@@ -289,6 +293,19 @@ struct LayerRun {
         const float *cur = slab + kbl * (T_OUT * 256);
         const float *nxt = (kbl + 1 < KPS) ? cur + T_OUT * 256 : pipe.peek_next();
         kblock<T_OUT>(cur, nxt, b, acc, pipe.pa0, pipe.pa1, lane);
+        if (++kbl == KPS) {
+            pipe.release();
+            slab = pipe.acquire();
+            kbl = 0;
+        }
+    }
+    // a k-block of the stream that is not multiplied (FOLD: the additional-input columns arrive as a per-ray vector):
+    // advance like step() and re-prime the A-operand prefetch from the block behind it
+    __device__ __forceinline__ void skip() {
+        const float *cur = slab + kbl * (T_OUT * 256);
+        const f4 *np = reinterpret_cast<const f4 *>((kbl + 1 < KPS) ? cur + T_OUT * 256 : pipe.peek_next()) + lane;
+        pipe.pa0 = np[0];
+        pipe.pa1 = np[64];
         if (++kbl == KPS) {
             pipe.release();
             slab = pipe.acquire();

@@ -44,6 +44,7 @@ struct Tuning {
     bool warp_resident;             // SNERF_WARP_RESIDENT             (1)
     bool warp_bwd_ring;             // SNERF_WARP_BWD_RING             (0)
     bool warp_fold;                 // SNERF_WARP_FOLD=0               warp inference: pose k-blocks per sample instead of the per-ray fold
+    bool mlp_fold;                  // SNERF_MLP_FOLD=0                fp32 inference: per-ray additional inputs as k-blocks per sample
     bool wgrad_bf16;                // SNERF_WGRAD_BF16                (1)
     bool wgrad_f16;                 // SNERF_WGRAD_F16                 (1)
     bool wgrad_narrow_f16;          // SNERF_WGRAD_NARROW_F16          (1)

@@ -736,3 +736,42 @@ def test_warp_inference_folds_the_pose_columns_per_ray(dev, tag, pdim, qdim, pos
             close(out[0].detach().cpu().numpy().reshape(B, Ns, 3), ref, 1e-5, 2e-6)
         close(inf[0].cpu().numpy(), trn[0].detach().cpu().numpy(), 1e-5, 1e-6)
         close(inf[1].cpu().numpy(), trn[1].detach().cpu().numpy(), 1e-6, 1e-6)       # warped points
+
+
+# ------------------------------------------------------------------------------------------ per-ray additional inputs folded (r03)
+@pytest.mark.parametrize("add_dim,add_first,skips,width", [(69, True, (4,), 256), (2, False, (4,), 256), (69, True, (), 256),
+                                                           (20, True, (1, 5), 128), (69, False, (3,), 200)])
+def test_inference_folds_per_ray_additional_inputs(dev, add_dim, add_first, skips, width):
+    """The additional inputs of append_smpl_params / append_to_nerf (and the vertex floats of AppendVerticesNet) are
+    per-ray constants: the fp32 inference kernel takes W_add . add once per ray and layer (csrc/mlp.hip:
+    mlp_add_fold_kernel) and skips those k-blocks; the training forward multiplies them per sample.  Folded inference,
+    unfolded training forward and the torch evaluation of models/render_ray_net.py:42-61 must agree - on rays of 64 samples
+    and of 7 (a wave's 16 samples then span 3 rays), ragged against the 128-sample tile."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(add_dim + width)
+    kw = dict(n_layers=8, width=width, skips=skips, additional_input_dim=add_dim)
+    params = syn.make_render_ray_net_params(41 + add_dim, 30.0, 10.0, **kw)
+    net = RenderRayNet(8, width, 60, 24, add_dim, skips=list(skips))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.to(dev)
+    P = R.tparams(params, requires_grad=False)
+    pe, de = PositionalEncoder(10, 0), PositionalEncoder(4, 0)
+    for B, Ns in ((41, 64), (333, 7)):
+        x = rng.uniform(-2, 2, (B, Ns, 3)).astype(F32)
+        d = rng.normal(size=(B, 3)).astype(F32)
+        add = rng.uniform(-1, 1, (B, add_dim)).astype(F32)
+        dn = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(F32)
+        pex = R.posenc(torch.from_numpy(x), 10, 0)
+        addx = torch.from_numpy(add)[:, None, :].expand(B, Ns, add_dim)
+        ded = R.posenc(torch.from_numpy(dn), 4, 0)[:, None, :].expand(B, Ns, 24)
+        rows = torch.cat([addx, pex, ded] if add_first else [pex, addx, ded], -1).reshape(B * Ns, -1)
+        ref = R.render_ray_net(P, rows, n_layers=8, additional_input_dim=add_dim, skips=skips).numpy()
+        with torch.no_grad():
+            inf = net.forward_fused(T(x, dev), T(d, dev), Ns, pe, de, additional=T(add, dev), add_first=add_first)
+        trn = net.forward_fused(T(x, dev), T(d, dev), Ns, pe, de, additional=T(add, dev), add_first=add_first)
+        assert trn.requires_grad and not inf.requires_grad
+        tol = 5e-5 * max(1.0, np.abs(ref).max())
+        close(inf.cpu().numpy().reshape(-1, 4), ref, 0, tol)
+        close(trn.detach().cpu().numpy().reshape(-1, 4), ref, 0, tol)
+        close(inf.cpu().numpy(), trn.detach().cpu().numpy(), 0, 0.2 * tol)
