@@ -200,7 +200,12 @@ int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *params_flat, flo
 /* Fused positional encoding + MLP.  x [n, 3] sample positions; directions dirs: [n/samples_per_ray, 3]
  * when dirs_per_sample == 0 (one per ray, samples of a ray contiguous) or [n, 3]; directions are
  * normalised inside (models/nerf_pipeline.py:33-34).  add: nullable [n/samples_per_ray, add_dim].
- * raw [n, 4] = [rgb | sigma] (models/render_ray_net.py:61). */
+ * raw [n, 4] = [rgb | sigma] (models/render_ray_net.py:61).
+ * dirs_per_sample is a bit set: bit 0 = directions per sample; bit 1 (SNERF_FWD_NO_RAY_FOLD) = multiply the additional-input
+ * columns per sample, in the order of snerf_mlp_fwd_train_f32 (whose `raw` this call then reproduces bit for bit), instead
+ * of folding them into one vector per ray and layer (the default: same values up to the summation order of those columns). */
+#define SNERF_FWD_DIRS_PER_SAMPLE 1
+#define SNERF_FWD_NO_RAY_FOLD 2
 int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                       const float *dirs, int dirs_per_sample, const float *add,
                       int64_t n, int samples_per_ray, float *raw, snerf_stream_t stream);

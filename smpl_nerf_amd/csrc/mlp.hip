@@ -358,7 +358,7 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
 // duration of the two launches.  Returns 1 when the fold does not apply (the caller then runs the per-sample form).
 template <int NW>
 static int launch_fwd_folded(const Plan &P, const FwdArgs &A, hipStream_t s) {
-    if (!P.add_dim || !tuning().mlp_fold || A.n % A.spr != 0) return 1;
+    if (!P.add_dim || A.no_fold || !tuning().mlp_fold || A.n % A.spr != 0) return 1;
     int slots = 0;
     for (int l = 0; l < P.nlayers; ++l)
         for (int sg = 0; sg < P.layer[l].nseg; ++sg) slots += P.layer[l].seg[sg].type == SEG_ADD ? 1 : 0;
@@ -448,7 +448,8 @@ extern "C" int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed
     A.raw = raw;
     A.n = n;
     A.spr = samples_per_ray;
-    A.dirs_per_sample = dirs_per_sample ? 1 : 0;
+    A.dirs_per_sample = (dirs_per_sample & SNERF_FWD_DIRS_PER_SAMPLE) ? 1 : 0;
+    A.no_fold = (dirs_per_sample & SNERF_FWD_NO_RAY_FOLD) ? 1 : 0;
     return launch_fwd<false, false>(P, A, (hipStream_t)stream);
 }
 

@@ -42,6 +42,7 @@ struct FwdArgs {
     // sum_c W_l[o, add columns] * add[ray][c] for layer 0 (slot 0) and the skip layers in order (mlp.hip: mlp_add_fold_kernel)
     const float *fold;
     int fold_slots;
+    int no_fold;         // (host only) the caller asked for the per-sample form: SNERF_FWD_NO_RAY_FOLD
     int act_rows;      // f16x3 training forward: the per-layer |X| exponents go behind this many tile-rows of `act`
     // split-bf16 training forward only: encoder / additional k-block counts of the 16-wide (fp32) plan, which
     // defines the activation layout the backward kernels read

@@ -128,9 +128,11 @@ def _train_sizes(desc, n):
     return sizes[0].value, sizes[1].value, sizes[3].value
 
 
-def _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, act=None):
+def _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, act=None, like_training=False):
     """One launch of the fused encode + MLP kernel on n = raw.shape[0] samples: inference (act None) or the training
-    forward that also saves the layer inputs into `act`."""
+    forward that also saves the layer inputs into `act`.  like_training: an inference launch whose `raw` must equal the
+    training forward's bit for bit (the block-wise backward recomputes with the training kernel): no per-ray fold of the
+    additional inputs (include/smplnerf.h: SNERF_FWD_NO_RAY_FOLD)."""
     lib = _lib.load()
     n = raw.shape[0]
     train = act is not None
@@ -159,8 +161,8 @@ def _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, act=None):
                 check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
                                                   ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
             else:
-                check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr), ptr(raw),
-                                            current_stream()), "snerf_mlp_fwd_f32")
+                check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample | (2 if like_training else 0), ptr(add), n,
+                                            int(spr), ptr(raw), current_stream()), "snerf_mlp_fwd_f32")
 
 
 def _launch_backward(net, desc, ns, act, d_raw, n, sizes, flat, input_grad, x=None, d=None, per_sample=0, spr=1,
@@ -226,7 +228,7 @@ class _FusedMlpFn(torch.autograd.Function):
             per_sample_bytes = 4.0 * (act_floats + dy_floats) / n
             ctx.block = max(group, int(budget / per_sample_bytes) // group * group)
         if ctx.block and ctx.block < n:
-            _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw)          # inference kernel: nothing saved
+            _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, like_training=True)   # inference kernel: nothing saved
             ctx.act = None
             ctx.inputs = (x, d, add)
         else:
