@@ -59,8 +59,10 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 102 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
-                             snerf_composite_bwd_all_f32, snerf_mlp_bwd_chunk_*; composite forward accepts any N */
+#define SNERF_VERSION 103 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+                             snerf_composite_bwd_all_f32, snerf_mlp_bwd_chunk_*; composite forward accepts any N
+                             0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
+                             folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form) */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
