@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(Plan P, const float *__re
 // constants (the pipelines expand one row per ray over its samples: models/append_smpl_params_pipeline.py,
 // append_to_nerf_pipeline.py, append_vertices_pipeline.py), so W_add . add is evaluated once per ray by
 // mlp_add_fold_kernel and added to the accumulators here; their k-blocks of the stream are skipped, not multiplied.
-template <int WIDTH, int NWAVES, bool ENCODED, bool TRAIN, bool FOLD = false>
-__global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
+template <int WIDTH, int NWAVES, bool ENCODED, bool TRAIN, bool FOLD>
+__device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;   // tiles of the trunk
     constexpr int TD = WIDTH / 32;  // tiles of the directional branch
@@ -267,6 +267,17 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
     } while (PERSIST && (tile += gridDim.x) < A.n_tiles);
 }
 
+// the kernels: the body above with and without the per-ray fold (two kernel names: the profiles of the rounds key on the
+// first one's)
+template <int WIDTH, int NWAVES, bool ENCODED, bool TRAIN>
+__global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_kernel(FwdArgs A) {
+    mlp_fwd_body<WIDTH, NWAVES, ENCODED, TRAIN, false>(A);
+}
+template <int WIDTH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void mlp_fwd_fold_kernel(FwdArgs A) {
+    mlp_fwd_body<WIDTH, NWAVES, false, false, true>(A);
+}
+
 static int fill_args(const snerf_mlp_desc *desc, Plan &P, FwdArgs &A) {
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "mlp: desc is null");
@@ -345,12 +356,15 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // SNERF_FWD_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
     const bool persistent = tuning().fwd_persistent;
     const int64_t grid = (!TRAIN && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
-    if (P.width == 256)
-        SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN, FOLD>), dim3((unsigned)grid), dim3(NW * 64), s, B);
-    else if (P.width == 128)
-        SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN, FOLD>), dim3((unsigned)grid), dim3(NW * 64), s, B);
-    else
-        SNERF_LAUNCH_RING((mlp_fwd_kernel<64, NW, ENCODED, TRAIN, FOLD>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+    if constexpr (FOLD) {
+        if (P.width == 256) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        else SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<64, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+    } else {
+        if (P.width == 256) SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        else SNERF_LAUNCH_RING((mlp_fwd_kernel<64, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+    }
     return check_launch("mlp_fwd");
 }
 
