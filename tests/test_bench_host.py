@@ -131,7 +131,7 @@ def test_committed_r03_bench_lines_are_self_consistent():
     assert {p["rays_per_step_per_gpu"] for p in t["operating_points"]} == {64, 800, 2048}
     s = json.loads(open(P("r03_bench_smpl_nerf.json.log")).read().strip().splitlines()[-1])
     w = s["warp_roofline"]
-    assert w["flop_per_unit"] == 52736 and abs(w["frac"] - w["achieved"] / 157.3) <= 1e-12 and 0.6 <= w["frac"] <= 0.7
+    assert w["flop_per_unit"] == 52736 and abs(w["frac"] - w["achieved"] / 157.3) <= 1e-12 and 0.8 <= w["frac"] <= 0.95 and w["pose_columns_folded_per_ray"]   # 0.65 before the per-ray pose fold
     assert "train" in s and s["train"]["cpu_baseline"]["value"] > 0 and s["cpu_baseline"]["value"] > 0
     c = json.loads(open(P("r03_bench_coarse_only.json.log")).read().strip().splitlines()[-1])
     assert c["config"]["ray_samples_per_ray"] == 64 and c["cpu_baseline"]["value"] > 0 and "configs[0]" in c["config"]["workload"]
