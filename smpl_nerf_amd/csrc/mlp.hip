@@ -372,7 +372,8 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
 // duration of the two launches.  Returns 1 when the fold does not apply (the caller then runs the per-sample form).
 template <int NW>
 static int launch_fwd_folded(const Plan &P, const FwdArgs &A, hipStream_t s) {
-    if (!P.add_dim || A.no_fold || !tuning().mlp_fold || A.n % A.spr != 0) return 1;
+    // (a fold pays when a ray's vector is reused: with fewer than 8 samples per ray the table costs more than it saves)
+    if (!P.add_dim || A.no_fold || !tuning().mlp_fold || A.spr < 8 || A.n % A.spr != 0) return 1;
     int slots = 0;
     for (int l = 0; l < P.nlayers; ++l)
         for (int sg = 0; sg < P.layer[l].nseg; ++sg) slots += P.layer[l].seg[sg].type == SEG_ADD ? 1 : 0;

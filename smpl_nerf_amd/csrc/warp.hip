@@ -484,7 +484,7 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
             // inference with pose columns and at least one position k-block: the per-ray fold (warp_ray_bias_kernel); the
             // table lives in a stream-ordered allocation for the duration of the two launches
             float *ray_bias = nullptr;
-            if (!act && P.add_dim > 0 && P.pos_nkb > 0 && tuning().warp_fold && n % samples_per_ray == 0) {
+            if (!act && P.add_dim > 0 && P.pos_nkb > 0 && tuning().warp_fold && samples_per_ray >= 8 && n % samples_per_ray == 0) {
                 const int64_t n_rays = n / samples_per_ray, floats = n_rays * P.width;
                 if (hipMallocAsync(reinterpret_cast<void **>(&ray_bias), (size_t)floats * sizeof(float), s) != hipSuccess) {
                     (void)hipGetLastError();

@@ -721,7 +721,7 @@ def test_warp_inference_folds_the_pose_columns_per_ray(dev, tag, pdim, qdim, pos
     net = _warp(dev, params, pdim, qdim)
     P = R.tparams(params, requires_grad=False)
     pe = PositionalEncoder(*pos_enc)
-    for B, Ns in ((37, 64), (301, 7)):
+    for B, Ns in ((37, 64), (301, 9), (50, 7)):      # 9: a wave's 16 samples span 3 rays; 7: below the fold's threshold of 8
         x = rng.uniform(-1.5, 1.5, (B, Ns, 3)).astype(F32)
         pose = rng.uniform(-1, 1, (B, qdim)).astype(F32)          # what the pipeline passes: the encoded (or raw) pose per ray
         o = rng.normal(size=(B, 3)).astype(F32)
@@ -757,7 +757,7 @@ def test_inference_folds_per_ray_additional_inputs(dev, add_dim, add_first, skip
     net = net.to(dev)
     P = R.tparams(params, requires_grad=False)
     pe, de = PositionalEncoder(10, 0), PositionalEncoder(4, 0)
-    for B, Ns in ((41, 64), (333, 7)):
+    for B, Ns in ((41, 64), (333, 9), (50, 7)):      # 9: a wave's 16 samples span 3 rays; 7: below the fold's threshold of 8
         x = rng.uniform(-2, 2, (B, Ns, 3)).astype(F32)
         d = rng.normal(size=(B, 3)).astype(F32)
         add = rng.uniform(-1, 1, (B, add_dim)).astype(F32)
