@@ -196,6 +196,8 @@ def cpu_baseline(workload, params, data_np, n_rays, run_fine=1):
     default_threads = torch.get_num_threads()
     P = [T.tparams(p) for p in params]
     pe, de = T.PositionalEncoder(10, False), T.PositionalEncoder(4, False)
+    if workload == "append_vertices":
+        run_fine = 0          # the reference's AppendVerticesPipeline raises in its fine branch (:71): its coarse pass is the CPU figure
     targs = T.Args(run_fine=run_fine)
     per_ray = 256 if run_fine else 64
 
@@ -203,6 +205,21 @@ def cpu_baseline(workload, params, data_np, n_rays, run_fine=1):
         data = [torch.from_numpy(np.ascontiguousarray(a[:n])) for a in data_np]
         if workload == "smpl_nerf":
             return lambda: T.smpl_nerf_pipeline_forward(P[0], P[1], P[2], targs, pe, de, T.PositionalEncoder(10, False), data)
+        if workload == "append_smpl_params":
+            targs.human_pose_encoding = 0
+            return lambda: T.append_pose_pipeline_forward(P[0], P[1], targs, pe, de, T.PositionalEncoder(10, False), data)
+        if workload == "append_vertices":   # estimator -> body model -> [vertices | PE(x) | PE(d)] rows, like the reference's forward
+            from smpl_nerf_amd import synthetic as syn
+            from smpl_nerf_amd.synthetic_smpl import IndexPoseEstimator, LinearBodyModel
+            est = IndexPoseEstimator(torch.from_numpy(syn.human_poses((41, 38), 0, 60, 60)), torch.zeros(1, 10))
+            body = LinearBodyModel(seed=3)
+
+            def fwd():
+                goal_poses, betas = est(data[4])
+                verts = body(betas=betas, return_verts=True, body_pose=goal_poses,
+                             global_orient=torch.zeros(1, 3).expand(len(data[0]), -1)).vertices
+                return T.append_vertices_pipeline_forward_coarse(P[0], verts, targs, pe, de, data)
+            return fwd
         return lambda: T.nerf_pipeline_forward(P[0], P[1], targs, pe, de, data)
 
     probe, small = {}, make_fwd(min(256, n_rays))
@@ -224,11 +241,19 @@ def cpu_baseline(workload, params, data_np, n_rays, run_fine=1):
             ts.append(time.perf_counter() - t0)
         torch.set_num_threads(default_threads)
     dt = statistics.median(ts)
+    what = {"nerf": "NerfPipeline.forward", "smpl_nerf": "SmplNerfPipeline.forward",
+            "append_smpl_params": "AppendSmplParamsPipeline.forward (the calibration record is the nerf pipeline's: this "
+                                  "pipeline adds 69 input columns to the same ops)",
+            "append_vertices": "AppendVerticesPipeline.forward up to its coarse result - the fine branch raises in the reference "
+                               "(append_vertices_pipeline.py:71) - with the [samples, 20754] rows materialised and the dead "
+                               "vertices_net evaluated like the reference does; estimator and body model are the synthetic "
+                               "stand-ins; speed not calibrated against the reference (it cannot run here: smplx / SMPL file absent)"
+            }.get(workload, workload)
     info = {"value": n_rays * per_ray / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
             "host_cpu": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch_default_threads": default_threads,
             "thread_probe_ray_samples_per_s": {str(k): v for k, v in sorted(probe.items())},
             "sample": f"first {n_rays} rays of the same frame, same weights ({n_rays * per_ray} ray-samples per pass; warm-up 1, "
-                      f"median of 5 passes, {dt:.2f} s each): oracle/torch_cpu_path.py = the reference's NerfPipeline.forward "
+                      f"median of 5 passes, {dt:.2f} s each): oracle/torch_cpu_path.py = the reference's {what} "
                       f"restated op for op on PyTorch-CPU fp32, torch.set_num_threads({threads}) = the fastest of the probed "
                       f"counts",
             "calibration_vs_reference_in_build_container": _calibration()}
@@ -675,14 +700,17 @@ def main():
             line["train"] = train
         if train_alt:
             line["train_other_precisions"] = train_alt
-        if world == 1 and a.cpu_rays > 0 and a.workload in ("nerf", "smpl_nerf"):
-            n = min(a.cpu_rays, rays)
+        if world == 1 and a.cpu_rays > 0:
+            # (append_vertices: the reference materialises 83 KB per sample - a far smaller sample fills the time budget)
+            n = min(a.cpu_rays if a.workload != "append_vertices" else min(a.cpu_rays, 64), rays)
             info, ref = cpu_baseline(a.workload, params, data_np, n, run_fine)
             line["cpu_baseline"] = info
-            if isinstance(train, dict) and "error" not in train and a.cpu_train_rays > 0 and run_fine:
+            if (isinstance(train, dict) and "error" not in train and a.cpu_train_rays > 0 and run_fine
+                    and a.workload in ("nerf", "smpl_nerf")):
                 train["cpu_baseline"] = cpu_train_baseline(a.workload, params, data_np, min(a.cpu_train_rays, rays),
                                                            info["cores"], TRAIN_LR)
-            line["rgb_fine_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[1][:n].cpu().numpy() - ref[1])))
+            if a.workload != "append_vertices":     # (its CPU figure is the coarse pass only)
+                line["rgb_fine_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[1][:n].cpu().numpy() - ref[1])))
             line["rgb_coarse_max_abs_diff_vs_oracle"] = float(np.max(np.abs(out[0][:n].cpu().numpy() - ref[0])))
         _flush_c_stdio()
         print(json.dumps(line), file=json_out, flush=True)

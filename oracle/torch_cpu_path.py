@@ -202,6 +202,74 @@ def smpl_nerf_pipeline_forward(Pc, Pf, Pw, args, position_encoder, direction_enc
     return rgb, rgb_fine, warp_f, ray_samples_fine, warped_f, densities_fine
 
 
+def append_pose_pipeline_forward(Pc, Pf, args, position_encoder, direction_encoder, human_pose_encoder, data, two_joints=False):
+    """models/append_smpl_params_pipeline.py:14-91 (two_joints: append_to_nerf_pipeline.py:14-90): the pose row of a ray is
+    expanded over its samples and concatenated IN FRONT of the encodings, rows [pose | PE(x) | PE(d)] (:49-51);
+    data = [ray_samples, ray_translation, ray_direction, z_vals, goal_pose, rgb_truth]."""
+    ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
+    if two_joints:
+        goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)
+    pose = human_pose_encoder.encode(goal_pose) if args.human_pose_encoding else goal_pose          # :29-37
+    kw = dict(additional_input_dim=pose.shape[-1])
+
+    def rows(samples, denc):
+        B, N = samples.shape[:2]
+        pz = pose[..., None, :].expand(B, N, pose.shape[-1])
+        enc = position_encoder.encode(samples)
+        return torch.cat([pz.reshape(-1, pz.shape[-1]), enc.view(-1, enc.shape[-1]), denc.reshape(-1, denc.shape[-1])], -1)
+
+    csd = ray_direction[..., None, :].expand(ray_direction.shape[0], ray_samples.shape[1], ray_direction.shape[-1])
+    directions_encoding = direction_encoder.encode(csd / torch.norm(csd, dim=-1, keepdim=True))
+    raw = render_ray_net(Pc, rows(ray_samples, directions_encoding), **kw).view(ray_samples.shape[0], ray_samples.shape[1], 4)
+    rgb, weights, densities = raw2outputs(raw, z_vals, csd, args)
+    if not args.run_fine:
+        return rgb, rgb, ray_samples, densities
+    z_vals, ray_samples_fine = fine_sampling(ray_translation, ray_direction, z_vals, weights, args)
+    def_ = directions_encoding[..., :1, :].expand(directions_encoding.shape[0], ray_samples_fine.shape[1], directions_encoding.shape[-1])
+    raw_f = render_ray_net(Pf, rows(ray_samples_fine, def_), **kw).reshape(ray_samples_fine.shape[0], ray_samples_fine.shape[1], 4)
+    fsd = ray_direction[..., None, :].expand(ray_direction.shape[0], ray_samples_fine.shape[1], ray_direction.shape[-1])
+    rgb_fine, _, densities = raw2outputs(raw_f, z_vals, fsd, args)
+    return rgb, rgb_fine, ray_samples_fine, densities
+
+
+def append_vertices_net(P, x, n_layers=8, positions_dim=60, directions_dim=24, additional_input_dim=20670, skips=(4,)):
+    """models/append_vertices_net.py:43-66 as the reference EXECUTES it: `vertices_net` runs on the vertex columns of every
+    row and its result is dropped (:48-50) - part of what the reference's CPU pays, so the timing port pays it too."""
+    lin = lambda v, n: torch.nn.functional.linear(v, P[n + ".weight"], P[n + ".bias"])
+    positions = x[..., :positions_dim]
+    verts = x[..., positions_dim:positions_dim + additional_input_dim]
+    i = 0
+    while f"vertices_net.{i}.weight" in P:
+        verts = torch.relu(lin(verts, f"vertices_net.{i}"))
+        i += 1
+    directions = x[..., x.shape[-1] - directions_dim:]
+    o = torch.relu(lin(positions, "positions_pose_input"))
+    for i in range(n_layers - 1):
+        o = torch.relu(lin(torch.cat([o, positions], -1) if i in skips else o, f"positional_net.{i}"))
+    o = lin(o, "additional_linear_layer")
+    sigma = lin(o, "sigma_out_layer")
+    o = torch.relu(lin(lin(torch.cat([o, directions], -1), "directional_input"), "directional_net.0"))
+    return torch.cat([lin(o, "rgb_out_layer"), sigma], -1)
+
+
+def append_vertices_pipeline_forward_coarse(Pc, vertices, args, position_encoder, direction_encoder, data):
+    """models/append_vertices_pipeline.py:16-63 up to the coarse result - the part of it the reference can run (its fine
+    branch raises at :71) - given the posed vertices [B, 6890, 3] of the body model (:38-40).  The rows are materialised
+    like the reference's: [vertices_flat (20 670) | PE(x) | PE(d)] per SAMPLE (:56-58), 83 KB each."""
+    ray_samples, ray_translation, ray_direction, z_vals = data[:4]
+    B, N = ray_samples.shape[:2]
+    vflat = vertices.reshape(B, -1)
+    vrows = vflat[..., None, :].expand(B, N, vflat.shape[-1])
+    enc = position_encoder.encode(ray_samples)
+    csd = ray_direction[..., None, :].expand(B, N, 3)
+    denc = direction_encoder.encode(csd / torch.norm(csd, dim=-1, keepdim=True))
+    inputs = torch.cat([vrows.reshape(-1, vflat.shape[-1]), enc.view(-1, enc.shape[-1]), denc.view(-1, denc.shape[-1])], -1)
+    # (the net is built with additional_input_dim = 6890, train.py:206-211: vertices_net reads row columns 60 .. 6950)
+    raw = append_vertices_net(Pc, inputs, additional_input_dim=Pc["vertices_net.0.weight"].shape[1]).view(B, N, 4)
+    rgb, weights, densities = raw2outputs(raw, z_vals, csd, args)
+    return rgb, rgb, ray_samples, densities
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # training step (solver/nerf_solver.py:76-87, solver/smpl_nerf_solver.py:75-86)
 # ----------------------------------------------------------------------------------------------------------------

@@ -87,3 +87,36 @@ def test_training_restatement_reproduces_the_reference_curve_prefix():
         batch = [torch.from_numpy(np.ascontiguousarray(a[g["idx"][i]])) for a in data]
         loss = Tc.train_step(state, batch)
         assert loss == g["losses"][i], (i, loss, g["losses"][i])
+
+
+def test_torch_cpu_ports_of_the_append_pipelines_follow_the_oracle():
+    """bench.py's cpu_baseline for the append_smpl_params / append_vertices workloads times oracle/torch_cpu_path.py's
+    restatements of models/append_smpl_params_pipeline.py:14-91 and models/append_vertices_pipeline.py:16-63 (+ the net of
+    append_vertices_net.py:43-66 with its dead vertices_net branch evaluated like the reference does).  Same results as the
+    numpy oracle's (pinned by g10 / g9): coarse pass to round-off; the fine pass within the sampler's known sensitivity to the
+    host's fp32 normalising sum."""
+    import torch
+    from oracle import torch_cpu_path as TC
+    data = syn.frame_batch(12, 12, seed=3)
+    n = data[0].shape[0]
+    tt = lambda arrs: [torch.from_numpy(np.ascontiguousarray(a)) for a in arrs]
+    pose = np.tile(syn.human_poses()[3][None], (n, 1)).astype(np.float32)
+    params = [syn.make_scene_net_params(s, add_first=True, additional_input_dim=69) for s in (301, 303)]
+    d6 = list(data[:4]) + [pose, data[4]]
+    enc = (O.PositionalEncoder(10, 0), O.PositionalEncoder(4, 0))
+    tenc = (TC.PositionalEncoder(10, False), TC.PositionalEncoder(4, False))
+    ref = O.append_pose_pipeline_forward(params[0], params[1], O.Args(human_pose_encoding=0), *enc, O.PositionalEncoder(10, 0), d6)
+    ta = TC.Args(run_fine=1)
+    ta.human_pose_encoding = 0
+    with torch.no_grad():
+        out = TC.append_pose_pipeline_forward(TC.tparams(params[0]), TC.tparams(params[1]), ta, *tenc,
+                                              TC.PositionalEncoder(10, False), tt(d6))
+    assert np.abs(out[0].numpy() - ref[0]).max() <= 2e-6
+    assert np.mean(np.abs(out[1].numpy() - ref[1]) > 1e-4) <= 0.05
+    pv = syn.make_append_vertices_params(201)
+    verts = (np.random.default_rng(0).normal(size=(n, 6890, 3)) * 0.3).astype(np.float32)
+    ref = O.append_vertices_pipeline_forward(pv, pv, verts, O.Args(run_fine=0), *enc, data)
+    with torch.no_grad():
+        out = TC.append_vertices_pipeline_forward_coarse(TC.tparams(pv), torch.from_numpy(verts), TC.Args(run_fine=0), *tenc,
+                                                         tt(data))
+    assert np.abs(out[0].numpy() - ref[0]).max() <= 2e-6 and np.abs(out[3].numpy() - ref[3]).max() <= 2e-6

@@ -35,8 +35,8 @@ timeout 900 python $ROOT/bench.py --gpus 8 --steps 3 --warmup 1 --no-pmc --no-al
 timeout 600 python $ROOT/bench.py --coarse-only --no-pmc --no-alt --steps 20 > $OUT/bench_coarse_only.json.log 2>/dev/null
 timeout 600 python $ROOT/bench.py --workload smpl_nerf --no-pmc --steps 10 --cpu-rays 1024 --cpu-train-rays 256 > $OUT/bench_smpl_nerf.json.log 2>/dev/null
 timeout 600 python $ROOT/bench.py --workload smpl_nerf --res 256 --no-pmc --no-alt --steps 5 --cpu-rays 0 --points= > $OUT/bench_smpl_nerf_256.json.log 2>/dev/null
-timeout 600 python $ROOT/bench.py --workload append_vertices --res 256 --no-pmc --no-alt --steps 5 --cpu-rays 0 --points= > $OUT/bench_append_vertices_256.json.log 2>/dev/null
-timeout 600 python $ROOT/bench.py --workload append_smpl_params --no-pmc --no-alt --steps 10 --cpu-rays 0 --points= > $OUT/bench_append_smpl_params.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py --workload append_vertices --res 256 --no-pmc --no-alt --steps 5 --cpu-rays 64 --points= > $OUT/bench_append_vertices_256.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py --workload append_smpl_params --no-pmc --no-alt --steps 10 --cpu-rays 1024 --points= > $OUT/bench_append_smpl_params.json.log 2>/dev/null
 timeout 600 python $ROOT/bench.py > $OUT/bench_default.json.log 2>/dev/null
 cd $ROOT
 python tools/make_pmc_profile.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
