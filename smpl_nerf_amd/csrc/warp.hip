@@ -486,7 +486,9 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
             float *ray_bias = nullptr;
             if (!act && P.add_dim > 0 && P.pos_nkb > 0 && tuning().warp_fold && samples_per_ray >= 8 && n % samples_per_ray == 0) {
                 const int64_t n_rays = n / samples_per_ray, floats = n_rays * P.width;
-                if (hipMallocAsync(reinterpret_cast<void **>(&ray_bias), (size_t)floats * sizeof(float), s) != hipSuccess) {
+                if ((floats + 255) / 256 > 0x7fffffffLL) {
+                    ray_bias = nullptr;   // (more rays than a grid holds: the per-sample form)
+                } else if (hipMallocAsync(reinterpret_cast<void **>(&ray_bias), (size_t)floats * sizeof(float), s) != hipSuccess) {
                     (void)hipGetLastError();
                     ray_bias = nullptr;   // no memory for the table: the unfolded kernel needs none
                 } else {
