@@ -775,3 +775,52 @@ def test_inference_folds_per_ray_additional_inputs(dev, add_dim, add_first, skip
         close(inf.cpu().numpy().reshape(-1, 4), ref, 0, tol)
         close(trn.detach().cpu().numpy().reshape(-1, 4), ref, 0, tol)
         close(inf.cpu().numpy(), trn.detach().cpu().numpy(), 0, 0.2 * tol)
+
+
+def test_random_network_shapes_against_torch(dev):
+    """A seeded sweep over what the reference's parser leaves free - depth, width, skip layers, encoder sizes, additional
+    (per-ray) inputs in both column orders, directional input on / off, samples per ray - inference (with the per-ray
+    folds and the 64-sample tiles where they apply) and the training forward against the torch restatement of
+    models/render_ray_net.py:42-61."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(20260929)
+    for case in range(24):
+        n_layers = int(rng.integers(1, 11))
+        width = int(rng.choice([8, 33, 64, 90, 128, 177, 256]))
+        skips = tuple(sorted(set(int(v) for v in rng.integers(0, max(1, n_layers - 1), size=int(rng.integers(0, 3))))))
+        pL, pid = int(rng.integers(1, 11)), int(rng.integers(0, 2))
+        dL, did = int(rng.integers(1, 5)), int(rng.integers(0, 2))
+        add_dim = int(rng.choice([0, 0, 2, 20, 69]))
+        add_first = bool(rng.integers(0, 2))
+        use_dir = int(rng.integers(0, 4) > 0)
+        B, Ns = int(rng.integers(3, 40)), int(rng.choice([5, 16, 64]))
+        pdim, ddim = 3 * (pid + 2 * pL), 3 * (did + 2 * dL)
+        kw = dict(n_layers=n_layers, width=width, positions_dim=pdim, directions_dim=ddim, additional_input_dim=add_dim,
+                  skips=skips, use_directional_input=use_dir)
+        params = syn.make_render_ray_net_params(1000 + case, 10.0, 5.0, **kw)
+        net = RenderRayNet(n_layers, width, pdim, ddim, add_dim, skips=list(skips), use_directional_input=use_dir)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        net = net.to(dev)
+        x = rng.uniform(-1.5, 1.5, (B, Ns, 3)).astype(F32)
+        d = rng.normal(size=(B, 3)).astype(F32)
+        add = rng.uniform(-1, 1, (B, add_dim)).astype(F32) if add_dim else None
+        dn = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(F32)
+        cols = [R.posenc(torch.from_numpy(x), pL, pid)]
+        if add_dim:
+            a = torch.from_numpy(add)[:, None, :].expand(B, Ns, add_dim)
+            cols = [a] + cols if add_first else cols + [a]
+        cols.append(R.posenc(torch.from_numpy(dn), dL, did)[:, None, :].expand(B, Ns, ddim))
+        rows = torch.cat(cols, -1).reshape(B * Ns, -1)
+        ref = R.render_ray_net(R.tparams(params, requires_grad=False), rows, n_layers=n_layers, positions_dim=pdim,
+                               directions_dim=ddim, additional_input_dim=add_dim, skips=skips,
+                               use_directional_input=use_dir).numpy()
+        pe, de = PositionalEncoder(pL, pid), PositionalEncoder(dL, did)
+        extra = dict(additional=T(add, dev), add_first=add_first) if add_dim else {}
+        with torch.no_grad():
+            inf = net.forward_fused(T(x, dev), T(d, dev), Ns, pe, de, **extra)
+        trn = net.forward_fused(T(x, dev), T(d, dev), Ns, pe, de, **extra)
+        tol = 1e-4 * max(1.0, np.abs(ref).max())
+        msg = f"case {case}: {kw}, add_first {add_first}, B {B}, Ns {Ns}"
+        np.testing.assert_allclose(inf.cpu().numpy().reshape(-1, 4), ref, rtol=0, atol=tol, err_msg=msg)
+        np.testing.assert_allclose(trn.detach().cpu().numpy().reshape(-1, 4), ref, rtol=0, atol=tol, err_msg=msg)
