@@ -824,3 +824,53 @@ def test_random_network_shapes_against_torch(dev):
         msg = f"case {case}: {kw}, add_first {add_first}, B {B}, Ns {Ns}"
         np.testing.assert_allclose(inf.cpu().numpy().reshape(-1, 4), ref, rtol=0, atol=tol, err_msg=msg)
         np.testing.assert_allclose(trn.detach().cpu().numpy().reshape(-1, 4), ref, rtol=0, atol=tol, err_msg=msg)
+
+
+def test_random_network_shapes_gradients_against_torch(dev):
+    """The same sweep for the backward: every parameter gradient and the gradient of the per-ray additional inputs (where
+    the case has them) against torch autograd over the restated net."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(929)
+    for case in range(14):
+        n_layers = int(rng.integers(1, 9))
+        width = int(rng.choice([16, 50, 64, 100, 128, 200, 256]))
+        skips = tuple(sorted(set(int(v) for v in rng.integers(0, max(1, n_layers - 1), size=int(rng.integers(0, 3))))))
+        pL, dL = int(rng.integers(1, 11)), int(rng.integers(1, 5))
+        add_dim = int(rng.choice([0, 2, 20, 69]))
+        add_first = bool(rng.integers(0, 2))
+        B, Ns = int(rng.integers(3, 30)), int(rng.choice([5, 16, 64]))
+        pdim, ddim = 6 * pL, 6 * dL
+        kw = dict(n_layers=n_layers, width=width, positions_dim=pdim, directions_dim=ddim, additional_input_dim=add_dim, skips=skips)
+        params = syn.make_render_ray_net_params(2000 + case, 10.0, 5.0, **kw)
+        net = RenderRayNet(n_layers, width, pdim, ddim, add_dim, skips=list(skips))
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        net = net.to(dev)
+        x = rng.uniform(-1.5, 1.5, (B, Ns, 3)).astype(F32)
+        d = rng.normal(size=(B, 3)).astype(F32)
+        gout = rng.normal(size=(B * Ns, 4)).astype(F32)
+        dn = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(F32)
+        P = R.tparams(params)
+        cols = [R.posenc(torch.from_numpy(x), pL, 0)]
+        add_t = None
+        if add_dim:
+            add_t = torch.from_numpy(rng.uniform(-1, 1, (B, add_dim)).astype(F32)).requires_grad_(True)
+            a = add_t[:, None, :].expand(B, Ns, add_dim)
+            cols = [a] + cols if add_first else cols + [a]
+        cols.append(R.posenc(torch.from_numpy(dn), dL, 0)[:, None, :].expand(B, Ns, ddim))
+        ref = R.render_ray_net(P, torch.cat(cols, -1).reshape(B * Ns, -1), n_layers=n_layers, positions_dim=pdim,
+                               directions_dim=ddim, additional_input_dim=add_dim, skips=skips)
+        (ref * torch.from_numpy(gout)).sum().backward()
+        extra = {}
+        if add_dim:
+            add_g = T(add_t.detach().numpy(), dev).requires_grad_(True)
+            extra = dict(additional=add_g, add_first=add_first)
+        raw = net.forward_fused(T(x, dev), T(d, dev), Ns, PositionalEncoder(pL, 0), PositionalEncoder(dL, 0), **extra)
+        (raw.reshape(-1, 4) * T(gout, dev)).sum().backward()
+        msg = f"case {case}: {kw}, add_first {add_first}, B {B}, Ns {Ns}"
+        for k, p in net.named_parameters():
+            g = P[k].grad.numpy()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(np.abs(g).max(), 1e-12), err_msg=msg + " " + k)
+        if add_dim:
+            g = add_t.grad.numpy()
+            np.testing.assert_allclose(add_g.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(np.abs(g).max(), 1e-12), err_msg=msg + " d_add")
