@@ -874,3 +874,48 @@ def test_random_network_shapes_gradients_against_torch(dev):
         if add_dim:
             g = add_t.grad.numpy()
             np.testing.assert_allclose(add_g.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(np.abs(g).max(), 1e-12), err_msg=msg + " d_add")
+
+
+def test_random_warp_net_shapes_against_torch(dev):
+    """Seeded sweep for WarpFieldNet: width, position encoder, pose columns, samples per ray - fused inference (per-ray pose
+    fold from 8 samples per ray), training forward and the gradients of linear1 / linear2 / the pose rows against torch."""
+    from smpl_nerf_amd.nets import WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    rng = np.random.default_rng(4242)
+    for case in range(12):
+        width = int(rng.choice([16, 64, 100, 128, 200, 256]))
+        pL, pid = int(rng.integers(0, 11)), int(rng.integers(0, 2))
+        if pL == 0:
+            pid = 1
+        qdim = int(rng.choice([2, 40, 69]))
+        B, Ns = int(rng.integers(3, 40)), int(rng.choice([5, 9, 64]))
+        pdim = 3 * (pid + 2 * pL)
+        params = syn.make_warp_field_params(3000 + case, positions_dim=pdim, pose_dim=qdim, width=width, out_scale=0.5)
+        net = WarpFieldNet(8, width, pdim, qdim)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        net = net.to(dev)
+        x = rng.uniform(-1.5, 1.5, (B, Ns, 3)).astype(F32)
+        o = rng.normal(size=(B, 3)).astype(F32)
+        gout = rng.normal(size=(B * Ns, 3)).astype(F32)
+        P = R.tparams(params)
+        pose_t = torch.from_numpy(rng.uniform(-1, 1, (B, qdim)).astype(F32)).requires_grad_(True)
+        rows = torch.cat([R.posenc(torch.from_numpy(x), pL, pid), pose_t[:, None, :].expand(B, Ns, qdim)], -1).reshape(B * Ns, -1)
+        ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(rows, P["linear1.weight"], P["linear1.bias"])),
+                                         P["linear2.weight"], P["linear2.bias"])
+        (ref * torch.from_numpy(gout)).sum().backward()
+        pe = PositionalEncoder(pL, pid)
+        msg = f"case {case}: width {width}, pos ({pL}, {pid}), pose {qdim}, B {B}, Ns {Ns}"
+        with torch.no_grad():
+            inf = net.forward_fused(T(x, dev), T(pose_t.detach().numpy(), dev), T(o, dev), Ns, pe)
+        pose_g = T(pose_t.detach().numpy(), dev).requires_grad_(True)
+        trn = net.forward_fused(T(x, dev), pose_g, T(o, dev), Ns, pe)
+        tol = 2e-5 * max(1.0, ref.detach().abs().max().item())
+        np.testing.assert_allclose(inf[0].cpu().numpy(), ref.detach().numpy(), rtol=0, atol=tol, err_msg=msg)
+        np.testing.assert_allclose(trn[0].detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=tol, err_msg=msg)
+        np.testing.assert_allclose(inf[1].cpu().numpy(), x.reshape(-1, 3) + ref.detach().numpy(), rtol=0, atol=2 * tol, err_msg=msg)
+        (trn[0] * T(gout, dev)).sum().backward()
+        for k, p in net.named_parameters():
+            g = P[k].grad.numpy()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(np.abs(g).max(), 1e-12), err_msg=msg + " " + k)
+        g = pose_t.grad.numpy()
+        np.testing.assert_allclose(pose_g.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(np.abs(g).max(), 1e-12), err_msg=msg + " d_pose")
