@@ -422,7 +422,7 @@ static int plan16(const snerf_mlp_desc *desc, Plan &P, const char *what) {
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "%s: desc is null", what);
     if (make_plan(*desc, P, why, 32) != 0) return fail(SNERF_E_BADARG, "%s: %s", what, why);
-    if (P.width != 256) return fail(SNERF_E_BADARG, "%s: the split-bf16 path supports width 256 only", what);
+    if (desc->width != 256) return fail(SNERF_E_BADARG, "%s: the split-bf16 path supports width 256 only", what);
     return SNERF_OK;
 }
 

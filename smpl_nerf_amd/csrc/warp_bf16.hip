@@ -85,7 +85,7 @@ static int warp_plan32(const snerf_warp_desc *desc, Plan &P, const char *what) {
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "%s: desc is null", what);
     if (make_warp_plan(*desc, P, why, 32) != 0) return fail(SNERF_E_BADARG, "%s: %s", what, why);
-    if (P.width != 256) return fail(SNERF_E_BADARG, "%s: the split-bf16 path supports width 256 only", what);
+    if (desc->width != 256) return fail(SNERF_E_BADARG, "%s: the split-bf16 path supports width 256 only", what);
     return SNERF_OK;
 }
 
