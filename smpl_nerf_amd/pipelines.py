@@ -116,6 +116,8 @@ class NerfPipeline(nn.Module):
         if mc.precision != mf.precision:
             raise RuntimeError("render_rays: both nets must use the same precision mode")
         prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": _lib.SPLIT_F16X3}[mc.precision]
+        if mc.width != 256 or mf.width != 256:
+            prec = 0      # the split-precision kernels exist for width 256; other widths run exact fp32 like forward() does
         descs, packed = [], []
         for m in (mc, mf):
             d = m.desc_for_encoders(self.position_encoder, self.direction_encoder, False)
@@ -212,6 +214,8 @@ class SmplNerfPipeline(NerfPipeline):
         if not (mc.precision == mf.precision == mw.precision):
             raise RuntimeError("render_rays: all nets must use the same precision mode (set_precision)")
         prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": _lib.SPLIT_F16X3}[mc.precision]
+        if any(m.width != 256 for m in (mc, mf, self.model_warp_field)):
+            prec = 0      # (split precision: width 256 only - other widths run exact fp32, like forward())
         goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)
         pose_enc = self.human_pose_encoder.encode(goal_pose.contiguous()).contiguous()
         descs, packed = [], []

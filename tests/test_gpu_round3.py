@@ -919,3 +919,26 @@ def test_random_warp_net_shapes_against_torch(dev):
             np.testing.assert_allclose(p.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(np.abs(g).max(), 1e-12), err_msg=msg + " " + k)
         g = pose_t.grad.numpy()
         np.testing.assert_allclose(pose_g.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(np.abs(g).max(), 1e-12), err_msg=msg + " d_pose")
+
+
+def test_split_precision_on_other_widths_runs_exact_fp32(dev):
+    """The split-precision kernels exist for width 256; a pipeline of narrower nets with set_precision("bf16x6") runs the
+    exact-fp32 kernels in forward() and in the one-call render_rays - same results as precision "fp32", no error."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline
+    nets = []
+    for seed in (5, 6):
+        params = syn.make_render_ray_net_params(seed, 30.0, 10.0, n_layers=4, width=96, skips=(1,))
+        m = RenderRayNet(4, 96, 60, 24, skips=[1])
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        nets.append(m.to(dev).eval())
+    data = [T(a[:300], dev) for a in syn.frame_batch(32, 32, seed=2)]
+    outs = {}
+    for prec in ("fp32", "bf16x6", "f16x3"):
+        pipe = NerfPipeline(nets[0], nets[1], O.Args(), PositionalEncoder(10, 0), PositionalEncoder(4, 0)).set_precision(prec)
+        with torch.no_grad():
+            outs[prec] = (pipe(data), pipe.render_rays(data))
+    for prec in ("bf16x6", "f16x3"):
+        for a, b in zip(outs["fp32"][0] + outs["fp32"][1], outs[prec][0] + outs[prec][1]):
+            assert torch.equal(a, b)
