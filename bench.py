@@ -387,6 +387,11 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev):
     losses = [float(l) for l in losses]
     evals = world * steps * rays * 256
     mlp_ms = sum(v[1] for k, v in kern.items() if k.startswith(("mlp_bwd", "mlp_fwd_train"))) / steps
+    one_call = any(k.startswith("train_step") for k in kern)
+    if one_call:
+        # the step is one C-ABI call (snerf_nerf_train_step_f32): the event pair brackets ALL its kernels (compositing,
+        # sampler, loss, Adam included), so the fraction below is a lower bound on the MLP kernels' own
+        mlp_ms = sum(v[1] for k, v in kern.items() if k.startswith("train_step")) / steps
     flop_step = 3 * FLOP_PER_EVAL * rays * 256          # fwd + dgrad + wgrad of the two RenderRayNets
     peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
     tf = flop_step / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None
@@ -397,6 +402,9 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev):
             "loss_first": losses[0], "loss_last": losses[-1], "rgb_fine_std_last_step": fine_std,
             "mlp_kernels_ms_per_step": mlp_ms, "mlp_algorithmic_tflops": tf, "mlp_peak_tflops": peak,
             "mlp_roofline_frac": tf / peak if tf else None,
+            "step_entry": ("snerf_nerf_train_step_f32 (one C-ABI call per step; mlp_kernels_ms_per_step brackets the whole call)"
+                           if one_call else "autograd (torch.autograd.Function per kernel group) + HipAdam"),
+            "rays_per_chunk": tr.rays_per_chunk if one_call else None,
             "kernels_ms_per_step": {k: v[1] / steps for k, v in sorted(kern.items())},
             "collective": (f"one all-reduce of {sum(p.numel() for p in tr.params)} fp32 gradients per step"
                            if world > 1 else "none (1 GPU)")}

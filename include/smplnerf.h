@@ -59,10 +59,12 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 103 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
-                             snerf_composite_bwd_all_f32, snerf_mlp_bwd_chunk_*; composite forward accepts any N
+#define SNERF_VERSION 104 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+                             snerf_composite_bwd_all_f32; composite forward accepts any N
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
-                             folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form) */
+                             folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
+                             0.1.4: + the training step as one call (snerf_nerf_train_step_f32 / _grads_f32, snerf_adam_step_f32,
+                             snerf_mlp_stream_slots) */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -393,6 +395,93 @@ int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, const void *pa
                                const float *noise_fine, int64_t B, int Nc, int Nf, int white_background,
                                void *workspace, float *rgb, float *rgb_fine, float *warp_fine, float *samples_fine,
                                float *warped_fine, float *densities_fine, snerf_stream_t stream);
+
+/* ---- a9 + 8(f)-2: the per-batch body of NerfSolver.train as one call (solver/nerf_solver.py:76-87) ---------------------
+ *     rgb, rgb_fine, .. = pipeline(batch); loss = MSE(rgb, gt) + MSE(rgb_fine, gt); loss.backward(); Adam.step()
+ * (models/nerf_pipeline.py:14-67, solver/nerf_solver.py:48-52, :31-33).  Everything is enqueued on `stream`; nothing is
+ * allocated, nothing synchronises, and no argument changes from step to step except the batch pointers (the optimiser's
+ * step counter and bias corrections live on the device): the call can be captured into a HIP graph and replayed.
+ *
+ * Weight streams.  A training step consumes two streams per net - `packed` (snerf_mlp_pack_f32 / snerf_mlp_pack_bf16) and
+ * `packed_t` (snerf_mlp_pack_t_f32 / snerf_mlp_pack_t_bf16 with input_grad = 0) - which the caller packs ONCE; afterwards the
+ * optimiser step keeps them current: fp32 streams are refreshed in place, element by element, through the slot tables of
+ * snerf_mlp_stream_slots (no re-pack launches); split-precision streams (pre-split parts) are re-packed inside the call. */
+
+/* slot_fwd[i] / slot_t[i] (int32, snerf_mlp_param_floats entries each, nullable): index of the float of the fp32 forward /
+ * transposed (input_grad = 0) stream that holds parameter i of params_flat, or -1 (biases do not appear in the transposed
+ * stream).  Every parameter occupies at most one float of each stream. */
+int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, snerf_stream_t stream);
+
+/* torch.optim.Adam(params, lr, betas, eps, weight_decay) (amsgrad = False) over ONE flat fp32 parameter buffer - the
+ * statements of torch's single-tensor update in their order (solver/nerf_solver.py:11-14, 31-33, 87). */
+typedef struct snerf_adam_state {
+    float *params;       /* [n_params] */
+    const float *grads;  /* [n_params] */
+    float *exp_avg;      /* [n_params], zero before the first step */
+    float *exp_avg_sq;   /* [n_params], zero before the first step */
+    int64_t n_params;
+    float *scratch;      /* device, 2 floats per range of a call (64 floats cover the maximum of 32 ranges) */
+    double lr, beta1, beta2, eps, weight_decay;
+} snerf_adam_state;
+/* A run of adjacent parameter tensors that take part in a step.  torch keeps one step counter per parameter tensor and
+ * skips tensors whose .grad is None (the fine net with run_fine = 0): leave those out of the ranges.  step: DEVICE int64
+ * [n_steps] = the counters of the range's tensors (0 before the first step), all equal on entry - tensors with different
+ * counts go into different ranges - and all incremented by the call; the bias corrections use step[0] + 1. */
+typedef struct snerf_adam_range {
+    int64_t begin, end;  /* parameters [begin, end) of the flat buffer */
+    int64_t *step;
+    int32_t n_steps;
+} snerf_adam_range;
+/* A RenderRayNet inside the flat buffer whose weight streams the step keeps current. */
+typedef struct snerf_adam_net {
+    const snerf_mlp_desc *desc;
+    int64_t param_offset; /* its snerf_mlp_param_floats parameters (state_dict order) start at params + param_offset */
+    int32_t precision;    /* 0: fp32 streams (refreshed in place); 2 / 3 / SNERF_SPLIT_F16X3: split streams (re-packed) */
+    void *packed;         /* nullable: not kept current */
+    void *packed_t;       /* nullable */
+    const int32_t *slot_fwd, *slot_t; /* snerf_mlp_stream_slots (precision 0 only) */
+} snerf_adam_net;
+/* One optimiser step on the ranges (HOST array, at most 32) with the streams of at most 8 nets (HOST array) kept current. */
+int snerf_adam_step_f32(const snerf_adam_state *state, const snerf_adam_range *ranges_host, int n_ranges,
+                        const snerf_adam_net *nets_host, int n_nets, snerf_stream_t stream);
+
+/* The batch as the Solver hands it to the pipeline (solver/nerf_solver.py:77-81) plus what utils.py draws inside. */
+typedef struct snerf_nerf_batch {
+    const float *ray_samples;  /* [B, Nc, 3] */
+    const float *rays_o;       /* [B, 3] */
+    const float *rays_d;       /* [B, 3] */
+    const float *z_vals;       /* [B, Nc] */
+    const float *rgb_truth;    /* [B, 3] */
+    const float *u;            /* [Nf] = linspace(0, 1, Nf) (utils.py:204-206); unused with Nf == 0 */
+    const float *noise_coarse; /* nullable [B, Nc]: sigma noise (utils.py:171-173) */
+    const float *noise_fine;   /* nullable [B, Nc + Nf] */
+    int64_t B;
+    int32_t Nc, Nf;            /* Nf == 0 is run_fine = 0: loss = 2 MSE(rgb), no fine gradients (nerf_pipeline.py:43-44) */
+    int32_t white_background;
+} snerf_nerf_batch;
+
+/* Forward with saved layer inputs, loss, backward: grad_coarse / grad_fine (snerf_mlp_param_floats floats each, state_dict
+ * order, OVERWRITTEN; grad_fine untouched with Nf == 0) = what autograd leaves in .grad after loss.backward();
+ * loss [3] = {MSE(rgb) + MSE(rgb_fine), MSE(rgb), MSE(rgb_fine)}; rgb / rgb_fine [B, 3] = the rendered colours.
+ * precision as in snerf_render_rays_f32 (packed_* / packed_t_* from the matching pack calls).
+ * The batch is walked in chunks of rays_per_chunk rays (<= 0 or > B: one chunk): d loss / d rgb of a ray does not depend on
+ * the other rays, so forward and backward run chunk by chunk and the parameter gradients are summed in chunk order - the
+ * saved activations (21 KB per ray-sample) are sized by the chunk, nothing is recomputed.
+ * workspace: snerf_nerf_train_workspace_bytes(...) bytes, 256-byte aligned. */
+int64_t snerf_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B, int Nc,
+                                         int Nf, int64_t rays_per_chunk);
+int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                               const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
+                               const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
+                               float *grad_fine, float *loss, float *rgb, float *rgb_fine, snerf_stream_t stream);
+/* snerf_nerf_train_grads_f32 followed by snerf_adam_step_f32 (single-GPU step; a data-parallel trainer calls the two halves
+ * with its gradient all-reduce in between). */
+int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                              const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
+                              const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
+                              float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
+                              const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
+                              snerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,32 @@ class WarpDesc(ctypes.Structure):
 
 _P = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
+
+class AdamState(ctypes.Structure):
+    """struct snerf_adam_state - torch.optim.Adam over one flat fp32 buffer (solver/nerf_solver.py:11-14, 31-33)."""
+    _fields_ = [("params", _P), ("grads", _P), ("exp_avg", _P), ("exp_avg_sq", _P), ("n_params", c_int64),
+                ("scratch", _P), ("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+                ("weight_decay", c_double)]
+
+
+class AdamRange(ctypes.Structure):
+    """struct snerf_adam_range - adjacent parameter tensors taking part in a step, with their device step counters."""
+    _fields_ = [("begin", c_int64), ("end", c_int64), ("step", _P), ("n_steps", c_int32)]
+
+
+class AdamNet(ctypes.Structure):
+    """struct snerf_adam_net - a RenderRayNet inside the flat buffer whose weight streams the optimiser step keeps current."""
+    _fields_ = [("desc", POINTER(MlpDesc)), ("param_offset", c_int64), ("precision", c_int32), ("packed", _P),
+                ("packed_t", _P), ("slot_fwd", _P), ("slot_t", _P)]
+
+
+class NerfBatch(ctypes.Structure):
+    """struct snerf_nerf_batch - the Solver's batch (solver/nerf_solver.py:77-81) plus u and the sigma noise."""
+    _fields_ = [("ray_samples", _P), ("rays_o", _P), ("rays_d", _P), ("z_vals", _P), ("rgb_truth", _P), ("u", _P),
+                ("noise_coarse", _P), ("noise_fine", _P), ("B", c_int64), ("Nc", c_int32), ("Nf", c_int32),
+                ("white_background", c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/smplnerf.h declares
 SIGNATURES = {
     "snerf_version": (c_int, []),
@@ -88,6 +114,13 @@ SIGNATURES = {
                                            _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "snerf_render_rays_f32": (c_int, [POINTER(MlpDesc), _P, POINTER(MlpDesc), _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64,
                                       c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "snerf_mlp_stream_slots": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
+    "snerf_adam_step_f32": (c_int, [POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P]),
+    "snerf_nerf_train_workspace_bytes": (c_int64, [POINTER(MlpDesc), POINTER(MlpDesc), c_int64, c_int, c_int, c_int64]),
+    "snerf_nerf_train_grads_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
+                                           _P, _P, _P, _P, _P, _P, _P]),
+    "snerf_nerf_train_step_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
+                                          _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P]),
 }
 
 _lib = None

@@ -41,30 +41,9 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(Plan P, const float *__re
     while (li + 1 < P.nlayers && slab >= P.layer[li + 1].first_slab) ++li;
     const Layer &Ly = P.layer[li];
     const int sl = slab - Ly.first_slab;
-    const int kps = SLAB_TILES / Ly.t_out;
-    const float *Wm = params + Ly.w_off;
-    const float *bias = params + Ly.b_off;
     for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
-        float val = 0.f;
-        if (e < SLAB_A_FLOATS) {
-            const int per_kb = Ly.t_out * 256;
-            const int kbl = e / per_kb;
-            int rem = e - kbl * per_kb;
-            const int to = rem >> 8;
-            rem &= 255;
-            const int l = rem >> 2, r = rem & 3;
-            const int i = l & 15, g = l >> 4;
-            const int row = 16 * to + i;
-            const int kb = sl * kps + kbl;
-            if (kbl < kps && kb < Ly.nkb && row < Ly.n_out) {
-                const int col = slot_to_col(Ly, kb, g, r);
-                if (col >= 0) val = Wm[(int64_t)row * Ly.n_in + col];
-            }
-        } else if (sl == 0) {
-            const int jj = e - SLAB_A_FLOATS;
-            if (jj < Ly.n_out) val = bias[jj];
-        }
-        dst[e] = val;
+        const int64_t src = fwd_slab_src(Ly, sl, e);
+        dst[e] = src >= 0 ? params[src] : 0.f;
     }
 }
 

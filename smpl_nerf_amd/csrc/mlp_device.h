@@ -12,7 +12,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 struct TrainLayout;
 // defined in mlp_train.hip: split-K wgrad + fixed-order reduce for any (Plan, TrainLayout)
 int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
-                 float *flat_grad, hipStream_t s, int wide_nsplit = 0);
+                 float *flat_grad, hipStream_t s, int wide_nsplit = 0, bool accumulate = false);
+// defined in mlp_train.hip / mlp_train_bf16.hip: dgrad + wgrad + reduce of one net on n samples (the bodies of snerf_mlp_bwd_f32 /
+// snerf_mlp_bwd_inputs_f32 and their split-precision twins); accumulate: flat_grad += instead of = (train_step.hip)
+int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n, float *dy,
+               float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample, int spr, float *d_x,
+               float *d_dirs, snerf_stream_t stream, bool accumulate = false);
+int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act, const float *d_raw, int64_t n,
+                    float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample, int spr,
+                    float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate = false);
 // defined in mlp.hip: packs params_flat into the slab stream described by `P` (any plan)
 int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStream_t s, const char *what);
 

@@ -209,6 +209,31 @@ __host__ __device__ inline int slot_to_col(const Layer &Ly, int kb, int g, int r
     return -1;
 }
 
+// Index into params_flat of the parameter that element `e` of the layer's slab number `sl` holds in the fp32 forward
+// stream, or -1 for zero padding.  One definition for the packer (mlp.hip: mlp_pack_kernel) and for the slot tables through
+// which the optimiser step refreshes the stream in place (train_step.hip).
+__host__ __device__ inline int64_t fwd_slab_src(const Layer &Ly, int sl, int e) {
+    if (e < SLAB_A_FLOATS) {
+        const int kps = SLAB_TILES / Ly.t_out;
+        const int per_kb = Ly.t_out * 256;
+        const int kbl = e / per_kb;
+        int rem = e - kbl * per_kb;
+        const int to = rem >> 8;
+        rem &= 255;
+        const int l = rem >> 2, r = rem & 3;
+        const int i = l & 15, g = l >> 4;
+        const int row = 16 * to + i;
+        const int kb = sl * kps + kbl;
+        if (kbl < kps && kb < Ly.nkb && row < Ly.n_out) {
+            const int col = slot_to_col(Ly, kb, g, r);
+            if (col >= 0) return Ly.w_off + (int64_t)row * Ly.n_in + col;
+        }
+        return -1;
+    }
+    const int jj = e - SLAB_A_FLOATS;
+    return (sl == 0 && jj < Ly.n_out) ? Ly.b_off + jj : -1;
+}
+
 // 32-wide counterpart of slot_to_col
 __host__ __device__ inline int slot_to_col32(const Layer &Ly, int kb, int g, int e) {
     for (int s = 0; s < Ly.nseg; ++s) {
@@ -356,6 +381,42 @@ inline void make_bwd_plan(const Plan &P, BwdPlan &B, bool input_grad = false, in
     }
     B.nl = nl;
     B.total_slabs = slab;
+}
+// The same for the fp32 transposed (dgrad) stream: element `e` of slab number `sl` of backward layer `Bl`
+// (mlp_train.hip: mlp_pack_t_kernel; train_step.hip: slot tables).
+__host__ __device__ inline int64_t bwd_slab_src(const Plan &P, const BwdLayer &Bl, int sl, int e) {
+    const Layer &Ly = P.layer[Bl.fwd];
+    if (e < SLAB_A_FLOATS) {
+        const int kps = SLAB_TILES / Bl.t_out;
+        const int per_kb = Bl.t_out * 256;
+        const int kbl = e / per_kb;
+        int rem = e - kbl * per_kb;
+        const int to = rem >> 8;
+        rem &= 255;
+        const int l = rem >> 2, r = rem & 3;
+        const int i = l & 15, g = l >> 4;
+        const int kb = sl * kps + kbl;
+        const int row = 16 * kb + 4 * g + r;  // forward output feature (contraction index)
+        // forward input column produced by output row (to, i) of the transpose
+        const Seg &sg = Ly.seg[Bl.seg];
+        int col = -1;
+        if (sg.type == SEG_PE) {
+            if (to < sg.nkb) {  // slot (i>>2, i&3) of encoder k-block `to`
+                const int c = pe_slot_col(sg.L, sg.ident, to, i >> 2, i & 3);
+                if (c >= 0) col = sg.col_off + c;
+            }
+        } else if (16 * to + i < sg.ncols) {
+            col = sg.col_off + 16 * to + i;
+        }
+        if (kbl < kps && kb < Bl.nkb && row < Ly.n_out && col >= 0) return Ly.w_off + (int64_t)row * Ly.n_in + col;
+        return -1;
+    }
+    if (sl == 0 && Bl.aux_fwd >= 0) {
+        const Layer &La = P.layer[Bl.aux_fwd];
+        const int jj = e - SLAB_A_FLOATS;
+        if (jj < La.seg[0].ncols) return La.w_off + jj;  // row 0 of the sigma head
+    }
+    return -1;
 }
 inline int bwd_total_slabs(const Plan &P, bool input_grad = false, int kw = 16) {
     BwdPlan B;

@@ -47,40 +47,10 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(Plan P, BwdPlan B, cons
     int bi = 0;
     while (bi + 1 < B.nl && slab >= B.layer[bi + 1].first_slab) ++bi;
     const BwdLayer &Bl = B.layer[bi];
-    const Layer &Ly = P.layer[Bl.fwd];
     const int sl = slab - Bl.first_slab;
-    const int kps = SLAB_TILES / Bl.t_out;
-    const float *Wm = params + Ly.w_off;
     for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
-        float val = 0.f;
-        if (e < SLAB_A_FLOATS) {
-            const int per_kb = Bl.t_out * 256;
-            const int kbl = e / per_kb;
-            int rem = e - kbl * per_kb;
-            const int to = rem >> 8;
-            rem &= 255;
-            const int l = rem >> 2, r = rem & 3;
-            const int i = l & 15, g = l >> 4;
-            const int kb = sl * kps + kbl;
-            const int row = 16 * kb + 4 * g + r;  // forward output feature (contraction index)
-            // forward input column produced by output row (to, i) of the transpose
-            const Seg &sg = Ly.seg[Bl.seg];
-            int col = -1;
-            if (sg.type == SEG_PE) {
-                if (to < sg.nkb) {  // slot (i>>2, i&3) of encoder k-block `to`
-                    const int c = pe_slot_col(sg.L, sg.ident, to, i >> 2, i & 3);
-                    if (c >= 0) col = sg.col_off + c;
-                }
-            } else if (16 * to + i < sg.ncols) {
-                col = sg.col_off + 16 * to + i;
-            }
-            if (kb < Bl.nkb && row < Ly.n_out && col >= 0) val = Wm[(int64_t)row * Ly.n_in + col];
-        } else if (sl == 0 && Bl.aux_fwd >= 0) {
-            const Layer &La = P.layer[Bl.aux_fwd];
-            const int jj = e - SLAB_A_FLOATS;
-            if (jj < La.seg[0].ncols) val = params[La.w_off + jj];  // row 0 of the sigma head
-        }
-        dst[e] = val;
+        const int64_t src = bwd_slab_src(P, Bl, sl, e);
+        dst[e] = src >= 0 ? params[src] : 0.f;
     }
 }
 
@@ -780,7 +750,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 // sum over the G partials and scatter slot order -> state_dict order
 // G_wide / G_narrow: number of sample chunks (partials) the wide and the narrow jobs were split into
 __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayout L, const float *__restrict__ part,
-                                                               int G_wide, int G_narrow, int fold, float *__restrict__ flat_grad) {
+                                                               int G_wide, int G_narrow, int fold, int accumulate,
+                                                               float *__restrict__ flat_grad) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= L.gp_floats) return;
     int l = 0;
@@ -808,9 +779,10 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
     // the bias sums of a layer ride with its first non-empty segment; a folded pair was written by the wide job's chunks
     // a folded pair was written by its carrier's (wide) workgroups
     const int G = (seg < Ly.nseg && wgrad_kind(P, l, seg, fold) != 2) ? G_wide : G_narrow;
+    // accumulate: this launch is one ray chunk of a larger batch (train_step.hip) - the chunks' sums are added in chunk order
     float sum = 0.f;
     for (int c = 0; c < G; ++c) sum += part[(int64_t)c * L.gp_floats + e];
-    flat_grad[dst] = sum;
+    flat_grad[dst] = accumulate ? flat_grad[dst] + sum : sum;
 }
 
 int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, float *packed_t, hipStream_t s, const char *what) {
@@ -820,7 +792,7 @@ int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, flo
 
 // split-K wgrad + reduce for any (Plan, TrainLayout)
 int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
-                 float *flat_grad, hipStream_t s, int wide_nsplit) {
+                 float *flat_grad, hipStream_t s, int wide_nsplit, bool accumulate) {
     // chunks: at most the wgrad_chunks(n) the partial buffer is sized for; with more wide workgroups than CUs, as many as
     // fill whole rounds of the chip (9 wide jobs x 128 chunks on 256 CUs = 4.5 rounds, the last one half empty: 113
     // chunks = 3.97 rounds of 13 % longer workgroups)
@@ -868,7 +840,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             if ((rc = check_launch("wgrad_direct"))) return rc;
         }
     }
-    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, G_narrow, W.fold, flat_grad);
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((L.gp_floats + 255) / 256), dim3(256), 0, s, P, L, gpart, G, G_narrow, W.fold, accumulate ? 1 : 0, flat_grad);
     return check_launch("wgrad_reduce");
 }
 
@@ -892,9 +864,10 @@ extern "C" int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *par
 }
 
 namespace snerf {
-static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n,
-                      float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample,
-                      int spr, float *d_x, float *d_dirs, snerf_stream_t stream) {
+// accumulate: flat_grad += instead of = (one ray chunk of a larger batch, train_step.hip)
+int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n,
+               float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample,
+               int spr, float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate) {
     Plan P;
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "mlp_bwd: desc is null");
@@ -961,7 +934,7 @@ static int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const f
     }
     int rc = check_launch("mlp_bwd(dgrad)");
     if (rc) return rc;
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);
 }
 }  // namespace snerf
 

@@ -929,10 +929,10 @@ static int launch_dgrad_bf16(const BwdArgs &A, hipStream_t s) {
     return check_launch("mlp_bwd_bf16(dgrad)");
 }
 
-static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
-                           const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad, const float *x,
-                           const float *dirs, int dirs_per_sample, int spr, float *d_x, float *d_dirs,
-                           snerf_stream_t stream) {
+int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+                    const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad, const float *x,
+                    const float *dirs, int dirs_per_sample, int spr, float *d_x, float *d_dirs,
+                    snerf_stream_t stream, bool accumulate) {
     Plan P;
     if (nsplit != 2 && nsplit != 3 && nsplit != SNERF_SPLIT_F16X3)
         return fail(SNERF_E_BADARG, "mlp_bwd_bf16: nsplit must be 2, 3 or %d (f16x3)", SNERF_SPLIT_F16X3);
@@ -997,7 +997,7 @@ static int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int
     const bool bf16_wgrad = tuning().wgrad_bf16;
     // SNERF_WGRAD_F16=0: three bf16 parts for the wide jobs of an f16x3 step (A/B knob)
     const bool f16_wgrad = tuning().wgrad_f16;
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? ((f16 && !f16_wgrad) ? 3 : nsplit) : 0);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? ((f16 && !f16_wgrad) ? 3 : nsplit) : 0, accumulate);
 }
 
 }  // namespace snerf

@@ -1,0 +1,436 @@
+// The per-batch body of NerfSolver.train (solver/nerf_solver.py:76-87) as ONE C-ABI call:
+//
+//     rgb, rgb_fine, ... = pipeline(batch)            models/nerf_pipeline.py:14-67 (activations saved)
+//     loss = MSE(rgb, gt) + MSE(rgb_fine, gt)         solver/nerf_solver.py:48-52
+//     loss.backward()                                 autograd through compositing and both RenderRayNets
+//     Adam.step()                                     solver/nerf_solver.py:31-33, 87 (torch.optim.Adam, one group)
+//
+// Pure sequencing of the library's own kernels on the caller's stream plus three small ones that live here: the MSE
+// value / gradient, the Adam update over the flat parameter buffer, and the slot tables through which that update writes
+// every new weight straight into the MFMA-ordered forward stream and the transposed dgrad stream (no re-pack launches).
+// No allocation, no host synchronisation, no step-dependent host scalars (the step counter and the bias corrections live on
+// the device): the call can be captured into a HIP graph.
+//
+// Ray chunks.  The loss is a mean over rays, so d loss / d rgb of a ray does not depend on the other rays of the batch:
+// the batch is walked in chunks of `rays_per_chunk` rays - forward, loss gradient, backward per chunk, parameter gradients
+// summed over the chunks in chunk order - and the saved layer inputs / d Y buffers (21 KB per sample) are sized by the
+// chunk, not by the batch.  Nothing is recomputed (the autograd form needs the whole forward before any backward; the
+// reference keeps 2.6 MB per ray alive).
+#include "mlp_device.h"
+
+namespace snerf {
+
+static int64_t align256(int64_t b) { return (b + 255) & ~int64_t(255); }
+
+// ------------------------------------------------------------------------------------------------
+// slot tables: parameter i of params_flat -> its element of the forward / transposed fp32 stream (or -1)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fwd_slot_table_kernel(Plan P, int32_t *__restrict__ slot) {
+    const int slab = blockIdx.x;
+    int li = 0;
+    while (li + 1 < P.nlayers && slab >= P.layer[li + 1].first_slab) ++li;
+    const Layer &Ly = P.layer[li];
+    const int sl = slab - Ly.first_slab;
+    for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
+        const int64_t src = fwd_slab_src(Ly, sl, e);
+        if (src >= 0) slot[src] = slab * SLAB_FLOATS + e;
+    }
+}
+__global__ __launch_bounds__(256) void bwd_slot_table_kernel(Plan P, BwdPlan B, int32_t *__restrict__ slot) {
+    const int slab = blockIdx.x;
+    int bi = 0;
+    while (bi + 1 < B.nl && slab >= B.layer[bi + 1].first_slab) ++bi;
+    const BwdLayer &Bl = B.layer[bi];
+    const int sl = slab - Bl.first_slab;
+    for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
+        const int64_t src = bwd_slab_src(P, Bl, sl, e);
+        if (src >= 0) slot[src] = slab * SLAB_FLOATS + e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss: MSE(rgb, gt) + MSE(rgb_fine, gt), mean over all B * 3 values each (nn.MSELoss(), solver/nerf_solver.py:48-52)
+// ------------------------------------------------------------------------------------------------
+// One workgroup per chunk (a chunk is a few thousand rays): d rgb = (2 / (3 B)) (rgb - gt) like mse_loss_backward, the sums
+// of squares in fp64, accumulated over the chunks in chunk order (deterministic).  fine == nullptr is run_fine = 0: the
+// pipeline returns `rgb` twice (models/nerf_pipeline.py:43-44), so the loss is 2 MSE(rgb) and both gradients land on rgb.
+constexpr int MSE_THREADS = 1024;
+__global__ __launch_bounds__(MSE_THREADS) void mse_grad_kernel(const float *__restrict__ rgb_c, const float *__restrict__ rgb_f,
+                                                               const float *__restrict__ gt, int64_t count, float norm,
+                                                               float *__restrict__ d_c, float *__restrict__ d_f,
+                                                               double *__restrict__ acc, int first, int last, double inv_total,
+                                                               float *__restrict__ loss_out) {
+    __shared__ double s_sum[2][MSE_THREADS / WAVE];
+    double sc = 0.0, sf = 0.0;
+    for (int64_t i = threadIdx.x; i < count; i += MSE_THREADS) {
+        const float t = gt[i];
+        const float ec = __fsub_rn(rgb_c[i], t);
+        const float gc = __fmul_rn(norm, ec);
+        sc += (double)ec * (double)ec;
+        if (rgb_f) {
+            const float ef = __fsub_rn(rgb_f[i], t);
+            d_f[i] = __fmul_rn(norm, ef);
+            d_c[i] = gc;
+            sf += (double)ef * (double)ef;
+        } else {
+            d_c[i] = __fadd_rn(gc, gc);
+        }
+    }
+    sc = wave_sum(sc);
+    sf = wave_sum(sf);
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) s_sum[0][wave] = sc, s_sum[1][wave] = sf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tc = 0.0, tf = 0.0;
+        for (int w = 0; w < MSE_THREADS / WAVE; ++w) tc += s_sum[0][w], tf += s_sum[1][w];
+        if (!rgb_f) tf = tc;
+        tc += first ? 0.0 : acc[0];
+        tf += first ? 0.0 : acc[1];
+        acc[0] = tc;
+        acc[1] = tf;
+        if (last) {
+            const float lc = (float)(tc * inv_total), lf = (float)(tf * inv_total);
+            loss_out[0] = __fadd_rn(lc, lf);
+            loss_out[1] = lc;
+            loss_out[2] = lf;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, amsgrad = False, maximize = False; solver/nerf_solver.py:11-14, 31-33)
+// ------------------------------------------------------------------------------------------------
+// The statements of torch's single-tensor update in their order, in fp32 with the Python scalars rounded to fp32 where
+// torch hands them to a kernel, and with the fused multiply-adds torch's CPU kernels (the reference's optimiser runs there)
+// contain - add(alpha), lerp_ and addcmul_ are `fmadd`s in ATen's vectorised code; established by bit comparison with
+// torch.optim.Adam on the CPU (tools/ab/adam_debug.py; tests/test_gpu_round4.py holds both moments to equality; the parameters
+// land within one unit in the last place - torch's vectorised CPU sqrt is not correctly rounded on every host, IEEE sqrt here):
+//     grad = fma(weight_decay, param, grad)                        (only if weight_decay != 0)
+//     exp_avg     = fma(1 - beta1, grad - exp_avg, exp_avg)        lerp_
+//     exp_avg_sq  = fma((1 - beta2) * grad, grad, exp_avg_sq * beta2)
+//     denom       = sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps
+//     param       = param + (-(lr / (1 - beta1^t)) * exp_avg) / denom
+// t and the two step-dependent scalars live on the device (a captured graph replays with the right values).  torch keeps one
+// step counter per parameter TENSOR (a tensor whose .grad is None is skipped and does not count): a range carries the counters
+// of its tensors, all equal on entry, all incremented here.
+constexpr int ADAM_MAX_RANGES = 32;
+struct AdamRanges {
+    int n;
+    int64_t *step[ADAM_MAX_RANGES];
+    int n_steps[ADAM_MAX_RANGES];
+};
+__global__ __launch_bounds__(64) void adam_scalars_kernel(AdamRanges R, double lr, double beta1, double beta2, float *__restrict__ scal) {
+    const int r = blockIdx.x;
+    const int64_t t = R.step[r][0] + 1;     // (read by every lane before any lane writes: one wave, in lock-step)
+    for (int i = threadIdx.x; i < R.n_steps[r]; i += 64) R.step[r][i] = t;
+    if (threadIdx.x == 0) {
+        const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+        scal[2 * r + 0] = (float)(-(lr / bc1));
+        scal[2 * r + 1] = (float)sqrt(bc2);
+    }
+}
+
+constexpr int ADAM_MAX_NETS = 8;
+struct AdamNet {
+    int64_t begin, end;          // this net's kernel-ordered parameters inside the flat buffer
+    float *packed, *packed_t;    // fp32 streams refreshed in place (nullable)
+    const int32_t *slot_fwd, *slot_t;
+};
+struct AdamArgs {
+    float *p;
+    const float *g;
+    float *m, *v;
+    const float *scal;
+    float w1, beta2, w2, eps, wd;
+    int n_nets;
+    AdamNet net[ADAM_MAX_NETS];
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs A, int64_t begin, int64_t end, int range) {
+    const int64_t i = begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= end) return;
+    const float neg_step = A.scal[2 * range], bc2_sqrt = A.scal[2 * range + 1];
+    float p = A.p[i], g = A.g[i];
+    if (A.wd != 0.f) g = __fmaf_rn(A.wd, p, g);
+    float m = A.m[i], v = A.v[i];
+    m = __fmaf_rn(A.w1, __fsub_rn(g, m), m);
+    v = __fmaf_rn(__fmul_rn(A.w2, g), g, __fmul_rn(v, A.beta2));
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), A.eps);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(neg_step, m), denom));
+    A.m[i] = m;
+    A.v[i] = v;
+    A.p[i] = p;
+#pragma unroll
+    for (int k = 0; k < ADAM_MAX_NETS; ++k) {
+        if (k >= A.n_nets) break;
+        const AdamNet &N = A.net[k];
+        if (i >= N.begin && i < N.end) {
+            const int64_t j = i - N.begin;
+            if (N.packed) {
+                const int s = N.slot_fwd[j];
+                if (s >= 0) N.packed[s] = p;
+            }
+            if (N.packed_t) {
+                const int s = N.slot_t[j];
+                if (s >= 0) N.packed_t[s] = p;
+            }
+        }
+    }
+}
+
+static bool split_code(int precision) { return precision == 2 || precision == 3 || precision == SNERF_SPLIT_F16X3; }
+
+}  // namespace snerf
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, snerf_stream_t stream) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "mlp_stream_slots: desc is null");
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_stream_slots: %s", why);
+    hipStream_t s = (hipStream_t)stream;
+    if (slot_fwd) {
+        if (hipMemsetAsync(slot_fwd, 0xff, (size_t)P.param_floats * sizeof(int32_t), s) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "mlp_stream_slots: memset failed");
+        hipLaunchKernelGGL(fwd_slot_table_kernel, dim3(P.total_slabs), dim3(256), 0, s, P, slot_fwd);
+        if (int rc = check_launch("mlp_stream_slots(fwd)")) return rc;
+    }
+    if (slot_t) {
+        BwdPlan B;
+        make_bwd_plan(P, B, false);
+        if (hipMemsetAsync(slot_t, 0xff, (size_t)P.param_floats * sizeof(int32_t), s) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "mlp_stream_slots: memset failed");
+        hipLaunchKernelGGL(bwd_slot_table_kernel, dim3(B.total_slabs), dim3(256), 0, s, P, B, slot_t);
+        if (int rc = check_launch("mlp_stream_slots(t)")) return rc;
+    }
+    return SNERF_OK;
+}
+
+extern "C" int snerf_adam_step_f32(const snerf_adam_state *st, const snerf_adam_range *ranges_host, int n_ranges,
+                                   const snerf_adam_net *nets_host, int n_nets, snerf_stream_t stream) {
+    using namespace snerf;
+    if (!st || !st->params || !st->grads || !st->exp_avg || !st->exp_avg_sq || !st->scratch)
+        return fail(SNERF_E_BADARG, "adam_step: null pointer in the optimiser state");
+    if (st->n_params < 0 || n_ranges < 0 || n_ranges > ADAM_MAX_RANGES || n_nets < 0 || n_nets > ADAM_MAX_NETS)
+        return fail(SNERF_E_BADARG, "adam_step: bad n_params / n_ranges / n_nets (at most %d ranges, %d nets)", ADAM_MAX_RANGES,
+                    ADAM_MAX_NETS);
+    if ((n_ranges && !ranges_host) || (n_nets && !nets_host)) return fail(SNERF_E_BADARG, "adam_step: null range / net array");
+    if (n_ranges == 0) return SNERF_OK;
+    AdamRanges R{};
+    R.n = n_ranges;
+    for (int r = 0; r < n_ranges; ++r) {
+        const snerf_adam_range &g = ranges_host[r];
+        if (g.begin < 0 || g.end > st->n_params || g.begin > g.end || !g.step || g.n_steps < 1)
+            return fail(SNERF_E_BADARG, "adam_step: range %d: outside the parameter buffer, or no step counters", r);
+        R.step[r] = g.step;
+        R.n_steps[r] = g.n_steps;
+    }
+    if (!(st->lr >= 0.0) || !(st->eps >= 0.0) || !(st->beta1 >= 0.0 && st->beta1 < 1.0) || !(st->beta2 >= 0.0 && st->beta2 < 1.0) ||
+        !(st->weight_decay >= 0.0))
+        return fail(SNERF_E_BADARG, "adam_step: invalid hyper-parameters (torch.optim.Adam's own checks)");
+    hipStream_t s = (hipStream_t)stream;
+    AdamArgs A{};
+    A.p = st->params;
+    A.g = st->grads;
+    A.m = st->exp_avg;
+    A.v = st->exp_avg_sq;
+    A.scal = st->scratch;
+    A.w1 = (float)(1.0 - st->beta1);
+    A.beta2 = (float)st->beta2;
+    A.w2 = (float)(1.0 - st->beta2);
+    A.eps = (float)st->eps;
+    A.wd = (float)st->weight_decay;
+    Plan P;
+    const char *why;
+    for (int k = 0; k < n_nets; ++k) {
+        const snerf_adam_net &N = nets_host[k];
+        if (!N.desc || make_plan(*N.desc, P, why) != 0) return fail(SNERF_E_BADARG, "adam_step: net %d has a bad descriptor", k);
+        if (N.param_offset < 0 || N.param_offset + P.param_floats > st->n_params)
+            return fail(SNERF_E_BADARG, "adam_step: net %d does not lie inside the flat parameter buffer", k);
+        if (N.precision != 0 && !split_code(N.precision)) return fail(SNERF_E_BADARG, "adam_step: net %d: bad precision code", k);
+        AdamNet &D = A.net[A.n_nets];
+        D.begin = N.param_offset;
+        D.end = N.param_offset + P.param_floats;
+        if (N.precision == 0) {   // fp32 streams: refreshed in place by the update kernel
+            D.packed = reinterpret_cast<float *>(N.packed);
+            D.packed_t = reinterpret_cast<float *>(N.packed_t);
+            D.slot_fwd = N.slot_fwd;
+            D.slot_t = N.slot_t;
+            if ((D.packed && !D.slot_fwd) || (D.packed_t && !D.slot_t))
+                return fail(SNERF_E_BADARG, "adam_step: net %d: an fp32 stream needs its slot table (snerf_mlp_stream_slots)", k);
+            if (D.packed || D.packed_t) ++A.n_nets;
+        }
+    }
+    hipLaunchKernelGGL(adam_scalars_kernel, dim3(n_ranges), dim3(64), 0, s, R, st->lr, st->beta1, st->beta2, st->scratch);
+    if (int rc = check_launch("adam_step(scalars)")) return rc;
+    for (int r = 0; r < n_ranges; ++r) {
+        const int64_t b = ranges_host[r].begin, e = ranges_host[r].end;
+        if (b == e) continue;
+        const int64_t grid = (e - b + 255) / 256;
+        if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "adam_step: range too large");
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, s, A, b, e, r);
+        if (int rc = check_launch("adam_step")) return rc;
+    }
+    // split-precision streams hold pre-split parts (and, f16x3, per-layer scales): re-packed from the new parameters
+    for (int k = 0; k < n_nets; ++k) {
+        const snerf_adam_net &N = nets_host[k];
+        if (N.precision == 0) continue;
+        const float *pf = st->params + N.param_offset;
+        int rc;
+        if (N.packed && (rc = snerf_mlp_pack_bf16(N.desc, pf, N.packed, N.precision, stream))) return rc;
+        if (N.packed_t && (rc = snerf_mlp_pack_t_bf16(N.desc, pf, N.packed_t, N.precision, 0, stream))) return rc;
+    }
+    return SNERF_OK;
+}
+
+namespace snerf {
+
+struct TrainWs {
+    int64_t raw_c, weights_c, z_fine, pts_f, raw_f, d_rgb_c, d_rgb_f, d_raw, act_c, act_f, dy, gpart, loss_acc, total;
+};
+
+static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t chunk, int Nc, int Nf, TrainWs &w) {
+    const int64_t N = Nc + Nf;
+    int64_t act_c = 0, dy_c = 0, gp_c = 0, act_f = 0, dy_f = 0, gp_f = 0;
+    int rc;
+    if ((rc = snerf_mlp_train_sizes(dc, chunk * Nc, &act_c, &dy_c, nullptr, &gp_c, nullptr))) return rc;
+    if (Nf > 0 && (rc = snerf_mlp_train_sizes(df, chunk * N, &act_f, &dy_f, nullptr, &gp_f, nullptr))) return rc;
+    int64_t off = 0;
+    auto take = [&](int64_t floats) {
+        const int64_t o = off;
+        off += align256(floats * 4);
+        return o;
+    };
+    w.raw_c = take(chunk * Nc * 4);
+    w.weights_c = take(chunk * Nc);
+    w.z_fine = take(Nf > 0 ? chunk * N : 0);
+    w.pts_f = take(Nf > 0 ? chunk * N * 3 : 0);
+    w.raw_f = take(Nf > 0 ? chunk * N * 4 : 0);
+    w.d_rgb_c = take(chunk * 3);
+    w.d_rgb_f = take(chunk * 3);
+    w.d_raw = take(chunk * N * 4);
+    w.act_c = take(act_c);
+    w.act_f = take(act_f);
+    w.dy = take(dy_c > dy_f ? dy_c : dy_f);
+    w.gpart = take(gp_c > gp_f ? gp_c : gp_f);
+    w.loss_acc = take(4);
+    w.total = off;
+    return SNERF_OK;
+}
+
+static int64_t effective_chunk(int64_t B, int64_t rays_per_chunk) {
+    if (rays_per_chunk <= 0 || rays_per_chunk > B) return B > 0 ? B : 1;
+    return rays_per_chunk;
+}
+
+}  // namespace snerf
+
+extern "C" int64_t snerf_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B,
+                                                    int Nc, int Nf, int64_t rays_per_chunk) {
+    using namespace snerf;
+    if (!desc_coarse || B < 0 || Nc < 1 || Nf < 0 || (Nf > 0 && !desc_fine))
+        return fail(SNERF_E_BADARG, "nerf_train_workspace_bytes: bad arguments");
+    TrainWs w{};
+    if (int rc = train_ws(desc_coarse, desc_fine, effective_chunk(B, rays_per_chunk), Nc, Nf, w)) return rc;
+    return w.total;
+}
+
+extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                          const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                          int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                          float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                          snerf_stream_t stream) {
+    using namespace snerf;
+    if (precision != 0 && !split_code(precision))
+        return fail(SNERF_E_BADARG, "nerf_train_grads: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
+    if (!batch) return fail(SNERF_E_BADARG, "nerf_train_grads: batch is null");
+    const int64_t B = batch->B;
+    const int Nc = batch->Nc, Nf = batch->Nf, N = Nc + Nf;
+    if (B < 1 || Nc < 1 || Nf < 0) return fail(SNERF_E_BADARG, "nerf_train_grads: need B >= 1, Nc >= 1, Nf >= 0");
+    if (!desc_coarse || !packed_coarse || !packed_t_coarse || !batch->ray_samples || !batch->rays_d || !batch->z_vals ||
+        !batch->rgb_truth || !workspace || !grad_coarse || !loss || !rgb || !rgb_fine)
+        return fail(SNERF_E_BADARG, "nerf_train_grads: null pointer");
+    if (Nf > 0 && (!desc_fine || !packed_fine || !packed_t_fine || !grad_fine || !batch->rays_o || !batch->u))
+        return fail(SNERF_E_BADARG, "nerf_train_grads: the fine pass needs desc_fine, its streams, grad_fine, rays_o and u");
+    if (desc_coarse->add_dim || (Nf > 0 && desc_fine->add_dim))
+        return fail(SNERF_E_BADARG, "nerf_train_grads: nets with additional inputs train through snerf_mlp_fwd_train_* / snerf_mlp_bwd_*");
+    if (!aligned(workspace, 256)) return fail(SNERF_E_ALIGN, "nerf_train_grads: workspace must be 256-byte aligned");
+    if (precision != 0 && (desc_coarse->width != 256 || (Nf > 0 && desc_fine->width != 256)))
+        return fail(SNERF_E_BADARG, "nerf_train_grads: the split-precision kernels exist for width 256");
+    const int64_t chunk = effective_chunk(B, rays_per_chunk);
+    TrainWs w{};
+    int rc;
+    if ((rc = train_ws(desc_coarse, desc_fine, chunk, Nc, Nf, w))) return rc;
+    char *ws = reinterpret_cast<char *>(workspace);
+    auto f = [&](int64_t off) { return reinterpret_cast<float *>(ws + off); };
+    float *raw_c = f(w.raw_c), *weights_c = f(w.weights_c), *z_fine = f(w.z_fine), *pts_f = f(w.pts_f), *raw_f = f(w.raw_f);
+    float *d_rgb_c = f(w.d_rgb_c), *d_rgb_f = f(w.d_rgb_f), *d_raw = f(w.d_raw), *act_c = f(w.act_c), *act_f = f(w.act_f);
+    float *dy = f(w.dy), *gpart = f(w.gpart);
+    double *loss_acc = reinterpret_cast<double *>(ws + w.loss_acc);
+    hipStream_t s = (hipStream_t)stream;
+    const int wb = batch->white_background ? 1 : 0;
+    const float norm = (float)(2.0 / (3.0 * (double)B));      // mse_loss_backward: 2 / numel
+    const double inv_total = 1.0 / (3.0 * (double)B);
+    auto fwd_train = [&](const snerf_mlp_desc *d, const void *packed, const float *x, const float *dirs, int64_t n, int spr,
+                         float *raw, float *act) {
+        if (precision == 0)
+            return snerf_mlp_fwd_train_f32(d, reinterpret_cast<const float *>(packed), x, dirs, 0, nullptr, n, spr, raw, act, stream);
+        return snerf_mlp_fwd_train_bf16_f32(d, packed, precision, x, dirs, 0, nullptr, n, spr, raw, act, stream);
+    };
+    auto bwd = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, int64_t n, float *grad, bool accumulate) {
+        if (precision == 0)
+            return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw, n, dy, gpart, grad, nullptr, nullptr, 0, 1,
+                              nullptr, nullptr, stream, accumulate);
+        return launch_bwd_bf16(d, packed_t, precision, act, d_raw, n, dy, gpart, grad, nullptr, nullptr, 0, 1, nullptr, nullptr,
+                               stream, accumulate);
+    };
+    for (int64_t r0 = 0; r0 < B; r0 += chunk) {
+        const int64_t b = (B - r0 < chunk) ? B - r0 : chunk;
+        const float *x = batch->ray_samples + r0 * Nc * 3, *d = batch->rays_d + r0 * 3, *z = batch->z_vals + r0 * Nc;
+        const float *gt = batch->rgb_truth + r0 * 3;
+        const float *nz_c = batch->noise_coarse ? batch->noise_coarse + r0 * Nc : nullptr;
+        const float *nz_f = batch->noise_fine ? batch->noise_fine + r0 * N : nullptr;
+        float *rgb_c = rgb + r0 * 3, *rgb_fo = rgb_fine + r0 * 3;
+        // forward (models/nerf_pipeline.py:29-65) with every layer input saved
+        if ((rc = fwd_train(desc_coarse, packed_coarse, x, d, b * Nc, Nc, raw_c, act_c))) return rc;
+        if ((rc = snerf_composite_fwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, rgb_c, Nf > 0 ? weights_c : nullptr, nullptr, stream))) return rc;
+        if (Nf > 0) {
+            if ((rc = snerf_sample_pdf_f32(z, weights_c, batch->u, batch->rays_o + r0 * 3, d, b, Nc, Nf, nullptr, nullptr, z_fine,
+                                           pts_f, stream)))
+                return rc;
+            if ((rc = fwd_train(desc_fine, packed_fine, pts_f, d, b * N, N, raw_f, act_f))) return rc;
+            if ((rc = snerf_composite_fwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, rgb_fo, nullptr, nullptr, stream))) return rc;
+        }
+        // loss value and d loss / d rgb (solver/nerf_solver.py:48-52, 85-86)
+        hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(MSE_THREADS), 0, s, rgb_c, Nf > 0 ? rgb_fo : nullptr, gt, b * 3, norm,
+                           d_rgb_c, d_rgb_f, loss_acc, r0 == 0 ? 1 : 0, r0 + b >= B ? 1 : 0, inv_total, loss);
+        if ((rc = check_launch("nerf_train_grads(mse)"))) return rc;
+        // backward: compositing, then dgrad + wgrad + reduce of each net (the hierarchical samples are detached, utils.py:260)
+        if (Nf > 0) {
+            if ((rc = snerf_composite_bwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, d_rgb_f, d_raw, nullptr, stream))) return rc;
+            if ((rc = bwd(desc_fine, packed_t_fine, act_f, b * N, grad_fine, r0 > 0))) return rc;
+        }
+        if ((rc = snerf_composite_bwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, d_rgb_c, d_raw, nullptr, stream))) return rc;
+        if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, b * Nc, grad_coarse, r0 > 0))) return rc;
+    }
+    if (Nf == 0 && rgb_fine != rgb &&
+        hipMemcpyAsync(rgb_fine, rgb, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail(SNERF_E_LAUNCH, "nerf_train_grads: device copy failed");
+    return SNERF_OK;
+}
+
+extern "C" int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                         const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                         int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                         float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                         const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
+                                         const snerf_adam_net *nets_host, int n_nets, snerf_stream_t stream) {
+    int rc = snerf_nerf_train_grads_f32(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision,
+                                        batch, rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream);
+    if (rc) return rc;
+    return snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream);
+}

@@ -51,6 +51,11 @@ class RayGenerator:
         from . import dist as sdist
         if world is None:
             world, rank = sdist.world_rank()
+        if len(poses) < world:
+            # checked on EVERY rank: a rank with an empty shard would draw nothing while the others enter the step's
+            # all-reduce, and the job would hang
+            raise ValueError(f"RayGenerator.for_rank: {len(poses)} frames cannot be sharded by image over {world} ranks "
+                             "(every rank needs at least one frame)")
         ids = sdist.shard_frame_indices(len(poses), world, rank)
         poses = np.asarray(poses, np.float64).reshape(-1, 4, 4)[ids]
         if images is not None:

@@ -10,14 +10,21 @@
 Every rank holds a replica of the weights and draws its own rays (rays are independent); the loss of
 the global batch is the mean of the per-rank losses, so averaging the gradients reproduces the
 single-process gradient of the concatenated batch.
+
+On the GPU the whole body above is ONE call into the HIP library for a plain NerfPipeline
+(snerf_nerf_train_step_f32; with more than one rank its two halves, snerf_nerf_train_grads_f32 and
+snerf_adam_step_f32, around the all-reduce), and the optimiser of every pipeline is the library's Adam over the flat
+parameter buffer (HipAdam): no torch.optim, no autograd graph, no re-pack of the weight streams.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import time
 
 import torch
 
+from . import _lib
 from . import dist as sdist
 from . import io as sio
 
@@ -55,10 +62,139 @@ def flatten_parameters_(models):
     return flat, torch.zeros_like(flat), segments, order
 
 
+class HipAdam:
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) (solver/nerf_solver.py:11-14, 31-33) over the trainer's flat
+    parameter / gradient buffers, the update being ONE launch of the library's Adam kernel (snerf_adam_step_f32: the
+    statements of torch's single-tensor update in their order).  Same surface as the torch optimiser where the trainer and
+    checkpoints touch it: param_groups (hyper-parameters are read at every step), zero_grad, step, state_dict /
+    load_state_dict in torch.optim.Adam's own format (a checkpoint moves between the two).  Like torch, a parameter whose
+    .grad is None is skipped and its step counter does not advance (one device counter per parameter tensor)."""
+
+    def __init__(self, params, flat_p, flat_g, views, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params, self.flat_p, self.flat_g, self.views = list(params), flat_p, flat_g, views
+        dev = flat_p.device
+        self.exp_avg = torch.zeros_like(flat_p)
+        self.exp_avg_sq = torch.zeros_like(flat_p)
+        self.steps = torch.zeros(len(self.params), dtype=torch.int64, device=dev)     # torch: state[p]["step"]
+        self._host_steps = [0] * len(self.params)      # mirror of `steps` (grouping only; the device counters are what the kernel reads)
+        self.scratch = torch.zeros(64, dtype=torch.float32, device=dev)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.offsets.append(off)
+        self.param_groups = [{"params": self.params, "lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
+                              "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                              "differentiable": False, "fused": None, "decoupled_weight_decay": False}]
+        self._range_cache = (None, None, 0)
+
+    # -- C structures -------------------------------------------------------------------------------------------
+    def c_state(self):
+        g = self.param_groups[0]
+        return _lib.AdamState(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                              self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self.scratch.data_ptr(), float(g["lr"]),
+                              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+
+    def c_ranges(self, has_grad):
+        """(snerf_adam_range array, count) for the parameters flagged in `has_grad` (one bool per parameter tensor): runs
+        of adjacent tensors with equal step counts.  Advances the host mirror of the counters."""
+        hs = self._host_steps
+        key = (tuple(has_grad), tuple(hs[i] == hs[i - 1] for i in range(1, len(hs))))
+        if self._range_cache[0] != key:
+            runs, i, n = [], 0, len(self.params)
+            while i < n:
+                if not has_grad[i]:
+                    i += 1
+                    continue
+                j = i
+                while j + 1 < n and has_grad[j + 1] and self._host_steps[j + 1] == self._host_steps[i]:
+                    j += 1
+                runs.append((i, j + 1))
+                i = j + 1
+            if len(runs) > 32:
+                raise RuntimeError("HipAdam: more than 32 runs of parameters with different gradient / step patterns")
+            arr = (_lib.AdamRange * max(len(runs), 1))()
+            for k, (a, b) in enumerate(runs):
+                arr[k] = _lib.AdamRange(self.offsets[a], self.offsets[b], self.steps.data_ptr() + 8 * a, b - a)
+            self._range_cache = (key, arr, len(runs))
+        for i, h in enumerate(has_grad):
+            if h:
+                self._host_steps[i] += 1
+        return self._range_cache[1], self._range_cache[2]
+
+    # -- torch.optim.Optimizer surface -------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def bind_gradients(self):
+        """Every gradient into its slot of the flat buffer (the backward kernels wrote most of them there already: the grad
+        sinks); afterwards p.grad is that view.  Returns the has-grad flags."""
+        flags = []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            flags.append(g is not None)
+            if g is not None and g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+                p.grad = v
+        return flags
+
+    @torch.no_grad()
+    def step(self, nets=None, n_nets=0):
+        """One update from the gradients in p.grad.  nets: optional snerf_adam_net array (weight streams to keep current)."""
+        ranges, n = self.c_ranges(self.bind_gradients())
+        if n == 0:
+            return
+        st = self.c_state()
+        lib = _lib.load()
+        with torch.cuda.device(self.flat_p.device):
+            _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, n, nets, n_nets, _lib.current_stream()),
+                       "snerf_adam_step_f32")
+
+    def state_dict(self):
+        """torch.optim.Adam.state_dict()'s format (loads into a torch.optim.Adam over the same parameter list)."""
+        steps = self.steps.cpu().tolist()
+        self._host_steps = list(steps)
+        state = {}
+        for i, t in enumerate(steps):
+            if t > 0:
+                a, b = self.offsets[i], self.offsets[i + 1]
+                shp = self.params[i].shape
+                state[i] = {"step": torch.tensor(float(t)), "exp_avg": self.exp_avg[a:b].view(shp).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[a:b].view(shp).clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.params):
+            raise ValueError("HipAdam.load_state_dict: the checkpoint has a different number of parameters")
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            self.param_groups[0][k] = tuple(group[k]) if k == "betas" else group[k]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = [0] * len(self.params)
+        for i, st in sd["state"].items():
+            i = int(i)
+            a, b = self.offsets[i], self.offsets[i + 1]
+            self.exp_avg[a:b].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[a:b].copy_(st["exp_avg_sq"].reshape(-1))
+            steps[i] = int(round(float(st["step"])))
+        self._host_steps = steps
+        self.steps.copy_(torch.tensor(steps, dtype=torch.int64))
+        self._range_cache = (None, None, 0)
+
+
 class DataParallelTrainer:
     default_adam_args = {"lr": 1e-4, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0}  # nerf_solver.py:11-14
 
-    def __init__(self, pipeline, models, lr: float = 5e-4, weight_decay: float = 0.0, loss_func=None, fused=None):
+    def __init__(self, pipeline, models, lr: float = 5e-4, weight_decay: float = 0.0, loss_func=None, fused=None,
+                 one_call=None):
         self.pipeline = pipeline
         self.models = list(models)
         self.world, self.rank = sdist.world_rank()
@@ -88,10 +224,28 @@ class DataParallelTrainer:
                     m.mark_weights_changed()
         args = dict(self.default_adam_args)
         args.update({"lr": lr, "weight_decay": weight_decay})
+        # optimiser: the library's Adam over the flat buffer wherever the parameters live on the GPU (`fused` None or
+        # "hip"); fused = True / False select torch.optim.Adam(fused=True) / the unfused torch optimiser (CPU tests, A/B runs)
+        on_gpu = self._flat_p is not None and self._flat_p.is_cuda
         if fused is None:
-            fused = all(p.is_cuda for p in self.params)
-        self.optim = torch.optim.Adam(self.params, fused=fused, **args) if fused else torch.optim.Adam(self.params, **args)
+            fused = "hip" if on_gpu else False
+        if fused == "hip":
+            if not on_gpu:
+                raise RuntimeError("DataParallelTrainer: the HIP optimiser needs fp32 parameters on one GPU")
+            self.optim = HipAdam(self.params, self._flat_p, self._flat_g, self._views, **args)
+        elif fused:
+            self.optim = torch.optim.Adam(self.params, fused=True, **args)
+        else:
+            self.optim = torch.optim.Adam(self.params, **args)
         self.loss_func = loss_func or torch.nn.MSELoss()
+        # the one-call training step (snerf_nerf_train_step_f32): None = wherever it applies (a plain NerfPipeline trained
+        # with the default loss through HipAdam), False = always the autograd path
+        self.one_call = one_call
+        # rays per chunk of the one-call step: the saved activations are sized by the chunk, not by the batch (include/smplnerf.h)
+        self.rays_per_chunk = int(os.environ.get("SNERF_TRAIN_CHUNK_RAYS", "2048"))
+        self._oc = None            # state of the one-call path (descriptors, slot tables, workspace)
+        self.last_outputs = None   # (rgb, rgb_fine) of the last one-call step
+        self.timing = None         # optional dict: HIP-event pairs around the gradient all-reduce (bench.py)
 
     def loss(self, rgb, rgb_fine, rgb_truth):
         return self.loss_func(rgb, rgb_truth) + self.loss_func(rgb_fine, rgb_truth)  # nerf_solver.py:48-52
@@ -127,14 +281,154 @@ class DataParallelTrainer:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
-        sdist.allreduce_mean_(self._flat_g)
+        self._allreduce_flat()
         for p, v in zip(self.params, self._views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v
 
+    def _allreduce_flat(self):
+        """The one collective of a step, optionally between two HIP events (bench.py reads self.timing)."""
+        if self.timing is not None and self._flat_g.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sdist.allreduce_mean_(self._flat_g)
+            e1.record()
+            self.timing.setdefault("allreduce_events", []).append((e0, e1))
+        else:
+            sdist.allreduce_mean_(self._flat_g)
+
+    # ------------------------------------------------------------------ the one-call step
+    def _one_call_state(self):
+        """Descriptors, segment offsets and slot tables of the one-call path, or None when it does not apply: a plain
+        NerfPipeline over two RenderRayNets (no additional inputs) that are exactly this trainer's models, the default
+        MSE loss, the library's optimiser, every parameter trainable."""
+        if self._oc is not None:
+            return self._oc or None
+        from .nets import RenderRayNet
+        from .pipelines import NerfPipeline
+        self._oc = False
+        pipe = self.pipeline
+        if self.one_call is False or type(pipe) is not NerfPipeline or not isinstance(self.optim, HipAdam):
+            return None
+        mc, mf = pipe.model_coarse, pipe.model_fine
+        if type(mc) is not RenderRayNet or type(mf) is not RenderRayNet or mc is mf:
+            return None
+        if len(self.models) != 2 or {id(m) for m in self.models} != {id(mc), id(mf)}:
+            return None
+        if type(self).loss is not DataParallelTrainer.loss or type(self.loss_func) is not torch.nn.MSELoss or \
+                self.loss_func.reduction != "mean":
+            return None
+        if mc.additional_input_dim or mf.additional_input_dim or not all(p.requires_grad for p in self.params):
+            return None
+        seg = {id(m): (off, n) for m, off, n in self._segments}
+        if id(mc) not in seg or id(mf) not in seg:
+            return None
+        lib = _lib.load()
+        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib}
+        # parameter tensors of each net (indices into self.params): the optimiser's has-grad flags of a step
+        index = {id(p): i for i, p in enumerate(self.params)}
+        oc["tensors"] = tuple(frozenset(index[id(p)] for p in m._ordered_params()) for m in (mc, mf))
+        self._oc = oc
+        return oc
+
+    def _slot_tables(self, oc, net, desc):
+        key = (id(net), net._desc_key(desc))
+        hit = oc["slots"].get(key)
+        if hit is None:
+            n = int(oc["lib"].snerf_mlp_param_floats(desc))
+            dev = self._flat_p.device
+            hit = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+            with torch.cuda.device(dev):
+                _lib.check(oc["lib"].snerf_mlp_stream_slots(desc, hit[0].data_ptr(), hit[1].data_ptr(), _lib.current_stream()),
+                           "snerf_mlp_stream_slots")
+            oc["slots"][key] = hit
+        return hit
+
+    @torch.no_grad()
+    def _step_one_call(self, oc, batch):
+        from . import ops
+        from .nets import _split_code
+        lib = oc["lib"]
+        pipe, args = self.pipeline, self.pipeline.args
+        ray_samples, rays_o, rays_d, z_vals, rgb_truth = (t.contiguous() for t in batch)
+        dev = self._flat_p.device
+        B, Nc = z_vals.shape
+        Nf = int(args.number_fine_samples) if args.run_fine else 0
+        mc, mf = oc["nets"]
+        ns = _split_code(mc, 0)
+        if Nf and _split_code(mf, 0) != ns:
+            raise RuntimeError("DataParallelTrainer: both nets must use the same precision mode")
+        descs, packed, packed_t, nets_c = [], [], [], (_lib.AdamNet * 2)()
+        for k, m in enumerate((mc, mf)):
+            d = m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder, False)
+            descs.append(d)
+            if k == 1 and not Nf:          # run_fine = 0: the fine net takes no part (models/nerf_pipeline.py:43-44)
+                packed.append(None), packed_t.append(None)
+                continue
+            if ns:
+                packed.append(m.packed_weights_bf16(d, ns, training=True))
+                packed_t.append(m.packed_weights_t_bf16(d, ns, False))
+                sf = st = None
+            else:
+                packed.append(m.packed_weights(d, training=True))
+                packed_t.append(m.packed_weights_t(d, False))
+                sf, st = self._slot_tables(oc, m, d)
+            nets_c[k] = _lib.AdamNet(ctypes.pointer(d), oc["seg"][k][0], ns, packed[k].data_ptr(), packed_t[k].data_ptr(),
+                                     _lib.ptr(sf), _lib.ptr(st))
+        n_nets = 2 if Nf else 1
+        need = int(lib.snerf_nerf_train_workspace_bytes(descs[0], descs[1] if Nf else None, B, Nc, Nf, self.rays_per_chunk))
+        if need < 0:
+            _lib.check(need, "snerf_nerf_train_workspace_bytes")
+        if oc["ws"] is None or oc["ws"].numel() < need:
+            oc["ws"] = None
+            oc["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(4 + 6 * B, dtype=torch.float32, device=dev)
+        loss, rgb, rgb_fine = out[:3], out[4:4 + 3 * B].view(B, 3), out[4 + 3 * B:].view(B, 3)
+        u = ops.uniform_u(Nf, dev) if Nf else None
+        nz_c = pipe._noise((B, Nc), dev)
+        nz_f = pipe._noise((B, Nc + Nf), dev) if Nf else None
+        cb = _lib.NerfBatch(ray_samples.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(),
+                            rgb_truth.data_ptr(), _lib.ptr(u), _lib.ptr(nz_c), _lib.ptr(nz_f), B, Nc, Nf,
+                            1 if args.white_background else 0)
+        (oc_off, oc_n), (of_off, of_n) = oc["seg"]
+        g_c = self._flat_g.data_ptr() + 4 * oc_off
+        g_f = self._flat_g.data_ptr() + 4 * of_off
+        head = (descs[0], packed[0].data_ptr(), packed_t[0].data_ptr(), descs[1] if Nf else None, _lib.ptr(packed[1]),
+                _lib.ptr(packed_t[1]), ns, ctypes.byref(cb), self.rays_per_chunk, oc["ws"].data_ptr(), g_c, g_f if Nf else None,
+                loss.data_ptr(), rgb.data_ptr(), rgb_fine.data_ptr())
+        opt = self.optim
+        live = oc["tensors"][0] | (oc["tensors"][1] if Nf or self.world > 1 else frozenset())
+        flags = [i in live for i in range(len(self.params))]
+        with torch.cuda.device(dev), _lib.timed(f"train_step[B={B}]"):
+            if self.world == 1:
+                ranges, nr = opt.c_ranges(flags)
+                st = opt.c_state()
+                _lib.check(lib.snerf_nerf_train_step_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets,
+                                                         _lib.current_stream()), "snerf_nerf_train_step_f32")
+            else:
+                _lib.check(lib.snerf_nerf_train_grads_f32(*head, _lib.current_stream()), "snerf_nerf_train_grads_f32")
+                if not Nf:      # every rank contributes the same shape: zeros for the net that took no part
+                    self._flat_g[of_off:of_off + of_n].zero_()
+                self._allreduce_flat()
+                ranges, nr = opt.c_ranges(flags)
+                st = opt.c_state()
+                _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, nr, nets_c, n_nets, _lib.current_stream()),
+                           "snerf_adam_step_f32")
+        # p.grad = what autograd would have left: views of the flat gradient buffer (None for a net that took no part)
+        for i, (p, v) in enumerate(zip(self.params, self._views)):
+            want = v if flags[i] else None
+            if p.grad is not want:
+                p.grad = want
+        self.last_outputs = (rgb, rgb_fine)
+        return loss[0]
+
     def step(self, batch):
         """One optimisation step on this rank's batch (list of tensors, rgb_truth last). Returns the
         local loss tensor (not synchronised with the host)."""
+        oc = self._one_call_state()
+        if oc is not None and len(batch) == 5 and all(t.is_cuda and t.dtype == torch.float32 for t in batch) and \
+                not getattr(self.pipeline.args, "strict_cumsum", 0):
+            return self._step_one_call(oc, batch)
         self.optim.zero_grad(set_to_none=True)
         self._arm_grad_sinks()
         out = self.pipeline(batch)
@@ -142,7 +436,7 @@ class DataParallelTrainer:
         loss.backward()
         self.sync_gradients()
         self.optim.step()
-        # fused optimisers update the parameters without bumping autograd's version counters, which the nets' packed
+        # the optimisers update the parameters without bumping autograd's version counters, which the nets' packed
         # weight caches key on: tell them
         for m in self.models:
             if hasattr(m, "mark_weights_changed"):
@@ -231,13 +525,24 @@ class DataParallelTrainer:
 
 class RayBatchLoader:
     """The shuffled DataLoader over RaysFromImagesDataset (train.py:96-100) with the rays generated on the device
-    (raygen.RayGenerator): `iterations` batches of `batch_size` uniformly drawn rays per epoch; each rank draws from its
-    own generator seed (base + rank).  Data-parallel runs shard the data set BY IMAGE (1200 images -> 150 per
-    GPU): build this rank's generator with RayGenerator.for_rank(...), which keeps only frames rank, rank + world, ...
-    on the device - the union over ranks covers every frame exactly once and no image is replicated."""
+    (raygen.RayGenerator).  Data-parallel runs shard the data set BY IMAGE (1200 images -> 150 per GPU): build
+    this rank's generator with RayGenerator.for_rank(...), which keeps only frames rank, rank + world, ... on the
+    device - the union over ranks covers every frame exactly once and no image is replicated.  Each rank draws from its own
+    generator seed (base + rank).
 
-    def __init__(self, ray_generator, batch_size: int, iterations: int, seed: int = 0):
-        self.gen, self.batch_size, self.iterations = ray_generator, int(batch_size), int(iterations)
+    shuffle = True (the reference's loader: DataLoader(shuffle=True, drop_last=False), train.py:100): an epoch is a random
+    permutation of this rank's rays cut into batches of `batch_size` - every ray exactly once, the last batch short - with a
+    new permutation per epoch; `iterations` then caps the number of batches (None: the whole epoch).  Ranks whose shards
+    differ in size must agree on `iterations` (the gradient all-reduce of a step is collective).
+    shuffle = False: `iterations` batches of uniformly drawn rays, with replacement (no epoch structure)."""
+
+    def __init__(self, ray_generator, batch_size: int, iterations: int = None, seed: int = 0, shuffle: bool = False):
+        self.gen, self.batch_size = ray_generator, int(batch_size)
+        self.shuffle = bool(shuffle)
+        if iterations is None and not self.shuffle:
+            raise ValueError("RayBatchLoader: draws with replacement need `iterations`")
+        full = -(-ray_generator.n_rays // self.batch_size)
+        self.iterations = full if iterations is None else (min(int(iterations), full) if self.shuffle else int(iterations))
         _, rank = sdist.world_rank()
         self.rng = torch.Generator(device=ray_generator.device)
         self.rng.manual_seed(int(seed) + rank)
@@ -246,8 +551,16 @@ class RayBatchLoader:
         return self.iterations
 
     def __iter__(self):
-        for _ in range(self.iterations):
-            yield self.gen.random_batch(self.batch_size, generator=self.rng)
+        if not self.shuffle:
+            for _ in range(self.iterations):
+                yield self.gen.random_batch(self.batch_size, generator=self.rng)
+            return
+        dev = self.gen.device
+        perm = torch.randperm(self.gen.n_rays, device=dev, generator=self.rng)
+        for i in range(self.iterations):
+            idx = perm[i * self.batch_size:(i + 1) * self.batch_size]
+            jit = torch.rand((idx.shape[0],), device=dev, dtype=torch.float64, generator=self.rng)   # one scalar per ray (Q8)
+            yield self.gen.batch(idx, jit)
 
 
 class FrameLoader:
