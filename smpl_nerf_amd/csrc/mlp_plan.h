@@ -423,8 +423,14 @@ inline int bwd_total_slabs(const Plan &P, bool input_grad = false, int kw = 16) 
     make_bwd_plan(P, B, input_grad, kw);
     return B.total_slabs;
 }
-// number of K-splits (sample chunks) of the wgrad kernel for n samples
+// K-splits (sample chunks) of the wgrad kernels for n samples.  wgrad_chunks: the most any job is split into = what the
+// partial buffer is sized for (chunks of >= 128 samples, at most 128 of them); wgrad_chunks_1k: chunks of >= 1024 samples -
+// the narrow jobs' split, and the wide jobs' wherever that already fills the chip (mlp_train.hip: launch_wgrad).
 inline int wgrad_chunks(int64_t n) {
+    int64_t g = (n + 127) / 128;
+    return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
+}
+inline int wgrad_chunks_1k(int64_t n) {
     int64_t g = (n + 1023) / 1024;
     return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
 }

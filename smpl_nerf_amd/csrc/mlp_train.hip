@@ -796,7 +796,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     // chunks: at most the wgrad_chunks(n) the partial buffer is sized for; with more wide workgroups than CUs, as many as
     // fill whole rounds of the chip (9 wide jobs x 128 chunks on 256 CUs = 4.5 rounds, the last one half empty: 113
     // chunks = 3.97 rounds of 13 % longer workgroups)
-    const int G_narrow = wgrad_chunks(n);   // (the single-wave narrow jobs gain nothing from longer chunks)
+    const int G_narrow = wgrad_chunks_1k(n);   // (the narrow jobs gain nothing from other chunk lengths)
     int G = G_narrow;
     {
         const int n_cu = device_cu_count("wgrad");
@@ -806,6 +806,11 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             // (fewer whole rounds = fewer partials for the reduce: measured r03, 4 / 3 / 2 / 1 rounds -> the same step time)
             const int rounds = (int)((int64_t)jobs * G / n_cu);
             G = min(G, max(1, rounds * n_cu / jobs));
+        } else if (jobs > 0) {
+            // small calls (the README's 64-ray batches: 4096 + 12 288 samples): 1024-sample chunks would put 9 x 4 workgroups
+            // on 256 CUs - shorter chunks, one round of the chip (r04: 267 -> ~70 us per launch at 4096 samples; the reduce
+            // reads 28 partials instead of 4)
+            G = max(G, min(wgrad_chunks(n), max(1, n_cu / jobs)));
         }
     }
     WgradArgs W{};
@@ -915,23 +920,34 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     A.dir_id = desc->dir_identity ? 1 : 0;
     A.dir_nkb = P.dir_nkb;
     A.use_dir = desc->use_dir ? 1 : 0;
-    constexpr int BW = 8;  // 8 waves = 128 samples per workgroup, like the forward
-    const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
-    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
+    // 8 waves = 128 samples per workgroup, like the forward; calls of <= 64 x CUs samples (the README's 64-ray batches) run
+    // 4-wave workgroups on 64-sample tiles like the forward does (mlp.hip: launch_fwd): below one tile per CU the launch is
+    // the latency of one tile's pass through the weight stream, and a wave that has its SIMD's matrix pipe to itself
+    // passes in two thirds of the time (r04: 290 -> 190 us at 4096 samples)
+    const int n_cu = device_cu_count("mlp_bwd");
+    if (n_cu < 1) return n_cu;
+    const bool small = tuning().fwd_small_tiles && n <= (int64_t)64 * n_cu;
     const bool wide_pe = input_grad && bwd_pe_tiles(P).pos == 8;
-    if (P.width == 256) {
-        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-        else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-    } else if (P.width == 128) {
-        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-        else SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-    } else {
-        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-        else SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-    }
+    auto launch = [&](auto bw_c) -> int {
+        constexpr int BW = decltype(bw_c)::value;
+        const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
+        if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
+        if (P.width == 256) {
+            if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        } else if (P.width == 128) {
+            if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        } else {
+            if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else SNERF_LAUNCH_RING((mlp_bwd_kernel<64, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+        }
+        return SNERF_OK;
+    };
+    if (int lrc = small ? launch(std::integral_constant<int, 4>{}) : launch(std::integral_constant<int, 8>{})) return lrc;
     int rc = check_launch("mlp_bwd(dgrad)");
     if (rc) return rc;
     return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);

@@ -165,7 +165,8 @@ def test_hip_adam_follows_torch_adam(dev, wd):
     seg = flat_p[segments[0][1]:segments[0][1] + n]
     _lib.check(lib.snerf_mlp_pack_f32(desc, seg.data_ptr(), fresh.data_ptr(), s), "pack")
     _lib.check(lib.snerf_mlp_pack_t_f32(desc, seg.data_ptr(), fresh_t.data_ptr(), 0, s), "pack_t")
-    assert torch.equal(packed, fresh) and torch.equal(packed_t, fresh_t)
+    used_t = int(st.max()) + 1          # (the buffer is sized for the longer input-gradient stream: its tail is never written)
+    assert torch.equal(packed, fresh) and torch.equal(packed_t[:used_t], fresh_t[:used_t])
     # checkpoints move between the optimisers (torch's own state_dict format)
     ref2 = torch.optim.Adam([torch.nn.Parameter(q.detach().clone()) for q in ref_params], lr=1.0)
     ref2.load_state_dict(sd)
