@@ -342,10 +342,42 @@ def pmc_traffic(argv_child, kernel_substr, timeout_s=240):
 TRAIN_LR = 3e-5
 
 
-def train_section(precision, workload, data, rays, steps, world, rank, dev):
+def gather_per_rank(entry, grouped):
+    """[entry of rank 0, entry of rank 1, ...] on every rank (the record proves which ranks and devices took part)."""
+    if not grouped:
+        return [entry]
+    import torch.distributed as dist
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, entry)
+    return out
+
+
+def collective_info(backend, n_floats, what):
+    import torch.distributed as dist
+    return {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size_seen_by_backend": dist.get_world_size(),
+            "rank_seen_by_backend": dist.get_rank(), "op": what, "bytes": 4 * n_floats}
+
+
+def raygen_loader(dev, res, n_frames, batch, world, rank):
+    """SURVEY 8(f)-1 in the timed region: a multi-frame data set resident on the GPU, sharded BY IMAGE over the ranks
+    (raygen.RayGenerator.for_rank), one shuffled epoch of `batch`-ray batches per pass (trainer.RayBatchLoader(shuffle=True) =
+    DataLoader(shuffle=True), train.py:100).  Procedural images (no data set in the image)."""
+    import numpy as np
+    from smpl_nerf_amd import synthetic as syn
+    from smpl_nerf_amd.raygen import RayGenerator
+    from smpl_nerf_amd.trainer import RayBatchLoader
+    poses = np.stack([syn.sphere_pose(360.0 * i / n_frames, 20.0 * np.sin(i), 2.4) for i in range(n_frames)])
+    base = syn.procedural_image(res, res)          # one procedural frame, rolled per pose: distinct pixels per frame, cheap to build
+    images = np.stack([np.roll(base, (3 * i) % res, axis=1) for i in range(n_frames)]).astype(np.float32)
+    gen = RayGenerator.for_rank(poses, res, res, np.pi / 3, 1.0, 4.0, 64, dev, images=images, world=world, rank=rank)
+    return gen, RayBatchLoader(gen, batch, seed=4321, shuffle=True)
+
+
+def train_section(precision, workload, data, rays, steps, world, rank, dev, backend=None, loader=None):
     """Secondary measurement (not `value`): data-parallel training steps - forward with saved activations, MSE
     coarse+fine, HIP backward, one flat all-reduce of the gradients, Adam - on `rays` rays per GPU drawn from this rank's
-    frame (solver/nerf_solver.py:76-87).  Fresh nets per call (the step updates them)."""
+    frame (solver/nerf_solver.py:76-87), or, with `loader`, generated on the device per step from this rank's shard of a
+    multi-frame data set (inside the timed region).  Fresh nets per call (the step updates them)."""
     import torch
     from smpl_nerf_amd import _lib
     from smpl_nerf_amd.dist import barrier, max_over_ranks
@@ -358,32 +390,46 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev):
     # lr: small enough that both nets stay alive on this synthetic scene (at 1e-4 and above Adam's first steps push the
     # fine net's densities below zero everywhere: the rendered colour and every gradient become exactly 0, and the
     # backward kernels would be timed on all-zero operands)
-    tr = DataParallelTrainer(pipe, models, lr=TRAIN_LR)
+    tr = DataParallelTrainer(pipe, models, lr=TRAIN_LR, sync_at_world_one=backend is not None)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     n_total = data[0].shape[0]
-    batches = []
-    for _ in range(4):
-        idx = torch.randperm(n_total, generator=g)[:rays].to(dev)
-        batches.append([t[idx].contiguous() for t in data])
+    if loader is not None:
+        def endless():
+            while True:
+                for b in loader:
+                    if b[0].shape[0] == rays:      # (the short last batch of an epoch is skipped: steps of equal size)
+                        yield b
+        feed = endless()
+        next_batch = lambda i: next(feed)
+    else:
+        batches = []
+        for _ in range(4):
+            idx = torch.randperm(n_total, generator=g)[:rays].to(dev)
+            batches.append([t[idx].contiguous() for t in data])
+        next_batch = lambda i: batches[i % 4]
     losses = []
     for i in range(2):
-        losses.append(tr.step(batches[i % 4]))
+        losses.append(tr.step(next_batch(i)))
     barrier(dev)
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats(dev)
+    tr.timing = {}
     with _lib.profile() as prof:
         t0 = time.perf_counter()
         for i in range(steps):
-            losses.append(tr.step(batches[i % 4]))
+            losses.append(tr.step(next_batch(i)))
         t_host = time.perf_counter() - t0          # the Python loop returned: everything is enqueued
         torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0
         barrier(dev)
         dt = time.perf_counter() - t0
     kern = prof.summary()
     peak_mem = torch.cuda.max_memory_allocated(dev)
     dt = max_over_ranks(dt, dev)
+    ar = [e0.elapsed_time(e1) for e0, e1 in tr.timing.get("allreduce_events", [])]
+    tr.timing = None
     with torch.no_grad():   # the trained nets still render something (not collapsed to zero density)
-        fine_std = float(pipe(batches[0])[1].std())
+        fine_std = float(pipe(next_batch(0))[1].std())
     losses = [float(l) for l in losses]
     evals = world * steps * rays * 256
     mlp_ms = sum(v[1] for k, v in kern.items() if k.startswith(("mlp_bwd", "mlp_fwd_train"))) / steps
@@ -406,8 +452,20 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev):
                            if one_call else "autograd (torch.autograd.Function per kernel group) + HipAdam"),
             "rays_per_chunk": tr.rays_per_chunk if one_call else None,
             "kernels_ms_per_step": {k: v[1] / steps for k, v in sorted(kern.items())},
-            "collective": (f"one all-reduce of {sum(p.numel() for p in tr.params)} fp32 gradients per step"
-                           if world > 1 else "none (1 GPU)")}
+            "batches": ("generated on the device per step: RayBatchLoader(shuffle=True) over this rank's frames "
+                        f"({loader.gen.n_frames} of the data set's frames, {loader.gen.n_rays} rays; raygen + pixel gather inside the "
+                        "timed region)" if loader is not None else "4 resident batches drawn from this rank's frame"),
+            "raygen_ms_per_step": (kern["raygen"][1] / steps if "raygen" in kern else None),
+            "collective": (dict(collective_info(backend, sum(p.numel() for p in tr.params),
+                                                "one all-reduce (sum, then / world) of the flat fp32 gradient buffer per step"),
+                                allreduce_ms_per_step=(sum(ar) / len(ar) if ar else None), allreduce_calls=len(ar),
+                                broadcast_ms=tr.broadcast_ms,
+                                timing="HIP events on the compute stream around dist.sync (includes the / world)")
+                           if backend else "none (1 GPU, no process group)"),
+            "per_rank": gather_per_rank({"rank": rank, "device": torch.cuda.get_device_name(dev),
+                                         "arch": torch.cuda.get_device_properties(dev).gcnArchName, "device_index": dev.index,
+                                         "ms_per_step": dt_own / steps * 1e3, "value": steps * rays * 256 / dt_own,
+                                         "loss_last": losses[-1]}, backend is not None)}
 
 
 # ---------------------------------------------------------------------------------------------------- main
@@ -435,6 +493,13 @@ def main():
     ap.add_argument("--points", default="64,800,2048",
                     help="comma-separated ray counts of the extra operating points (render; training at 2048 when among them); "
                          "empty = skip")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): one frame per rank; strong: ONE frame split by rows over the ranks (dist.shard_rays), the "
+                         "rendered rows all-gathered into the frame on every rank (dist.gather_rows) inside the timed region")
+    ap.add_argument("--train-from-raygen", action="store_true",
+                    help="training steps fed by RayBatchLoader(shuffle=True) over a multi-frame RayGenerator sharded by image "
+                         "(rays generated on the device inside the timed region) instead of resident batches")
+    ap.add_argument("--raygen-frames", type=int, default=64, help="frames of the synthetic data set of --train-from-raygen")
     ap.add_argument("--no-alt", action="store_true", help="skip the other precision modes")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     a = ap.parse_args()
@@ -493,33 +558,59 @@ def main():
     add_cols = int(getattr(nets[0], "additional_input_dim", 0)) if d0 is None else int(d0.add_dim)
     n_add_layers = 1 + sum(1 for i in range(nets[0].n_layers - 1) if i in nets[0].skips)
     FOLDED_FLOP_PER_EVAL = 2 * add_cols * nets[0].width * n_add_layers if os.environ.get("SNERF_MLP_FOLD", "1") != "0" else 0
-    # each rank renders its own frame: rays of independent images shard across GPUs (weak scaling)
-    frame_id = shard_frames(world, rank)
+    # weak scaling (default): each rank renders its own frame - rays of independent images shard across GPUs.
+    # strong scaling: ONE frame, its rays split by rows over the ranks (dist.shard_rays), the rendered rows all-gathered into
+    # the whole frame on every rank (dist.gather_rows) - the only collective a cooperative render needs.
+    strong = a.scaling == "strong"
+    from smpl_nerf_amd.dist import gather_rows, shard_rays
+    frame_id = 0 if strong else shard_frames(world, rank)
     data_np = frame_inputs(a.workload, a.res, frame_id)
     if a.rays:
         if a.rays > data_np[0].shape[0]:
             raise SystemExit(f"--rays {a.rays} exceeds the {a.res}x{a.res} frame")
         data_np = [x[:a.rays] for x in data_np]
+    frame_rays = data_np[0].shape[0]
+    full_np = data_np
+    if strong:
+        data_np = shard_rays(data_np, world, rank)
     data = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in data_np]
     rays = data[0].shape[0]
     evals_per_step = rays * per_ray
+    # what the whole job processes per step: `world` frames (weak) or the one frame (strong)
+    job_evals_per_step = frame_rays * per_ray if strong else world * evals_per_step
+
+    def render_step():
+        out = pipe(data)
+        if strong:
+            return out, gather_rows(out[1], frame_rays)
+        return out, None
 
     with torch.no_grad():
         for _ in range(a.warmup):
-            out = pipe(data)
+            out, frame = render_step()
         barrier(dev)
         torch.cuda.synchronize()
         _flush_c_stdio()       # (the barrier above was the group's first collective)
         with _lib.profile() as prof:
             t0 = time.perf_counter()
             for _ in range(a.steps):
-                out = pipe(data)
+                out, frame = render_step()
             t_host = time.perf_counter() - t0      # the Python loop returned: everything is enqueued
             torch.cuda.synchronize()
+            elapsed_own = time.perf_counter() - t0
             barrier(dev)
             elapsed = time.perf_counter() - t0
         kern = prof.summary()
     elapsed = max_over_ranks(elapsed, dev)
+    per_rank = gather_per_rank({"rank": rank, "device": torch.cuda.get_device_name(dev),
+                                "arch": torch.cuda.get_device_properties(dev).gcnArchName, "device_index": dev.index,
+                                "rays_per_step": rays, "ms_per_step": elapsed_own / a.steps * 1e3,
+                                "value": a.steps * evals_per_step / elapsed_own}, grouped)
+    strong_check = None
+    if strong and rank == 0:      # the assembled frame against this rank rendering the whole frame alone (outside the timed region)
+        with torch.no_grad():
+            whole = pipe([torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in full_np])[1]
+        strong_check = float((whole - frame).abs().max())
 
     def operating_point(n, steps=20):
         """Render `n` rays per step (the first n of the frame): ms per step, host enqueue time, C-ABI calls."""
@@ -550,7 +641,7 @@ def main():
                 "ms_per_step_with_event_pairs": dt / steps * 1e3, "host_ms_with_event_pairs": th / steps * 1e3}
 
     points = None
-    if a.points and world == 1:
+    if a.points and world == 1 and not grouped:
         points = [operating_point(n) for n in sorted({int(v) for v in a.points.split(",") if v.strip()}) if n <= rays]
 
     def mlp_launch_stats(k, steps):
@@ -606,13 +697,20 @@ def main():
     train = train_alt = None
     if a.train_rays > 0 and run_fine:
         try:
-            train = train_section(a.precision, a.workload, data, min(a.train_rays, rays), a.train_steps, world, rank, dev)
+            loader = None
+            if a.train_from_raygen:
+                if a.workload != "nerf":
+                    raise SystemExit("--train-from-raygen feeds the nerf workload (five-tensor batches)")
+                _, loader = raygen_loader(dev, a.res, a.raygen_frames, min(a.train_rays, frame_rays), world, rank)
+            tb = backend if grouped else None
+            train = train_section(a.precision, a.workload, data, min(a.train_rays, frame_rays if loader else rays), a.train_steps,
+                                  world, rank, dev, tb, loader)
             if a.points and world == 1:   # the reference's own batch sizes (config_parser.py:53, README quickstart)
                 pts = []
                 for n in sorted({int(v) for v in a.points.split(",") if v.strip()}):
                     if n == min(a.train_rays, rays) or n > rays:
                         continue
-                    t = train_section(a.precision, a.workload, data, n, a.train_steps, world, rank, dev)
+                    t = train_section(a.precision, a.workload, data, n, a.train_steps, world, rank, dev, tb)
                     pts.append({k: t[k] for k in ("value", "rays_per_step_per_gpu", "ms_per_step", "host_enqueue_ms_per_step",
                                                    "c_abi_calls_per_step", "mlp_kernels_ms_per_step", "mlp_roofline_frac",
                                                    "peak_allocated_bytes")})
@@ -621,7 +719,7 @@ def main():
                 train_alt = {}
                 for prec in ("bf16x6", "f16x3", "fp32"):
                     if prec != a.precision:
-                        t = train_section(prec, a.workload, data, min(a.train_rays, rays), a.train_steps, world, rank, dev)
+                        t = train_section(prec, a.workload, data, min(a.train_rays, rays), a.train_steps, world, rank, dev, tb)
                         train_alt[prec] = {k: t[k] for k in ("value", "ms_per_step", "loss_first", "loss_last",
                                                              "mlp_kernels_ms_per_step", "mlp_algorithmic_tflops",
                                                              "mlp_roofline_frac")}
@@ -629,7 +727,7 @@ def main():
             train = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        value = world * a.steps * evals_per_step / elapsed
+        value = a.steps * job_evals_per_step / elapsed
         # dominant kernel = the fused encode+MLP kernel; it is launched twice per step (coarse: rays*64 samples, fine:
         # rays*192).  Roofline over ALL its launches in the timed region, so that the average launch duration is the
         # number rocprofv3 --stats reports for the kernel.
@@ -660,20 +758,29 @@ def main():
         line = {
             "metric": metric,
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": MODES[a.precision][2], "data": "synthetic",
             "config": {"workload": (COARSE_ONLY if a.coarse_only else WORKLOADS[a.workload]).format(r=a.res)
                                    + (f"; first {rays} rays of the frame per step" if a.rays else ""),
                        "rays_per_step_per_gpu": rays, "ray_samples_per_ray": per_ray,
-                       "parallelism": f"dp{world} (rays of independent frames per rank, no data-path collective"
+                       "parallelism": (f"dp{world} (one frame split by rows over the ranks; the rendered rows are all-gathered into "
+                                       f"the frame on every rank each step" if strong else
+                                       f"dp{world} (rays of independent frames per rank, no data-path collective")
                                       + (f"; process group on {backend}" if backend else "") + ")"},
-            "rays_per_s": world * a.steps * rays / elapsed,
+            "rays_per_s": a.steps * (frame_rays if strong else world * rays) / elapsed,
             "host_enqueue_ms_per_step": t_host / a.steps * 1e3,
             "c_abi_calls_per_step": sum(v[0] for v in kern.values()) / a.steps,
             "roofline": roof,
             "precision": a.precision,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(kern.items())},
         }
+        if grouped:     # an N > 1 record proves itself: who took part, on which devices, how long each rank took
+            line["per_rank"] = per_rank
+            line["collective"] = (dict(collective_info(backend, frame_rays * 3, "all-gather of the rendered rows (rgb_fine) into the "
+                                                       "frame on every rank, once per step (dist.gather_rows)"),
+                                       strong_frame_max_abs_diff_vs_single_rank_render=strong_check) if strong else
+                                  dict(collective_info(backend, 0, "none in the render path (barrier + max-over-ranks of the elapsed "
+                                                                   "time only); the train section has the gradient all-reduce")))
         if alt:
             line["other_precisions_1gpu"] = alt
             if "bf16x6" in alt and a.precision == "fp32":

@@ -27,8 +27,9 @@
  *   - per HIP device ordinal (up to 64 devices): the CU count and, per kernel, whether its dynamic-LDS limit was
  *     raised (hipFuncSetAttribute is per device) - so one process may drive several GPUs through the library;
  *   - tuning knobs: the environment variables below are read ONCE, at the first call that consults them.  They choose
- *     between equivalent kernels / launch shapes for A/B measurements; results are identical under every setting, and
- *     a release build can ignore them.  (unset = default)
+ *     between equivalent kernels / launch shapes for A/B measurements; results are identical under every setting - except
+ *     the two fold knobs, which change the summation order of the folded columns - and a release build can ignore them.
+ *     (unset = default)
  *       SNERF_FWD_PERSISTENT=0            fp32 render kernel: one workgroup per 128-sample tile instead of one per CU
  *       SNERF_FWD_WAVES=4                 fp32 kernels: two 4-wave workgroups per CU instead of one 8-wave workgroup
  *       SNERF_FWD_SMALL_TILES=0           fp32 forward: 128-sample tiles also for calls of <= 64 x CUs samples (default: 64-sample
@@ -36,10 +37,9 @@
  *       SNERF_BF16_PERSISTENT=0           split-precision forward / dgrad: one workgroup per tile
  *       SNERF_WARP_RESIDENT=0             warp net: slab-streaming kernel instead of the LDS-resident one
  *       SNERF_WARP_BWD_RING=1             warp backward: slab-ring dgrad instead of the ring-free one
- *       SNERF_MLP_FOLD=0                  fp32 inference of nets with additional inputs: their columns as k-blocks per sample (default:
- *                                         one vector per ray and layer - the additional inputs are per-ray constants)
- *       SNERF_WARP_FOLD=0                 warp inference: the pose columns of linear1 as k-blocks per sample (default: folded into
- *                                         one 256-vector per ray - the pose encoding is a per-ray constant)
+ *       SNERF_MLP_FOLD=0                  fp32 inference of nets with additional inputs: their columns as k-blocks per sample even
+ *                                         when the caller brings a fold workspace (snerf_mlp_fwd_ws_f32)
+ *       SNERF_WARP_FOLD=0                 warp inference: the pose columns of linear1 as k-blocks per sample even with a workspace
  *       SNERF_WGRAD_BF16=0                split-precision steps: all weight-gradient GEMMs in fp32
  *       SNERF_WGRAD_F16=0                 f16x3 steps: three bf16 parts for the wide weight-gradient GEMMs
  *       SNERF_WGRAD_NARROW_F16=0          f16x3 steps: narrow weight-gradient jobs in fp32
@@ -47,7 +47,8 @@
  *       SNERF_WGRAD_FOLD=0                fp32 steps: every narrow weight-gradient pair as its own job (default: the sigma head
  *                                         and the direction-encoding columns ride with directional_input's wide job)
  *     (smpl_nerf_amd/ reads two more, on the Python side only: SNERF_PRECISION = default arithmetic of new nets;
- *     SNERF_TRAIN_ACT_GB = default activation budget of a training forward call, 64.)
+ *     SNERF_TRAIN_ACT_GB = activation budget of a training forward call on the autograd path, default a quarter of the
+ *     device memory free at the call; SNERF_TRAIN_CHUNK_RAYS = rays per chunk of the one-call training step, default 2048.)
  */
 #ifndef SMPLNERF_H
 #define SMPLNERF_H
@@ -64,7 +65,8 @@ extern "C" {
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
                              folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
                              0.1.4: + the training step as one call (snerf_nerf_train_step_f32 / _grads_f32, snerf_adam_step_f32,
-                             snerf_mlp_stream_slots) */
+                             snerf_mlp_stream_slots); the per-ray fold tables moved from stream-ordered allocations inside
+                             the library to caller workspaces (snerf_mlp_fwd_ws_f32, snerf_warp_fwd_ws_f32): the library allocates nothing */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -205,14 +207,25 @@ int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *params_flat, flo
  * when dirs_per_sample == 0 (one per ray, samples of a ray contiguous) or [n, 3]; directions are
  * normalised inside (models/nerf_pipeline.py:33-34).  add: nullable [n/samples_per_ray, add_dim].
  * raw [n, 4] = [rgb | sigma] (models/render_ray_net.py:61).
- * dirs_per_sample is a bit set: bit 0 = directions per sample; bit 1 (SNERF_FWD_NO_RAY_FOLD) = multiply the additional-input
- * columns per sample, in the order of snerf_mlp_fwd_train_f32 (whose `raw` this call then reproduces bit for bit), instead
- * of folding them into one vector per ray and layer (the default: same values up to the summation order of those columns). */
+ * dirs_per_sample is a bit set (other bits: SNERF_E_BADARG): bit 0 = directions per sample; bit 1 (SNERF_FWD_NO_RAY_FOLD,
+ * snerf_mlp_fwd_ws_f32 only) = multiply the additional-input columns per sample even when a fold workspace is given, in the
+ * order of snerf_mlp_fwd_train_f32 (whose `raw` the call then reproduces bit for bit). */
 #define SNERF_FWD_DIRS_PER_SAMPLE 1
 #define SNERF_FWD_NO_RAY_FOLD 2
 int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                       const float *dirs, int dirs_per_sample, const float *add,
                       int64_t n, int samples_per_ray, float *raw, snerf_stream_t stream);
+
+/* The same call with a caller-allocated workspace for the per-ray fold: nets with additional inputs (add_dim > 0) read them
+ * as per-RAY constants, so W_add . add is evaluated once per ray into a table of snerf_mlp_fold_workspace_bytes(desc, n,
+ * samples_per_ray) bytes (0 when the fold does not apply: no additional inputs, fewer than 8 samples per ray, ...) and added to
+ * the accumulators; their k-blocks are skipped (same values up to the summation order of those columns).  workspace NULL
+ * (= snerf_mlp_fwd_f32): the per-sample form.  A workspace smaller than needed is SNERF_E_BADARG - the library allocates
+ * nothing and never switches form silently.  16-byte aligned. */
+int64_t snerf_mlp_fold_workspace_bytes(const snerf_mlp_desc *desc, int64_t n, int samples_per_ray);
+int snerf_mlp_fwd_ws_f32(const snerf_mlp_desc *desc, const float *packed, const float *x, const float *dirs,
+                         int dirs_per_sample, const float *add, int64_t n, int samples_per_ray, float *raw, void *workspace,
+                         int64_t workspace_bytes, snerf_stream_t stream);
 
 /* ---- a2 on the bf16 matrix cores with fp32-class accuracy (split-bf16, inference) -------------------------
  * Every fp32 operand is split into nsplit bf16 parts and the cross terms are accumulated in fp32:
@@ -327,6 +340,14 @@ int snerf_warp_pack_f32(const snerf_warp_desc *desc, const float *params_flat, f
 int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
                        const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
                        float *warp, float *warped, float *sdirs, snerf_stream_t stream);
+
+/* With a caller-allocated workspace of snerf_warp_fold_workspace_bytes(desc, n, samples_per_ray) bytes (0: the fold does not
+ * apply) the pose columns of linear1 - per-ray constants - are folded into one vector per ray; NULL (= snerf_warp_fwd_f32):
+ * the per-sample form; too small: SNERF_E_BADARG.  Same contract as snerf_mlp_fwd_ws_f32. */
+int64_t snerf_warp_fold_workspace_bytes(const snerf_warp_desc *desc, int64_t n, int samples_per_ray);
+int snerf_warp_fwd_ws_f32(const snerf_warp_desc *desc, const float *packed, const float *x, const float *pose_enc,
+                          const float *o, int64_t n, int samples_per_ray, float *warp, float *warped, float *sdirs,
+                          void *workspace, int64_t workspace_bytes, snerf_stream_t stream);
 
 /* The same forward on the bf16 matrix cores (split-bf16, always three parts / six products: fp32-class accuracy - the warp
  * moves the sample in front of the 2^9 band of the position encoding).  packed from snerf_warp_pack_bf16

@@ -114,6 +114,10 @@ SIGNATURES = {
                                            _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "snerf_render_rays_f32": (c_int, [POINTER(MlpDesc), _P, POINTER(MlpDesc), _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64,
                                       c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "snerf_mlp_fold_workspace_bytes": (c_int64, [POINTER(MlpDesc), c_int64, c_int]),
+    "snerf_mlp_fwd_ws_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P, c_int64, _P]),
+    "snerf_warp_fold_workspace_bytes": (c_int64, [POINTER(WarpDesc), c_int64, c_int]),
+    "snerf_warp_fwd_ws_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int64, _P]),
     "snerf_mlp_stream_slots": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
     "snerf_adam_step_f32": (c_int, [POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P]),
     "snerf_nerf_train_workspace_bytes": (c_int64, [POINTER(MlpDesc), POINTER(MlpDesc), c_int64, c_int, c_int, c_int64]),

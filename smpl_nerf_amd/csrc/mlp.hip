@@ -347,29 +347,39 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
     return check_launch("mlp_fwd");
 }
 
-// inference with per-ray additional inputs: pre-pass + FOLD kernel; the table lives in a stream-ordered allocation for the
-// duration of the two launches.  Returns 1 when the fold does not apply (the caller then runs the per-sample form).
-template <int NW>
-static int launch_fwd_folded(const Plan &P, const FwdArgs &A, hipStream_t s) {
-    // (a fold pays when a ray's vector is reused: with fewer than 8 samples per ray the table costs more than it saves)
-    if (!P.add_dim || A.no_fold || !tuning().mlp_fold || A.spr < 8 || A.n % A.spr != 0) return 1;
+// slots (layers with an additional-input segment) and bytes of the per-ray fold table of a call, 0 when the fold does not apply
+// (a fold pays when a ray's vector is reused: with fewer than 8 samples per ray the table costs more than it saves)
+static int64_t fold_table_bytes(const Plan &P, int64_t n, int spr, int *slots_out = nullptr) {
+    if (!P.add_dim || !tuning().mlp_fold || tuning().fwd_waves == 4 || spr < 8 || n <= 0 || n % spr != 0) return 0;
     int slots = 0;
     for (int l = 0; l < P.nlayers; ++l)
         for (int sg = 0; sg < P.layer[l].nseg; ++sg) slots += P.layer[l].seg[sg].type == SEG_ADD ? 1 : 0;
-    const int64_t n_rays = A.n / A.spr, floats = n_rays * slots * P.width;
-    if (!slots || (floats + 255) / 256 > 0x7fffffffLL) return 1;
-    float *table = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&table), (size_t)floats * sizeof(float), s) != hipSuccess) {
-        (void)hipGetLastError();
-        return 1;   // no memory for the table: the per-sample form needs none
-    }
-    hipLaunchKernelGGL(mlp_add_fold_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, s, P, A.packed, A.add, n_rays, slots, table);
+    const int64_t floats = (n / spr) * slots * P.width;
+    if (!slots || (floats + 255) / 256 > 0x7fffffffLL) return 0;
+    if (slots_out) *slots_out = slots;
+    return floats * (int64_t)sizeof(float);
+}
+
+// inference with per-ray additional inputs: pre-pass + FOLD kernel; the table lives in the CALLER's workspace
+// (snerf_mlp_fold_workspace_bytes).  Returns 1 when the fold does not apply or no workspace was given (the caller then runs
+// the per-sample form); a workspace that is too small is an error, never a silent switch.
+template <int NW>
+static int launch_fwd_folded(const Plan &P, const FwdArgs &A, hipStream_t s) {
+    if (A.no_fold || !A.fold_ws) return 1;
+    int slots = 0;
+    const int64_t bytes = fold_table_bytes(P, A.n, A.spr, &slots);
+    if (!bytes) return 1;
+    if (A.fold_ws_bytes < bytes)
+        return fail(SNERF_E_BADARG, "mlp_fwd: workspace of %lld bytes, the per-ray fold needs %lld (snerf_mlp_fold_workspace_bytes)",
+                    (long long)A.fold_ws_bytes, (long long)bytes);
+    if (!aligned(A.fold_ws, 16)) return fail(SNERF_E_ALIGN, "mlp_fwd: workspace must be 16-byte aligned");
+    const int64_t n_rays = A.n / A.spr, floats = bytes / (int64_t)sizeof(float);
+    hipLaunchKernelGGL(mlp_add_fold_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, s, P, A.packed, A.add, n_rays, slots,
+                       A.fold_ws);
     FwdArgs B = A;
-    B.fold = table;
+    B.fold = A.fold_ws;
     B.fold_slots = slots;
-    const int rc = launch_fwd_nw<NW, false, false, true>(P, B, s);
-    (void)hipFreeAsync(table, s);
-    return rc;
+    return launch_fwd_nw<NW, false, false, true>(P, B, s);
 }
 
 template <bool ENCODED, bool TRAIN>
@@ -377,7 +387,7 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // 8 waves (128 samples) per workgroup = one workgroup per CU, 2 waves per SIMD (85.7 % of the fp32 MFMA
     // peak on the 128x128 frame); SNERF_FWD_WAVES=4 selects two independent 4-wave workgroups per CU instead
     // (83.1 %; twice the L2->LDS weight traffic).  Tuning knob, read once.
-    if (!ENCODED && !TRAIN && tuning().fwd_waves != 4) {   // per-ray additional inputs: the folded form (8-wave tiles)
+    if (!ENCODED && !TRAIN && tuning().fwd_waves != 4) {   // per-ray additional inputs + a workspace: the folded form (8-wave tiles)
         const int rc = launch_fwd_folded<FWD_WAVES>(P, A, s);
         if (rc != 1) return rc;
     }
@@ -421,20 +431,34 @@ extern "C" int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *param
     return launch_pack(P, params_flat, packed, (hipStream_t)stream, "mlp_pack");
 }
 
-extern "C" int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x, const float *dirs,
-                                 int dirs_per_sample, const float *add, int64_t n, int samples_per_ray, float *raw,
-                                 snerf_stream_t stream) {
+extern "C" int64_t snerf_mlp_fold_workspace_bytes(const snerf_mlp_desc *desc, int64_t n, int samples_per_ray) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "mlp_fold_workspace_bytes: desc is null");
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "mlp_fold_workspace_bytes: %s", why);
+    if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "mlp_fold_workspace_bytes: bad n/samples_per_ray");
+    return fold_table_bytes(P, n, samples_per_ray);
+}
+
+extern "C" int snerf_mlp_fwd_ws_f32(const snerf_mlp_desc *desc, const float *packed, const float *x, const float *dirs,
+                                    int dirs_per_sample, const float *add, int64_t n, int samples_per_ray, float *raw,
+                                    void *workspace, int64_t workspace_bytes, snerf_stream_t stream) {
     using namespace snerf;
     Plan P;
     FwdArgs A{};
     int rc = fill_args(desc, P, A);
     if (rc) return rc;
     if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "mlp_fwd: bad n/samples_per_ray");
+    if (dirs_per_sample & ~(SNERF_FWD_DIRS_PER_SAMPLE | SNERF_FWD_NO_RAY_FOLD))
+        return fail(SNERF_E_BADARG, "mlp_fwd: dirs_per_sample is a bit set of SNERF_FWD_DIRS_PER_SAMPLE | SNERF_FWD_NO_RAY_FOLD (got %d)",
+                    dirs_per_sample);
     if (n == 0) return SNERF_OK;
     if (!packed || !x || !raw) return fail(SNERF_E_BADARG, "mlp_fwd: null pointer");
     if (A.use_dir && !dirs) return fail(SNERF_E_BADARG, "mlp_fwd: dirs is null");
     if (A.add_dim && !add) return fail(SNERF_E_BADARG, "mlp_fwd: add is null");
     if (!aligned(packed, 16) || !aligned(raw, 16)) return fail(SNERF_E_ALIGN, "mlp_fwd: packed/raw must be 16-byte aligned");
+    if (workspace_bytes < 0) return fail(SNERF_E_BADARG, "mlp_fwd: negative workspace_bytes");
     A.packed = packed;
     A.x = x;
     A.dirs = dirs;
@@ -444,7 +468,15 @@ extern "C" int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed
     A.spr = samples_per_ray;
     A.dirs_per_sample = (dirs_per_sample & SNERF_FWD_DIRS_PER_SAMPLE) ? 1 : 0;
     A.no_fold = (dirs_per_sample & SNERF_FWD_NO_RAY_FOLD) ? 1 : 0;
+    A.fold_ws = reinterpret_cast<float *>(workspace);
+    A.fold_ws_bytes = workspace ? workspace_bytes : 0;
     return launch_fwd<false, false>(P, A, (hipStream_t)stream);
+}
+
+extern "C" int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x, const float *dirs,
+                                 int dirs_per_sample, const float *add, int64_t n, int samples_per_ray, float *raw,
+                                 snerf_stream_t stream) {
+    return snerf_mlp_fwd_ws_f32(desc, packed, x, dirs, dirs_per_sample, add, n, samples_per_ray, raw, nullptr, 0, stream);
 }
 
 extern "C" int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,

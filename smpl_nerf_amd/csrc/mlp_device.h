@@ -51,6 +51,8 @@ struct FwdArgs {
     const float *fold;
     int fold_slots;
     int no_fold;         // (host only) the caller asked for the per-sample form: SNERF_FWD_NO_RAY_FOLD
+    float *fold_ws;      // (host only) caller's workspace for the per-ray fold table, or null: per-sample form
+    int64_t fold_ws_bytes;
     int act_rows;      // f16x3 training forward: the per-layer |X| exponents go behind this many tile-rows of `act`
     // split-bf16 training forward only: encoder / additional k-block counts of the 16-wide (fp32) plan, which
     // defines the activation layout the backward kernels read

@@ -108,7 +108,11 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
     why = "";
     P.kw = kw;
     if (d.n_layers < 1 || d.n_layers > 16) { why = "n_layers must be in [1,16]"; return -1; }
-    if (d.width < 2 || d.width > 256) { why = "width must be in [2, 256]"; return -1; }
+    if (d.width < 2 || d.width > 256) {
+        why = "width must be in [2, 256] (--netwidth above 256 is not supported: the layer chain lives in registers, two accumulator "
+              "sets of width x 16 samples per wave)";
+        return -1;
+    }
     if (d.pos_freqs < 0 || d.pos_freqs > 16 || d.dir_freqs < 0 || d.dir_freqs > 16) { why = "bad encoder frequencies"; return -1; }
     if (d.add_dim < 0 || d.add_dim > 4096) { why = "bad add_dim"; return -1; }
     // W / WD: the layer widths of the parameters (RenderRayNet: width and width // 2).  The kernels exist for trunks of 64, 128 and

@@ -38,15 +38,16 @@ static int mlp_per_sample_dirs(const snerf_mlp_desc *desc, const void *packed, i
     return snerf_mlp_fwd_bf16_f32(desc, packed, precision, x, sdirs, 1, nullptr, n, spr, raw, stream);
 }
 static int warp(const snerf_warp_desc *desc, const void *packed, int precision, const float *x, const float *pose_enc,
-                const float *o, int64_t n, int spr, float *w, float *warped, float *sdirs, snerf_stream_t stream) {
+                const float *o, int64_t n, int spr, float *w, float *warped, float *sdirs, void *fold_ws, int64_t fold_bytes,
+                snerf_stream_t stream) {
     if (precision == 0)
-        return snerf_warp_fwd_f32(desc, reinterpret_cast<const float *>(packed), x, pose_enc, o, n, spr, w, warped, sdirs,
-                                  stream);
+        return snerf_warp_fwd_ws_f32(desc, reinterpret_cast<const float *>(packed), x, pose_enc, o, n, spr, w, warped, sdirs,
+                                     fold_ws, fold_bytes, stream);
     return snerf_warp_fwd_bf16_f32(desc, packed, x, pose_enc, o, n, spr, w, warped, sdirs, stream);
 }
 
 struct SmplWs {
-    int64_t base, warp_c, warped_c, sdirs_c, sdirs_f, total;
+    int64_t base, warp_c, warped_c, sdirs_c, sdirs_f, fold, fold_bytes, total;
 };
 static SmplWs smpl_ws(int64_t B, int Nc, int Nf) {
     SmplWs w{};
@@ -57,6 +58,8 @@ static SmplWs smpl_ws(int64_t B, int Nc, int Nf) {
     w.warped_c = off, off += align16(B * Nc * 3 * 4);
     w.sdirs_c = off, off += align16(B * Nc * 3 * 4);
     w.sdirs_f = off, off += align16(B * N * 3 * 4);
+    w.fold_bytes = B * 256 * 4;   // per-ray pose fold of the fp32 warp kernel: one row of <= 256 floats per ray (warp.hip)
+    w.fold = off, off += align16(w.fold_bytes);
     w.total = off;
     return w;
 }
@@ -157,7 +160,8 @@ extern "C" int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, con
     const int N = Nc + Nf;
     int rc;
     // coarse: warp the given samples, net on (x', x' - o), compositing scaled per sample (:38-63)
-    if ((rc = warp(desc_warp, packed_warp, precision, ray_samples, pose_enc, rays_o, B * Nc, Nc, warp_c, warped_c, sdirs_c, stream)))
+    if ((rc = warp(desc_warp, packed_warp, precision, ray_samples, pose_enc, rays_o, B * Nc, Nc, warp_c, warped_c, sdirs_c, ws + sw.fold,
+                   sw.fold_bytes, stream)))
         return rc;
     if ((rc = mlp_per_sample_dirs(desc_coarse, packed_coarse, precision, warped_c, sdirs_c, B * Nc, Nc, raw_c, stream))) return rc;
     if ((rc = snerf_composite_fwd_f32(raw_c, z_vals, sdirs_c, 1, noise_coarse, B, Nc, white_background, rgb, weights_c, alpha_c,
@@ -168,7 +172,7 @@ extern "C" int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, con
                                    stream)))
         return rc;
     if ((rc = warp(desc_warp, packed_warp, precision, samples_fine, pose_enc, rays_o, B * N, N, warp_fine, warped_fine, sdirs_f,
-                   stream)))
+                   ws + sw.fold, sw.fold_bytes, stream)))
         return rc;
     if ((rc = mlp_per_sample_dirs(desc_fine, packed_fine, precision, warped_fine, sdirs_f, B * N, N, raw_f, stream))) return rc;
     return snerf_composite_fwd_f32(raw_f, z_fine, rays_d, 0, noise_fine, B, N, white_background, rgb_fine, nullptr,

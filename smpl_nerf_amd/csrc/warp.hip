@@ -424,7 +424,33 @@ extern "C" int snerf_warp_pack_f32(const snerf_warp_desc *desc, const float *par
 namespace snerf {
 static int launch_warp_fwd(const snerf_warp_desc *desc, const float *packed, const float *x, const float *pose_enc,
                            const float *o, int64_t n, int samples_per_ray, float *warp, float *warped, float *sdirs,
-                           float *act, snerf_stream_t stream);
+                           float *act, snerf_stream_t stream, void *workspace = nullptr, int64_t workspace_bytes = 0);
+// bytes of the per-ray pose-fold table of an inference call, 0 when the fold does not apply (warp_ray_bias_kernel)
+static int64_t warp_fold_bytes(const Plan &P, int64_t n, int spr) {
+    const int T = P.width / 16, nkb0 = P.pos_nkb + P.add_nkb;
+    if (!tuning().warp_resident || warp_resident_bytes(T, nkb0) > 160 * 1024) return 0;
+    if (!(P.add_dim > 0 && P.pos_nkb > 0 && tuning().warp_fold && spr >= 8 && n > 0 && n % spr == 0)) return 0;
+    const int64_t floats = (n / spr) * P.width;
+    if ((floats + 255) / 256 > 0x7fffffffLL) return 0;   // (more rays than a grid holds: the per-sample form)
+    return floats * (int64_t)sizeof(float);
+}
+}
+extern "C" int64_t snerf_warp_fold_workspace_bytes(const snerf_warp_desc *desc, int64_t n, int samples_per_ray) {
+    using namespace snerf;
+    Plan P;
+    const char *why;
+    if (!desc) return fail(SNERF_E_BADARG, "warp_fold_workspace_bytes: desc is null");
+    if (make_warp_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "warp_fold_workspace_bytes: %s", why);
+    if (n < 0 || samples_per_ray < 1) return fail(SNERF_E_BADARG, "warp_fold_workspace_bytes: bad n/samples_per_ray");
+    return warp_fold_bytes(P, n, samples_per_ray);
+}
+extern "C" int snerf_warp_fwd_ws_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
+                                     const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
+                                     float *warp, float *warped, float *sdirs, void *workspace, int64_t workspace_bytes,
+                                     snerf_stream_t stream) {
+    if (workspace_bytes < 0) return snerf::fail(SNERF_E_BADARG, "warp_fwd: negative workspace_bytes");
+    return snerf::launch_warp_fwd(desc, packed, x, pose_enc, o, n, samples_per_ray, warp, warped, sdirs, nullptr, stream,
+                                  workspace, workspace ? workspace_bytes : 0);
 }
 extern "C" int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
                                   const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
@@ -439,7 +465,7 @@ extern "C" int snerf_warp_fwd_train_f32(const snerf_warp_desc *desc, const float
 }
 static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *packed, const float *x, const float *pose_enc,
                                   const float *o, int64_t n, int samples_per_ray, float *warp, float *warped,
-                                  float *sdirs, float *act, snerf_stream_t stream) {
+                                  float *sdirs, float *act, snerf_stream_t stream, void *workspace, int64_t workspace_bytes) {
     Plan P;
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "warp_fwd: desc is null");
@@ -481,19 +507,18 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
             const int n_cu = device_cu_count("warp_fwd");
             if (n_cu < 1) return n_cu;
             const int64_t g = A.n_tiles < n_cu ? A.n_tiles : n_cu;
-            // inference with pose columns and at least one position k-block: the per-ray fold (warp_ray_bias_kernel); the
-            // table lives in a stream-ordered allocation for the duration of the two launches
-            float *ray_bias = nullptr;
-            if (!act && P.add_dim > 0 && P.pos_nkb > 0 && tuning().warp_fold && samples_per_ray >= 8 && n % samples_per_ray == 0) {
-                const int64_t n_rays = n / samples_per_ray, floats = n_rays * P.width;
-                if ((floats + 255) / 256 > 0x7fffffffLL) {
-                    ray_bias = nullptr;   // (more rays than a grid holds: the per-sample form)
-                } else if (hipMallocAsync(reinterpret_cast<void **>(&ray_bias), (size_t)floats * sizeof(float), s) != hipSuccess) {
-                    (void)hipGetLastError();
-                    ray_bias = nullptr;   // no memory for the table: the unfolded kernel needs none
-                } else {
+            // inference with pose columns, at least one position k-block and a workspace: the per-ray fold (warp_ray_bias_kernel),
+            // its table in the CALLER's workspace (snerf_warp_fold_workspace_bytes); no workspace: the per-sample form
+            if (!act && workspace) {
+                if (const int64_t need = warp_fold_bytes(P, n, samples_per_ray)) {
+                    if (workspace_bytes < need)
+                        return fail(SNERF_E_BADARG, "warp_fwd: workspace of %lld bytes, the per-ray fold needs %lld "
+                                    "(snerf_warp_fold_workspace_bytes)", (long long)workspace_bytes, (long long)need);
+                    if (!aligned(workspace, 16)) return fail(SNERF_E_ALIGN, "warp_fwd: workspace must be 16-byte aligned");
+                    float *ray_bias = reinterpret_cast<float *>(workspace);
+                    const int64_t floats = need / (int64_t)sizeof(float);
                     hipLaunchKernelGGL(warp_ray_bias_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, s, packed, pose_enc,
-                                       n_rays, P.add_dim, P.pos_nkb, P.add_nkb, T, ray_bias);
+                                       n / samples_per_ray, P.add_dim, P.pos_nkb, P.add_nkb, T, ray_bias);
                     A.ray_bias = ray_bias;
                 }
             }
@@ -513,7 +538,6 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
                 else SNERF_WARP_RES(128, 16, false);
             }
 #undef SNERF_WARP_RES
-            if (ray_bias) (void)hipFreeAsync(ray_bias, s);
             return check_launch("warp_fwd(resident)");
         }
     }

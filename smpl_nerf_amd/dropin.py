@@ -12,6 +12,11 @@ What it does (INTEGRATION.md sections 1-2 as code):
     models.render_ray_net.RenderRayNet, models.warp_field_net.WarpFieldNet, models.append_vertices_net.AppendVerticesNet,
     models.{nerf,smpl_nerf,append_vertices,append_smpl_params,append_to_nerf}_pipeline.* - including the copies that
     `from x import y` left in solver/*.py, train.py, inference.py.
+  * wraps the reference's render entry point, inference.inference (inference.py:222-265), in torch.no_grad(): the reference
+    calls `pipeline(data)` there in eval mode but WITH autograd recording (inference.py:247-253) - the graph is built and
+    thrown away per batch - and with recording on, these pipelines would run their training forward (every layer input
+    stored, 10.7 KB per ray-sample) instead of the inference kernels.  No result changes: nothing in that function
+    differentiates.
 The reference's PositionalEncoder is left alone: the pipelines only read its number_frequencies / include_identity (the
 encoding itself is fused into the MLP kernel), and its encode() works on GPU tensors where a pipeline calls it.
 
@@ -53,10 +58,33 @@ def _register_torchsearchsorted():
     sys.modules["torchsearchsorted"] = mod
 
 
+# reference module -> functions that only render (no backward inside): run under torch.no_grad()
+NO_GRAD_FUNCTIONS = {"inference": ("inference",)}
+
+
+def _no_grad(fn):
+    import functools
+
+    import torch
+
+    @functools.wraps(fn)
+    def rendered_without_autograd(*args, **kw):
+        with torch.no_grad():
+            return fn(*args, **kw)
+
+    rendered_without_autograd._snerf_no_grad = True
+    return rendered_without_autograd
+
+
 def _patch_module(mod):
     """Rebind the path's names in one (reference) module; returns how many bindings changed."""
     table = REPLACEMENTS.get(getattr(mod, "__name__", ""), {})
     changed = 0
+    for name in NO_GRAD_FUNCTIONS.get(getattr(mod, "__name__", ""), ()):
+        cur = mod.__dict__.get(name)
+        if callable(cur) and not getattr(cur, "_snerf_no_grad", False):
+            setattr(mod, name, _no_grad(cur))
+            changed += 1
     for name, new in table.items():           # the defining module: remember the original, then replace it
         cur = mod.__dict__.get(name)
         if cur is not None and cur is not new:

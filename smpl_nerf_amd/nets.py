@@ -26,6 +26,7 @@ def _encoder_shape(dim: int):
 
 
 _ENCODED_ROWS = -1  # marker passed in the `per_sample` slot of _FusedMlpFn
+MAX_WIDTH = 256     # --netwidth limit of the fused kernels (csrc/mlp_plan.h: make_plan)
 
 
 def _need_f32_cuda(what: str, *tensors):
@@ -119,6 +120,15 @@ def _split_code(net, per_sample):
     return {"bf16x6": 3, "bf16x3": 2, "f16x3": _lib.SPLIT_F16X3}.get(net.precision, 0)
 
 
+def _fold_workspace(size_fn, desc, n, spr, dev):
+    """(tensor or None, bytes) - the caller-allocated table of the per-ray fold of an fp32 inference call (include/smplnerf.h:
+    snerf_mlp_fold_workspace_bytes / snerf_warp_fold_workspace_bytes; 0 bytes = the fold does not apply)."""
+    nbytes = int(size_fn(desc, n, int(spr)))
+    if nbytes < 0:
+        check(nbytes, "fold_workspace_bytes")
+    return (torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes) if nbytes else (None, 0)
+
+
 def _train_sizes(desc, n):
     """(act_floats, dy_floats, gpart_floats) of snerf_mlp_train_sizes for n samples."""
     lib = _lib.load()
@@ -160,9 +170,13 @@ def _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, act=None, li
             if train:
                 check(lib.snerf_mlp_fwd_train_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr),
                                                   ptr(raw), ptr(act), current_stream()), "snerf_mlp_fwd_train_f32")
+            elif like_training or add is None:
+                check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr), ptr(raw),
+                                            current_stream()), "snerf_mlp_fwd_f32")
             else:
-                check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample | (2 if like_training else 0), ptr(add), n,
-                                            int(spr), ptr(raw), current_stream()), "snerf_mlp_fwd_f32")
+                ws, nb = _fold_workspace(lib.snerf_mlp_fold_workspace_bytes, desc, n, spr, raw.device)
+                check(lib.snerf_mlp_fwd_ws_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n, int(spr), ptr(raw),
+                                               ptr(ws), nb, current_stream()), "snerf_mlp_fwd_ws_f32")
 
 
 def _launch_backward(net, desc, ns, act, d_raw, n, sizes, flat, input_grad, x=None, d=None, per_sample=0, spr=1,
@@ -222,15 +236,21 @@ class _FusedMlpFn(torch.autograd.Function):
         act_floats, dy_floats, gpart_floats = _train_sizes(desc, n)
         raw = torch.empty((n, 4), device=dev, dtype=torch.float32)
         group = 1 if per_sample == _ENCODED_ROWS else spr            # blocks are whole rays (per-ray directions / inputs)
-        budget = int(getattr(net, "activation_budget_bytes", 0) or 0)
+        budget = getattr(net, "activation_budget_bytes", 0)
+        if budget is None:       # default: a share of what is free on THIS device right now (other nets, the optimiser, gpart live there too)
+            budget = int(0.25 * torch.cuda.mem_get_info(dev)[0])
+        budget = int(budget or 0)
         ctx.block = 0
-        if budget > 0 and 4 * (act_floats + dy_floats) > budget and n > group:
-            per_sample_bytes = 4.0 * (act_floats + dy_floats) / n
+        if budget > 0 and 4 * (act_floats + dy_floats + gpart_floats) > budget and n > group:
+            per_sample_bytes = 4.0 * (act_floats + dy_floats + gpart_floats) / n
             ctx.block = max(group, int(budget / per_sample_bytes) // group * group)
         if ctx.block and ctx.block < n:
             _launch_forward(net, desc, ns, x, d, per_sample, spr, add, raw, like_training=True)   # inference kernel: nothing saved
             ctx.act = None
-            ctx.inputs = (x, d, add)
+            # through save_for_backward: an in-place change of the inputs or of a parameter between forward and backward
+            # (the recompute reads both) raises autograd's version-counter error instead of giving silently wrong gradients
+            ctx.save_for_backward(x, d, add, *params)
+            ctx.blocked_inputs = True
         else:
             ctx.block = 0
             act = torch.empty(act_floats, device=dev, dtype=torch.float32)
@@ -291,7 +311,7 @@ class _FusedMlpFn(torch.autograd.Function):
             ctx.act = None
             _FusedMlpFn._input_grads_from_dy(ctx, dy, n, d_x if ctx.rows_grad else None, d_add)
         else:                    # blocks of whole rays: recompute the layer inputs, back-propagate, accumulate
-            xin, din, addin = ctx.inputs
+            xin, din, addin = ctx.saved_tensors[:3]
             per_sample = ctx.per_sample
             tmp = None
             for s0 in range(0, n, ctx.block):
@@ -322,7 +342,6 @@ class _FusedMlpFn(torch.autograd.Function):
                 _FusedMlpFn._input_grads_from_dy(ctx, dy, m, d_x[s0:s0 + m] if ctx.rows_grad else None,
                                                  None if d_add is None else d_add[s0 // spr:(s0 + m) // spr])
                 del act, dy
-            ctx.inputs = None
         if ctx.input_grad:
             if not per_sample:       # one direction per ray: sum the per-sample contributions
                 d_d = d_d.view(-1, spr, 3).sum(1)
@@ -395,6 +414,11 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
     def __init__(self, n_layers=8, width=256, positions_dim=60, directions_dim=24, additional_input_dim=0,
                  skips=[4], use_directional_input=1):
         super(RenderRayNet, self).__init__()
+        if not 2 <= int(width) <= MAX_WIDTH or not 1 <= int(n_layers) <= 16:
+            # the reference's parser accepts any --netwidth / --netdepth (config_parser.py:19-20); every configuration it ships
+            # uses 256 / 8.  Fail here, by name, rather than at the first forward
+            raise ValueError(f"RenderRayNet: width {width} / n_layers {n_layers} not supported by the HIP kernels: "
+                             f"2 <= width <= {MAX_WIDTH} (the layer chain is register-resident), 1 <= n_layers <= 16")
         self.n_layers = n_layers
         self.width = width
         self.positions_dim = positions_dim
@@ -429,10 +453,12 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         # (v_mfma_f32_16x16x4_f32) or split-bf16 "bf16x6" (3 parts, fp32-class accuracy) / "bf16x3" (2 parts, ~1e-5
         # relative); activations, gradients, the narrow wgrad jobs and the reductions are fp32 in every mode
         self.precision = os.environ.get("SNERF_PRECISION", "fp32")
-        # training memory bound: saved layer inputs + d Y of ONE forward call above this many bytes are not kept but
-        # recomputed block by block in the backward (_FusedMlpFn).  Default: 64 GB of the 288 GB per call - a 4096-ray step
-        # (22 GB) keeps everything, a 256x256 frame (357 GB) trains in six blocks.  0 = never recompute.
-        self.activation_budget_bytes = int(float(os.environ.get("SNERF_TRAIN_ACT_GB", "64")) * (1 << 30))
+        # training memory bound (autograd path): saved layer inputs + d Y + wgrad partials of ONE forward call above this many
+        # bytes are not kept but recomputed block by block in the backward (_FusedMlpFn).  None (default) = 25 % of the device
+        # memory that is free when the forward runs (on an otherwise empty MI355X: a 4096-ray step of 22 GB keeps everything, a
+        # 256x256 frame of 357 GB trains in a few blocks); SNERF_TRAIN_ACT_GB sets a fixed figure; 0 = never recompute.
+        env = os.environ.get("SNERF_TRAIN_ACT_GB")
+        self.activation_budget_bytes = int(float(env) * (1 << 30)) if env else None
 
     # ------------------------------------------------------------------ parameter plumbing
     def _ordered_params(self):
@@ -605,9 +631,10 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
                                                  int(samples_per_ray), ptr(raw), current_stream()), "snerf_mlp_fwd_bf16_f32")
             return raw
         packed = self.packed_weights(desc)
+        ws, nb = _fold_workspace(lib.snerf_mlp_fold_workspace_bytes, desc, n, samples_per_ray, x.device) if add is not None else (None, 0)
         with torch.cuda.device(x.device), _lib.timed(f"mlp_fwd[n={n}]"):
-            check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n,
-                                        int(samples_per_ray), ptr(raw), current_stream()), "snerf_mlp_fwd_f32")
+            check(lib.snerf_mlp_fwd_ws_f32(desc, ptr(packed), ptr(x), ptr(d), per_sample, ptr(add), n,
+                                           int(samples_per_ray), ptr(raw), ptr(ws), nb, current_stream()), "snerf_mlp_fwd_ws_f32")
         return raw
 
     @property
@@ -689,6 +716,8 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
 
     def __init__(self, n_layers=8, width=256, positions_dim=60, pose_dim=24):
         super(WarpFieldNet, self).__init__()
+        if not 1 <= int(width) <= MAX_WIDTH:
+            raise ValueError(f"WarpFieldNet: width {width} not supported by the HIP kernels (1 <= --netwidth_warp <= {MAX_WIDTH})")
         self.positions_dim = positions_dim
         self.direcions_dim = pose_dim  # (sic) reference attribute name, :12
         self.width = width
@@ -785,9 +814,10 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
                       "snerf_warp_fwd_bf16_f32")
             return warp, warped, sdirs
         packed = self._packed(desc)
+        ws, nb = _fold_workspace(lib.snerf_warp_fold_workspace_bytes, desc, n, samples_per_ray, x.device)
         with torch.cuda.device(x.device), _lib.timed(f"warp_fwd[n={n}]"):
-            check(lib.snerf_warp_fwd_f32(desc, ptr(packed), ptr(x), ptr(pe), ptr(o), n, int(samples_per_ray), ptr(warp),
-                                         ptr(warped), ptr(sdirs), current_stream()), "snerf_warp_fwd_f32")
+            check(lib.snerf_warp_fwd_ws_f32(desc, ptr(packed), ptr(x), ptr(pe), ptr(o), n, int(samples_per_ray), ptr(warp),
+                                            ptr(warped), ptr(sdirs), ptr(ws), nb, current_stream()), "snerf_warp_fwd_ws_f32")
         return warp, warped, sdirs
 
     @property
@@ -850,7 +880,8 @@ class AppendVerticesNet(RenderRayNet):
                                                  int(samples_per_ray), ptr(raw), current_stream()), "snerf_mlp_fwd_bf16_f32")
             return raw
         packed = self.packed_weights(desc)
+        ws, nb = _fold_workspace(lib.snerf_mlp_fold_workspace_bytes, desc, n, samples_per_ray, add.device)
         with torch.cuda.device(add.device), _lib.timed(f"mlp_fwd[n={n}]"):
-            check(lib.snerf_mlp_fwd_f32(desc, ptr(packed), ptr(dummy_x), ptr(d), 0, ptr(add), n, int(samples_per_ray),
-                                        ptr(raw), current_stream()), "snerf_mlp_fwd_f32")
+            check(lib.snerf_mlp_fwd_ws_f32(desc, ptr(packed), ptr(dummy_x), ptr(d), 0, ptr(add), n, int(samples_per_ray),
+                                           ptr(raw), ptr(ws), nb, current_stream()), "snerf_mlp_fwd_ws_f32")
         return raw

@@ -194,10 +194,14 @@ class DataParallelTrainer:
     default_adam_args = {"lr": 1e-4, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0}  # nerf_solver.py:11-14
 
     def __init__(self, pipeline, models, lr: float = 5e-4, weight_decay: float = 0.0, loss_func=None, fused=None,
-                 one_call=None):
+                 one_call=None, sync_at_world_one=False):
         self.pipeline = pipeline
         self.models = list(models)
         self.world, self.rank = sdist.world_rank()
+        # the gradient all-reduce runs when there is more than one rank - or, on request, in a process group of ONE rank
+        # (bench.py on a 1-GPU box: the collective of the path on RCCL with nothing to exchange; the mean over one rank is the
+        # identity)
+        self._sync = self.world > 1 or (bool(sync_at_world_one) and sdist.is_dist())
         # one flat parameter buffer and one flat gradient buffer for all nets (what is all-reduced is the flat
         # gradient the backward kernels wrote)
         self._flat_p, self._flat_g, self._segments, order = flatten_parameters_(self.models)
@@ -211,7 +215,9 @@ class DataParallelTrainer:
                 self._views.append(self._flat_g[off:off + p.numel()].view(p.shape))
                 off += p.numel()
         # every rank must start from the same replica (DDP broadcasts at construction; so does this)
+        self.broadcast_ms = None
         if self.world > 1:
+            t0 = time.perf_counter()
             if self._flat_p is not None:
                 sdist.broadcast_(self._flat_p, 0)
             else:
@@ -222,6 +228,9 @@ class DataParallelTrainer:
                     sdist.broadcast_(buf, 0)
                 if hasattr(m, "mark_weights_changed"):
                     m.mark_weights_changed()
+            if self._flat_p is not None and self._flat_p.is_cuda:
+                torch.cuda.synchronize(self._flat_p.device)
+            self.broadcast_ms = (time.perf_counter() - t0) * 1e3
         args = dict(self.default_adam_args)
         args.update({"lr": lr, "weight_decay": weight_decay})
         # optimiser: the library's Adam over the flat buffer wherever the parameters live on the GPU (`fused` None or
@@ -268,7 +277,7 @@ class DataParallelTrainer:
         decays its moments (and applies weight_decay), whereas a single process skips it.  The reference has no multi-GPU
         path to compare with; the multi-rank path keeps the collective's shape fixed instead of exchanging a has-grad
         mask (which would put a device -> host read into every step)."""
-        if self.world == 1:
+        if not self._sync:
             return
         if self._flat_g is None:       # parameters could not be flattened: per-tensor fallback, fixed list, zeros for None
             for p in self.params:
@@ -397,10 +406,10 @@ class DataParallelTrainer:
                 _lib.ptr(packed_t[1]), ns, ctypes.byref(cb), self.rays_per_chunk, oc["ws"].data_ptr(), g_c, g_f if Nf else None,
                 loss.data_ptr(), rgb.data_ptr(), rgb_fine.data_ptr())
         opt = self.optim
-        live = oc["tensors"][0] | (oc["tensors"][1] if Nf or self.world > 1 else frozenset())
+        live = oc["tensors"][0] | (oc["tensors"][1] if Nf or self._sync else frozenset())
         flags = [i in live for i in range(len(self.params))]
         with torch.cuda.device(dev), _lib.timed(f"train_step[B={B}]"):
-            if self.world == 1:
+            if not self._sync:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
                 _lib.check(lib.snerf_nerf_train_step_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets,

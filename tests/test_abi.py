@@ -60,6 +60,12 @@ def test_mlp_descriptor_arithmetic(lib):
     assert lib.snerf_mlp_packed_floats(w200) == lib.snerf_mlp_packed_floats(d0)       # the stream of the 256-wide kernel
     bad = _lib.MlpDesc(8, 320, 10, 0, 4, 0, 0, 0, 1)
     assert lib.snerf_mlp_param_floats(bad) < 0
+    assert lib.snerf_mlp_pack_f32(bad, None, None, None) == -1 and b"above 256 is not supported" in lib.snerf_last_error_string()
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    with pytest.raises(ValueError, match="width 320"):          # config_parser.py:20 accepts it; the limit is named up front
+        RenderRayNet(8, 320, 60, 24)
+    with pytest.raises(ValueError, match="netwidth_warp"):
+        WarpFieldNet(8, 512, 60, 40)
     assert lib.snerf_mlp_packed_bf16_bytes(w200, 3) < 0     # the split-precision entry points: width 256 only
     assert lib.snerf_mlp_pack_f32(d, None, None, None) == -1
 

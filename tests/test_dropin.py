@@ -84,3 +84,34 @@ def test_install_normalises_the_root(tmp_path):
     assert not dropin._under(os.path.realpath(REF) + "2/utils.py", root)
     with pytest.raises(FileNotFoundError):
         dropin.install(str(tmp_path / "nope"))
+
+
+def test_install_wraps_the_render_entry_point_in_no_grad(tmp_path):
+    """inference.inference (inference.py:222-265) calls pipeline(data) with autograd recording on (:247-253); the drop-in
+    runs it under torch.no_grad() so that the pipelines take their inference kernels.  A stand-in module of that name under a
+    scratch root (the reference's own inference.py needs imageio / torchvision at import)."""
+    import torch
+    from smpl_nerf_amd import dropin
+    root = tmp_path / "checkout"
+    root.mkdir()
+    (root / "inference.py").write_text("import torch\n\ndef inference(x=1):\n    'render'\n    return torch.is_grad_enabled(), x\n")
+    saved_path, saved_meta, saved_mod = list(sys.path), list(sys.meta_path), sys.modules.pop("inference", None)
+    try:
+        dropin._installed = False
+        sys.path.insert(0, str(root))
+        import inference as inf                                    # imported BEFORE install: swept
+        assert inf.inference() == (True, 1)
+        assert dropin.install(str(root)) >= 1
+        assert inf.inference(5) == (False, 5) and inf.inference.__doc__ == "render"
+        assert torch.is_grad_enabled()
+        assert dropin.install(str(root)) == 0                      # idempotent: not wrapped twice
+        sys.modules.pop("inference")
+        inf2 = importlib.import_module("inference")                # imported AFTER install: patched on import
+        assert inf2.inference() == (False, 1)
+    finally:
+        sys.meta_path[:] = saved_meta
+        sys.path[:] = saved_path
+        sys.modules.pop("inference", None)
+        if saved_mod is not None:
+            sys.modules["inference"] = saved_mod
+        dropin._installed = False

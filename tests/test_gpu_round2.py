@@ -563,8 +563,33 @@ def test_bench_launches_its_own_ranks(dev):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["dtype"] == "f32"
-    assert line["train"]["collective"].startswith("one all-reduce of 1220872 fp32")
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-12
+    # the N > 1 record proves itself: which ranks on which devices, what the backend saw, what the one
+    # collective of the training step moved and how long it took
+    assert [p["rank"] for p in line["per_rank"]] == [0, 1] and all(p["value"] > 0 and p["device"] for p in line["per_rank"])
+    assert abs(line["value"] - 2 * 2 * 16384 * 256 / (line["ms_per_step"] * 2e-3)) <= 1e-6 * line["value"]
+    assert line["collective"]["world_size_seen_by_backend"] == 2 and line["collective"]["bytes"] == 0
+    c = line["train"]["collective"]
+    assert c["world_size_seen_by_backend"] == 2 and c["bytes"] == 4 * 1220872 and c["allreduce_calls"] == 2
+    assert c["allreduce_ms_per_step"] > 0 and c["broadcast_ms"] > 0 and c["backend"] in ("gloo", "nccl (RCCL)")
+    assert [p["rank"] for p in line["train"]["per_rank"]] == [0, 1]
+
+
+def test_bench_strong_scaling_mode_assembles_one_frame(dev):
+    """`bench.py --gpus 2 --scaling strong`: ONE 128 x 128 frame split by rows over the ranks (dist.shard_rays), the rendered
+    rows all-gathered into the frame on every rank inside the timed region (dist.gather_rows): the assembled frame
+    equals the single-rank render bit for bit (rays are independent), value counts the frame once."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--steps", "2",
+                        "--warmup", "1", "--cpu-rays", "0", "--train-rays", "0", "--no-alt", "--no-pmc"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert sum(p["rays_per_step"] for p in line["per_rank"]) == 16384
+    assert abs(line["value"] - 16384 * 256 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    c = line["collective"]
+    assert c["bytes"] == 16384 * 3 * 4 and c["strong_frame_max_abs_diff_vs_single_rank_render"] == 0.0
 
 
 # ------------------------------------------------------------------------------------------ f-3: the reference's files

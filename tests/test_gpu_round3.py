@@ -525,6 +525,12 @@ def test_bench_takes_its_rccl_branch_at_world_size_one():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and "nccl" in line["config"]["parallelism"] and line["value"] > 5e7
     assert line["train"]["value"] > 1e7
+    # the record of a grouped run: the backend's own view, the all-reduce timed on RCCL, per-rank entries
+    assert line["collective"]["backend"] == "nccl (RCCL)" and line["collective"]["world_size_seen_by_backend"] == 1
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["rank"] == 0 and "gfx950" in line["per_rank"][0]["arch"]
+    c = line["train"]["collective"]
+    assert c["backend"] == "nccl (RCCL)" and c["bytes"] == 4 * 1220872 and c["allreduce_calls"] == 2
+    assert 0 < c["allreduce_ms_per_step"] < 50 and len(line["train"]["per_rank"]) == 1
 
 
 def test_smpl_render_rays_covers_the_modes_without_a_one_call_entry(dev):

@@ -351,3 +351,67 @@ def test_shuffled_epochs_visit_every_ray_once(dev):
     assert len(RayBatchLoader(gen, 100, iterations=3, shuffle=True)) == 3
     with pytest.raises(ValueError):
         RayGenerator.for_rank(poses, h, w, np.pi / 3, 1.0, 4.0, 64, dev, world=4, rank=3)
+
+
+# ------------------------------------------------------------------------------------------ fold workspaces (b-2 boundary)
+def test_per_ray_fold_tables_live_in_the_callers_workspace(dev):
+    """the library allocates nothing.  snerf_mlp_fwd_ws_f32 / snerf_warp_fwd_ws_f32 take the per-ray fold
+    table as a caller workspace of snerf_*_fold_workspace_bytes bytes: exactly that many bytes are written (guard bands), NULL
+    is the per-sample form (= snerf_mlp_fwd_f32 / snerf_warp_fwd_f32, same values up to the summation order of the folded
+    columns), a workspace that is too small is an error and not a silent switch of form."""
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(3)
+    rays, spr = 37, 24
+    n = rays * spr
+    x = (torch.rand(n, 3, device=dev) - 0.5) * 3
+    d = torch.randn(rays, 3, device=dev)
+    net = RenderRayNet(8, 256, 60, 24, additional_input_dim=69, skips=[4]).to(dev)
+    desc = net.desc_for_encoders(PositionalEncoder(10, 0), PositionalEncoder(4, 0), add_first=True)
+    add = torch.randn(rays, 69, device=dev)
+    packed = net.packed_weights(desc)
+    need = int(lib.snerf_mlp_fold_workspace_bytes(desc, n, spr))
+    assert need == rays * 2 * 256 * 4                             # layer 0 and the skip layer: one 256-vector per ray each
+    assert lib.snerf_mlp_fold_workspace_bytes(desc, rays * 4, 4) == 0          # fewer than 8 samples per ray: no fold
+    plain_desc = RenderRayNet(8, 256, 60, 24, skips=[4]).desc_for_encoders(PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+    assert lib.snerf_mlp_fold_workspace_bytes(plain_desc, n, spr) == 0         # no additional inputs: nothing to fold
+    band = 1024
+    buf = torch.full((need + 2 * band,), 0xA5, dtype=torch.uint8, device=dev)
+    raw_ws, raw_plain, raw_nofold = (torch.zeros(n, 4, device=dev) for _ in range(3))
+    args = (desc, packed.data_ptr(), x.data_ptr(), d.data_ptr())
+    _lib.check(lib.snerf_mlp_fwd_ws_f32(*args, 0, add.data_ptr(), n, spr, raw_ws.data_ptr(), buf.data_ptr() + band, need, s), "ws")
+    _lib.check(lib.snerf_mlp_fwd_f32(*args, 0, add.data_ptr(), n, spr, raw_plain.data_ptr(), s), "plain")
+    _lib.check(lib.snerf_mlp_fwd_ws_f32(*args, 2, add.data_ptr(), n, spr, raw_nofold.data_ptr(), buf.data_ptr() + band, need, s), "nofold")
+    torch.cuda.synchronize()
+    assert bool((buf[:band] == 0xA5).all()) and bool((buf[band + need:] == 0xA5).all())
+    assert not bool((buf[band:band + need] == 0xA5).all())        # the table was written there
+    assert torch.equal(raw_plain, raw_nofold)                     # SNERF_FWD_NO_RAY_FOLD: the per-sample form even with a workspace
+    scale = float(raw_plain.abs().max())
+    assert 0 < float((raw_ws - raw_plain).abs().max()) <= 2e-5 * scale
+    untouched = torch.full((n, 4), 7.0, device=dev)
+    rc = lib.snerf_mlp_fwd_ws_f32(*args, 0, add.data_ptr(), n, spr, untouched.data_ptr(), buf.data_ptr() + band, need - 4, s)
+    assert rc == -1 and b"snerf_mlp_fold_workspace_bytes" in lib.snerf_last_error_string()
+    assert lib.snerf_mlp_fwd_ws_f32(*args, 4, add.data_ptr(), n, spr, untouched.data_ptr(), None, 0, s) == -1   # unknown bit
+    torch.cuda.synchronize()
+    assert bool((untouched == 7.0).all())
+    # the warp net: one 256-vector per ray
+    mw = WarpFieldNet(8, 256, 60, 40).to(dev)
+    wdesc = _lib.WarpDesc(256, 10, 0, 40)
+    wpacked = mw._packed(wdesc)
+    pose = torch.randn(rays, 40, device=dev)
+    o = torch.randn(rays, 3, device=dev)
+    wneed = int(lib.snerf_warp_fold_workspace_bytes(wdesc, n, spr))
+    assert wneed == rays * 256 * 4
+    wbuf = torch.full((wneed + 2 * band,), 0xA5, dtype=torch.uint8, device=dev)
+    outs = [[torch.zeros(n, 3, device=dev) for _ in range(3)] for _ in range(2)]
+    wargs = (wdesc, wpacked.data_ptr(), x.data_ptr(), pose.data_ptr(), o.data_ptr(), n, spr)
+    _lib.check(lib.snerf_warp_fwd_ws_f32(*wargs, *[t.data_ptr() for t in outs[0]], wbuf.data_ptr() + band, wneed, s), "warp ws")
+    _lib.check(lib.snerf_warp_fwd_f32(*wargs, *[t.data_ptr() for t in outs[1]], s), "warp plain")
+    torch.cuda.synchronize()
+    assert bool((wbuf[:band] == 0xA5).all()) and bool((wbuf[band + wneed:] == 0xA5).all())
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+    rc = lib.snerf_warp_fwd_ws_f32(*wargs, *[t.data_ptr() for t in outs[0]], wbuf.data_ptr() + band, wneed - 4, s)
+    assert rc == -1 and b"snerf_warp_fold_workspace_bytes" in lib.snerf_last_error_string()
