@@ -373,7 +373,7 @@ def raygen_loader(dev, res, n_frames, batch, world, rank):
     return gen, RayBatchLoader(gen, batch, seed=4321, shuffle=True)
 
 
-def train_section(precision, workload, data, rays, steps, world, rank, dev, backend=None, loader=None):
+def train_section(precision, workload, data, rays, steps, world, rank, dev, backend=None, loader=None, input_grads=False):
     """Secondary measurement (not `value`): data-parallel training steps - forward with saved activations, MSE
     coarse+fine, HIP backward, one flat all-reduce of the gradients, Adam - on `rays` rays per GPU drawn from this rank's
     frame (solver/nerf_solver.py:76-87), or, with `loader`, generated on the device per step from this rank's shard of a
@@ -387,6 +387,9 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
         m.train()
         for p in m.parameters():
             p.requires_grad_(True)
+    if input_grads and workload == "append_vertices":      # the estimator is trained too: gradient through smpl_model into its poses
+        pipe.smpl_estimator.goal_poses.requires_grad_(True)
+        models = models + [pipe.smpl_estimator]
     # lr: small enough that both nets stay alive on this synthetic scene (at 1e-4 and above Adam's first steps push the
     # fine net's densities below zero everywhere: the rendered colour and every gradient become exactly 0, and the
     # backward kernels would be timed on all-zero operands)
@@ -406,6 +409,8 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
         for _ in range(4):
             idx = torch.randperm(n_total, generator=g)[:rays].to(dev)
             batches.append([t[idx].contiguous() for t in data])
+            if input_grads and workload == "append_smpl_params":
+                batches[-1][4].requires_grad_(True)           # d loss / d goal_pose (69 per-ray columns)
         next_batch = lambda i: batches[i % 4]
     losses = []
     for i in range(2):
@@ -451,6 +456,7 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
             "step_entry": ("snerf_nerf_train_step_f32 (one C-ABI call per step; mlp_kernels_ms_per_step brackets the whole call)"
                            if one_call else "autograd (torch.autograd.Function per kernel group) + HipAdam"),
             "rays_per_chunk": tr.rays_per_chunk if one_call else None,
+            "input_gradients": bool(input_grads),
             "kernels_ms_per_step": {k: v[1] / steps for k, v in sorted(kern.items())},
             "batches": ("generated on the device per step: RayBatchLoader(shuffle=True) over this rank's frames "
                         f"({loader.gen.n_frames} of the data set's frames, {loader.gen.n_rays} rays; raygen + pixel gather inside the "
@@ -500,6 +506,10 @@ def main():
                     help="training steps fed by RayBatchLoader(shuffle=True) over a multi-frame RayGenerator sharded by image "
                          "(rays generated on the device inside the timed region) instead of resident batches")
     ap.add_argument("--raygen-frames", type=int, default=64, help="frames of the synthetic data set of --train-from-raygen")
+    ap.add_argument("--train-input-grads", action="store_true",
+                    help="train section of the pose- / vertex-conditioned workloads with the gradient flowing into the per-ray "
+                         "inputs: append_vertices trains its pose estimator (AppendVerticesSolver's second parameter group, "
+                         "models/append_vertices_pipeline.py:30-58), append_smpl_params differentiates the goal pose")
     ap.add_argument("--no-alt", action="store_true", help="skip the other precision modes")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     a = ap.parse_args()
@@ -640,9 +650,30 @@ def main():
                 "gpu_kernels_ms_per_step": sum(v[1] for v in k.values()) / steps,
                 "ms_per_step_with_event_pairs": dt / steps * 1e3, "host_ms_with_event_pairs": th / steps * 1e3}
 
+    def eval_without_no_grad(n, steps=20):
+        """inference.py:247-253 as the reference ships it: eval mode, autograd recording ON - the pipelines then run their
+        training forward (every layer input stored) and drop the graph.  dropin.install() wraps that loop in no_grad; this row
+        is what an unwrapped caller pays."""
+        sub = [t[:n].contiguous() for t in data]
+        for _ in range(3):
+            pipe(sub)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe(sub)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"rays_per_step": n, "mode": "eval_without_no_grad: inference.py:247-253 unwrapped (autograd recording on -> training "
+                                           "forward, layer inputs stored and dropped)",
+                "ms_per_step": dt / steps * 1e3, "ray_samples_per_s": n * per_ray * steps / dt,
+                "peak_allocated_bytes": int(torch.cuda.max_memory_allocated(dev))}
+
     points = None
     if a.points and world == 1 and not grouped:
         points = [operating_point(n) for n in sorted({int(v) for v in a.points.split(",") if v.strip()}) if n <= rays]
+        if 800 <= rays and run_fine:
+            points.append(eval_without_no_grad(800))
 
     def mlp_launch_stats(k, steps):
         mlp = {n: v for n, v in k.items() if n.startswith("mlp_fwd")}
@@ -704,7 +735,7 @@ def main():
                 _, loader = raygen_loader(dev, a.res, a.raygen_frames, min(a.train_rays, frame_rays), world, rank)
             tb = backend if grouped else None
             train = train_section(a.precision, a.workload, data, min(a.train_rays, frame_rays if loader else rays), a.train_steps,
-                                  world, rank, dev, tb, loader)
+                                  world, rank, dev, tb, loader, a.train_input_grads)
             if a.points and world == 1:   # the reference's own batch sizes (config_parser.py:53, README quickstart)
                 pts = []
                 for n in sorted({int(v) for v in a.points.split(",") if v.strip()}):

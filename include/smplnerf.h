@@ -24,6 +24,8 @@
  *
  * State.  The library keeps no caller-visible state between calls.  What it does keep, process-wide:
  *   - the error text of the last failure, per thread (snerf_last_error_string);
+ *   - two HIP events per host thread and device, created at the first training call that is given an auxiliary stream
+ *     (fork / join of the concurrent backward; never destroyed);
  *   - per HIP device ordinal (up to 64 devices): the CU count and, per kernel, whether its dynamic-LDS limit was
  *     raised (hipFuncSetAttribute is per device) - so one process may drive several GPUs through the library;
  *   - tuning knobs: the environment variables below are read ONCE, at the first call that consults them.  They choose
@@ -65,7 +67,7 @@ extern "C" {
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
                              folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
                              0.1.4: + the training step as one call (snerf_nerf_train_step_f32 / _grads_f32, snerf_adam_step_f32,
-                             snerf_mlp_stream_slots); the per-ray fold tables moved from stream-ordered allocations inside
+                             snerf_mlp_stream_slots), snerf_dy_contract_f32; the per-ray fold tables moved from stream-ordered allocations inside
                              the library to caller workspaces (snerf_mlp_fwd_ws_f32, snerf_warp_fwd_ws_f32): the library allocates nothing */
 
 #define SNERF_OK 0
@@ -170,6 +172,14 @@ int snerf_sample_pdf_bins_strict_f32(const float *bins, const float *weights, co
  * z_samples [B, Nf].  2 <= Nb <= 1023. */
 int snerf_sample_pdf_bins_f32(const float *bins, const float *weights, const float *u, int64_t B,
                               int Nb, int Nf, int64_t *inds, float *z_samples, snerf_stream_t stream);
+
+/* Backward of sample_pdf(bins, weights, args) (utils.py:194-228 under autograd; fine_sampling detaches its result,
+ * utils.py:260, so no pipeline needs it): d_z_samples [B, Nf] -> d_bins [B, Nb], d_weights [B, Nb-1], with the forward's
+ * searchsorted indices `inds` [B, Nf] held fixed (integers carry no gradient in the reference either). */
+int snerf_sample_pdf_bins_bwd_f32(const float *bins, const float *weights, const float *u, const int64_t *inds,
+                                  const float *tot /* nullable [B]: the strict forward's normalising sums */,
+                                  const float *d_z_samples, int64_t B, int Nb, int Nf, float *d_bins, float *d_weights,
+                                  snerf_stream_t stream);
 
 /* ---- a2: RenderRayNet -----------------------------------------------------------------------------
  * Mirrors RenderRayNet.__init__ (models/render_ray_net.py:8): n_layers, width, skips as a bit mask
@@ -282,6 +292,21 @@ int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_fl
  *     dy[((first_row[l] + f / 16) * n + s) * 16 + f % 16]                                   (tile-row-major) */
 #define SNERF_MAX_MLP_LAYERS 21
 int snerf_mlp_dy_layout(const snerf_mlp_desc *desc, int32_t *n_layers, int32_t *first_row, int32_t *n_out, int32_t *n_in);
+/* Gradients w.r.t. inputs that enter a layer through plain weight columns - per-ray additional inputs, already-encoded input
+ * rows, the pose rows of the warp net - as contractions of a stored d Y_l with those columns (what autograd leaves in the
+ * .grad of x when y = x W^T; models/render_ray_net.py:43-50, models/append_vertices_pipeline.py:30-58):
+ *     out[s, out_col0 + c] (+)= sum_{f < n_feat} d Y_l[s, f] * w[f, col0 + c],   c < ncols
+ * dy / first_row: the backward's `dy` buffer and the layer's first tile-row (snerf_mlp_dy_layout; the warp net's layer 0 is
+ * tile-row 0); w [n_feat, w_stride] row-major = the layer's weight matrix in params_flat (n_feat <= 256).
+ * samples_per_ray == 0: one output row per sample, out [n, out_stride].  samples_per_ray > 0: the rows of a ray's samples
+ * are summed (the pipelines expand one input row per ray over its samples), out [n / samples_per_ray, out_stride];
+ * scratch: snerf_dy_contract_scratch_floats(n, ncols, samples_per_ray) floats.  accumulate != 0: out += (several layers
+ * read the same inputs: layer 0 and every skip layer). */
+int64_t snerf_dy_contract_scratch_floats(int64_t n, int ncols, int samples_per_ray);
+int snerf_dy_contract_f32(const float *dy, int64_t n, int first_row, int n_feat, const float *w, int w_stride, int col0,
+                          int ncols, int samples_per_ray, float *out, int64_t out_stride, int out_col0, int accumulate,
+                          float *scratch, snerf_stream_t stream);
+
 /* snerf_mlp_fwd_f32 that also saves every layer input into `act` (act_floats): fp32 tile-rows, followed by one
  * sign bit per ReLU output (the masks the split-bf16 dgrad reads instead of the activation rows). */
 int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
@@ -488,13 +513,18 @@ typedef struct snerf_nerf_batch {
  * The batch is walked in chunks of rays_per_chunk rays (<= 0 or > B: one chunk): d loss / d rgb of a ray does not depend on
  * the other rays, so forward and backward run chunk by chunk and the parameter gradients are summed in chunk order - the
  * saved activations (21 KB per ray-sample) are sized by the chunk, nothing is recomputed.
+ * aux_stream (nullable): a second stream of the caller's.  Chunks of at most 16 384 fine samples (the README's 64-ray
+ * batches) leave most of the chip idle in every kernel; there the coarse net's backward - independent of the fine net's, the
+ * hierarchical samples being detached (utils.py:260) - is enqueued on aux_stream beside it (forked from and joined back into
+ * `stream` with events, also under graph capture).  NULL: everything on `stream`.  Same results either way.
  * workspace: snerf_nerf_train_workspace_bytes(...) bytes, 256-byte aligned. */
 int64_t snerf_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B, int Nc,
                                          int Nf, int64_t rays_per_chunk);
 int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                                const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
                                const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
-                               float *grad_fine, float *loss, float *rgb, float *rgb_fine, snerf_stream_t stream);
+                               float *grad_fine, float *loss, float *rgb, float *rgb_fine, snerf_stream_t stream,
+                               snerf_stream_t aux_stream);
 /* snerf_nerf_train_grads_f32 followed by snerf_adam_step_f32 (single-GPU step; a data-parallel trainer calls the two halves
  * with its gradient all-reduce in between). */
 int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
@@ -502,7 +532,7 @@ int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *pac
                               const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
                               float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
                               const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
-                              snerf_stream_t stream);
+                              snerf_stream_t stream, snerf_stream_t aux_stream);
 
 #ifdef __cplusplus
 }

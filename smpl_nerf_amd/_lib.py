@@ -71,6 +71,7 @@ SIGNATURES = {
     "snerf_sample_pdf_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "snerf_sample_pdf_strict_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "snerf_sample_pdf_bins_strict_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    "snerf_sample_pdf_bins_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "snerf_sample_pdf_bins_f32": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "snerf_mlp_param_floats": (c_int64, [POINTER(MlpDesc)]),
     "snerf_mlp_packed_floats": (c_int64, [POINTER(MlpDesc)]),
@@ -118,13 +119,15 @@ SIGNATURES = {
     "snerf_mlp_fwd_ws_f32": (c_int, [POINTER(MlpDesc), _P, _P, _P, c_int, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "snerf_warp_fold_workspace_bytes": (c_int64, [POINTER(WarpDesc), c_int64, c_int]),
     "snerf_warp_fwd_ws_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int64, _P]),
+    "snerf_dy_contract_scratch_floats": (c_int64, [c_int64, c_int, c_int]),
+    "snerf_dy_contract_f32": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int64, c_int, c_int, _P, _P]),
     "snerf_mlp_stream_slots": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
     "snerf_adam_step_f32": (c_int, [POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P]),
     "snerf_nerf_train_workspace_bytes": (c_int64, [POINTER(MlpDesc), POINTER(MlpDesc), c_int64, c_int, c_int, c_int64]),
     "snerf_nerf_train_grads_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
-                                           _P, _P, _P, _P, _P, _P, _P]),
+                                           _P, _P, _P, _P, _P, _P, _P, _P]),
     "snerf_nerf_train_step_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
-                                          _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P]),
+                                          _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P, _P]),
 }
 
 _lib = None

@@ -217,6 +217,93 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pdf_kernel(
     }
 }
 
+
+// ---- backward of sample_pdf(bins, weights) (utils.py:194-228 under autograd) -------------------------------------------------
+// The reference's fine_sampling detaches the samples (utils.py:260), but sample_pdf itself is differentiable w.r.t. bins and
+// weights; the searchsorted indices carry no gradient, so with `inds` held fixed the map is piecewise linear:
+//     t = (u - c0) / denom,  denom = c1 - c0 (1 where that is < 1e-5),  sample = b0 + t (b1 - b0)
+//     d b0 = g (1 - t)   d b1 = g t   d t = g (b1 - b0)   d c0 = -d t / denom - d denom   d c1 = d denom = -d t t / denom
+//     d pdf_i = sum_{k > i} d cdf_k        d w_m = d pdf_m / tot - (sum_i d pdf_i (w_i + 1e-5)) / tot^2
+// One wave per ray; every lane owns bins k = lane, lane + 64, ... and walks the Nf samples for the ones that gather it
+// (deterministic: no atomics); sums in fp64.
+__global__ __launch_bounds__(SP_THREADS) void sample_pdf_bwd_kernel(const float *__restrict__ bins, const float *__restrict__ weights,
+                                                                    const float *__restrict__ u, const int64_t *__restrict__ inds,
+                                                                    const float *__restrict__ tot_in, const float *__restrict__ d_zs,
+                                                                    int64_t B, int Nb, int Nf, float *__restrict__ d_bins,
+                                                                    float *__restrict__ d_weights) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * SP_WAVES + wave;
+    if (ray >= B) return;
+    const int M = Nb - 1;
+    const int per_wave = sp_round4(2 * Nb) + 4 * sp_round4(Nf);
+    float *s_cdf = smem + wave * per_wave;       // [Nb]
+    float *s_dc = s_cdf + Nb;                    // [Nb]  d cdf
+    float *s_c0 = s_cdf + sp_round4(2 * Nb);     // [Nf] per sample: d c0, d c1, d b0, d b1
+    float *s_c1 = s_c0 + sp_round4(Nf), *s_b0 = s_c1 + sp_round4(Nf), *s_b1 = s_b0 + sp_round4(Nf);
+    const float *br = bins + ray * Nb, *wr = weights + ray * M;
+    double part = 0.0;
+    for (int i = lane; i < M; i += WAVE) part += (double)__fadd_rn(wr[i], 1e-5f);
+    const float tot = tot_in ? tot_in[ray] : (float)wave_sum(part);   // (strict mode: the forward's normalising sum -> the forward's cdf)
+    if (lane == 0) s_cdf[0] = 0.f;
+    double carry = 0.0;
+    for (int c0 = 0; c0 < M; c0 += WAVE) {
+        const int k = c0 + lane;
+        double p = 0.0;
+        if (k < M) p = (double)__fdiv_rn(__fadd_rn(wr[k], 1e-5f), tot);
+        const double incl = wave_scan_add(p) + carry;
+        if (k < M) s_cdf[k + 1] = (float)incl;
+        carry = wave_last(incl);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int f = lane; f < Nf; f += WAVE) {
+        const int ind = (int)inds[ray * Nf + f];
+        const int below = max(0, ind - 1), above = min(Nb - 1, ind);
+        const float c0 = s_cdf[below], c1 = s_cdf[above], b0 = br[below], b1 = br[above];
+        const float raw = c1 - c0;
+        const bool active = !(raw < 1e-5f);
+        const float denom = active ? raw : 1.f;
+        const float t = (u[f] - c0) / denom;
+        const float g = d_zs[ray * Nf + f];
+        const float dt = g * (b1 - b0);
+        const float dden = active ? -dt * t / denom : 0.f;
+        s_c0[f] = -dt / denom - dden;
+        s_c1[f] = dden;
+        s_b0[f] = g * (1.f - t);
+        s_b1[f] = g * t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int k = lane; k < Nb; k += WAVE) {
+        double dc = 0.0, db = 0.0;
+        for (int f = 0; f < Nf; ++f) {
+            const int ind = (int)inds[ray * Nf + f];
+            const int below = max(0, ind - 1), above = min(Nb - 1, ind);
+            if (below == k) dc += (double)s_c0[f], db += (double)s_b0[f];
+            if (above == k) dc += (double)s_c1[f], db += (double)s_b1[f];
+        }
+        s_dc[k] = (float)dc;
+        d_bins[ray * Nb + k] = (float)db;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // d pdf_i = sum_{k = i + 1}^{Nb - 1} d cdf_k (cdf_0 = 0 is a constant); S = sum_i d pdf_i (w_i + 1e-5)
+    double s_part = 0.0;
+    for (int i = lane; i < M; i += WAVE) {
+        double dp = 0.0;
+        for (int k = i + 1; k < Nb; ++k) dp += (double)s_dc[k];
+        s_part += dp * (double)__fadd_rn(wr[i], 1e-5f);
+        d_weights[ray * M + i] = (float)dp;   // d pdf for now; finished below
+    }
+    const double S = wave_sum(s_part);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const double tt = (double)tot;
+    for (int i = lane; i < M; i += WAVE) d_weights[ray * M + i] = (float)((double)d_weights[ray * M + i] / tt - S / (tt * tt));
+}
+
 }  // namespace snerf
 
 namespace snerf {
@@ -284,4 +371,23 @@ static int snerf::launch_sample_pdf(bool direct, const float *z, const float *we
         hipLaunchKernelGGL((sample_pdf_kernel<false, 0, 0>), dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, z,
                            weights, u, o, d, tot, B, Nc, Nf, inds, z_samples, z_fine, pts);
     return check_launch("sample_pdf");
+}
+
+extern "C" int snerf_sample_pdf_bins_bwd_f32(const float *bins, const float *weights, const float *u, const int64_t *inds,
+                                             const float *tot, const float *d_z_samples, int64_t B, int Nb, int Nf, float *d_bins,
+                                             float *d_weights, snerf_stream_t stream) {
+    using namespace snerf;
+    if (B < 0) return fail(SNERF_E_BADARG, "sample_pdf_bins_bwd: negative B");
+    if (Nb < 2 || Nb > 1023 || Nf < 1 || Nf > 1024) return fail(SNERF_E_BADARG, "sample_pdf_bins_bwd: need 2 <= Nb <= 1023 and 1 <= Nf <= 1024");
+    if (B == 0) return SNERF_OK;
+    if (!bins || !weights || !u || !inds || !d_z_samples || !d_bins || !d_weights) return fail(SNERF_E_BADARG, "sample_pdf_bins_bwd: null pointer");
+    const size_t lds = (size_t)SP_WAVES * (sp_round4(2 * Nb) + 4 * sp_round4(Nf)) * sizeof(float);     // <= 4 * (2048 + 4096) * 4 = 96 KiB
+    static LdsRaised raised;
+    if (lds > 64 * 1024)
+        if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(sample_pdf_bwd_kernel), 128 * 1024, raised, "sample_pdf_bins_bwd")) return rc;
+    const int64_t grid = (B + SP_WAVES - 1) / SP_WAVES;
+    if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "sample_pdf_bins_bwd: B too large");
+    hipLaunchKernelGGL(sample_pdf_bwd_kernel, dim3((unsigned)grid), dim3(SP_THREADS), lds, (hipStream_t)stream, bins, weights, u, inds,
+                       tot, d_z_samples, B, Nb, Nf, d_bins, d_weights);
+    return check_launch("sample_pdf_bins_bwd");
 }

@@ -290,8 +290,32 @@ extern "C" int snerf_adam_step_f32(const snerf_adam_state *st, const snerf_adam_
 namespace snerf {
 
 struct TrainWs {
-    int64_t raw_c, weights_c, z_fine, pts_f, raw_f, d_rgb_c, d_rgb_f, d_raw, act_c, act_f, dy, gpart, loss_acc, total;
+    int64_t raw_c, weights_c, z_fine, pts_f, raw_f, d_rgb_c, d_rgb_f, d_raw, act_c, act_f, dy, gpart, loss_acc;
+    int64_t d_raw2, dy2, gpart2;   // second set for the coarse net's backward when it runs beside the fine net's (small chunks)
+    bool concurrent;
+    int64_t total;
 };
+
+// Chunks of at most this many fine samples leave most of the chip idle in every kernel (a 64-ray batch is 96 workgroups of
+// 128 samples): there the backward of the coarse net - independent of the fine net's: the hierarchical samples are
+// detached, utils.py:260 - runs beside it on the caller's auxiliary stream.  A pure size rule, so that the workspace size
+// does not depend on the device.
+constexpr int64_t CONCURRENT_MAX_FINE_SAMPLES = 64 * 256;
+
+// fork / join events of the concurrent backward: one pair per host thread and device (include/smplnerf.h "State")
+static int fork_join_events(hipEvent_t &fork, hipEvent_t &join) {
+    static thread_local hipEvent_t ev[MAX_DEVICES][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return fail(SNERF_E_LAUNCH, "nerf_train: cannot query the current device");
+    for (int k = 0; k < 2; ++k)
+        if (!ev[dev][k] && hipEventCreateWithFlags(&ev[dev][k], hipEventDisableTiming) != hipSuccess) {
+            ev[dev][k] = nullptr;
+            return fail(SNERF_E_LAUNCH, "nerf_train: cannot create an event");
+        }
+    fork = ev[dev][0];
+    join = ev[dev][1];
+    return SNERF_OK;
+}
 
 static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t chunk, int Nc, int Nf, TrainWs &w) {
     const int64_t N = Nc + Nf;
@@ -318,6 +342,10 @@ static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t 
     w.dy = take(dy_c > dy_f ? dy_c : dy_f);
     w.gpart = take(gp_c > gp_f ? gp_c : gp_f);
     w.loss_acc = take(4);
+    w.concurrent = Nf > 0 && chunk * N <= CONCURRENT_MAX_FINE_SAMPLES;
+    w.d_raw2 = take(w.concurrent ? chunk * Nc * 4 : 0);
+    w.dy2 = take(w.concurrent ? dy_c : 0);
+    w.gpart2 = take(w.concurrent ? gp_c : 0);
     w.total = off;
     return SNERF_OK;
 }
@@ -343,7 +371,7 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
                                           const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
                                           int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
                                           float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
-                                          snerf_stream_t stream) {
+                                          snerf_stream_t stream, snerf_stream_t aux_stream) {
     using namespace snerf;
     if (precision != 0 && !split_code(precision))
         return fail(SNERF_E_BADARG, "nerf_train_grads: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
@@ -370,6 +398,12 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
     float *raw_c = f(w.raw_c), *weights_c = f(w.weights_c), *z_fine = f(w.z_fine), *pts_f = f(w.pts_f), *raw_f = f(w.raw_f);
     float *d_rgb_c = f(w.d_rgb_c), *d_rgb_f = f(w.d_rgb_f), *d_raw = f(w.d_raw), *act_c = f(w.act_c), *act_f = f(w.act_f);
     float *dy = f(w.dy), *gpart = f(w.gpart);
+    // small chunks with an auxiliary stream: the coarse net's backward beside the fine net's, on its own scratch buffers
+    const bool concurrent = w.concurrent && aux_stream && aux_stream != stream;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (concurrent && (rc = fork_join_events(ev_fork, ev_join))) return rc;
+    float *d_raw_c = concurrent ? f(w.d_raw2) : d_raw, *dy_c = concurrent ? f(w.dy2) : dy, *gpart_c = concurrent ? f(w.gpart2) : gpart;
+    const snerf_stream_t stream_c = concurrent ? aux_stream : stream;
     double *loss_acc = reinterpret_cast<double *>(ws + w.loss_acc);
     hipStream_t s = (hipStream_t)stream;
     const int wb = batch->white_background ? 1 : 0;
@@ -381,12 +415,13 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
             return snerf_mlp_fwd_train_f32(d, reinterpret_cast<const float *>(packed), x, dirs, 0, nullptr, n, spr, raw, act, stream);
         return snerf_mlp_fwd_train_bf16_f32(d, packed, precision, x, dirs, 0, nullptr, n, spr, raw, act, stream);
     };
-    auto bwd = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, int64_t n, float *grad, bool accumulate) {
+    auto bwd = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, const float *d_raw_, int64_t n, float *dy_,
+                   float *gpart_, float *grad, bool accumulate, snerf_stream_t st) {
         if (precision == 0)
-            return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw, n, dy, gpart, grad, nullptr, nullptr, 0, 1,
-                              nullptr, nullptr, stream, accumulate);
-        return launch_bwd_bf16(d, packed_t, precision, act, d_raw, n, dy, gpart, grad, nullptr, nullptr, 0, 1, nullptr, nullptr,
-                               stream, accumulate);
+            return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw_, n, dy_, gpart_, grad, nullptr, nullptr, 0, 1,
+                              nullptr, nullptr, st, accumulate);
+        return launch_bwd_bf16(d, packed_t, precision, act, d_raw_, n, dy_, gpart_, grad, nullptr, nullptr, 0, 1, nullptr, nullptr,
+                               st, accumulate);
     };
     for (int64_t r0 = 0; r0 < B; r0 += chunk) {
         const int64_t b = (B - r0 < chunk) ? B - r0 : chunk;
@@ -410,12 +445,16 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
                            d_rgb_c, d_rgb_f, loss_acc, r0 == 0 ? 1 : 0, r0 + b >= B ? 1 : 0, inv_total, loss);
         if ((rc = check_launch("nerf_train_grads(mse)"))) return rc;
         // backward: compositing, then dgrad + wgrad + reduce of each net (the hierarchical samples are detached, utils.py:260)
+        if (concurrent && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent((hipStream_t)aux_stream, ev_fork, 0) != hipSuccess))
+            return fail(SNERF_E_LAUNCH, "nerf_train_grads: cannot fork onto the auxiliary stream");
         if (Nf > 0) {
             if ((rc = snerf_composite_bwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, d_rgb_f, d_raw, nullptr, stream))) return rc;
-            if ((rc = bwd(desc_fine, packed_t_fine, act_f, b * N, grad_fine, r0 > 0))) return rc;
+            if ((rc = bwd(desc_fine, packed_t_fine, act_f, d_raw, b * N, dy, gpart, grad_fine, r0 > 0, stream))) return rc;
         }
-        if ((rc = snerf_composite_bwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, d_rgb_c, d_raw, nullptr, stream))) return rc;
-        if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, b * Nc, grad_coarse, r0 > 0))) return rc;
+        if ((rc = snerf_composite_bwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, d_rgb_c, d_raw_c, nullptr, stream_c))) return rc;
+        if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, d_raw_c, b * Nc, dy_c, gpart_c, grad_coarse, r0 > 0, stream_c))) return rc;
+        if (concurrent && (hipEventRecord(ev_join, (hipStream_t)aux_stream) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess))
+            return fail(SNERF_E_LAUNCH, "nerf_train_grads: cannot join the auxiliary stream");
     }
     if (Nf == 0 && rgb_fine != rgb &&
         hipMemcpyAsync(rgb_fine, rgb, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -428,9 +467,9 @@ extern "C" int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, cons
                                          int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
                                          float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
                                          const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
-                                         const snerf_adam_net *nets_host, int n_nets, snerf_stream_t stream) {
+                                         const snerf_adam_net *nets_host, int n_nets, snerf_stream_t stream, snerf_stream_t aux_stream) {
     int rc = snerf_nerf_train_grads_f32(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision,
-                                        batch, rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream);
+                                        batch, rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream);
     if (rc) return rc;
     return snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream);
 }

@@ -56,42 +56,59 @@ def flat_parameter_vector(params) -> torch.Tensor:
     return torch.cat([p.detach().reshape(-1).float() for p in params])
 
 
-def _layer_output_grads(desc, dy, n, layers):
-    """{l: d Y_l [n, n_out_l]} for the forward layers in `layers`, gathered from the tile-row-major `dy` buffer the
-    backward kernels leave behind (include/smplnerf.h: snerf_mlp_dy_layout)."""
+def _dy_rows(desc):
+    """(first tile-row, n_out) of every forward layer in the `dy` buffer the backward kernels leave behind
+    (include/smplnerf.h: snerf_mlp_dy_layout)."""
     lib = _lib.load()
     cnt = ctypes.c_int32()
     rows = (ctypes.c_int32 * 21)()
     nout = (ctypes.c_int32 * 21)()
     check(lib.snerf_mlp_dy_layout(desc, ctypes.byref(cnt), rows, nout, None), "snerf_mlp_dy_layout")
-    out = {}
-    for l in layers:
-        t = (nout[l] + 15) // 16
-        blk = dy[rows[l] * n * 16:(rows[l] + t) * n * 16].view(t, n, 16)
-        out[l] = blk.permute(1, 0, 2).reshape(n, t * 16)[:, :nout[l]]
-    return out
+    return [(rows[l], nout[l]) for l in range(cnt.value)]
 
 
-def _extra_input_grads(net, desc, dy, n, want_pos, want_dir):
+def _contract(dy, n, first_row, n_feat, weight, col0, ncols, spr, out, out_col0, accumulate):
+    """out[s or ray, out_col0 + c] (+)= sum_f d Y[s, f] * weight[f, col0 + c] (summed over the samples of a ray when spr > 0):
+    snerf_dy_contract_f32 on the stored tile-rows - no gathered [n, 256] copy, no library GEMM."""
+    lib = _lib.load()
+    w = weight.detach()
+    if not w.is_contiguous() or w.dtype != torch.float32:
+        w = w.contiguous().float()
+    if spr == 1:
+        spr = 0          # one sample per "ray": per-sample rows, no partial sums
+    scratch = None
+    if spr:
+        scratch = torch.empty(int(lib.snerf_dy_contract_scratch_floats(n, ncols, int(spr))), device=dy.device, dtype=torch.float32)
+    with torch.cuda.device(dy.device), _lib.timed(f"dy_contract[n={n}]"):
+        check(lib.snerf_dy_contract_f32(ptr(dy), n, int(first_row), int(n_feat), ptr(w), w.shape[1], int(col0), int(ncols),
+                                        int(spr), ptr(out), out.stride(0), int(out_col0), 1 if accumulate else 0, ptr(scratch),
+                                        current_stream()), "snerf_dy_contract_f32")
+
+
+def _extra_input_grads(net, desc, dy, n, d_rows=None, d_add=None, spr=1):
     """Gradients w.r.t. the non-hidden input columns of the net, as contractions of the stored d Y_l with the weight
     columns that read them (what autograd does in the reference, models/render_ray_net.py:43-56): layer 0 and the skip
     layers read [positions | additional] (in the column order of the weight matrix), directional_input reads the
-    direction encoding.  Returns (d_posadd [n, pin] or None, d_direnc [n, dir_dim] or None)."""
+    direction encoding.  d_rows [n, row_floats] (zero-filled by the caller): gradient of already-encoded input rows
+    [positions (+ additional) | ... | directions]; d_add [n / spr, add_dim]: gradient of the per-ray additional inputs,
+    summed over the samples of each ray."""
     nh = net.n_layers - 1
     pin = net.positions_pose_input.weight.shape[1]       # positions (+ additional) columns
-    with torch.no_grad():
-        d_pa = d_dir = None
-        if want_pos:
-            readers = [(0, net.positions_pose_input.weight, 0)]
-            readers += [(i + 1, net.positional_net[i].weight, net.width) for i in range(nh) if i in net.skips]
-            g = _layer_output_grads(desc, dy, n, [l for l, _, _ in readers])
-            for l, w, c0 in readers:
-                term = g[l] @ w[:, c0:c0 + pin]
-                d_pa = term if d_pa is None else d_pa + term
-        if want_dir and net.use_directional_input:
-            g = _layer_output_grads(desc, dy, n, [nh + 3])
-            d_dir = g[nh + 3] @ net.directional_input.weight[:, net.width:]
-    return d_pa, d_dir
+    layout = _dy_rows(desc)
+    readers = [(0, net.positions_pose_input.weight, 0)]
+    readers += [(i + 1, net.positional_net[i].weight, net.width) for i in range(nh) if i in net.skips]
+    if d_rows is not None:
+        for l, w, c0 in readers:
+            _contract(dy, n, layout[l][0], layout[l][1], w, c0, pin, 0, d_rows, 0, True)
+        if net.use_directional_input:
+            l = nh + 3
+            ddim = net.directional_input.weight.shape[1] - net.width
+            _contract(dy, n, layout[l][0], layout[l][1], net.directional_input.weight, net.width, ddim, 0, d_rows,
+                      d_rows.shape[1] - ddim, True)
+    if d_add is not None:
+        a0 = 0 if desc.add_first else 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
+        for k, (l, w, c0) in enumerate(readers):
+            _contract(dy, n, layout[l][0], layout[l][1], w, c0 + a0, desc.add_dim, spr, d_add, 0, k > 0)
 
 
 def _wide_encoders(desc) -> bool:
@@ -273,17 +290,11 @@ class _FusedMlpFn(torch.autograd.Function):
     def _input_grads_from_dy(ctx, dy, n, d_x_rows, d_add):
         """Contractions of the stored d Y_l of a block of n samples: encoded-row gradients into d_x_rows [n, row_floats],
         per-ray additional-input gradients into d_add [n / spr, add_dim]."""
-        net, desc = ctx.net, ctx.desc
         if ctx.rows_grad:        # encoded rows = [positions (+ additional) | ... | directions]
-            d_pa, d_dir = _extra_input_grads(net, desc, dy, n, True, True)
             d_x_rows.zero_()
-            d_x_rows[:, :d_pa.shape[1]] = d_pa
-            if d_dir is not None:
-                d_x_rows[:, ctx.row_floats - d_dir.shape[1]:] += d_dir
-        elif ctx.add_grad:       # per-ray constants: sum the per-sample contributions of the ray
-            d_pa, _ = _extra_input_grads(net, desc, dy, n, True, False)
-            a0 = 0 if desc.add_first else 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
-            d_add.copy_(d_pa[:, a0:a0 + desc.add_dim].reshape(-1, ctx.spr, desc.add_dim).sum(1))
+            _extra_input_grads(ctx.net, ctx.desc, dy, n, d_rows=d_x_rows)
+        elif ctx.add_grad:       # per-ray constants: the per-sample contributions of a ray are summed in the kernel
+            _extra_input_grads(ctx.net, ctx.desc, dy, n, d_add=d_add, spr=ctx.spr)
 
     @staticmethod
     def backward(ctx, d_raw):
@@ -699,12 +710,10 @@ class _WarpFn(torch.autograd.Function):
                                          current_stream()), "snerf_warp_bwd_f32")
         ctx.act = None
         d_pose = None
-        if ctx.pose_grad:      # d h [n, width] (tile-rows 0 .. T-1 of dy) contracted with linear1's pose columns, summed per ray
-            T = (desc.width + 15) // 16      # (a width that is not a kernel width runs zero-padded: the first tiles hold it)
-            with torch.no_grad():
-                dh = dy[:T * n * 16].view(T, n, 16).permute(1, 0, 2).reshape(n, T * 16)[:, :desc.width]
-                pos_dim = 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
-                d_pose = (dh @ net.linear1.weight[:, pos_dim:]).view(-1, ctx.spr, desc.pose_dim).sum(1)
+        if ctx.pose_grad:      # d h (tile-rows 0 .. of dy: layer 0) contracted with linear1's pose columns, summed per ray
+            pos_dim = 3 * ((1 if desc.pos_identity else 0) + 2 * desc.pos_freqs)
+            d_pose = torch.empty((n // ctx.spr, desc.pose_dim), device=dev, dtype=torch.float32)
+            _contract(dy, n, 0, desc.width, net.linear1.weight, pos_dim, desc.pose_dim, ctx.spr, d_pose, 0, False)
         return (None, None, None, d_pose, None, None) + tuple(_grads_from_flat(flat, ctx.shapes))
 
 

@@ -303,6 +303,7 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, args) -> torch.Tensor:
     zs = torch.empty((B, Nf), device=bins.device, dtype=torch.float32)
     inds = torch.empty((B, Nf), device=bins.device, dtype=torch.long) if want_grad else None
     lib = _lib.load()
+    tot = None
     with torch.cuda.device(bins.device):
         if getattr(args, "strict_cumsum", 0):
             tot = reference_normalising_sum(weights)
@@ -313,40 +314,31 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, args) -> torch.Tensor:
                                                 current_stream()), "snerf_sample_pdf_bins_f32")
     if not want_grad:
         return zs
-    return _SamplePdfGrad.apply(bins_in, weights_in, zs, inds, u)
+    return _SamplePdfGrad.apply(bins_in, weights_in, zs, inds, u, tot)
 
 
 class _SamplePdfGrad(torch.autograd.Function):
     """sample_pdf under autograd (the reference's fine_sampling detaches the result, utils.py:260, but sample_pdf itself is
-    differentiable w.r.t. bins and weights, utils.py:200-228).  The values are the kernel's; the gradient is the
-    reference's: with the searchsorted indices held fixed (integers carry no gradient there either), utils.py:200-228 is
-    re-evaluated on the device under torch autograd and differentiated - a piecewise-linear map whose pieces the kernel's
-    `inds` select."""
+    differentiable w.r.t. bins and weights, utils.py:200-228).  The values are the forward kernel's; the gradient is the
+    reference's with the searchsorted indices held fixed (integers carry no gradient there either) - a piecewise-linear map
+    whose pieces the kernel's `inds` select, differentiated by snerf_sample_pdf_bins_bwd_f32."""
 
     @staticmethod
-    def forward(ctx, bins, weights, zs, inds, u):
-        ctx.save_for_backward(bins.detach(), weights.detach(), inds, u)
+    def forward(ctx, bins, weights, zs, inds, u, tot):
+        ctx.save_for_backward(bins.detach(), weights.detach(), inds, u, tot)
         return zs
 
     @staticmethod
     def backward(ctx, d_zs):
-        bins, weights, inds, u = ctx.saved_tensors
-        with torch.enable_grad():
-            b = bins.clone().requires_grad_(True)
-            w = weights.clone().requires_grad_(True)
-            wp = w + 1e-5                                                          # utils.py:200
-            pdf = wp / torch.sum(wp, -1, keepdim=True)                             # :201
-            cdf = torch.cumsum(pdf, -1)
-            cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)             # :202-203
-            below = torch.clamp(inds - 1, min=0)                                   # :213-214
-            above = torch.clamp(inds, max=cdf.shape[-1] - 1)
-            c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)      # :219-220
-            b0, b1 = torch.gather(b, 1, below), torch.gather(b, 1, above)
-            denom = c1 - c0
-            denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)       # :223-224
-            samples = b0 + (u[None, :] - c0) / denom * (b1 - b0)                   # :225-226
-            gb, gw = torch.autograd.grad(samples, (b, w), d_zs.contiguous().float())
-        return gb, gw, None, None, None
+        bins, weights, inds, u, tot = ctx.saved_tensors
+        B, Nb = bins.shape
+        d_zs = d_zs.contiguous().float()
+        gb, gw = torch.empty_like(bins), torch.empty_like(weights)
+        lib = _lib.load()
+        with torch.cuda.device(bins.device):
+            check(lib.snerf_sample_pdf_bins_bwd_f32(ptr(bins), ptr(weights), ptr(u), ptr(inds), ptr(tot), ptr(d_zs), B, Nb, inds.shape[1],
+                                                    ptr(gb), ptr(gw), current_stream()), "snerf_sample_pdf_bins_bwd_f32")
+        return gb, gw, None, None, None, None
 
 
 def fine_sampling(ray_translation: torch.Tensor, samples_directions: torch.Tensor, z_vals: torch.Tensor,

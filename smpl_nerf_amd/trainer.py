@@ -334,6 +334,8 @@ class DataParallelTrainer:
             return None
         lib = _lib.load()
         oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib}
+        # second stream for the coarse net's backward of small batches (include/smplnerf.h: aux_stream); SNERF_TRAIN_AUX_STREAM=0: none
+        oc["aux"] = torch.cuda.Stream(self._flat_p.device) if os.environ.get("SNERF_TRAIN_AUX_STREAM", "1") != "0" else None
         # parameter tensors of each net (indices into self.params): the optimiser's has-grad flags of a step
         index = {id(p): i for i, p in enumerate(self.params)}
         oc["tensors"] = tuple(frozenset(index[id(p)] for p in m._ordered_params()) for m in (mc, mf))
@@ -406,6 +408,7 @@ class DataParallelTrainer:
                 _lib.ptr(packed_t[1]), ns, ctypes.byref(cb), self.rays_per_chunk, oc["ws"].data_ptr(), g_c, g_f if Nf else None,
                 loss.data_ptr(), rgb.data_ptr(), rgb_fine.data_ptr())
         opt = self.optim
+        aux = oc["aux"].cuda_stream if oc["aux"] is not None else None
         live = oc["tensors"][0] | (oc["tensors"][1] if Nf or self._sync else frozenset())
         flags = [i in live for i in range(len(self.params))]
         with torch.cuda.device(dev), _lib.timed(f"train_step[B={B}]"):
@@ -413,9 +416,9 @@ class DataParallelTrainer:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
                 _lib.check(lib.snerf_nerf_train_step_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets,
-                                                         _lib.current_stream()), "snerf_nerf_train_step_f32")
+                                                         _lib.current_stream(), aux), "snerf_nerf_train_step_f32")
             else:
-                _lib.check(lib.snerf_nerf_train_grads_f32(*head, _lib.current_stream()), "snerf_nerf_train_grads_f32")
+                _lib.check(lib.snerf_nerf_train_grads_f32(*head, _lib.current_stream(), aux), "snerf_nerf_train_grads_f32")
                 if not Nf:      # every rank contributes the same shape: zeros for the net that took no part
                     self._flat_g[of_off:of_off + of_n].zero_()
                 self._allreduce_flat()

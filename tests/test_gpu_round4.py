@@ -288,7 +288,7 @@ def test_one_call_step_in_a_hip_graph(dev):
     captured into a graph (torch.cuda.graph drives hipStreamBeginCapture on the stream the library launches on) and
     replayed, it walks the same trajectory as eager steps."""
     tr, pipe, mc, mf = _trainer(dev)
-    batch = _batch(dev, 128)
+    batch = _batch(dev, 64)         # (a batch small enough for the coarse backward to run on the auxiliary stream: fork / join are captured too)
     eager, _, emc, emf = _trainer(dev)
     for _ in range(2):
         tr.step(batch), eager.step(batch)
@@ -312,6 +312,28 @@ def test_one_call_step_in_a_hip_graph(dev):
     for a, b in zip(tr.params, eager.params):
         assert torch.equal(a, b)
     assert int(tr.optim.steps[0]) == 6
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+def test_small_batches_run_the_coarse_backward_on_the_auxiliary_stream(dev, prec, monkeypatch):
+    """Chunks of <= 16 384 fine samples (the README's 64-ray batches): the coarse net's backward runs beside the fine net's on
+    the trainer's second stream (include/smplnerf.h: aux_stream) - the same kernels on their own scratch buffers, so the
+    trajectory equals the single-stream one bit for bit."""
+    lib = _lib.load()
+    finals = []
+    for aux in ("1", "0"):
+        monkeypatch.setenv("SNERF_TRAIN_AUX_STREAM", aux)
+        tr, pipe, mc, mf = _trainer(dev, prec, lr=1e-3)
+        batch = _batch(dev, 64)
+        losses = [float(tr.step(batch)) for _ in range(4)]
+        assert (tr._oc["aux"] is not None) == (aux == "1")
+        finals.append((losses, [p.detach().clone() for p in tr.params]))
+    assert finals[0][0] == finals[1][0] and finals[0][0][3] < finals[0][0][0]
+    for a, b in zip(finals[0][1], finals[1][1]):
+        assert torch.equal(a, b)
+    d = mc.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder)
+    # the second set of backward scratch buffers exists only where the concurrent form applies (a pure size rule)
+    assert lib.snerf_nerf_train_workspace_bytes(d, d, 64, 64, 128, 0) > 64 * lib.snerf_nerf_train_workspace_bytes(d, d, 4096, 64, 128, 0) // 4096
 
 
 def test_trainer_falls_back_to_autograd_where_the_one_call_step_does_not_apply(dev):
