@@ -38,6 +38,23 @@ timeout 600 python $ROOT/bench.py --workload smpl_nerf --res 256 --no-pmc --no-a
 timeout 600 python $ROOT/bench.py --workload append_vertices --res 256 --no-pmc --no-alt --steps 5 --cpu-rays 64 --points= > $OUT/bench_append_vertices_256.json.log 2>/dev/null
 timeout 600 python $ROOT/bench.py --workload append_smpl_params --no-pmc --no-alt --steps 10 --cpu-rays 1024 --points= > $OUT/bench_append_smpl_params.json.log 2>/dev/null
 timeout 600 python $ROOT/bench.py > $OUT/bench_default.json.log 2>/dev/null
+# (f) round 4: the one-call training step at the README's 64-ray batch (kernel trace), the operating-point table with the ray-chunk
+#     sizes and the autograd form beside it, the input-gradient contraction against the r03 form
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train64 -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --no-alt --cpu-rays 0 --points= --train-rays 64 --train-steps 50 > $OUT/train64_under_rocprof.json.log 2> $OUT/trace_train64.err
+find $OUT/trace_train64 -name "*kernel_stats.csv" -exec cp {} $OUT/train64_kernel_stats.csv \;
+rm -rf $OUT/trace_train64
+timeout 600 python $ROOT/tools/ab/train_points.py --autograd --chunks 0,1024,2048 --steps 20 2>/dev/null | grep rays > $OUT/train_points.txt
+( timeout 300 python $ROOT/tools/ab/input_grad_ab.py; timeout 300 python $ROOT/tools/ab/input_grad_ab.py --spr 64 --cols 60 ) 2>/dev/null | grep -v amdgpu.ids > $OUT/input_grad_ab.txt
+# (g) training fed by on-device ray generation over configs[3]'s data set shape (1200 frames of 256 x 256, sharded by image), shuffled epochs
+timeout 900 python $ROOT/bench.py --res 256 --train-from-raygen --raygen-frames 1200 --train-rays 2048 --train-steps 20 --steps 2 --warmup 1 --no-alt --no-pmc --cpu-rays 0 --points= > $OUT/bench_train_from_raygen.json.log 2>/dev/null
+# (h) the pose- / vertex-conditioned workloads with the gradient flowing into the per-ray inputs (estimator trained / d goal_pose)
+timeout 600 python $ROOT/bench.py --workload append_vertices --train-input-grads --no-alt --no-pmc --steps 3 --cpu-rays 0 --points= > $OUT/bench_append_vertices_input_grads.json.log 2>/dev/null
+timeout 600 python $ROOT/bench.py --workload append_smpl_params --train-input-grads --no-alt --no-pmc --steps 3 --cpu-rays 0 --points= > $OUT/bench_append_smpl_params_input_grads.json.log 2>/dev/null
+# (i) multi-rank dry runs on this 1-GPU box (gloo, ranks share the device): strong scaling (one frame split by rows), the coarse-only
+#     line north_star quotes at 1 / 2 / 4 / 8 GPUs, and the RCCL branch at world size one
+timeout 900 python $ROOT/bench.py --gpus 2 --scaling strong --steps 3 --warmup 1 --no-pmc --no-alt --cpu-rays 0 --points= --train-rays 0 > $OUT/bench_2ranks_strong_1gpu_gloo.json.log 2>/dev/null
+timeout 900 python $ROOT/bench.py --gpus 8 --coarse-only --steps 3 --warmup 1 --no-pmc --no-alt --cpu-rays 0 --points= --train-rays 0 > $OUT/bench_8ranks_coarse_only_1gpu_gloo.json.log 2>/dev/null
+SNERF_BENCH_FORCE_GROUP=1 SNERF_DIST_BACKEND=nccl timeout 600 python $ROOT/bench.py --steps 5 --warmup 2 --no-pmc --no-alt --cpu-rays 0 --points= --train-rays 2048 --train-steps 10 > $OUT/bench_world1_rccl.json.log 2>/dev/null
 cd $ROOT
 python tools/make_pmc_profile.py $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
 python tools/make_pmc_profile.py --smpl-nerf $OUT/pmcs_sq $OUT/pmcs_fetch $OUT/pmcs_write > $OUT/pmc_summary_smpl_nerf.json 2> $OUT/pmc_summary_smpl.err
