@@ -780,8 +780,20 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
     // a folded pair was written by its carrier's (wide) workgroups
     const int G = (seg < Ly.nseg && wgrad_kind(P, l, seg, fold) != 2) ? G_wide : G_narrow;
     // accumulate: this launch is one ray chunk of a larger batch (train_step.hip) - the chunks' sums are added in chunk order
-    float sum = 0.f;
-    for (int c = 0; c < G; ++c) sum += part[(int64_t)c * L.gp_floats + e];
+    // four running sums (partials c, c + 4, c + 8, ... each): four loads in flight per thread instead of one - the kernel reads
+    // G x 2.6 MB and sat at the latency of its one outstanding load (r04: 0.125 -> ~0.07 ms at G = 113); the order is fixed
+    const float *p = part + e;
+    const int64_t gp = L.gp_floats;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= G; c += 4) {
+        s0 += p[(int64_t)c * gp];
+        s1 += p[(int64_t)(c + 1) * gp];
+        s2 += p[(int64_t)(c + 2) * gp];
+        s3 += p[(int64_t)(c + 3) * gp];
+    }
+    for (; c < G; ++c) s0 += p[(int64_t)c * gp];
+    const float sum = (s0 + s1) + (s2 + s3);
     flat_grad[dst] = accumulate ? flat_grad[dst] + sum : sum;
 }
 
