@@ -316,6 +316,9 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
     };
     // one stage (16 samples = 4 k-steps) of this wave's tiles.  MASKED: tiles past the edge of the job run with a = 0 and
     // are not stored (their LDS rows hold finite filler data), samples past `end` contribute a = 0.
+    // (Measured r04 and rejected: each wave issuing its pieces of stage st + 3 in front of k-step `wave >> 2` instead of at the
+    // top of the stage - so that only one of the four waves of a SIMD sits in its DMA issue at a time - 4.63 -> 6.19 ms per
+    // launch: the issue inside the pinned LDS-read / MFMA groups costs far more than the collision at the stage top.)
     auto stage_body = [&](auto masked_c, auto bias_c, int slot, int64_t s0) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_c)::value, BIAS = decltype(bias_c)::value;
         const float *ya = ring + slot * WL_SLOT_FLOATS + (TI * bi) * WL_ROW_FLOATS + lane;
@@ -808,11 +811,21 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     // chunks: at most the wgrad_chunks(n) the partial buffer is sized for; with more wide workgroups than CUs, as many as
     // fill whole rounds of the chip (9 wide jobs x 128 chunks on 256 CUs = 4.5 rounds, the last one half empty: 113
     // chunks = 3.97 rounds of 13 % longer workgroups)
-    const int G_narrow = wgrad_chunks_1k(n);   // (the narrow jobs gain nothing from other chunk lengths)
+    int G_narrow = wgrad_chunks_1k(n);
     int G = G_narrow;
+    const int fold = wide_nsplit ? 0 : tuning().wgrad_fold;   // the split-precision wide kernels do not carry folded tiles
     {
         const int n_cu = device_cu_count("wgrad");
         if (n_cu < 1) return n_cu;
+#ifndef WGD_WHOLE_ROUNDS
+#define WGD_WHOLE_ROUNDS 1
+#endif
+        // narrow jobs: 4-wave workgroups, three per CU (mlp_wgrad_direct_kernel: waves_per_eu(3, 3), 52 KB of LDS) - the same
+        // whole-rounds rule: 14 jobs x 128 chunks = 1792 workgroups are 2.33 rounds of 768 slots, 109 chunks are 1.99
+        if (const int jobs_d = WGD_WHOLE_ROUNDS ? wgrad_direct_jobs(P, fold) : 0) {
+            const int slots = 3 * n_cu;
+            if ((int64_t)jobs_d * G_narrow > slots) G_narrow = min(G_narrow, max(1, (int)((int64_t)jobs_d * G_narrow / slots) * slots / jobs_d));
+        }
         const int jobs = wgrad_jobs(P);
         if (jobs > 0 && (int64_t)jobs * G > n_cu) {
             // (fewer whole rounds = fewer partials for the reduce: measured r03, 4 / 3 / 2 / 1 rounds -> the same step time)
@@ -833,7 +846,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     W.xstat = reinterpret_cast<const int *>(act + (int64_t)L.act_rows * n * 16);   // (f16x3 wide jobs only)
     W.ystat = reinterpret_cast<const int *>(dy + (int64_t)L.dy_rows * n * 16);
     W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
-    W.fold = wide_nsplit ? 0 : tuning().wgrad_fold;   // the split-precision wide kernels do not carry folded tiles
+    W.fold = fold;
     static LdsRaised raised;   // per device
     int rc;
     if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_kernel), WL_LDS_BYTES, raised, "wgrad"))) return rc;

@@ -137,3 +137,47 @@ def test_committed_r03_bench_lines_are_self_consistent():
     assert c["config"]["ray_samples_per_ray"] == 64 and c["cpu_baseline"]["value"] > 0 and "configs[0]" in c["config"]["workload"]
     e = json.loads(open(P("r03_bench_8ranks_1gpu_gloo.json.log")).read().strip().splitlines()[-1])
     assert e["n_gpus"] == 8 and "gloo" in e["config"]["parallelism"]
+
+
+def test_committed_r04_bench_lines_are_self_consistent():
+    """Round 4: the driver-style line and the kernel trace agree; the training line is the one-call step within the memory
+    bound VERDICT r03 #4 set (<= 2.6 MB per ray at 4096 rays) with host enqueue below 0.3 ms at the reference's batch sizes;
+    the grouped dry runs carry per-rank and collective records (VERDICT r03 #2); raygen is < 1 % of a 2048-ray step."""
+    P = lambda n: os.path.join(ROOT, "profiles", n)
+    J = lambda n: json.loads(open(P(n)).read().strip().splitlines()[-1])
+    line = J("r04_bench_under_rocprof.json.log")
+    r = line["roofline"]
+    assert abs(line["value"] - 16384 * 256 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert abs(r["frac"] - 1215744 * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12 / 157.3) <= 1e-9 and r["frac"] >= 0.85
+    rows = list(csv.DictReader(open(P("r04_bench_kernel_stats.csv"))))
+    k = [x for x in rows if x["Name"].startswith("void snerf::mlp_fwd_kernel<256, 8, false, false>")][0]
+    assert int(k["Calls"]) == 2 * (line["steps"] + line["warmup"])
+    assert abs(float(k["AverageNs"]) * 1e-6 - r["avg_launch_ms"]) <= 0.02 * r["avg_launch_ms"]
+    d = J("r04_bench_default.json.log")
+    assert 0.9 <= d["roofline"]["traffic"] / d["roofline"]["algorithmic_hbm_bytes_per_launch"] <= 1.1
+    t = d["train"]
+    assert t["step_entry"].startswith("snerf_nerf_train_step_f32") and t["c_abi_calls_per_step"] == 1.0
+    assert t["peak_allocated_bytes"] <= 2.6e6 * t["rays_per_step_per_gpu"] and t["mlp_roofline_frac"] >= 0.78
+    pts = {p["rays_per_step_per_gpu"]: p for p in t["operating_points"]}
+    assert pts[64]["ms_per_step"] <= 1.9 and pts[2048]["ms_per_step"] <= 15.9
+    assert all(p["host_enqueue_ms_per_step"] < 0.3 for p in pts.values())
+    assert any("eval_without_no_grad" in p.get("mode", "") for p in d["operating_points_render"])
+    # the 64-ray trace: the step's kernels are the library's own - no pack kernel, no torch optimiser kernel per step
+    names = {x["Name"].split("(")[0]: int(x["Calls"]) for x in csv.DictReader(open(P("r04_train64_kernel_stats.csv")))}
+    assert names["snerf::adam_kernel"] == 52 and not any("multi_tensor_apply" in n for n in names)
+    assert names.get("snerf::mlp_pack_t_kernel", 0) <= 4 and names.get("snerf::mlp_pack_kernel", 0) <= 8     # initial packs only
+    g = J("r04_bench_train_from_raygen.json.log")["train"]
+    assert g["raygen_ms_per_step"] < 0.01 * g["ms_per_step"] and "1200 of the data set's frames" in g["batches"]
+    e = J("r04_bench_8ranks_1gpu_gloo.json.log")
+    assert [p["rank"] for p in e["per_rank"]] == list(range(8)) and e["collective"]["world_size_seen_by_backend"] == 8
+    c = e["train"]["collective"]
+    assert c["bytes"] == 4 * 1220872 and c["allreduce_ms_per_step"] > 0 and c["allreduce_calls"] == 3 and c["broadcast_ms"] > 0
+    s = J("r04_bench_2ranks_strong_1gpu_gloo.json.log")
+    assert s["scaling"] == "strong" and s["collective"]["strong_frame_max_abs_diff_vs_single_rank_render"] == 0.0
+    w = J("r04_bench_world1_rccl.json.log")
+    assert w["train"]["collective"]["backend"] == "nccl (RCCL)" and w["train"]["collective"]["allreduce_calls"] == 10
+    co = J("r04_bench_8ranks_coarse_only_1gpu_gloo.json.log")
+    assert co["config"]["ray_samples_per_ray"] == 64 and co["n_gpus"] == 8 and len(co["per_rank"]) == 8
+    for wl in ("append_vertices", "append_smpl_params"):
+        a = J(f"r04_bench_{wl}_input_grads.json.log")["train"]
+        assert a["input_gradients"] and any(k.startswith("dy_contract") for k in a["kernels_ms_per_step"])

@@ -437,3 +437,45 @@ def test_per_ray_fold_tables_live_in_the_callers_workspace(dev):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
     rc = lib.snerf_warp_fwd_ws_f32(*wargs, *[t.data_ptr() for t in outs[0]], wbuf.data_ptr() + band, wneed - 4, s)
     assert rc == -1 and b"snerf_warp_fold_workspace_bytes" in lib.snerf_last_error_string()
+
+
+def test_c_host_training_example(dev, tmp_path):
+    """examples/c_host/train_steps.c - plain C99, the C-ABI plus the HIP runtime, no Python in the process - runs the same
+    optimisation steps as DataParallelTrainer.step (ray chunks included): losses and final parameters bit for bit."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("gcc") or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("gcc / ROCm headers not available")
+    exe = str(tmp_path / "train_steps")
+    lib = os.path.join(root, "smpl_nerf_amd", "csrc", "libsmplnerf_hip.so")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_host", "train_steps.c"), lib,
+                    "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe],
+                   check=True)
+    from smpl_nerf_amd.ops import uniform_u
+    steps, chunk, lr = 4, 100, 1e-3
+    tr, pipe, mc, mf = _trainer(dev, lr=lr)
+    tr.rays_per_chunk = chunk
+    batch = _batch(dev, 250, stride=37)
+    B, Nc, Nf = batch[3].shape[0], batch[3].shape[1], 128
+    blob = struct.pack("<5id", 0x534e5254, B, Nc, Nf, 0, lr)
+    for m in (mc, mf):
+        blob += bytes(m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder, False))
+    for m in (mc, mf):
+        blob += torch.cat([p.detach().reshape(-1) for p in m._ordered_params()]).cpu().numpy().tobytes()
+    for t in batch:
+        blob += t.cpu().numpy().astype(np.float32).tobytes()
+    blob += uniform_u(Nf, dev).cpu().numpy().astype(np.float32).tobytes()
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(blob)
+    r = subprocess.run([exe, str(fin), str(fout), str(steps), str(chunk)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(fout.read_bytes(), dtype=np.float32)
+    losses = [float(tr.step(batch)) for _ in range(steps)]
+    want = np.concatenate([np.asarray(losses, np.float32)] +
+                          [torch.cat([p.detach().reshape(-1) for p in m._ordered_params()]).cpu().numpy() for m in (mc, mf)])
+    assert got.shape == want.shape and np.array_equal(got[:steps], want[:steps]) and losses[-1] < losses[0]
+    assert np.array_equal(got[steps:], want[steps:])
