@@ -35,16 +35,18 @@ def searchsorted(a: torch.Tensor, v: torch.Tensor, out: Optional[torch.LongTenso
     """Same contract as torchsearchsorted.searchsorted (searchsorted.py:20-53): 2-D `a` (sorted rows)
     and `v`, equal row counts or one of them a single row, int64 result of shape
     (max(rows), v.shape[1]); `out` may be supplied."""
-    assert len(a.shape) == 2, "input `a` must be 2-D."
-    assert len(v.shape) == 2, "input `v` mus(t be 2-D."
-    assert (a.shape[0] == v.shape[0] or a.shape[0] == 1 or v.shape[0] == 1), (
-        "`a` and `v` must have the same number of rows or one of them must have only one ")
-    assert a.device == v.device, "`a` and `v` must be on the same device"
+    # the reference's preconditions (searchsorted.py:21-36) as AssertionErrors, in this package's own words
+    assert a.dim() == 2, f"searchsorted: `a` must have two dimensions (rows of sorted values), got {a.dim()}"
+    assert v.dim() == 2, f"searchsorted: `v` must have two dimensions (rows of queries), got {v.dim()}"
+    assert a.shape[0] == v.shape[0] or a.shape[0] == 1 or v.shape[0] == 1, (
+        f"searchsorted: `a` has {a.shape[0]} rows and `v` {v.shape[0]}: the counts must match, or one side must be a single row "
+        "that is broadcast")
+    assert a.device == v.device, f"searchsorted: `a` is on {a.device} but `v` on {v.device}"
     result_shape = (max(a.shape[0], v.shape[0]), v.shape[1])
     if out is not None:
-        assert out.device == a.device, "`out` must be on the same device as `a`"
-        assert out.dtype == torch.long, "out.dtype must be torch.long"
-        assert out.shape == result_shape, "If the output tensor is provided, its shape must be correct."
+        assert out.device == a.device, f"searchsorted: `out` is on {out.device}, the inputs on {a.device}"
+        assert out.dtype == torch.long, f"searchsorted: `out` must be int64 (torch.long), got {out.dtype}"
+        assert out.shape == result_shape, f"searchsorted: `out` has shape {tuple(out.shape)}, the result has {result_shape}"
     else:
         out = torch.empty(result_shape, device=v.device, dtype=torch.long)
     for nm, t in (("a", a), ("v", v)):
