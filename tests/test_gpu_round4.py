@@ -479,3 +479,71 @@ def test_c_host_training_example(dev, tmp_path):
                           [torch.cat([p.detach().reshape(-1) for p in m._ordered_params()]).cpu().numpy() for m in (mc, mf)])
     assert got.shape == want.shape and np.array_equal(got[:steps], want[:steps]) and losses[-1] < losses[0]
     assert np.array_equal(got[steps:], want[steps:])
+
+
+# ------------------------------------------------------------------------------------------ shapes, ragged sizes, guard bands
+@pytest.mark.parametrize("shape", [dict(n_layers=4, width=128, skips=(1,), B=37, Nc=32, Nf=48, chunk=16, wb=1),
+                                   dict(n_layers=2, width=64, skips=(), B=5, Nc=16, Nf=16, chunk=0, wb=0),
+                                   dict(n_layers=8, width=256, skips=(4,), B=1, Nc=64, Nf=128, chunk=0, wb=0),
+                                   dict(n_layers=3, width=100, skips=(0, 1), B=129, Nc=64, Nf=128, chunk=50, wb=0),
+                                   dict(n_layers=8, width=256, skips=(), B=300, Nc=8, Nf=200, chunk=128, wb=1)])
+def test_one_call_step_over_network_and_batch_shapes(dev, shape):
+    """The one-call step against the autograd form for other depths / widths (zero-padded into the 64 / 128 / 256 kernels) /
+    skip masks, ragged ray counts (B = 1, 37, 129: partial tiles, ragged last chunk) and sample counts other than 64 + 128
+    (the sampler's generic instance): two steps, losses and parameters."""
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    B, Nc, Nf = shape["B"], shape["Nc"], shape["Nf"]
+    rng = np.random.default_rng(B + Nc)
+    o = rng.normal(0, 0.2, (B, 3)).astype(np.float32) + np.array([0, 0, 2.4], np.float32)
+    d = rng.normal(0, 0.3, (B, 3)).astype(np.float32) + np.array([0, 0, -1], np.float32)
+    z = np.sort(rng.uniform(1.0, 4.0, (B, Nc)).astype(np.float32), -1)
+    samples = o[:, None, :] + d[:, None, :] * z[:, :, None]
+    gt = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    batch = [T(a, dev) for a in (samples.astype(np.float32), o, d, z, gt)]
+    runs = []
+    for one_call in (None, False):
+        torch.manual_seed(21)
+        nets = []
+        for _ in range(2):
+            from smpl_nerf_amd.nets import RenderRayNet
+            m = RenderRayNet(shape["n_layers"], shape["width"], 60, 24, skips=list(shape["skips"])).to(dev).train()
+            with torch.no_grad():
+                m.sigma_out_layer.weight.mul_(20.0)          # densities that composite to something
+            nets.append(m)
+        pipe = NerfPipeline(nets[0], nets[1], PipelineArgs(white_background=shape["wb"], number_fine_samples=Nf),
+                            PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        tr = DataParallelTrainer(pipe, nets, lr=1e-3, one_call=one_call)
+        tr.rays_per_chunk = shape["chunk"]
+        losses = [float(tr.step(batch))]
+        grads = [p.grad.clone() for p in tr.params]           # of the first step: same parameters on both sides
+        losses.append(float(tr.step(batch)))
+        assert (tr._one_call_state() is not None) == (one_call is None)
+        runs.append((losses, grads, [p.detach().clone() for p in tr.params]))
+    close(runs[0][0][:1], runs[1][0][:1], 2e-6, 1e-8)      # the same forward
+    close(runs[0][0][1:], runs[1][0][1:], 1e-4, 1e-8)      # after one update from gradients summed in another order (chunks)
+    assert all(np.isfinite(runs[0][0]))
+    for ga, gb in zip(runs[0][1], runs[1][1]):
+        assert float((ga - gb).norm()) <= 5e-5 * float(gb.norm()) + 1e-10
+    for pa, pb in zip(runs[0][2], runs[1][2]):
+        assert float((pa - pb).abs().max()) <= 2e-4          # two Adam steps of 1e-3 each (Adam normalises the step to ~lr)
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_guard_bands_around_the_one_call_step(dev, prec):
+    """Every buffer the trainer hands to snerf_nerf_train_step_f32 - workspace (activations, d Y, partials, the second set
+    of the concurrent backward), loss / colour outputs, slot tables, weight streams - inside pattern bands: ragged batches
+    (1, 37, 64 rays), one chunk and ragged chunks, run_fine = 0; no band is touched."""
+    from test_gpu_round2 import _GuardBands
+    total = 0
+    with _GuardBands() as g:
+        for B, chunk, run_fine in ((1, 0, 1), (37, 16, 1), (64, 0, 1), (37, 0, 0)):
+            tr, pipe, mc, mf = _trainer(dev, prec if run_fine else "fp32", run_fine=run_fine)
+            tr.rays_per_chunk = chunk
+            batch = [t[:B].contiguous() for t in _batch(dev, 64)]
+            for _ in range(2):
+                loss = tr.step(batch)
+            assert bool(torch.isfinite(loss))
+            total += g.check()
+    assert total > 20
