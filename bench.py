@@ -462,7 +462,9 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
             "loss_first": losses[0], "loss_last": losses[-1], "rgb_fine_std_last_step": fine_std,
             "mlp_kernels_ms_per_step": mlp_ms, "mlp_algorithmic_tflops": tf, "mlp_peak_tflops": peak,
             "mlp_roofline_frac": tf / peak if tf else None,
-            "step_entry": ("snerf_nerf_train_step_f32 (one C-ABI call per step; mlp_kernels_ms_per_step brackets the whole call)"
+            "step_entry": ((("snerf_smpl_nerf_train_step_f32" if any(k.startswith("train_step_smpl") for k in kern) else
+                             "snerf_nerf_train_step_f32") + " (one C-ABI call per step; mlp_kernels_ms_per_step brackets the whole "
+                            "call - for smpl_nerf that includes the warp net's kernels, which the FLOP count of the fraction leaves out)")
                            if one_call else "autograd (torch.autograd.Function per kernel group) + HipAdam"),
             "rays_per_chunk": tr.rays_per_chunk if one_call else None,
             "input_gradients": bool(input_grads),

@@ -115,7 +115,7 @@ int main(int argc, char **argv) {
         HIP_OK(hipMalloc((void **)&slot_t, np[k] * sizeof(int32_t)));
         SNERF_OK_OR_DIE(snerf_mlp_pack_f32(&desc[k], pk, packed, stream));
         SNERF_OK_OR_DIE(snerf_mlp_pack_t_f32(&desc[k], pk, packed_t, 0, stream));
-        SNERF_OK_OR_DIE(snerf_mlp_stream_slots(&desc[k], slot_fwd, slot_t, stream));
+        SNERF_OK_OR_DIE(snerf_mlp_stream_slots(&desc[k], slot_fwd, slot_t, 0, stream));
         nets[k].desc = &desc[k];
         nets[k].param_offset = k ? np[0] : 0;
         nets[k].precision = 0;

@@ -454,9 +454,10 @@ int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, const void *pa
  * snerf_mlp_stream_slots (no re-pack launches); split-precision streams (pre-split parts) are re-packed inside the call. */
 
 /* slot_fwd[i] / slot_t[i] (int32, snerf_mlp_param_floats entries each, nullable): index of the float of the fp32 forward /
- * transposed (input_grad = 0) stream that holds parameter i of params_flat, or -1 (biases do not appear in the transposed
- * stream).  Every parameter occupies at most one float of each stream. */
-int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, snerf_stream_t stream);
+ * transposed stream that holds parameter i of params_flat, or -1 (biases do not appear in the transposed stream).
+ * input_grad selects WHICH transposed stream (snerf_mlp_pack_t_f32's input_grad: 0 for snerf_nerf_train_*, 1 for
+ * snerf_smpl_nerf_train_*).  Every parameter occupies at most one float of each stream. */
+int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, int input_grad, snerf_stream_t stream);
 
 /* torch.optim.Adam(params, lr, betas, eps, weight_decay) (amsgrad = False) over ONE flat fp32 parameter buffer - the
  * statements of torch's single-tensor update in their order (solver/nerf_solver.py:11-14, 31-33, 87). */
@@ -533,6 +534,36 @@ int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *pac
                               float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
                               const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
                               snerf_stream_t stream, snerf_stream_t aux_stream);
+
+/* ---- a7 + a9: SmplNerfSolver.train's per-batch body as one call (solver/smpl_nerf_solver.py:76-89 with the default loss,
+ * models/smpl_nerf_pipeline.py:16-100, human_pose_encoding = 1) ------------------------------------------------------
+ * snerf_nerf_train_* with the warp stage in front of both nets and its backward behind them: warp forward (saving its rows)
+ * -> net on (x', x' - o) -> compositing (coarse: scaled per sample by |x' - o|; fine: by the ray direction) -> ... -> MSE ->
+ * compositing backward (coarse: also into x' - o) -> net backward INTO its inputs (snerf_mlp_bwd_inputs_*: packed_t_* are the
+ * input_grad = 1 streams) -> d warp = d x' + d (x' - o) -> warp backward; the warp net's gradient is the sum over its two
+ * evaluations.  pose_enc [B, pose_dim] = the encoded two joint angles (:28-30).  The warp net trains in fp32 in every
+ * precision mode.  grad_warp: snerf_warp_param_floats floats.  Ray chunks, workspace, loss, rgb as in snerf_nerf_train_grads_f32.
+ * The step variant runs snerf_adam_step_f32 and then re-packs the warp net's two streams (packed_warp from snerf_warp_pack_f32,
+ * packed_t_warp from snerf_warp_pack_t_f32) from its parameters at params + warp_param_offset. */
+int64_t snerf_smpl_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine,
+                                              const snerf_warp_desc *desc_warp, int64_t B, int Nc, int Nf, int64_t rays_per_chunk);
+int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                    const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                    const snerf_warp_desc *desc_warp, const float *packed_warp, const float *packed_t_warp,
+                                    int precision, const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk,
+                                    void *workspace, float *grad_coarse, float *grad_fine, float *grad_warp, float *loss, float *rgb,
+                                    float *rgb_fine, snerf_stream_t stream);
+int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                   const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                   const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,
+                                   const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk, void *workspace,
+                                   float *grad_coarse, float *grad_fine, float *grad_warp, float *loss, float *rgb, float *rgb_fine,
+                                   const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
+                                   const snerf_adam_net *nets_host, int n_nets, int64_t warp_param_offset, snerf_stream_t stream);
+/* packed_warp / packed_t_warp (each nullable) from the warp net's parameters at params + warp_param_offset: what a
+ * data-parallel caller runs behind snerf_adam_step_f32. */
+int snerf_warp_repack_f32(const snerf_warp_desc *desc_warp, const float *params, int64_t n_params, int64_t warp_param_offset,
+                          float *packed_warp, float *packed_t_warp, snerf_stream_t stream);
 
 #ifdef __cplusplus
 }

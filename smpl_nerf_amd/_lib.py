@@ -121,7 +121,15 @@ SIGNATURES = {
     "snerf_warp_fwd_ws_f32": (c_int, [POINTER(WarpDesc), _P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int64, _P]),
     "snerf_dy_contract_scratch_floats": (c_int64, [c_int64, c_int, c_int]),
     "snerf_dy_contract_f32": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int64, c_int, c_int, _P, _P]),
-    "snerf_mlp_stream_slots": (c_int, [POINTER(MlpDesc), _P, _P, _P]),
+    "snerf_mlp_stream_slots": (c_int, [POINTER(MlpDesc), _P, _P, c_int, _P]),
+    "snerf_smpl_nerf_train_workspace_bytes": (c_int64, [POINTER(MlpDesc), POINTER(MlpDesc), POINTER(WarpDesc), c_int64, c_int, c_int,
+                                                        c_int64]),
+    "snerf_smpl_nerf_train_grads_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, POINTER(WarpDesc), _P, _P, c_int,
+                                                POINTER(NerfBatch), _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "snerf_smpl_nerf_train_step_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, POINTER(WarpDesc), _P, _P, c_int,
+                                               POINTER(NerfBatch), _P, c_int64, _P, _P, _P, _P, _P, _P, _P, POINTER(AdamState),
+                                               POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, c_int64, _P]),
+    "snerf_warp_repack_f32": (c_int, [POINTER(WarpDesc), _P, c_int64, c_int64, _P, _P, _P]),
     "snerf_adam_step_f32": (c_int, [POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P]),
     "snerf_nerf_train_workspace_bytes": (c_int64, [POINTER(MlpDesc), POINTER(MlpDesc), c_int64, c_int, c_int, c_int64]),
     "snerf_nerf_train_grads_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,

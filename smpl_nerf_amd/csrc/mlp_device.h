@@ -18,6 +18,9 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
 int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n, float *dy,
                float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample, int spr, float *d_x,
                float *d_dirs, snerf_stream_t stream, bool accumulate = false);
+// defined in warp.hip: the body of snerf_warp_bwd_f32
+int launch_warp_bwd(const snerf_warp_desc *desc, const float *packed_t, const float *act, const float *d_warp, int64_t n, float *dy,
+                    float *gpart, float *flat_grad, snerf_stream_t stream, bool accumulate = false);
 int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act, const float *d_raw, int64_t n,
                     float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample, int spr,
                     float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate = false);

@@ -186,7 +186,8 @@ static bool split_code(int precision) { return precision == 2 || precision == 3 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, snerf_stream_t stream) {
+extern "C" int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, int input_grad,
+                                      snerf_stream_t stream) {
     using namespace snerf;
     Plan P;
     const char *why;
@@ -201,7 +202,7 @@ extern "C" int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_
     }
     if (slot_t) {
         BwdPlan B;
-        make_bwd_plan(P, B, false);
+        make_bwd_plan(P, B, input_grad != 0);
         if (hipMemsetAsync(slot_t, 0xff, (size_t)P.param_floats * sizeof(int32_t), s) != hipSuccess)
             return fail(SNERF_E_LAUNCH, "mlp_stream_slots: memset failed");
         hipLaunchKernelGGL(bwd_slot_table_kernel, dim3(B.total_slabs), dim3(256), 0, s, P, B, slot_t);
@@ -472,4 +473,202 @@ extern "C" int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, cons
                                         batch, rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream);
     if (rc) return rc;
     return snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SmplNerfSolver.train's per-batch body (solver/smpl_nerf_solver.py:76-89 with the default loss; models/smpl_nerf_pipeline.py:16-100)
+// ------------------------------------------------------------------------------------------------
+namespace snerf {
+
+// out = a + b (+ c): d loss / d warp = what arrives at the warped samples through the net's positions, through its
+// per-sample view directions x' - o (and, in the coarse stage, through the compositing's distance scale |x' - o|)
+__global__ __launch_bounds__(256) void sum3_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c,
+                                                   int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = __fadd_rn(a[i], b[i]);
+    if (c) v = __fadd_rn(v, c[i]);
+    out[i] = v;
+}
+
+struct SmplTrainWs {
+    TrainWs base;
+    int64_t warp_c, warped_c, sdirs_c, warp_f, warped_f, sdirs_f, act_wc, act_wf, d_x, d_dirs, d_cdirs, d_warp, dy_w, gpart_w, total;
+};
+
+static int smpl_train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, const snerf_warp_desc *dw, int64_t chunk, int Nc, int Nf,
+                         SmplTrainWs &w) {
+    int rc;
+    if ((rc = train_ws(dc, df, chunk, Nc, Nf, w.base))) return rc;
+    const int64_t N = Nc + Nf, nmax = chunk * (Nf > 0 ? N : Nc);
+    int64_t act_c = 0, act_f = 0, dy_c = 0, dy_f = 0, gp_c = 0, gp_f = 0;
+    if ((rc = snerf_warp_train_sizes(dw, chunk * Nc, &act_c, &dy_c, nullptr, &gp_c))) return rc;
+    if (Nf > 0 && (rc = snerf_warp_train_sizes(dw, chunk * N, &act_f, &dy_f, nullptr, &gp_f))) return rc;
+    int64_t off = align256(w.base.total);
+    auto take = [&](int64_t floats) {
+        const int64_t o = off;
+        off += align256(floats * 4);
+        return o;
+    };
+    w.warp_c = take(chunk * Nc * 3);
+    w.warped_c = take(chunk * Nc * 3);
+    w.sdirs_c = take(chunk * Nc * 3);
+    w.warp_f = take(Nf > 0 ? chunk * N * 3 : 0);
+    w.warped_f = take(Nf > 0 ? chunk * N * 3 : 0);
+    w.sdirs_f = take(Nf > 0 ? chunk * N * 3 : 0);
+    w.act_wc = take(act_c);
+    w.act_wf = take(act_f);
+    w.d_x = take(nmax * 3);
+    w.d_dirs = take(nmax * 3);
+    w.d_cdirs = take(chunk * Nc * 3);
+    w.d_warp = take(nmax * 3);
+    w.dy_w = take(dy_c > dy_f ? dy_c : dy_f);
+    w.gpart_w = take(gp_c > gp_f ? gp_c : gp_f);
+    w.total = off;
+    return SNERF_OK;
+}
+
+}  // namespace snerf
+
+extern "C" int64_t snerf_smpl_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine,
+                                                         const snerf_warp_desc *desc_warp, int64_t B, int Nc, int Nf,
+                                                         int64_t rays_per_chunk) {
+    using namespace snerf;
+    if (!desc_coarse || !desc_warp || B < 0 || Nc < 1 || Nf < 0 || (Nf > 0 && !desc_fine))
+        return fail(SNERF_E_BADARG, "smpl_nerf_train_workspace_bytes: bad arguments");
+    SmplTrainWs w{};
+    if (int rc = smpl_train_ws(desc_coarse, desc_fine, desc_warp, effective_chunk(B, rays_per_chunk), Nc, Nf, w)) return rc;
+    return w.total;
+}
+
+extern "C" int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                               const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                               const snerf_warp_desc *desc_warp, const float *packed_warp, const float *packed_t_warp,
+                                               int precision, const snerf_nerf_batch *batch, const float *pose_enc,
+                                               int64_t rays_per_chunk, void *workspace, float *grad_coarse, float *grad_fine,
+                                               float *grad_warp, float *loss, float *rgb, float *rgb_fine, snerf_stream_t stream) {
+    using namespace snerf;
+    if (precision != 0 && !split_code(precision))
+        return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
+    if (!batch) return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: batch is null");
+    const int64_t B = batch->B;
+    const int Nc = batch->Nc, Nf = batch->Nf, N = Nc + Nf;
+    if (B < 1 || Nc < 1 || Nf < 0) return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: need B >= 1, Nc >= 1, Nf >= 0");
+    if (!desc_coarse || !packed_coarse || !packed_t_coarse || !desc_warp || !packed_warp || !packed_t_warp || !batch->ray_samples ||
+        !batch->rays_o || !batch->rays_d || !batch->z_vals || !batch->rgb_truth || !pose_enc || !workspace || !grad_coarse || !grad_warp ||
+        !loss || !rgb || !rgb_fine)
+        return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: null pointer");
+    if (Nf > 0 && (!desc_fine || !packed_fine || !packed_t_fine || !grad_fine || !batch->u))
+        return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: the fine pass needs desc_fine, its streams, grad_fine and u");
+    if (desc_coarse->add_dim || (Nf > 0 && desc_fine->add_dim)) return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: nets with additional inputs are not covered");
+    if (!desc_coarse->use_dir || (Nf > 0 && !desc_fine->use_dir))
+        return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: the nets read per-sample view directions (use_dir = 1)");
+    if (!aligned(workspace, 256)) return fail(SNERF_E_ALIGN, "smpl_nerf_train_grads: workspace must be 256-byte aligned");
+    if (precision != 0 && (desc_coarse->width != 256 || (Nf > 0 && desc_fine->width != 256)))
+        return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: the split-precision kernels exist for width 256");
+    const int64_t chunk = effective_chunk(B, rays_per_chunk);
+    SmplTrainWs w{};
+    int rc;
+    if ((rc = smpl_train_ws(desc_coarse, desc_fine, desc_warp, chunk, Nc, Nf, w))) return rc;
+    char *ws = reinterpret_cast<char *>(workspace);
+    auto f = [&](int64_t off) { return reinterpret_cast<float *>(ws + off); };
+    const TrainWs &b0 = w.base;
+    float *raw_c = f(b0.raw_c), *weights_c = f(b0.weights_c), *z_fine = f(b0.z_fine), *pts_f = f(b0.pts_f), *raw_f = f(b0.raw_f);
+    float *d_rgb_c = f(b0.d_rgb_c), *d_rgb_f = f(b0.d_rgb_f), *d_raw = f(b0.d_raw), *act_c = f(b0.act_c), *act_f = f(b0.act_f);
+    float *dy = f(b0.dy), *gpart = f(b0.gpart);
+    double *loss_acc = reinterpret_cast<double *>(ws + b0.loss_acc);
+    float *warp_c = f(w.warp_c), *warped_c = f(w.warped_c), *sdirs_c = f(w.sdirs_c), *warp_f = f(w.warp_f), *warped_f = f(w.warped_f);
+    float *sdirs_f = f(w.sdirs_f), *act_wc = f(w.act_wc), *act_wf = f(w.act_wf), *d_x = f(w.d_x), *d_dirs = f(w.d_dirs);
+    float *d_cdirs = f(w.d_cdirs), *d_warp = f(w.d_warp), *dy_w = f(w.dy_w), *gpart_w = f(w.gpart_w);
+    hipStream_t s = (hipStream_t)stream;
+    const int wb = batch->white_background ? 1 : 0;
+    const float norm = (float)(2.0 / (3.0 * (double)B));
+    const double inv_total = 1.0 / (3.0 * (double)B);
+    const int pose_dim = desc_warp->pose_dim;
+    auto fwd_train = [&](const snerf_mlp_desc *d, const void *packed, const float *x, const float *sd, int64_t n, int spr, float *raw,
+                         float *act) {
+        if (precision == 0)
+            return snerf_mlp_fwd_train_f32(d, reinterpret_cast<const float *>(packed), x, sd, 1, nullptr, n, spr, raw, act, stream);
+        return snerf_mlp_fwd_train_bf16_f32(d, packed, precision, x, sd, 1, nullptr, n, spr, raw, act, stream);
+    };
+    auto bwd_inputs = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, const float *x, const float *sd, int64_t n,
+                          int spr, float *grad, bool accumulate) {
+        if (precision == 0)
+            return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw, n, dy, gpart, grad, x, sd, 1, spr, d_x, d_dirs,
+                              stream, accumulate);
+        return launch_bwd_bf16(d, packed_t, precision, act, d_raw, n, dy, gpart, grad, x, sd, 1, spr, d_x, d_dirs, stream, accumulate);
+    };
+    auto sum3 = [&](const float *a, const float *b, const float *c, int64_t n) {
+        hipLaunchKernelGGL(sum3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, c, n, d_warp);
+        return check_launch("smpl_nerf_train_grads(sum)");
+    };
+    for (int64_t r0 = 0; r0 < B; r0 += chunk) {
+        const int64_t b = (B - r0 < chunk) ? B - r0 : chunk;
+        const float *x = batch->ray_samples + r0 * Nc * 3, *o = batch->rays_o + r0 * 3, *d = batch->rays_d + r0 * 3;
+        const float *z = batch->z_vals + r0 * Nc, *gt = batch->rgb_truth + r0 * 3, *pe = pose_enc + r0 * pose_dim;
+        const float *nz_c = batch->noise_coarse ? batch->noise_coarse + r0 * Nc : nullptr;
+        const float *nz_f = batch->noise_fine ? batch->noise_fine + r0 * N : nullptr;
+        float *rgb_c = rgb + r0 * 3, *rgb_fo = rgb_fine + r0 * 3;
+        const bool acc = r0 > 0;
+        // coarse stage: warp the given samples, net on (x', x' - o), compositing scaled per sample by |x' - o| (:38-63)
+        if ((rc = snerf_warp_fwd_train_f32(desc_warp, packed_warp, x, pe, o, b * Nc, Nc, warp_c, warped_c, sdirs_c, act_wc, stream))) return rc;
+        if ((rc = fwd_train(desc_coarse, packed_coarse, warped_c, sdirs_c, b * Nc, Nc, raw_c, act_c))) return rc;
+        if ((rc = snerf_composite_fwd_f32(raw_c, z, sdirs_c, 1, nz_c, b, Nc, wb, rgb_c, Nf > 0 ? weights_c : nullptr, nullptr, stream))) return rc;
+        if (Nf > 0) {   // hierarchical samples on the un-warped ray (:68), then the fine stage (:71-98)
+            if ((rc = snerf_sample_pdf_f32(z, weights_c, batch->u, o, d, b, Nc, Nf, nullptr, nullptr, z_fine, pts_f, stream))) return rc;
+            if ((rc = snerf_warp_fwd_train_f32(desc_warp, packed_warp, pts_f, pe, o, b * N, N, warp_f, warped_f, sdirs_f, act_wf, stream))) return rc;
+            if ((rc = fwd_train(desc_fine, packed_fine, warped_f, sdirs_f, b * N, N, raw_f, act_f))) return rc;
+            if ((rc = snerf_composite_fwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, rgb_fo, nullptr, nullptr, stream))) return rc;
+        }
+        hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(MSE_THREADS), 0, s, rgb_c, Nf > 0 ? rgb_fo : nullptr, gt, b * 3, norm,
+                           d_rgb_c, d_rgb_f, loss_acc, r0 == 0 ? 1 : 0, r0 + b >= B ? 1 : 0, inv_total, loss);
+        if ((rc = check_launch("smpl_nerf_train_grads(mse)"))) return rc;
+        bool warp_acc = acc;
+        if (Nf > 0) {   // fine: the compositing is scaled by the ray direction (an input), the net back-propagates into x' and x' - o
+            if ((rc = snerf_composite_bwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, d_rgb_f, d_raw, nullptr, stream))) return rc;
+            if ((rc = bwd_inputs(desc_fine, packed_t_fine, act_f, warped_f, sdirs_f, b * N, N, grad_fine, acc))) return rc;
+            if ((rc = sum3(d_x, d_dirs, nullptr, b * N * 3))) return rc;
+            if ((rc = launch_warp_bwd(desc_warp, packed_t_warp, act_wf, d_warp, b * N, dy_w, gpart_w, grad_warp, stream, warp_acc))) return rc;
+            warp_acc = true;
+        }
+        // coarse: the compositing's distance scale |x' - o| depends on the warp as well (:63)
+        if ((rc = snerf_composite_bwd_f32(raw_c, z, sdirs_c, 1, nz_c, b, Nc, wb, d_rgb_c, d_raw, d_cdirs, stream))) return rc;
+        if ((rc = bwd_inputs(desc_coarse, packed_t_coarse, act_c, warped_c, sdirs_c, b * Nc, Nc, grad_coarse, acc))) return rc;
+        if ((rc = sum3(d_x, d_dirs, d_cdirs, b * Nc * 3))) return rc;
+        if ((rc = launch_warp_bwd(desc_warp, packed_t_warp, act_wc, d_warp, b * Nc, dy_w, gpart_w, grad_warp, stream, warp_acc))) return rc;
+    }
+    if (Nf == 0 && rgb_fine != rgb &&
+        hipMemcpyAsync(rgb_fine, rgb, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail(SNERF_E_LAUNCH, "smpl_nerf_train_grads: device copy failed");
+    return SNERF_OK;
+}
+
+extern "C" int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                              const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                              const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,
+                                              const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk,
+                                              void *workspace, float *grad_coarse, float *grad_fine, float *grad_warp, float *loss,
+                                              float *rgb, float *rgb_fine, const snerf_adam_state *adam,
+                                              const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host,
+                                              int n_nets, int64_t warp_param_offset, snerf_stream_t stream) {
+    int rc = snerf_smpl_nerf_train_grads_f32(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
+                                             packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
+                                             grad_fine, grad_warp, loss, rgb, rgb_fine, stream);
+    if (rc) return rc;
+    if ((rc = snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream))) return rc;
+    return snerf_warp_repack_f32(desc_warp, adam ? adam->params : nullptr, adam ? adam->n_params : 0, warp_param_offset, packed_warp,
+                                 packed_t_warp, stream);
+}
+
+extern "C" int snerf_warp_repack_f32(const snerf_warp_desc *desc_warp, const float *params, int64_t n_params, int64_t warp_param_offset,
+                                     float *packed_warp, float *packed_t_warp, snerf_stream_t stream) {
+    using namespace snerf;
+    const int64_t nw = snerf_warp_param_floats(desc_warp);
+    if (nw < 0) return (int)nw;
+    if (!params || warp_param_offset < 0 || warp_param_offset + nw > n_params)
+        return fail(SNERF_E_BADARG, "warp_repack: the warp net does not lie inside the flat parameter buffer");
+    int rc;
+    if (packed_warp && (rc = snerf_warp_pack_f32(desc_warp, params + warp_param_offset, packed_warp, stream))) return rc;
+    if (packed_t_warp && (rc = snerf_warp_pack_t_f32(desc_warp, params + warp_param_offset, packed_t_warp, stream))) return rc;
+    return SNERF_OK;
 }

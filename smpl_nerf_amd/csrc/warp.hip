@@ -358,7 +358,12 @@ extern "C" int snerf_warp_pack_t_f32(const snerf_warp_desc *desc, const float *p
 extern "C" int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *packed_t, const float *act,
                                   const float *d_warp, int64_t n, float *dy, float *gpart, float *flat_grad,
                                   snerf_stream_t stream) {
-    using namespace snerf;
+    return snerf::launch_warp_bwd(desc, packed_t, act, d_warp, n, dy, gpart, flat_grad, stream, false);
+}
+
+// accumulate: flat_grad += (the warp net is evaluated twice per step - coarse and fine stage - and once more per ray chunk)
+int snerf::launch_warp_bwd(const snerf_warp_desc *desc, const float *packed_t, const float *act, const float *d_warp, int64_t n,
+                           float *dy, float *gpart, float *flat_grad, snerf_stream_t stream, bool accumulate) {
     Plan P;
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "warp_bwd: desc is null");
@@ -390,7 +395,7 @@ extern "C" int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *pack
     }
     int rc = check_launch("warp_bwd");
     if (rc) return rc;
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);
 }
 
 extern "C" int64_t snerf_warp_param_floats(const snerf_warp_desc *desc) {

@@ -309,20 +309,30 @@ class DataParallelTrainer:
     # ------------------------------------------------------------------ the one-call step
     def _one_call_state(self):
         """Descriptors, segment offsets and slot tables of the one-call path, or None when it does not apply: a plain
-        NerfPipeline over two RenderRayNets (no additional inputs) that are exactly this trainer's models, the default
-        MSE loss, the library's optimiser, every parameter trainable."""
+        NerfPipeline (snerf_nerf_train_step_f32) or a SmplNerfPipeline with the encoded pose (snerf_smpl_nerf_train_step_f32)
+        over RenderRayNets without additional inputs (and the WarpFieldNet) that are exactly this trainer's models, the
+        default MSE loss, the library's optimiser, every parameter trainable."""
         if self._oc is not None:
             return self._oc or None
-        from .nets import RenderRayNet
-        from .pipelines import NerfPipeline
+        from .nets import RenderRayNet, WarpFieldNet
+        from .pipelines import NerfPipeline, SmplNerfPipeline
         self._oc = False
         pipe = self.pipeline
-        if self.one_call is False or type(pipe) is not NerfPipeline or not isinstance(self.optim, HipAdam):
+        smpl = type(pipe) is SmplNerfPipeline
+        if self.one_call is False or not (type(pipe) is NerfPipeline or smpl) or not isinstance(self.optim, HipAdam):
             return None
         mc, mf = pipe.model_coarse, pipe.model_fine
         if type(mc) is not RenderRayNet or type(mf) is not RenderRayNet or mc is mf:
             return None
-        if len(self.models) != 2 or {id(m) for m in self.models} != {id(mc), id(mf)}:
+        mine = [mc, mf]
+        if smpl:        # the fused warp stage with the encoded pose (human_pose_encoding = 1; the raw-pose mode's fine branch fails like
+            mw = pipe.model_warp_field       # the reference's, quirk Q5, and stays on the autograd path)
+            if type(mw) is not WarpFieldNet or not getattr(pipe.args, "human_pose_encoding", 0):
+                return None
+            if not (mc.use_directional_input and mf.use_directional_input):
+                return None
+            mine.append(mw)
+        if len(self.models) != len(mine) or {id(m) for m in self.models} != {id(m) for m in mine}:
             return None
         if type(self).loss is not DataParallelTrainer.loss or type(self.loss_func) is not torch.nn.MSELoss or \
                 self.loss_func.reduction != "mean":
@@ -330,28 +340,31 @@ class DataParallelTrainer:
         if mc.additional_input_dim or mf.additional_input_dim or not all(p.requires_grad for p in self.params):
             return None
         seg = {id(m): (off, n) for m, off, n in self._segments}
-        if id(mc) not in seg or id(mf) not in seg:
+        if any(id(m) not in seg for m in mine):
             return None
         lib = _lib.load()
-        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib}
+        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None}
         # second stream for the coarse net's backward of small batches (include/smplnerf.h: aux_stream); SNERF_TRAIN_AUX_STREAM=0: none
         oc["aux"] = torch.cuda.Stream(self._flat_p.device) if os.environ.get("SNERF_TRAIN_AUX_STREAM", "1") != "0" else None
         # parameter tensors of each net (indices into self.params): the optimiser's has-grad flags of a step
         index = {id(p): i for i, p in enumerate(self.params)}
         oc["tensors"] = tuple(frozenset(index[id(p)] for p in m._ordered_params()) for m in (mc, mf))
+        if smpl:
+            mw = pipe.model_warp_field
+            oc["warp"] = {"net": mw, "seg": seg[id(mw)], "tensors": frozenset(index[id(p)] for p in mw._params()), "packed_t": None}
         self._oc = oc
         return oc
 
-    def _slot_tables(self, oc, net, desc):
-        key = (id(net), net._desc_key(desc))
+    def _slot_tables(self, oc, net, desc, input_grad=False):
+        key = (id(net), net._desc_key(desc), bool(input_grad))
         hit = oc["slots"].get(key)
         if hit is None:
             n = int(oc["lib"].snerf_mlp_param_floats(desc))
             dev = self._flat_p.device
             hit = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
             with torch.cuda.device(dev):
-                _lib.check(oc["lib"].snerf_mlp_stream_slots(desc, hit[0].data_ptr(), hit[1].data_ptr(), _lib.current_stream()),
-                           "snerf_mlp_stream_slots")
+                _lib.check(oc["lib"].snerf_mlp_stream_slots(desc, hit[0].data_ptr(), hit[1].data_ptr(), 1 if input_grad else 0,
+                                                            _lib.current_stream()), "snerf_mlp_stream_slots")
             oc["slots"][key] = hit
         return hit
 
@@ -361,7 +374,12 @@ class DataParallelTrainer:
         from .nets import _split_code
         lib = oc["lib"]
         pipe, args = self.pipeline, self.pipeline.args
-        ray_samples, rays_o, rays_d, z_vals, rgb_truth = (t.contiguous() for t in batch)
+        W = oc["warp"]
+        goal_pose = None
+        if W is not None:
+            ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.contiguous() for t in batch)
+        else:
+            ray_samples, rays_o, rays_d, z_vals, rgb_truth = (t.contiguous() for t in batch)
         dev = self._flat_p.device
         B, Nc = z_vals.shape
         Nf = int(args.number_fine_samples) if args.run_fine else 0
@@ -376,18 +394,36 @@ class DataParallelTrainer:
             if k == 1 and not Nf:          # run_fine = 0: the fine net takes no part (models/nerf_pipeline.py:43-44)
                 packed.append(None), packed_t.append(None)
                 continue
+            ig = W is not None          # the warp stage: the nets back-propagate into their inputs (input_grad = 1 streams)
             if ns:
                 packed.append(m.packed_weights_bf16(d, ns, training=True))
-                packed_t.append(m.packed_weights_t_bf16(d, ns, False))
+                packed_t.append(m.packed_weights_t_bf16(d, ns, ig))
                 sf = st = None
             else:
                 packed.append(m.packed_weights(d, training=True))
-                packed_t.append(m.packed_weights_t(d, False))
-                sf, st = self._slot_tables(oc, m, d)
+                packed_t.append(m.packed_weights_t(d, ig))
+                sf, st = self._slot_tables(oc, m, d, ig)
             nets_c[k] = _lib.AdamNet(ctypes.pointer(d), oc["seg"][k][0], ns, packed[k].data_ptr(), packed_t[k].data_ptr(),
                                      _lib.ptr(sf), _lib.ptr(st))
         n_nets = 2 if Nf else 1
-        need = int(lib.snerf_nerf_train_workspace_bytes(descs[0], descs[1] if Nf else None, B, Nc, Nf, self.rays_per_chunk))
+        if W is not None:
+            mw, pe_ = W["net"], pipe.position_encoder
+            wdesc = _lib.WarpDesc(mw.width, pe_.number_frequencies, 1 if pe_.include_identity else 0, mw.direcions_dim)
+            packed_w = mw._packed(wdesc, training=True)
+            if W["packed_t"] is None or W["packed_t"][0] is not packed_w:      # (a re-built forward stream = the weights changed behind the step)
+                sizes = [ctypes.c_int64() for _ in range(4)]
+                _lib.check(lib.snerf_warp_train_sizes(wdesc, 0, *[ctypes.byref(v) for v in sizes]), "snerf_warp_train_sizes")
+                pt = torch.empty(sizes[2].value, device=dev, dtype=torch.float32)
+                seg_w = self._flat_p[W["seg"][0]:W["seg"][0] + W["seg"][1]]
+                with torch.cuda.device(dev):
+                    _lib.check(lib.snerf_warp_pack_t_f32(wdesc, seg_w.data_ptr(), pt.data_ptr(), _lib.current_stream()), "snerf_warp_pack_t_f32")
+                W["packed_t"] = (packed_w, pt)
+            packed_t_w = W["packed_t"][1]
+            two = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1).contiguous()          # models/smpl_nerf_pipeline.py:28
+            pose_enc = pipe.human_pose_encoder.encode(two).contiguous()                              # :30
+            need = int(lib.snerf_smpl_nerf_train_workspace_bytes(descs[0], descs[1] if Nf else None, wdesc, B, Nc, Nf, self.rays_per_chunk))
+        else:
+            need = int(lib.snerf_nerf_train_workspace_bytes(descs[0], descs[1] if Nf else None, B, Nc, Nf, self.rays_per_chunk))
         if need < 0:
             _lib.check(need, "snerf_nerf_train_workspace_bytes")
         if oc["ws"] is None or oc["ws"].numel() < need:
@@ -410,9 +446,36 @@ class DataParallelTrainer:
         opt = self.optim
         aux = oc["aux"].cuda_stream if oc["aux"] is not None else None
         live = oc["tensors"][0] | (oc["tensors"][1] if Nf or self._sync else frozenset())
+        if W is not None:
+            live = live | W["tensors"]
         flags = [i in live for i in range(len(self.params))]
+        if W is not None:
+            w_off = W["seg"][0]
+            g_w = self._flat_g.data_ptr() + 4 * w_off
+            head = head[:6] + (wdesc, packed_w.data_ptr(), packed_t_w.data_ptr(), ns, ctypes.byref(cb), pose_enc.data_ptr(),
+                               self.rays_per_chunk, oc["ws"].data_ptr(), g_c, g_f if Nf else None, g_w, loss.data_ptr(), rgb.data_ptr(),
+                               rgb_fine.data_ptr())
+            with torch.cuda.device(dev), _lib.timed(f"train_step_smpl[B={B}]"):
+                if not self._sync:
+                    ranges, nr = opt.c_ranges(flags)
+                    st = opt.c_state()
+                    _lib.check(lib.snerf_smpl_nerf_train_step_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets, w_off,
+                                                                  _lib.current_stream()), "snerf_smpl_nerf_train_step_f32")
+                else:
+                    _lib.check(lib.snerf_smpl_nerf_train_grads_f32(*head, _lib.current_stream()), "snerf_smpl_nerf_train_grads_f32")
+                    if not Nf:
+                        self._flat_g[of_off:of_off + of_n].zero_()
+                    self._allreduce_flat()
+                    ranges, nr = opt.c_ranges(flags)
+                    st = opt.c_state()
+                    _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, nr, nets_c, n_nets, _lib.current_stream()),
+                               "snerf_adam_step_f32")
+                    _lib.check(lib.snerf_warp_repack_f32(wdesc, self._flat_p.data_ptr(), self._flat_p.numel(), w_off, packed_w.data_ptr(),
+                                                         packed_t_w.data_ptr(), _lib.current_stream()), "snerf_warp_repack_f32")
         with torch.cuda.device(dev), _lib.timed(f"train_step[B={B}]"):
-            if not self._sync:
+            if W is not None:
+                pass
+            elif not self._sync:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
                 _lib.check(lib.snerf_nerf_train_step_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets,
@@ -438,8 +501,8 @@ class DataParallelTrainer:
         """One optimisation step on this rank's batch (list of tensors, rgb_truth last). Returns the
         local loss tensor (not synchronised with the host)."""
         oc = self._one_call_state()
-        if oc is not None and len(batch) == 5 and all(t.is_cuda and t.dtype == torch.float32 for t in batch) and \
-                not getattr(self.pipeline.args, "strict_cumsum", 0):
+        if oc is not None and len(batch) == (5 if oc["warp"] is None else 6) and \
+                all(t.is_cuda and t.dtype == torch.float32 for t in batch) and not getattr(self.pipeline.args, "strict_cumsum", 0):
             return self._step_one_call(oc, batch)
         self.optim.zero_grad(set_to_none=True)
         self._arm_grad_sinks()

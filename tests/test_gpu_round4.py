@@ -80,7 +80,7 @@ def test_stream_slot_tables_point_at_every_parameter(dev, shape):
     _lib.check(lib.snerf_mlp_pack_t_f32(desc, flat.data_ptr(), packed_t.data_ptr(), 0, s), "pack_t")
     sf = torch.empty(n, dtype=torch.int32, device=dev)
     st = torch.empty(n, dtype=torch.int32, device=dev)
-    _lib.check(lib.snerf_mlp_stream_slots(desc, sf.data_ptr(), st.data_ptr(), s), "slots")
+    _lib.check(lib.snerf_mlp_stream_slots(desc, sf.data_ptr(), st.data_ptr(), 0, s), "slots")
     sf, st = sf.long(), st.long()
     assert int(sf.min()) >= 0 and int(sf.unique().numel()) == n       # every parameter, each at its own float
     assert torch.equal(packed[sf], flat)
@@ -122,7 +122,7 @@ def test_hip_adam_follows_torch_adam(dev, wd):
     packed, packed_t = net.packed_weights(desc, training=True), net.packed_weights_t(desc, False)
     n = int(lib.snerf_mlp_param_floats(desc))
     sf, st = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2))
-    _lib.check(lib.snerf_mlp_stream_slots(desc, sf.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream), "slots")
+    _lib.check(lib.snerf_mlp_stream_slots(desc, sf.data_ptr(), st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "slots")
     nets = (_lib.AdamNet * 1)(_lib.AdamNet(ctypes.pointer(desc), segments[0][1], 0, packed.data_ptr(), packed_t.data_ptr(),
                                            sf.data_ptr(), st.data_ptr()))
     gen = torch.Generator().manual_seed(11)
@@ -547,3 +547,74 @@ def test_guard_bands_around_the_one_call_step(dev, prec):
             assert bool(torch.isfinite(loss))
             total += g.check()
     assert total > 20
+
+
+# ------------------------------------------------------------------------------------------ a7: SmplNerfPipeline as one call
+def _smpl_trainer(dev, prec="fp32", one_call=None, lr=1e-3, **args_kw):
+    from smpl_nerf_amd.nets import WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import PipelineArgs, SmplNerfPipeline
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    pc, pf = syn.make_scene_nets(101)
+    mc, mf = _net(dev, pc, prec), _net(dev, pf, prec)
+    mw = WarpFieldNet(8, 256, 60, 40)
+    mw.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_params(103, out_scale=0.3).items()})
+    mw.precision = prec
+    mw = mw.to(dev).train()
+    pipe = SmplNerfPipeline(mc, mf, mw, PipelineArgs(human_pose_encoding=1, **args_kw), PositionalEncoder(10, 0), PositionalEncoder(4, 0),
+                            PositionalEncoder(10, 0))
+    tr = DataParallelTrainer(pipe, [mc, mf, mw], lr=lr, one_call=one_call)
+    return tr, pipe
+
+
+def _smpl_batch(dev, n):
+    b = _batch(dev, n, stride=61)
+    pose = T(syn.human_poses()[np.arange(n) % 10].astype(np.float32), dev)
+    return b[:4] + [pose, b[4]]
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("cfg", [dict(chunk=0), dict(chunk=48, white_background=1), dict(chunk=0, run_fine=0)])
+def test_smpl_nerf_one_call_step_equals_the_autograd_step(dev, prec, cfg):
+    """SmplNerfSolver's per-batch body (solver/smpl_nerf_solver.py:76-89, default loss) through snerf_smpl_nerf_train_step_f32
+    against the autograd form of the same pipeline (itself pinned to the reference's gradients, g11): warp net evaluated twice,
+    nets back-propagating into their inputs, the coarse compositing into x' - o; losses, first-step gradients of all three
+    nets, parameters after two steps; ray chunks; run_fine = 0."""
+    cfg = dict(cfg)
+    chunk = cfg.pop("chunk")
+    runs = []
+    for one_call in (None, False):
+        tr, pipe = _smpl_trainer(dev, prec, one_call=one_call, **cfg)
+        tr.rays_per_chunk = chunk
+        batch = _smpl_batch(dev, 100)
+        losses = [float(tr.step(batch))]
+        grads = [None if p.grad is None else p.grad.clone() for p in tr.params]
+        losses.append(float(tr.step(batch)))
+        assert (tr._one_call_state() is not None) == (one_call is None)
+        runs.append((losses, grads, [p.detach().clone() for p in tr.params]))
+    close(runs[0][0][:1], runs[1][0][:1], 2e-6, 1e-8)
+    close(runs[0][0][1:], runs[1][0][1:], 2e-4, 1e-8)
+    for ga, gb in zip(runs[0][1], runs[1][1]):
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
+    # (Adam's first steps move every parameter by ~lr x sign(gradient): where a gradient element is round-off around zero the
+    # two forms may step in opposite directions - bounded by the two steps themselves in the split modes)
+    for pa, pb in zip(runs[0][2], runs[1][2]):
+        assert float((pa - pb).abs().max()) <= (3e-4 if prec == "fp32" else 2.5e-3)
+
+
+def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
+    """After one-call steps the pipeline's inference (forward and the single-call render) reads the streams the step kept
+    current - the warp net's are re-packed inside the call - and equals a pipeline built from the new parameters."""
+    tr, pipe = _smpl_trainer(dev)
+    batch = _smpl_batch(dev, 64)
+    for _ in range(3):
+        tr.step(batch)
+    tr2, pipe2 = _smpl_trainer(dev)
+    for a, b in zip(tr.models, tr2.models):
+        b.load_state_dict(a.state_dict())
+    with torch.no_grad():
+        o1, o2 = pipe(batch), pipe2(batch)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
