@@ -133,7 +133,7 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc((void **)&out, (size_t)(4 * steps + 6 * B) * sizeof(float))); /* loss[3] per step (padded to 4), rgb, rgb_fine */
     float *rgb = out + 4 * steps, *rgb_fine = rgb + 3 * B;
 
-    snerf_nerf_batch batch = {samples, o, d, z, gt, u, NULL, NULL, B, Nc, Nf, wb};
+    snerf_nerf_batch batch = {samples, o, d, z, gt, u, NULL, NULL, NULL, B, Nc, Nf, wb};
     snerf_adam_state adam = {params, grads, m, v, n_params, scratch, lr, 0.9, 0.999, 1e-8, 0.0}; /* solver/nerf_solver.py:11-14 */
     snerf_adam_range range = {0, n_params, step, n_tensors};
     (void)N;

@@ -502,6 +502,8 @@ typedef struct snerf_nerf_batch {
     const float *u;            /* [Nf] = linspace(0, 1, Nf) (utils.py:204-206); unused with Nf == 0 */
     const float *noise_coarse; /* nullable [B, Nc]: sigma noise (utils.py:171-173) */
     const float *noise_fine;   /* nullable [B, Nc + Nf] */
+    const float *additional;   /* [B, add_dim] per-ray additional inputs of nets with add_dim > 0 (the pose rows of
+                                  models/append_smpl_params_pipeline.py:29-52, append_to_nerf_pipeline.py:26); else NULL */
     int64_t B;
     int32_t Nc, Nf;            /* Nf == 0 is run_fine = 0: loss = 2 MSE(rgb), no fine gradients (nerf_pipeline.py:43-44) */
     int32_t white_background;

@@ -52,7 +52,7 @@ class AdamNet(ctypes.Structure):
 class NerfBatch(ctypes.Structure):
     """struct snerf_nerf_batch - the Solver's batch (solver/nerf_solver.py:77-81) plus u and the sigma noise."""
     _fields_ = [("ray_samples", _P), ("rays_o", _P), ("rays_d", _P), ("z_vals", _P), ("rgb_truth", _P), ("u", _P),
-                ("noise_coarse", _P), ("noise_fine", _P), ("B", c_int64), ("Nc", c_int32), ("Nf", c_int32),
+                ("noise_coarse", _P), ("noise_fine", _P), ("additional", _P), ("B", c_int64), ("Nc", c_int32), ("Nf", c_int32),
                 ("white_background", c_int32)]
 
 

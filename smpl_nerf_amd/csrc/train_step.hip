@@ -385,8 +385,11 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
         return fail(SNERF_E_BADARG, "nerf_train_grads: null pointer");
     if (Nf > 0 && (!desc_fine || !packed_fine || !packed_t_fine || !grad_fine || !batch->rays_o || !batch->u))
         return fail(SNERF_E_BADARG, "nerf_train_grads: the fine pass needs desc_fine, its streams, grad_fine, rays_o and u");
-    if (desc_coarse->add_dim || (Nf > 0 && desc_fine->add_dim))
-        return fail(SNERF_E_BADARG, "nerf_train_grads: nets with additional inputs train through snerf_mlp_fwd_train_* / snerf_mlp_bwd_*");
+    const int add_dim = desc_coarse->add_dim;
+    if (Nf > 0 && desc_fine->add_dim != add_dim)
+        return fail(SNERF_E_BADARG, "nerf_train_grads: both nets must read the same per-ray additional inputs (add_dim %d vs %d)", add_dim,
+                    desc_fine->add_dim);
+    if (add_dim && !batch->additional) return fail(SNERF_E_BADARG, "nerf_train_grads: the nets have additional inputs but batch->additional is null");
     if (!aligned(workspace, 256)) return fail(SNERF_E_ALIGN, "nerf_train_grads: workspace must be 256-byte aligned");
     if (precision != 0 && (desc_coarse->width != 256 || (Nf > 0 && desc_fine->width != 256)))
         return fail(SNERF_E_BADARG, "nerf_train_grads: the split-precision kernels exist for width 256");
@@ -410,11 +413,11 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
     const int wb = batch->white_background ? 1 : 0;
     const float norm = (float)(2.0 / (3.0 * (double)B));      // mse_loss_backward: 2 / numel
     const double inv_total = 1.0 / (3.0 * (double)B);
-    auto fwd_train = [&](const snerf_mlp_desc *d, const void *packed, const float *x, const float *dirs, int64_t n, int spr,
-                         float *raw, float *act) {
+    auto fwd_train = [&](const snerf_mlp_desc *d, const void *packed, const float *x, const float *dirs, const float *add, int64_t n,
+                         int spr, float *raw, float *act) {
         if (precision == 0)
-            return snerf_mlp_fwd_train_f32(d, reinterpret_cast<const float *>(packed), x, dirs, 0, nullptr, n, spr, raw, act, stream);
-        return snerf_mlp_fwd_train_bf16_f32(d, packed, precision, x, dirs, 0, nullptr, n, spr, raw, act, stream);
+            return snerf_mlp_fwd_train_f32(d, reinterpret_cast<const float *>(packed), x, dirs, 0, add, n, spr, raw, act, stream);
+        return snerf_mlp_fwd_train_bf16_f32(d, packed, precision, x, dirs, 0, add, n, spr, raw, act, stream);
     };
     auto bwd = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, const float *d_raw_, int64_t n, float *dy_,
                    float *gpart_, float *grad, bool accumulate, snerf_stream_t st) {
@@ -431,14 +434,15 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
         const float *nz_c = batch->noise_coarse ? batch->noise_coarse + r0 * Nc : nullptr;
         const float *nz_f = batch->noise_fine ? batch->noise_fine + r0 * N : nullptr;
         float *rgb_c = rgb + r0 * 3, *rgb_fo = rgb_fine + r0 * 3;
+        const float *add = add_dim ? batch->additional + r0 * add_dim : nullptr;   // per-ray constants (append_smpl_params_pipeline.py:29-52)
         // forward (models/nerf_pipeline.py:29-65) with every layer input saved
-        if ((rc = fwd_train(desc_coarse, packed_coarse, x, d, b * Nc, Nc, raw_c, act_c))) return rc;
+        if ((rc = fwd_train(desc_coarse, packed_coarse, x, d, add, b * Nc, Nc, raw_c, act_c))) return rc;
         if ((rc = snerf_composite_fwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, rgb_c, Nf > 0 ? weights_c : nullptr, nullptr, stream))) return rc;
         if (Nf > 0) {
             if ((rc = snerf_sample_pdf_f32(z, weights_c, batch->u, batch->rays_o + r0 * 3, d, b, Nc, Nf, nullptr, nullptr, z_fine,
                                            pts_f, stream)))
                 return rc;
-            if ((rc = fwd_train(desc_fine, packed_fine, pts_f, d, b * N, N, raw_f, act_f))) return rc;
+            if ((rc = fwd_train(desc_fine, packed_fine, pts_f, d, add, b * N, N, raw_f, act_f))) return rc;
             if ((rc = snerf_composite_fwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, rgb_fo, nullptr, nullptr, stream))) return rc;
         }
         // loss value and d loss / d rgb (solver/nerf_solver.py:48-52, 85-86)

@@ -315,11 +315,12 @@ class DataParallelTrainer:
         if self._oc is not None:
             return self._oc or None
         from .nets import RenderRayNet, WarpFieldNet
-        from .pipelines import NerfPipeline, SmplNerfPipeline
+        from .pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline, NerfPipeline, SmplNerfPipeline
         self._oc = False
         pipe = self.pipeline
         smpl = type(pipe) is SmplNerfPipeline
-        if self.one_call is False or not (type(pipe) is NerfPipeline or smpl) or not isinstance(self.optim, HipAdam):
+        posed = type(pipe) in (AppendSmplParamsPipeline, AppendToNerfPipeline)    # per-ray pose columns in front of the encoding
+        if self.one_call is False or not (type(pipe) is NerfPipeline or smpl or posed) or not isinstance(self.optim, HipAdam):
             return None
         mc, mf = pipe.model_coarse, pipe.model_fine
         if type(mc) is not RenderRayNet or type(mf) is not RenderRayNet or mc is mf:
@@ -337,13 +338,15 @@ class DataParallelTrainer:
         if type(self).loss is not DataParallelTrainer.loss or type(self.loss_func) is not torch.nn.MSELoss or \
                 self.loss_func.reduction != "mean":
             return None
-        if mc.additional_input_dim or mf.additional_input_dim or not all(p.requires_grad for p in self.params):
+        if (not posed and (mc.additional_input_dim or mf.additional_input_dim)) or not all(p.requires_grad for p in self.params):
+            return None
+        if posed and (not mc.additional_input_dim or mc.additional_input_dim != mf.additional_input_dim):
             return None
         seg = {id(m): (off, n) for m, off, n in self._segments}
         if any(id(m) not in seg for m in mine):
             return None
         lib = _lib.load()
-        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None}
+        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None, "posed": posed}
         # second stream for the coarse net's backward of small batches (include/smplnerf.h: aux_stream); SNERF_TRAIN_AUX_STREAM=0: none
         oc["aux"] = torch.cuda.Stream(self._flat_p.device) if os.environ.get("SNERF_TRAIN_AUX_STREAM", "1") != "0" else None
         # parameter tensors of each net (indices into self.params): the optimiser's has-grad flags of a step
@@ -375,8 +378,16 @@ class DataParallelTrainer:
         lib = oc["lib"]
         pipe, args = self.pipeline, self.pipeline.args
         W = oc["warp"]
-        goal_pose = None
-        if W is not None:
+        goal_pose = add = None
+        if oc["posed"]:      # models/append_smpl_params_pipeline.py:29-37 / append_to_nerf_pipeline.py:26: the pose rows the nets read
+            ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.contiguous() for t in batch)
+            add = pipe._select(goal_pose).contiguous()
+            if args.human_pose_encoding:
+                add = pipe.human_pose_encoder.encode(add)
+            add = add.reshape(add.shape[0], -1).contiguous()
+            if add.shape[1] != oc["nets"][0].additional_input_dim:
+                raise RuntimeError("DataParallelTrainer: the pose rows do not match the nets' additional_input_dim")
+        elif W is not None:
             ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.contiguous() for t in batch)
         else:
             ray_samples, rays_o, rays_d, z_vals, rgb_truth = (t.contiguous() for t in batch)
@@ -389,7 +400,7 @@ class DataParallelTrainer:
             raise RuntimeError("DataParallelTrainer: both nets must use the same precision mode")
         descs, packed, packed_t, nets_c = [], [], [], (_lib.AdamNet * 2)()
         for k, m in enumerate((mc, mf)):
-            d = m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder, False)
+            d = m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder, bool(oc["posed"]))
             descs.append(d)
             if k == 1 and not Nf:          # run_fine = 0: the fine net takes no part (models/nerf_pipeline.py:43-44)
                 packed.append(None), packed_t.append(None)
@@ -435,7 +446,7 @@ class DataParallelTrainer:
         nz_c = pipe._noise((B, Nc), dev)
         nz_f = pipe._noise((B, Nc + Nf), dev) if Nf else None
         cb = _lib.NerfBatch(ray_samples.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(),
-                            rgb_truth.data_ptr(), _lib.ptr(u), _lib.ptr(nz_c), _lib.ptr(nz_f), B, Nc, Nf,
+                            rgb_truth.data_ptr(), _lib.ptr(u), _lib.ptr(nz_c), _lib.ptr(nz_f), _lib.ptr(add), B, Nc, Nf,
                             1 if args.white_background else 0)
         (oc_off, oc_n), (of_off, of_n) = oc["seg"]
         g_c = self._flat_g.data_ptr() + 4 * oc_off
@@ -501,8 +512,9 @@ class DataParallelTrainer:
         """One optimisation step on this rank's batch (list of tensors, rgb_truth last). Returns the
         local loss tensor (not synchronised with the host)."""
         oc = self._one_call_state()
-        if oc is not None and len(batch) == (5 if oc["warp"] is None else 6) and \
-                all(t.is_cuda and t.dtype == torch.float32 for t in batch) and not getattr(self.pipeline.args, "strict_cumsum", 0):
+        if oc is not None and len(batch) == (6 if (oc["warp"] is not None or oc["posed"]) else 5) and \
+                all(t.is_cuda and t.dtype == torch.float32 and not t.requires_grad for t in batch) and \
+                not getattr(self.pipeline.args, "strict_cumsum", 0):      # (a batch tensor that wants a gradient: the autograd path)
             return self._step_one_call(oc, batch)
         self.optim.zero_grad(set_to_none=True)
         self._arm_grad_sinks()

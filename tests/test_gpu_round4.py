@@ -618,3 +618,49 @@ def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
         o1, o2 = pipe(batch), pipe2(batch)
     for a, b in zip(o1, o2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+@pytest.mark.parametrize("kind", ["append_smpl_params", "append_smpl_params_encoded", "append_to_nerf"])
+def test_pose_conditioned_pipelines_one_call_step_equals_the_autograd_step(dev, prec, kind):
+    """f-4 (the paper's headline model): AppendSmplParamsPipeline / AppendToNerfPipeline - per-ray pose columns in front of the
+    encoding, raw or encoded (models/append_smpl_params_pipeline.py:29-52, append_to_nerf_pipeline.py:26) - train through
+    snerf_nerf_train_step_f32 with batch.additional; against the autograd form (pinned to the reference by g10): losses,
+    first-step gradients, ray chunks.  A pose that wants its own gradient keeps the autograd path."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline, PipelineArgs
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    enc = kind.endswith("encoded")
+    add_dim = {"append_smpl_params": 69, "append_smpl_params_encoded": 69 * 20, "append_to_nerf": 2}[kind]
+    runs = []
+    batch = _smpl_batch(dev, 100)
+    for one_call in (None, False):
+        params = [syn.make_scene_net_params(s, add_first=True, additional_input_dim=add_dim) for s in (301, 303)]
+        nets = []
+        for p in params:
+            m = RenderRayNet(8, 256, 60, 24, add_dim, skips=[4])
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+            m.precision = prec
+            nets.append(m.to(dev).train())
+        cls = AppendToNerfPipeline if kind == "append_to_nerf" else AppendSmplParamsPipeline
+        pipe = cls(nets[0], nets[1], PipelineArgs(human_pose_encoding=1 if enc else 0), PositionalEncoder(10, 0), PositionalEncoder(4, 0),
+                   PositionalEncoder(10, 0))
+        tr = DataParallelTrainer(pipe, nets, lr=1e-3, one_call=one_call)
+        tr.rays_per_chunk = 37
+        losses = [float(tr.step(batch))]
+        grads = [p.grad.clone() for p in tr.params]
+        losses.append(float(tr.step(batch)))
+        assert (tr._one_call_state() is not None) == (one_call is None)
+        runs.append((losses, grads))
+    # d loss / d goal_pose requested: the step must not swallow it (a fresh trainer: at this learning rate two steps drive the
+    # synthetic scene's densities below zero everywhere, after which every gradient is exactly 0 - DESIGN section 5)
+    tr = DataParallelTrainer(pipe, nets, lr=1e-6)
+    b2 = list(batch)
+    b2[4] = batch[4].clone().requires_grad_(True)
+    tr.step(b2)
+    assert tr._one_call_state() is not None and b2[4].grad is not None
+    close(runs[0][0][:1], runs[1][0][:1], 2e-6, 1e-8)
+    close(runs[0][0][1:], runs[1][0][1:], 2e-4, 1e-8)
+    for ga, gb in zip(runs[0][1], runs[1][1]):
+        assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
