@@ -314,17 +314,23 @@ class DataParallelTrainer:
         default MSE loss, the library's optimiser, every parameter trainable."""
         if self._oc is not None:
             return self._oc or None
-        from .nets import RenderRayNet, WarpFieldNet
-        from .pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline, NerfPipeline, SmplNerfPipeline
+        from .nets import AppendVerticesNet, RenderRayNet, WarpFieldNet
+        from .pipelines import (AppendSmplParamsPipeline, AppendToNerfPipeline, AppendVerticesPipeline, NerfPipeline,
+                                SmplNerfPipeline)
         self._oc = False
         pipe = self.pipeline
         smpl = type(pipe) is SmplNerfPipeline
         posed = type(pipe) in (AppendSmplParamsPipeline, AppendToNerfPipeline)    # per-ray pose columns in front of the encoding
-        if self.one_call is False or not (type(pipe) is NerfPipeline or smpl or posed) or not isinstance(self.optim, HipAdam):
+        verts = type(pipe) is AppendVerticesPipeline      # per-ray vertex floats (quirk Q7), estimator / body model not trained here
+        if self.one_call is False or not (type(pipe) is NerfPipeline or smpl or posed or verts) or not isinstance(self.optim, HipAdam):
             return None
         mc, mf = pipe.model_coarse, pipe.model_fine
-        if type(mc) is not RenderRayNet or type(mf) is not RenderRayNet or mc is mf:
+        want = AppendVerticesNet if verts else RenderRayNet
+        if type(mc) is not want or type(mf) is not want or mc is mf:
             return None
+        if verts and any(p.requires_grad for m in (pipe.smpl_estimator, pipe.smpl_model) if isinstance(m, torch.nn.Module)
+                         for p in m.parameters()):
+            return None        # a trained estimator (AppendVerticesSolver's second group) needs d loss / d vertices: the autograd path
         mine = [mc, mf]
         if smpl:        # the fused warp stage with the encoded pose (human_pose_encoding = 1; the raw-pose mode's fine branch fails like
             mw = pipe.model_warp_field       # the reference's, quirk Q5, and stays on the autograd path)
@@ -338,7 +344,8 @@ class DataParallelTrainer:
         if type(self).loss is not DataParallelTrainer.loss or type(self.loss_func) is not torch.nn.MSELoss or \
                 self.loss_func.reduction != "mean":
             return None
-        if (not posed and (mc.additional_input_dim or mf.additional_input_dim)) or not all(p.requires_grad for p in self.params):
+        if (not (posed or verts) and (mc.additional_input_dim or mf.additional_input_dim)) or \
+                not all(p.requires_grad for p in (self.params if not verts else [q for m in (mc, mf) for q in m._ordered_params()])):
             return None
         if posed and (not mc.additional_input_dim or mc.additional_input_dim != mf.additional_input_dim):
             return None
@@ -346,7 +353,7 @@ class DataParallelTrainer:
         if any(id(m) not in seg for m in mine):
             return None
         lib = _lib.load()
-        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None, "posed": posed}
+        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None, "posed": posed or verts, "verts": verts}
         # second stream for the coarse net's backward of small batches (include/smplnerf.h: aux_stream); SNERF_TRAIN_AUX_STREAM=0: none
         oc["aux"] = torch.cuda.Stream(self._flat_p.device) if os.environ.get("SNERF_TRAIN_AUX_STREAM", "1") != "0" else None
         # parameter tensors of each net (indices into self.params): the optimiser's has-grad flags of a step
@@ -379,7 +386,13 @@ class DataParallelTrainer:
         pipe, args = self.pipeline, self.pipeline.args
         W = oc["warp"]
         goal_pose = add = None
-        if oc["posed"]:      # models/append_smpl_params_pipeline.py:29-37 / append_to_nerf_pipeline.py:26: the pose rows the nets read
+        if oc["verts"]:      # models/append_vertices_pipeline.py:30-58: estimator -> body model -> the vertex floats the nets read (Q7)
+            ray_samples, rays_o, rays_d, z_vals, images, rgb_truth = (t.contiguous() for t in batch)
+            goal_poses, betas = pipe.smpl_estimator(images)
+            orient = torch.zeros([1, 3], device=ray_samples.device).expand(z_vals.shape[0], -1)
+            vertices = pipe.smpl_model(betas=betas, return_verts=True, body_pose=goal_poses, global_orient=orient).vertices
+            add = vertices.reshape(z_vals.shape[0], -1)[:, :oc["nets"][0].positions_dim].contiguous().float()
+        elif oc["posed"]:    # models/append_smpl_params_pipeline.py:29-37 / append_to_nerf_pipeline.py:26: the pose rows the nets read
             ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.contiguous() for t in batch)
             add = pipe._select(goal_pose).contiguous()
             if args.human_pose_encoding:
@@ -387,6 +400,7 @@ class DataParallelTrainer:
             add = add.reshape(add.shape[0], -1).contiguous()
             if add.shape[1] != oc["nets"][0].additional_input_dim:
                 raise RuntimeError("DataParallelTrainer: the pose rows do not match the nets' additional_input_dim")
+            add = add.float()
         elif W is not None:
             ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.contiguous() for t in batch)
         else:
@@ -400,7 +414,7 @@ class DataParallelTrainer:
             raise RuntimeError("DataParallelTrainer: both nets must use the same precision mode")
         descs, packed, packed_t, nets_c = [], [], [], (_lib.AdamNet * 2)()
         for k, m in enumerate((mc, mf)):
-            d = m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder, bool(oc["posed"]))
+            d = m.desc_for_rows() if oc["verts"] else m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder, bool(oc["posed"]))
             descs.append(d)
             if k == 1 and not Nf:          # run_fine = 0: the fine net takes no part (models/nerf_pipeline.py:43-44)
                 packed.append(None), packed_t.append(None)
@@ -513,7 +527,8 @@ class DataParallelTrainer:
         local loss tensor (not synchronised with the host)."""
         oc = self._one_call_state()
         if oc is not None and len(batch) == (6 if (oc["warp"] is not None or oc["posed"]) else 5) and \
-                all(t.is_cuda and t.dtype == torch.float32 and not t.requires_grad for t in batch) and \
+                all(t.is_cuda and not t.requires_grad and (t.dtype == torch.float32 or (oc["verts"] and i == 4))
+                    for i, t in enumerate(batch)) and \
                 not getattr(self.pipeline.args, "strict_cumsum", 0):      # (a batch tensor that wants a gradient: the autograd path)
             return self._step_one_call(oc, batch)
         self.optim.zero_grad(set_to_none=True)

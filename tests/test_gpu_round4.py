@@ -664,3 +664,41 @@ def test_pose_conditioned_pipelines_one_call_step_equals_the_autograd_step(dev, 
     close(runs[0][0][1:], runs[1][0][1:], 2e-4, 1e-8)
     for ga, gb in zip(runs[0][1], runs[1][1]):
         assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+def test_append_vertices_one_call_step_equals_the_autograd_step(dev, prec):
+    """a8 / configs[4]: AppendVerticesPipeline with a frozen estimator and body model (the vertex floats the nets read are
+    per-ray constants, quirk Q7) trains through snerf_nerf_train_step_f32 with batch.additional; the dead vertices_net
+    parameters get no gradient and are not updated, like in the reference; a TRAINED estimator keeps the autograd path."""
+    from test_gpu_round2 import _av_pipeline
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    b = _batch(dev, 100, stride=53)
+    images = (torch.arange(100, device=dev) % 10)
+    batch = b[:4] + [images, b[4]]
+    runs = []
+    for one_call in (None, False):
+        pipe, _ = _av_pipeline(dev, prec, n_poses=10, run_fine=1)
+        nets = [pipe.model_coarse.train(), pipe.model_fine.train()]
+        tr = DataParallelTrainer(pipe, nets, lr=1e-4, one_call=one_call)
+        tr.rays_per_chunk = 64
+        dead = [p.detach().clone() for p in nets[0].vertices_net.parameters()]
+        losses = [float(tr.step(batch))]
+        grads = [None if p.grad is None else p.grad.clone() for p in tr.params]
+        losses.append(float(tr.step(batch)))
+        assert (tr._one_call_state() is not None) == (one_call is None)
+        assert all(p.grad is None for p in nets[0].vertices_net.parameters())
+        assert all(torch.equal(a, p) for a, p in zip(dead, nets[0].vertices_net.parameters()))
+        runs.append((losses, grads))
+    close(runs[0][0][:1], runs[1][0][:1], 2e-6, 1e-8)
+    close(runs[0][0][1:], runs[1][0][1:], 2e-4, 1e-8)
+    for ga, gb in zip(runs[0][1], runs[1][1]):
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
+    pipe, _ = _av_pipeline(dev, prec, n_poses=10, run_fine=1)
+    pipe.smpl_estimator.goal_poses.requires_grad_(True)
+    tr = DataParallelTrainer(pipe, [pipe.model_coarse, pipe.model_fine, pipe.smpl_estimator], lr=1e-4)
+    assert tr._one_call_state() is None
+    tr.step(batch)
+    assert float(pipe.smpl_estimator.goal_poses.grad.abs().max()) > 0
