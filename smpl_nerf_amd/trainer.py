@@ -474,46 +474,35 @@ class DataParallelTrainer:
         if W is not None:
             live = live | W["tensors"]
         flags = [i in live for i in range(len(self.params))]
+        # the call(s): one entry when this rank steps alone; its two halves around the all-reduce otherwise
+        stream = _lib.current_stream
         if W is not None:
             w_off = W["seg"][0]
             g_w = self._flat_g.data_ptr() + 4 * w_off
             head = head[:6] + (wdesc, packed_w.data_ptr(), packed_t_w.data_ptr(), ns, ctypes.byref(cb), pose_enc.data_ptr(),
                                self.rays_per_chunk, oc["ws"].data_ptr(), g_c, g_f if Nf else None, g_w, loss.data_ptr(), rgb.data_ptr(),
                                rgb_fine.data_ptr())
-            with torch.cuda.device(dev), _lib.timed(f"train_step_smpl[B={B}]"):
-                if not self._sync:
-                    ranges, nr = opt.c_ranges(flags)
-                    st = opt.c_state()
-                    _lib.check(lib.snerf_smpl_nerf_train_step_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets, w_off,
-                                                                  _lib.current_stream()), "snerf_smpl_nerf_train_step_f32")
-                else:
-                    _lib.check(lib.snerf_smpl_nerf_train_grads_f32(*head, _lib.current_stream()), "snerf_smpl_nerf_train_grads_f32")
-                    if not Nf:
-                        self._flat_g[of_off:of_off + of_n].zero_()
-                    self._allreduce_flat()
-                    ranges, nr = opt.c_ranges(flags)
-                    st = opt.c_state()
-                    _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, nr, nets_c, n_nets, _lib.current_stream()),
-                               "snerf_adam_step_f32")
-                    _lib.check(lib.snerf_warp_repack_f32(wdesc, self._flat_p.data_ptr(), self._flat_p.numel(), w_off, packed_w.data_ptr(),
-                                                         packed_t_w.data_ptr(), _lib.current_stream()), "snerf_warp_repack_f32")
-        with torch.cuda.device(dev), _lib.timed(f"train_step[B={B}]"):
-            if W is not None:
-                pass
-            elif not self._sync:
+            name, tail = "snerf_smpl_nerf_train", ()
+            step_tail = lambda st, ranges, nr: (ctypes.byref(st), ranges, nr, nets_c, n_nets, w_off, stream())
+        else:
+            name, tail = "snerf_nerf_train", (aux,)
+            step_tail = lambda st, ranges, nr: (ctypes.byref(st), ranges, nr, nets_c, n_nets, stream(), aux)
+        with torch.cuda.device(dev), _lib.timed(f"train_step{'_smpl' if W is not None else ''}[B={B}]"):
+            if not self._sync:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
-                _lib.check(lib.snerf_nerf_train_step_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets,
-                                                         _lib.current_stream(), aux), "snerf_nerf_train_step_f32")
+                _lib.check(getattr(lib, name + "_step_f32")(*head, *step_tail(st, ranges, nr)), name + "_step_f32")
             else:
-                _lib.check(lib.snerf_nerf_train_grads_f32(*head, _lib.current_stream(), aux), "snerf_nerf_train_grads_f32")
+                _lib.check(getattr(lib, name + "_grads_f32")(*head, stream(), *tail), name + "_grads_f32")
                 if not Nf:      # every rank contributes the same shape: zeros for the net that took no part
                     self._flat_g[of_off:of_off + of_n].zero_()
                 self._allreduce_flat()
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
-                _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, nr, nets_c, n_nets, _lib.current_stream()),
-                           "snerf_adam_step_f32")
+                _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, nr, nets_c, n_nets, stream()), "snerf_adam_step_f32")
+                if W is not None:
+                    _lib.check(lib.snerf_warp_repack_f32(wdesc, self._flat_p.data_ptr(), self._flat_p.numel(), w_off, packed_w.data_ptr(),
+                                                         packed_t_w.data_ptr(), stream()), "snerf_warp_repack_f32")
         # p.grad = what autograd would have left: views of the flat gradient buffer (None for a net that took no part)
         for i, (p, v) in enumerate(zip(self.params, self._views)):
             want = v if flags[i] else None

@@ -702,3 +702,29 @@ def test_append_vertices_one_call_step_equals_the_autograd_step(dev, prec):
     assert tr._one_call_state() is None
     tr.step(batch)
     assert float(pipe.smpl_estimator.goal_poses.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("kind", ["nerf", "smpl_nerf"])
+def test_the_two_halves_of_the_step_equal_the_one_call(dev, kind):
+    """With several ranks the step runs as snerf_*_train_grads_f32 -> all-reduce of the flat gradient -> snerf_adam_step_f32
+    (-> snerf_warp_repack_f32): forced here on one rank (the all-reduce over no group is the identity), the trajectory equals
+    the single call's bit for bit, run_fine = 0 included (the idle fine net then contributes zeros and is stepped, like every
+    rank's would be - DESIGN section 7)."""
+    finals = []
+    for split in (False, True):
+        if kind == "nerf":
+            tr, pipe, _, _ = _trainer(dev, lr=1e-4)
+            batch = _batch(dev, 96)
+        else:
+            tr, pipe = _smpl_trainer(dev, lr=1e-4)
+            batch = _smpl_batch(dev, 96)
+        tr._sync = split
+        tr.rays_per_chunk = 40
+        losses = [float(tr.step(batch)) for _ in range(3)]
+        with torch.no_grad():
+            out = pipe(batch)
+        finals.append((losses, [p.detach().clone() for p in tr.params], out[1].clone()))
+    assert finals[0][0] == finals[1][0]
+    for a, b in zip(finals[0][1], finals[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(finals[0][2], finals[1][2])
