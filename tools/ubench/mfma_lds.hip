@@ -113,12 +113,117 @@ __global__ __launch_bounds__(512) void kb(float *out, long long *cyc, int iters,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 1.0f + 1e-3f * (float)(lane + e);
     const bf8 *ap = reinterpret_cast<const bf8 *>(lds) + lane;
+    // MODE 3: no workgroup barrier.  Three LDS counters hand the slabs over: landed[parity] (+1 per producing wave once its DMA
+    // pieces of a slab are in LDS), done (+1 per wave per slab consumed).  Slab s+2 is issued by half (s & 1) in the MIDDLE of slab s
+    // (once every wave has finished slab s-1, whose slot it takes), its landing is signalled in the middle of slab s+1, and it is
+    // needed at the start of slab s+2: nobody waits unless somebody is a full half slab behind.  Spins are bounded.
+    int *cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(lds) + 3 * PARTS * 16384);
+    if (MODE == 4) {
+        if (threadIdx.x < 2) cnt[threadIdx.x] = 8;   // half-slabs 0..3 count as resident
+        if (threadIdx.x == 2) cnt[2] = 0;
+        if (threadIdx.x == 3) cnt[3] = 0;
+        __syncthreads();
+        if (wave >= 4) __builtin_amdgcn_s_sleep(12);   // ~768 cycles: half of a half-slab period
+    }
+    if (MODE == 3) {
+        if (threadIdx.x < 2) cnt[threadIdx.x] = 4;
+        if (threadIdx.x == 2) cnt[2] = 0;
+        if (threadIdx.x == 3) cnt[3] = 0;
+        __syncthreads();
+    }
+    const int half = wave >= 4;
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
         if (SPLIT) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
             split_parts<PARTS>(v, b);
+        }
+        if (MODE == 3) {
+            const int need = 4 * ((it >> 1) + 1);
+            int spins = 0;
+            while (__hip_atomic_load(&cnt[it & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { cnt[3] = 1; break; }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int to = 0; to < 8; ++to) {
+                bf8 a[PARTS];
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p) a[p] = ap[(to * PARTS + p) * 64];
+#pragma unroll
+                for (int t = 0; t < PRODUCTS; ++t) acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t % PARTS], b[(t / PARTS + t) % PARTS], acc[to], 0, 0, 0);
+            }
+            if (half == (it & 1)) {   // producer of slab it + 2
+                spins = 0;
+                while (__hip_atomic_load(&cnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * it) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) { cnt[3] = 1; break; }
+                }
+                asm volatile("" ::: "memory");
+                const char *g = reinterpret_cast<const char *>(src) + lane * 16 + (size_t)(it & 31) * PARTS * 16384;
+                char *dst = reinterpret_cast<char *>(lds) + PARTS * 16384 * ((it + 2) % 3);
+#pragma unroll
+                for (int q = 0; q < PARTS * 4; ++q)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + ((wave & 3) * PARTS * 4 + q) * 1024),
+                                                     (__attribute__((address_space(3))) void *)(dst + ((wave & 3) * PARTS * 4 + q) * 1024), 16, 0, 0);
+            } else if (it) {          // my pieces of slab it + 1 were issued a slab ago
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&cnt[half], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int to = 8; to < 16; ++to) {
+                bf8 a[PARTS];
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p) a[p] = ap[(to * PARTS + p) * 64];
+#pragma unroll
+                for (int t = 0; t < PRODUCTS; ++t) acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t % PARTS], b[(t / PARTS + t) % PARTS], acc[to], 0, 0, 0);
+            }
+            if (lane == 0) __hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            continue;
+        }
+        if (MODE == 4) {
+            // half-slab granularity (6 ring slots of 8 tiles), no barrier, the two halves of the workgroup (= the two waves of every
+            // SIMD) started half a half-slab apart: half-slab h+4 is issued by half (h & 1) at the boundary after h (needs everyone
+            // past h-2), signalled landed at that half's next boundary, needed at the start of h+4.  Either half may run a whole
+            // half-slab ahead of the other without anybody waiting.
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                const int h = 2 * it + hs;
+                const int need = 4 * ((h >> 1) + 1);
+                int spins = 0;
+                while (__hip_atomic_load(&cnt[h & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                    if (++spins > (1 << 22)) { cnt[3] = 1; break; }
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int to = 8 * hs; to < 8 * hs + 8; ++to) {
+                    bf8 a[PARTS];
+#pragma unroll
+                    for (int p = 0; p < PARTS; ++p) a[p] = ap[(to * PARTS + p) * 64];
+#pragma unroll
+                    for (int t = 0; t < PRODUCTS; ++t) acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t % PARTS], b[(t / PARTS + t) % PARTS], acc[to], 0, 0, 0);
+                }
+                if (lane == 0) __hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (half == (h & 1)) {   // producer of half-slab h + 4
+                    spins = 0;
+                    while (__hip_atomic_load(&cnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * (h - 1)) {
+                        if (++spins > (1 << 22)) { cnt[3] = 1; break; }
+                    }
+                    asm volatile("" ::: "memory");
+                    const char *g = reinterpret_cast<const char *>(src) + lane * 16 + (size_t)(h & 63) * PARTS * 8192;
+                    char *dst = reinterpret_cast<char *>(lds) + PARTS * 8192 * ((h + 4) % 6);
+#pragma unroll
+                    for (int q = 0; q < PARTS * 2; ++q)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + ((wave & 3) * PARTS * 2 + q) * 1024),
+                                                         (__attribute__((address_space(3))) void *)(dst + ((wave & 3) * PARTS * 2 + q) * 1024), 16, 0, 0);
+                } else if (h) {          // my pieces of half-slab h + 3 were issued a half-slab ago
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(&cnt[half], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            continue;
         }
         if (MODE >= 1 && it) {
             if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -145,6 +250,11 @@ __global__ __launch_bounds__(512) void kb(float *out, long long *cyc, int iters,
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    if (MODE >= 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (cnt[3]) s = __builtin_nanf("");   // a bounded spin ran out
+    }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
@@ -156,7 +266,7 @@ void runb(const char *name) {
     hipMalloc(&cyc, 8 * 256 * 8);
     hipMalloc(&src, 32 * PARTS * 16384 + 65536);
     hipMemset(src, 0, 32 * PARTS * 16384 + 65536);
-    const int iters = 20000, lds_bytes = 3 * PARTS * 16384;
+    const int iters = 20000, lds_bytes = 3 * PARTS * 16384 + 16;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kb<MODE, PARTS, PRODUCTS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -169,8 +279,10 @@ void runb(const char *name) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     const double tflops = 256.0 * 8 * iters * 16.0 * PRODUCTS * 16384.0 / (ms * 1e-3) / 1e12;
-    printf("bf16 16x16x32, %d parts / %d products%s, %-40s wall %.3f ms = %.0f TFLOP/s of products (%.3f of 2500)\n", PARTS, PRODUCTS,
-           SPLIT ? " + VALU split" : "", name, ms, tflops, tflops / 2500.0);
+    float probe = 0.f;
+    hipMemcpy(&probe, out, 4, hipMemcpyDeviceToHost);
+    printf("bf16 16x16x32, %d parts / %d products%s, %-40s wall %.3f ms = %.0f TFLOP/s of products (%.3f of 2500)%s\n", PARTS, PRODUCTS,
+           SPLIT ? " + VALU split" : "", name, ms, tflops, tflops / 2500.0, probe != probe ? "  [SPIN LIMIT HIT]" : "");
     hipFree(out);
     hipFree(cyc);
     hipFree(src);
@@ -430,6 +542,14 @@ int main() {
     runb<2, 2, 3>("+ 32 KiB LDS-DMA refill per slab (halves alternate)");
     runb<2, 3, 6, true>("+ 48 KiB LDS-DMA refill per slab (halves alternate)");
     runb<2, 2, 3, true>("+ 32 KiB LDS-DMA refill per slab (halves alternate)");
+    runb<4, 3, 6>("+ 48 KiB refill, half-slab counters, halves de-phased");
+    runb<4, 2, 3>("+ 32 KiB refill, half-slab counters, halves de-phased");
+    runb<4, 3, 6, true>("+ 48 KiB refill, half-slab counters, halves de-phased");
+    runb<4, 2, 3, true>("+ 32 KiB refill, half-slab counters, halves de-phased");
+    runb<3, 3, 6>("+ 48 KiB refill, counters instead of the barrier");
+    runb<3, 2, 3>("+ 32 KiB refill, counters instead of the barrier");
+    runb<3, 3, 6, true>("+ 48 KiB refill, counters instead of the barrier");
+    runb<3, 2, 3, true>("+ 32 KiB refill, counters instead of the barrier");
     runc<0, 3, 6, false>("MFMA + one ds_read_b128 per 2 products");
     runc<1, 3, 6, false>("+ barrier per slab");
     runc<2, 3, 6, false>("+ 48 KiB LDS-DMA refill per slab (all 4 waves)");
