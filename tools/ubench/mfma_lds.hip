@@ -2,7 +2,9 @@
 // two ds_read_b128 of the next tile pair per 8 MFMAs), with and without the LDS reads, 1 or 2 waves per SIMD.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_lds.hip -o /tmp/mfma_lds && /tmp/mfma_lds
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
+#include <string.h>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // 0: MFMA only; 1: + 2 ds_read_b128 per 8 MFMAs (operands used); 2: ds_reads issued but MFMA operands constant;
@@ -81,6 +83,35 @@ __global__ __launch_bounds__(512) void k(float *out, long long *cyc, int iters, 
 // PRODUCTS products per output tile, 16 tiles per k-block = one slab of PARTS x 16 KiB per period.
 // MODE 0: MFMA + LDS reads; 1: + barrier per slab; 2: + the slab refill by LDS-DMA, issued by alternating halves (as shipped)
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4c __attribute__((ext_vector_type(4)));
+#ifdef SPLIT_DOT2
+// -DSPLIT_DOT2: the residual v - bf16(v) as ONE v_dot2c_f32_bf16 per value (acc = v; acc += pack.lo * -1 + pack.hi * 0) instead of
+// shift / mask + subtract; the parts are the same bits (the residual is exactly representable either way)
+typedef __bf16 bf2u __attribute__((ext_vector_type(2)));
+typedef float f2u __attribute__((ext_vector_type(2)));
+typedef unsigned u4u __attribute__((ext_vector_type(4)));
+template <int PARTS>
+__device__ inline void split_parts(const float (&v)[8], bf8 (&b)[PARTS]) {
+    unsigned c_lo = 0x0000bf80u, c_hi = 0xbf800000u;   // (-1, 0) and (0, -1) as bf16 pairs, kept out of the inline-constant encodings
+    asm volatile("" : "+s"(c_lo), "+s"(c_hi));
+    u4u w[PARTS];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float r0 = v[2 * i], r1 = v[2 * i + 1];
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) {
+            const bf2u pk = __builtin_convertvector(f2u{r0, r1}, bf2u);
+            w[p][i] = __builtin_bit_cast(unsigned, pk);
+            if (p + 1 < PARTS) {
+                r0 = __builtin_amdgcn_fdot2_f32_bf16(pk, __builtin_bit_cast(bf2u, c_lo), r0, false);
+                r1 = __builtin_amdgcn_fdot2_f32_bf16(pk, __builtin_bit_cast(bf2u, c_hi), r1, false);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PARTS; ++p) b[p] = __builtin_bit_cast(bf8, w[p]);
+}
+#else
 template <int PARTS>
 __device__ inline void split_parts(const float (&v)[8], bf8 (&b)[PARTS]) {
 #pragma unroll
@@ -92,6 +123,18 @@ __device__ inline void split_parts(const float (&v)[8], bf8 (&b)[PARTS]) {
             b[p][e] = h;
             r -= (float)h;
         }
+    }
+}
+#endif
+// the split of 512 values, for comparing the two forms bit by bit (main: `mfma_lds split-check`)
+__global__ void split_check_kernel(const float *in, unsigned *out) {
+    float v[8];
+    for (int e = 0; e < 8; ++e) v[e] = in[threadIdx.x * 8 + e];
+    bf8 b[3];
+    split_parts<3>(v, b);
+    for (int p = 0; p < 3; ++p) {
+        const u4c w = __builtin_bit_cast(u4c, b[p]);
+        for (int i = 0; i < 4; ++i) out[(threadIdx.x * 3 + p) * 4 + i] = w[i];
     }
 }
 template <int MODE, int PARTS, int PRODUCTS, bool SPLIT = false>
@@ -516,7 +559,52 @@ void run(const char *name, int threads) {
     hipFree(out);
     hipFree(cyc);
 }
-int main() {
+static unsigned host_bf16_rne(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static int split_check() {
+    const int n = 64 * 8;
+    float h[n];
+    unsigned seed = 12345u;
+    for (int i = 0; i < n; ++i) {
+        seed = seed * 1664525u + 1013904223u;
+        const float m = (float)((seed >> 8) & 0xffffff) / 16777216.0f * 2.0f - 1.0f;
+        const int e = (int)((seed >> 3) % 40) - 30;
+        h[i] = i < 8 ? (i & 1 ? -0.0f : 0.0f) : ldexpf(m, e);
+    }
+    float *din;
+    unsigned *dout, ho[64 * 12];
+    hipMalloc(&din, sizeof(h));
+    hipMalloc(&dout, sizeof(ho));
+    hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(split_check_kernel, dim3(1), dim3(64), 0, 0, din, dout);
+    hipMemcpy(ho, dout, sizeof(ho), hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int t = 0; t < 64; ++t)
+        for (int e = 0; e < 8; ++e) {
+            float r = h[t * 8 + e];
+            for (int p = 0; p < 3; ++p) {
+                const unsigned want = host_bf16_rne(r);
+                const unsigned got = (ho[(t * 3 + p) * 4 + e / 2] >> (16 * (e & 1))) & 0xffffu;
+                if (want != got && bad++ < 8) printf("value %d part %d: want %04x got %04x (v = %a)\n", t * 8 + e, p, want, got, h[t * 8 + e]);
+                unsigned wb = want << 16;
+                float wf;
+                memcpy(&wf, &wb, 4);
+                r -= wf;
+            }
+        }
+    printf("split check: %d of %d parts differ from round-to-nearest-even bf16 of the exact residuals\n", bad, n * 3);
+    return bad != 0;
+}
+int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "split-check")) return split_check();
+    if (argc > 1 && !strcmp(argv[1], "split")) {
+        runb<2, 3, 6, true>("+ 48 KiB LDS-DMA refill per slab (halves alternate)");
+        runb<2, 2, 3, true>("+ 32 KiB LDS-DMA refill per slab (halves alternate)");
+        return 0;
+    }
     run<0>("MFMA only", 256);
     run<0>("MFMA only", 512);
     run<1>("+ 2 ds_read_b128 per 8 MFMAs (used)", 256);
