@@ -516,8 +516,8 @@ typedef struct snerf_nerf_batch {
  * The batch is walked in chunks of rays_per_chunk rays (<= 0 or > B: one chunk): d loss / d rgb of a ray does not depend on
  * the other rays, so forward and backward run chunk by chunk and the parameter gradients are summed in chunk order - the
  * saved activations (21 KB per ray-sample) are sized by the chunk, nothing is recomputed.
- * aux_stream (nullable): a second stream of the caller's.  Chunks of at most 16 384 fine samples (the README's 64-ray
- * batches) leave most of the chip idle in every kernel; there the coarse net's backward - independent of the fine net's, the
+ * aux_stream (nullable): a second stream of the caller's.  Chunks of at most 262 144 samples (1024 rays of 64 + 192; the
+ * README's 64-ray batches) leave CUs idle in some kernel; there the coarse net's backward - independent of the fine net's, the
  * hierarchical samples being detached (utils.py:260) - is enqueued on aux_stream beside it (forked from and joined back into
  * `stream` with events, also under graph capture).  NULL: everything on `stream`.  Same results either way.
  * workspace: snerf_nerf_train_workspace_bytes(...) bytes, 256-byte aligned. */

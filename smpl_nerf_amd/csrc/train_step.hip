@@ -297,11 +297,16 @@ struct TrainWs {
     int64_t total;
 };
 
-// Chunks of at most this many fine samples leave most of the chip idle in every kernel (a 64-ray batch is 96 workgroups of
-// 128 samples): there the backward of the coarse net - independent of the fine net's: the hierarchical samples are
-// detached, utils.py:260 - runs beside it on the caller's auxiliary stream.  A pure size rule, so that the workspace size
-// does not depend on the device.
-constexpr int64_t CONCURRENT_MAX_FINE_SAMPLES = 64 * 256;
+// Chunks of at most this many samples (coarse + fine of a ray) leave much of the chip idle in some kernel (a 64-ray batch is 96
+// workgroups of 128 samples; at 800 rays the coarse passes fill 1.56 rounds of the CUs): there the backward of the coarse
+// net - independent of the fine net's: the hierarchical samples are detached, utils.py:260 - runs beside it on the caller's
+// auxiliary stream.  A pure size rule, so that the workspace size does not depend on the device.  Measured (tools/ab/
+// conc_ab.sh, ms per step without / with): 128 rays 1.49 / 1.33, 256: 2.42 / 2.29-2.35, 512: 4.00 / 3.96, 800: 6.60 / 6.45-6.48,
+// 1024: 7.80 / 7.83, 2048: 15.29 / 15.21 - above 1024 rays nothing is left to fill, and the second d Y buffer would cost memory.
+#ifndef SNERF_CONCURRENT_MAX_FINE_SAMPLES
+#define SNERF_CONCURRENT_MAX_FINE_SAMPLES (1024 * 256)
+#endif
+constexpr int64_t CONCURRENT_MAX_FINE_SAMPLES = SNERF_CONCURRENT_MAX_FINE_SAMPLES;
 
 // fork / join events of the concurrent backward: one pair per host thread and device (include/smplnerf.h "State")
 static int fork_join_events(hipEvent_t &fork, hipEvent_t &join) {

@@ -316,7 +316,7 @@ def test_one_call_step_in_a_hip_graph(dev):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
 def test_small_batches_run_the_coarse_backward_on_the_auxiliary_stream(dev, prec, monkeypatch):
-    """Chunks of <= 16 384 fine samples (the README's 64-ray batches): the coarse net's backward runs beside the fine net's on
+    """Chunks of <= 262 144 samples (up to 1024 rays; the README's 64-ray batches): the coarse net's backward runs beside the fine net's on
     the trainer's second stream (include/smplnerf.h: aux_stream) - the same kernels on their own scratch buffers, so the
     trajectory equals the single-stream one bit for bit."""
     lib = _lib.load()
