@@ -604,6 +604,44 @@ def test_smpl_nerf_one_call_step_equals_the_autograd_step(dev, prec, cfg):
         assert float((pa - pb).abs().max()) <= (3e-4 if prec == "fp32" else 2.5e-3)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("wb", [0, 1])
+def test_smpl_nerf_one_call_step_vs_the_reference_gradients(dev, wb, prec):
+    """The same batch, nets and loss as tests/golden/make_golden_smpl_grad.py (g11: the reference's SmplNerfPipeline
+    under autograd, models/smpl_nerf_pipeline.py:38-98) - here through snerf_smpl_nerf_train_step_f32 directly: loss, the digests
+    of all three nets' gradients, every element of the warp net's gradient."""
+    from smpl_nerf_amd.nets import WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import PipelineArgs, SmplNerfPipeline
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    g6, g = load_golden("g6_smpl_nerf_pipeline.npz"), load_golden("g11_smpl_grads.npz")
+    pc, pf = syn.make_scene_nets(101)
+    mc, mf = _net(dev, pc, prec), _net(dev, pf, prec)
+    mw = WarpFieldNet(8, 256, 60, 40)
+    mw.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_warp_field_params(103, out_scale=0.3).items()})
+    mw.precision = prec
+    mw = mw.to(dev).train()
+    pipe = SmplNerfPipeline(mc, mf, mw, PipelineArgs(white_background=wb), PositionalEncoder(10, 0), PositionalEncoder(4, 0),
+                            PositionalEncoder(10, 0))
+    tr = DataParallelTrainer(pipe, [mc, mf, mw], lr=1e-7)
+    assert tr._one_call_state() is not None
+    data = syn.frame_batch(128, 128, phi=5.0, theta=15.0, seed=9)
+    d = [T(a[g6["sub"]], dev) for a in data[:4]] + [T(g6["goal_pose"], dev), T(data[4][g6["sub"]], dev)]
+    loss = float(tr.step(d))
+    loose = 1.0
+    close([loss], g[f"loss_wb{wb}"], 1e-5 * loose, 1e-7)
+    for name, m in (("coarse", mc), ("fine", mf), ("warp", mw)):
+        for k, p in m.named_parameters():
+            ref = g[f"grad_wb{wb}/{name}.{k}"]
+            assert p.grad is not None, (name, k)
+            scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(p.numel()), 1e-12)
+            close(R.digest(p.grad), ref, 2e-2 * loose, 1e-2 * loose * scale)
+    for k, p in mw.named_parameters():
+        ref = g[f"warpfull_wb{wb}/{k}"].astype(np.float64)
+        got = p.grad.cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(got - ref) <= 1e-2 * loose * np.linalg.norm(ref), (k, np.linalg.norm(got - ref) / np.linalg.norm(ref))
+
+
 def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
     """After one-call steps the pipeline's inference (forward and the single-call render) reads the streams the step kept
     current - the warp net's are re-packed inside the call - and equals a pipeline built from the new parameters."""
