@@ -544,7 +544,9 @@ int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *pac
  * compositing backward (coarse: also into x' - o) -> net backward INTO its inputs (snerf_mlp_bwd_inputs_*: packed_t_* are the
  * input_grad = 1 streams) -> d warp = d x' + d (x' - o) -> warp backward; the warp net's gradient is the sum over its two
  * evaluations.  pose_enc [B, pose_dim] = the encoded two joint angles (:28-30).  The warp net trains in fp32 in every
- * precision mode.  grad_warp: snerf_warp_param_floats floats.  Ray chunks, workspace, loss, rgb as in snerf_nerf_train_grads_f32.
+ * precision mode.  In the split-precision modes the nets' input gradients exist for encoders of at most 4 position / 2
+ * direction k-blocks of 16 slots (the defaults: 10 / 4 frequencies without identity columns); wider ones are SNERF_E_BADARG
+ * here - run those nets with precision 0 (the Python trainer takes its autograd path, which routes that dgrad to fp32).  grad_warp: snerf_warp_param_floats floats.  Ray chunks, workspace, loss, rgb as in snerf_nerf_train_grads_f32.
  * The step variant runs snerf_adam_step_f32 and then re-packs the warp net's two streams (packed_warp from snerf_warp_pack_f32,
  * packed_t_warp from snerf_warp_pack_t_f32) from its parameters at params + warp_param_offset. */
 int64_t snerf_smpl_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine,

@@ -16,6 +16,26 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+__global__ __launch_bounds__(256) void debug_lds_poison_kernel(int floats) {
+    extern __shared__ float lds_all[];
+    for (int i = threadIdx.x; i < floats; i += 256) lds_all[i] = __int_as_float(0x7fc00000 | (i & 0xffff));
+    __syncthreads();
+    // keep the workgroup resident for a moment so that the launch spreads over every CU (one 160 KB workgroup per CU at a time)
+    if (lds_all[(threadIdx.x * 7) % floats] == 0.f) __builtin_amdgcn_s_sleep(1);
+    for (int k = 0; k < 64; ++k) __builtin_amdgcn_s_sleep(127);
+}
+void debug_poison_lds() {
+    static const int on = [] { const char *e = getenv("SNERF_DEBUG_POISON_LDS"); return e ? atoi(e) : 0; }();
+    if (!on) return;
+    constexpr int BYTES = 160 * 1024;
+    static std::atomic<int> raised{0};
+    if (!raised.load() &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(debug_lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES) == hipSuccess)
+        raised.store(1);
+    hipLaunchKernelGGL(debug_lds_poison_kernel, dim3(2048), dim3(256), BYTES, 0, BYTES / 4);
+    (void)hipGetLastError();
+}
+
 int device_cu_count(const char *what) {
     static std::atomic<int> cus[MAX_DEVICES];
     int dev = 0;

@@ -431,7 +431,10 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
         }
     };
     // stages [0, nfast) lie inside the chunk with all their samples
-    const int nfast = (!active || n_ti == TI) ? (int)((end - begin) / WL_STAGE) : 0;
+    // (begin < end: a chunk behind the end of the buffer has no stages at all.  r04: without this the difference went
+    // negative and the masked loop ran stages -k .. -1 - a = 0 against whatever the LDS held, which is 0 unless that is a NaN:
+    // the first process on a freshly booted GPU got NaN gradients, everybody else the right ones.  tools/ab/nan_hunt.py)
+    const int nfast = (begin < end && (!active || n_ti == TI)) ? (int)((end - begin) / WL_STAGE) : 0;
     if (want_bias) run(std::false_type{}, std::true_type{}, 0, nfast);
     else run(std::false_type{}, std::false_type{}, 0, nfast);
     run(std::true_type{}, std::true_type{}, nfast, nstages);
@@ -846,6 +849,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     W.xstat = reinterpret_cast<const int *>(act + (int64_t)L.act_rows * n * 16);   // (f16x3 wide jobs only)
     W.ystat = reinterpret_cast<const int *>(dy + (int64_t)L.dy_rows * n * 16);
     W.chunk = (((n + G - 1) / G) + 15) / 16 * 16;
+    G = (int)((n + W.chunk - 1) / W.chunk);   // rounding the chunk up to whole k-steps may leave trailing chunks empty: not launched
     W.fold = fold;
     static LdsRaised raised;   // per device
     int rc;
@@ -860,6 +864,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     }
     if (const int jobs = wgrad_direct_jobs(P, W.fold)) {
         W.chunk = (((n + G_narrow - 1) / G_narrow) + 15) / 16 * 16;
+        G_narrow = (int)((n + W.chunk - 1) / W.chunk);
         // f16x3 step: the narrow jobs with two fp16 parts as well (SNERF_WGRAD_NARROW_F16=0: fp32 MFMA)
         const bool narrow_f16 = tuning().wgrad_narrow_f16;
         if (wide_nsplit == SNERF_SPLIT_F16X3 && narrow_f16) {

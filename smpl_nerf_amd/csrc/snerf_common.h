@@ -15,9 +15,14 @@ namespace snerf {
 char *err_buf();
 int fail(int code, const char *fmt, ...);
 
+// SNERF_DEBUG_POISON_LDS=1 (debug aid, tests/test_gpu_round4.py): after every checked launch a kernel on the NULL stream
+// fills the LDS of every CU with NaNs, so that a kernel that reads LDS it has not written meets NaNs instead of whatever
+// the previous kernel left there (the first process on a freshly booted GPU meets arbitrary bits).
+void debug_poison_lds();
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SNERF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    debug_poison_lds();
     return SNERF_OK;
 }
 

@@ -338,6 +338,12 @@ class DataParallelTrainer:
                 return None
             if not (mc.use_directional_input and mf.use_directional_input):
                 return None
+            # the split-precision dgrad returns input gradients for the default-sized encoders only (identity columns or more
+            # frequencies need the fp32 variant and its own transposed stream): nets.py routes that per call, the one call does not
+            from .nets import _split_code, _wide_encoders
+            for m in (mc, mf):
+                if _split_code(m, 0) and _wide_encoders(m.desc_for_encoders(pipe.position_encoder, pipe.direction_encoder)):
+                    return None
             mine.append(mw)
         if len(self.models) != len(mine) or {id(m) for m in self.models} != {id(m) for m in mine}:
             return None

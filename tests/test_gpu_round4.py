@@ -642,6 +642,72 @@ def test_smpl_nerf_one_call_step_vs_the_reference_gradients(dev, wb, prec):
         assert np.linalg.norm(got - ref) <= 1e-2 * loose * np.linalg.norm(ref), (k, np.linalg.norm(got - ref) / np.linalg.norm(ref))
 
 
+def test_smpl_nerf_split_precision_with_identity_columns_takes_the_autograd_path(dev):
+    """Found by tools/ab/fuzz_train.py: the split-precision dgrad returns input gradients for the default-sized encoders only, so
+    a bf16x6 / f16x3 SmplNerfPipeline whose position encoder has identity columns (5 k-blocks) trains through the autograd path
+    (nets.py routes that one dgrad to the fp32 kernels) instead of failing in the one call; fp32 nets keep the one call."""
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import PipelineArgs, SmplNerfPipeline
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    batch = _smpl_batch(dev, 40)
+    for prec, one_call in (("f16x3", False), ("fp32", True)):
+        torch.manual_seed(5)
+        pe, de = PositionalEncoder(10, 1), PositionalEncoder(4, 0)
+        nets = [RenderRayNet(4, 256, 3 * pe.output_dim, 3 * de.output_dim, skips=[2]).to(dev).train() for _ in range(2)]
+        mw = WarpFieldNet(3, 128, 3 * pe.output_dim, 40).to(dev).train()
+        for m in nets:
+            m.precision = prec
+        pipe = SmplNerfPipeline(nets[0], nets[1], mw, PipelineArgs(), pe, de, PositionalEncoder(10, 0))
+        tr = DataParallelTrainer(pipe, nets + [mw], lr=1e-4)
+        assert (tr._one_call_state() is not None) == one_call
+        losses = [float(tr.step(batch)) for _ in range(2)]
+        assert all(np.isfinite(losses))
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mw.parameters())
+
+
+def _poison_the_allocator(dev):
+    """Every cached block the caching allocator hands out next holds NaNs."""
+    blocks = [torch.full((2 ** k,), float("nan"), device=dev) for k in (28, 26, 24)]
+    blocks += [torch.full((2 ** k,), float("nan"), device=dev) for k in range(6, 24) for _ in range(4)]
+    del blocks
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("kind", ["nerf", "smpl_nerf"])
+@pytest.mark.parametrize("one_call", [None, False])
+def test_training_steps_read_nothing_they_did_not_write(dev, kind, prec, one_call):
+    """Workspaces, activation / d Y buffers, partials and gradient buffers come from torch's caching allocator uninitialised; with
+    every cached block full of NaNs beforehand (and again before each step) three steps of either form of the step still give
+    finite losses and gradients - for the default encoders and for encoders with identity columns (a fifth k-block)."""
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs, SmplNerfPipeline
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    for ident in (0, 1):
+        torch.manual_seed(5)
+        _poison_the_allocator(dev)
+        pe, de = PositionalEncoder(10, ident), PositionalEncoder(4, 0)
+        nets = [RenderRayNet(4, 256, 3 * pe.output_dim, 3 * de.output_dim, skips=[2]).to(dev).train() for _ in range(2)]
+        for m in nets:
+            m.precision = prec
+        if kind == "smpl_nerf":
+            mw = WarpFieldNet(3, 128, 3 * pe.output_dim, 40).to(dev).train()
+            pipe = SmplNerfPipeline(nets[0], nets[1], mw, PipelineArgs(), pe, de, PositionalEncoder(10, 0))
+            models, batch = nets + [mw], _smpl_batch(dev, 40)
+        else:
+            pipe = NerfPipeline(nets[0], nets[1], PipelineArgs(), pe, de)
+            models, batch = nets, _batch(dev, 40, stride=61)
+        tr = DataParallelTrainer(pipe, models, lr=1e-4, one_call=one_call)
+        for _ in range(3):
+            _poison_the_allocator(dev)
+            assert np.isfinite(float(tr.step(batch)))
+        for m in models:
+            for k, p in m.named_parameters():
+                assert p.grad is not None and bool(torch.isfinite(p.grad).all()), (kind, prec, ident, k)
+        del tr, pipe, models, nets
+
+
 def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
     """After one-call steps the pipeline's inference (forward and the single-call render) reads the streams the step kept
     current - the warp net's are re-packed inside the call - and equals a pipeline built from the new parameters."""

@@ -1,0 +1,95 @@
+"""Randomised sweep of the one-call training step against the autograd form: random depth / width / skips / B / Nc / Nf / chunk /
+white background / use_directional_input / additional inputs, first-step loss and gradients compared.  Not part of the suite
+(minutes on the GPU); prints one line per case and a summary.
+
+    python tools/ab/fuzz_train.py [cases] [seed]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from smpl_nerf_amd.nets import RenderRayNet
+from smpl_nerf_amd.ops import PositionalEncoder
+from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+from smpl_nerf_amd.trainer import DataParallelTrainer
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(seed)
+bad = 0
+for case in range(cases):
+    depth = int(rng.integers(1, 13))
+    width = int(rng.choice([16, 33, 64, 100, 128, 200, 256, 256, 256]))
+    prec = str(rng.choice(["fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
+    kind = str(rng.choice(["nerf", "nerf", "smpl_nerf"]))
+    skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
+    B = int(rng.choice([1, 2, 5, 31, 64, 100, 129, 257, 600]))
+    Nc = int(rng.choice([3, 4, 7, 16, 33, 64, 100]))   # the sampler needs 3 coarse samples (one interior weight)
+    Nf = int(rng.choice([0, 1, 5, 64, 128, 150]))
+    chunk = int(rng.choice([0, 1, 17, 64, 200]))
+    wb = int(rng.integers(0, 2))
+    use_dir = int(rng.integers(0, 4) != 0)
+    Lp, Ld = int(rng.choice([10, 10, 6, 3])), int(rng.choice([4, 4, 2]))
+    idp, idd = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    run_fine = 1 if Nf > 0 else 0
+    o = rng.normal(0, 0.2, (B, 3)).astype(np.float32) + np.array([0, 0, 2.4], np.float32)
+    d = rng.normal(0, 0.3, (B, 3)).astype(np.float32) + np.array([0, 0, -1], np.float32)
+    z = np.sort(rng.uniform(1.0, 4.0, (B, Nc)).astype(np.float32), -1)
+    samples = (o[:, None, :] + d[:, None, :] * z[:, :, None]).astype(np.float32)
+    gt = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    batch = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (samples, o, d, z, gt)]
+    if kind == "smpl_nerf":
+        use_dir = 1
+        from smpl_nerf_amd import synthetic as syn
+        pose = torch.from_numpy(syn.human_poses()[np.arange(B) % 10].astype(np.float32)).to(dev)
+        batch = batch[:4] + [pose, batch[4]]
+    desc = f"{kind} {prec} depth {depth} width {width} skips {skips} B {B} Nc {Nc} Nf {Nf} chunk {chunk} wb {wb} dir {use_dir} L {Lp}/{Ld} id {idp}/{idd}"
+    try:
+        runs = []
+        for one_call in (None, False):
+            torch.manual_seed(1000 + case)
+            pe, de = PositionalEncoder(Lp, idp), PositionalEncoder(Ld, idd)
+            nets = []
+            for _ in range(2):
+                m = RenderRayNet(depth, width, 3 * pe.output_dim, 3 * de.output_dim, skips=list(skips),
+                                 use_directional_input=use_dir).to(dev).train()
+                with torch.no_grad():
+                    m.sigma_out_layer.weight.mul_(20.0)
+                m.precision = prec
+                nets.append(m)
+            args = PipelineArgs(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine)
+            if kind == "smpl_nerf":
+                from smpl_nerf_amd.nets import WarpFieldNet
+                from smpl_nerf_amd.pipelines import SmplNerfPipeline
+                wdepth, wwidth = int(2 + case % 7), int([256, 128, 100][case % 3])
+                mw = WarpFieldNet(wdepth, wwidth, 3 * pe.output_dim, 2 * 20).to(dev).train()
+                with torch.no_grad():
+                    for q in mw.parameters():
+                        q.mul_(0.3)
+                mw.precision = prec if wwidth == 256 else "fp32"
+                pipe = SmplNerfPipeline(nets[0], nets[1], mw, args, pe, de, PositionalEncoder(10, 0))
+                nets = nets + [mw]
+            else:
+                pipe = NerfPipeline(nets[0], nets[1], args, pe, de)
+            tr = DataParallelTrainer(pipe, nets, lr=1e-3, one_call=one_call)
+            tr.rays_per_chunk = chunk
+            loss = float(tr.step(batch))
+            assert (tr._one_call_state() is not None) == (one_call is None), "path"
+            runs.append((loss, [None if p.grad is None else p.grad.clone() for p in tr.params]))
+        (la, ga), (lb, gb) = runs
+        err = 0.0
+        for a, b in zip(ga, gb):
+            if b is None or a is None:
+                continue
+            err = max(err, float((a - b).norm()) / (float(b.norm()) + 1e-12)) if float(b.norm()) > 1e-9 else err
+        ok = abs(la - lb) <= 2e-6 * abs(lb) + 1e-8 and err <= (2e-4 if prec == "fp32" else 2e-3) and np.isfinite(la)
+        bad += not ok
+        print(("ok  " if ok else "BAD ") + desc + f": loss {la:.6f} / {lb:.6f}, max rel grad err {err:.2e}", flush=True)
+    except Exception as e:   # noqa: BLE001 - the sweep reports and goes on
+        bad += 1
+        print("EXC " + desc + f": {type(e).__name__}: {str(e)[:300]}", flush=True)
+print(f"{cases - bad} of {cases} cases agree")
