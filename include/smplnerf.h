@@ -48,6 +48,9 @@
  *       SNERF_WGRAD_F16_SPLIT_PER_WAVE=1  f16x3 wide weight-gradient GEMMs: every wave converts its own operands
  *       SNERF_WGRAD_FOLD=0                fp32 steps: every narrow weight-gradient pair as its own job (default: the sigma head
  *                                         and the direction-encoding columns ride with directional_input's wide job)
+ *       SNERF_DEBUG_POISON_LDS=1          debugging aid, not a tuning knob: every checked launch is followed by a kernel on the
+ *                                         NULL stream that fills the LDS of every CU with NaNs (a kernel that reads LDS it has not
+ *                                         written then computes with NaNs instead of its predecessor's leftovers); slow
  *     (smpl_nerf_amd/ reads two more, on the Python side only: SNERF_PRECISION = default arithmetic of new nets;
  *     SNERF_TRAIN_ACT_GB = activation budget of a training forward call on the autograd path, default a quarter of the
  *     device memory free at the call; SNERF_TRAIN_CHUNK_RAYS = rays per chunk of the one-call training step, default 2048.)

@@ -708,6 +708,26 @@ def test_training_steps_read_nothing_they_did_not_write(dev, kind, prec, one_cal
         del tr, pipe, models, nets
 
 
+@pytest.mark.parametrize("tool", ["lds_poison_sweep.py", "nan_hunt.py"])
+def test_no_kernel_depends_on_what_the_lds_held_before(dev, tool):
+    """SNERF_DEBUG_POISON_LDS=1 (csrc/snerf_common.h): every checked launch is followed by a kernel that fills the LDS of every CU
+    with NaNs, so a kernel that reads LDS it has not written computes with NaNs instead of the previous kernel's leftovers.
+    The regression behind it: the wide fp32 wgrad multiplied zeros with stale LDS for chunks behind the end of the buffer -
+    exact unless the LDS held NaNs, which it does for the first process on a freshly booted GPU (tools/ab/nan_hunt.py found
+    it).  Forward + backward over sample counts with ragged / empty trailing chunks in three precisions, and three training
+    steps of every pipeline / precision / form of the step, in a process of their own (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNERF_DEBUG_POISON_LDS="1", SNERF_TRAIN_AUX_STREAM="0")   # the poison kernel runs on the NULL stream
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab", tool)] + (["1"] if tool == "nan_hunt.py" else []),
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last in ("bad: 0", "non-finite gradient tensors seen: 0"), r.stdout[-3000:]
+
+
 def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
     """After one-call steps the pipeline's inference (forward and the single-call render) reads the streams the step kept
     current - the warp net's are re-packed inside the call - and equals a pipeline built from the new parameters."""
