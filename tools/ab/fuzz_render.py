@@ -1,0 +1,77 @@
+"""Randomised sweep of the inference path against the CPU torch restatement of the reference (oracle/torch_cpu_path.py): random
+depth / width / skips / encoders / use_directional_input / ray and sample counts / white background / precision, NerfPipeline
+under no_grad (the pipeline's kernels) and the single-call render.  rgb of the coarse pass must agree closely on every ray; the
+fine pass on all but a handful (a sample index may flip where a cdf value sits on a u).  Not part of the suite.
+
+    python tools/ab/fuzz_render.py [cases] [seed]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from oracle import torch_cpu_path as TP
+from smpl_nerf_amd.nets import RenderRayNet
+from smpl_nerf_amd.ops import PositionalEncoder
+from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(seed)
+bad = 0
+for case in range(cases):
+    depth = int(rng.integers(1, 13))
+    width = int(rng.choice([16, 33, 64, 100, 128, 200, 256, 256, 256]))
+    prec = str(rng.choice(["fp32", "fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
+    skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
+    B = int(rng.choice([1, 2, 5, 31, 64, 100, 129, 257, 600, 2049]))
+    Nc = int(rng.choice([3, 4, 7, 16, 33, 64, 100]))
+    Nf = int(rng.choice([0, 1, 5, 64, 128, 150]))
+    wb = int(rng.integers(0, 2))
+    use_dir = int(rng.integers(0, 4) != 0)
+    Lp, Ld = int(rng.choice([10, 10, 6, 3, 12])), int(rng.choice([4, 4, 2, 6]))
+    idp, idd = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    run_fine = 1 if Nf > 0 else 0
+    o = rng.normal(0, 0.2, (B, 3)).astype(np.float32) + np.array([0, 0, 2.4], np.float32)
+    d = rng.normal(0, 0.3, (B, 3)).astype(np.float32) + np.array([0, 0, -1], np.float32)
+    z = np.sort(rng.uniform(1.0, 4.0, (B, Nc)).astype(np.float32), -1)
+    samples = (o[:, None, :] + d[:, None, :] * z[:, :, None]).astype(np.float32)
+    gt = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    cpu = [torch.from_numpy(np.ascontiguousarray(a)) for a in (samples, o, d, z, gt)]
+    batch = [t.to(dev) for t in cpu]
+    desc = f"{prec} depth {depth} width {width} skips {skips} B {B} Nc {Nc} Nf {Nf} wb {wb} dir {use_dir} L {Lp}/{Ld} id {idp}/{idd}"
+    try:
+        torch.manual_seed(2000 + case)
+        pe, de = PositionalEncoder(Lp, idp), PositionalEncoder(Ld, idd)
+        nets = []
+        for _ in range(2):
+            m = RenderRayNet(depth, width, 3 * pe.output_dim, 3 * de.output_dim, skips=list(skips), use_directional_input=use_dir)
+            with torch.no_grad():
+                m.sigma_out_layer.weight.mul_(20.0)
+            m.precision = prec
+            nets.append(m)
+        P = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in nets]
+        nets = [m.to(dev).eval() for m in nets]
+        args = PipelineArgs(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine, strict_cumsum=1)
+        pipe = NerfPipeline(nets[0], nets[1], args, pe, de)
+        with torch.no_grad():
+            out = pipe(batch)
+            ref = TP.nerf_pipeline_forward(P[0], P[1], TP.Args(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine),
+                                           TP.PositionalEncoder(Lp, idp), TP.PositionalEncoder(Ld, idd), cpu,
+                                           net_kw=dict(n_layers=depth, positions_dim=3 * pe.output_dim, directions_dim=3 * de.output_dim,
+                                                       skips=tuple(skips), use_directional_input=use_dir))
+        tol = 2e-5 if prec == "fp32" else 3e-4
+        ec = (out[0].cpu() - ref[0]).abs().max(-1).values
+        ef = (out[1].cpu() - ref[1]).abs().max(-1).values
+        flips = int((ef > 10 * tol).sum())
+        ok = float(ec.max()) <= tol and flips <= max(1, B // 100) and bool(torch.isfinite(out[1]).all())
+        bad += not ok
+        print(("ok  " if ok else "BAD ") + desc + f": coarse max {float(ec.max()):.2e}, fine median {float(ef.median()):.2e} max {float(ef.max()):.2e} ({flips} rays off)",
+              flush=True)
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print("EXC " + desc + f": {type(e).__name__}: {str(e)[:300]}", flush=True)
+print(f"{cases - bad} of {cases} cases agree")
