@@ -96,9 +96,37 @@ for case in range(cases):
             if b is None or a is None:
                 continue
             err = max(err, float((a - b).norm()) / (float(b.norm()) + 1e-12)) if float(b.norm()) > 1e-9 else err
+        et, lt = -1.0, 0.0
+        if kind == "nerf" and prec == "fp32" and os.environ.get("FUZZ_VS_TORCH", "1") != "0":
+            # the same step on the CPU torch restatement of the reference (oracle/torch_cpu_path.py), from the same initial weights
+            from oracle import torch_cpu_path as TP
+            torch.manual_seed(1000 + case)
+            P = []
+            for _ in range(2):
+                m = RenderRayNet(depth, width, 3 * pe.output_dim, 3 * de.output_dim, add_dim, skips=list(skips), use_directional_input=use_dir)
+                with torch.no_grad():
+                    m.sigma_out_layer.weight.mul_(20.0)
+                P.append({k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()})
+            cb = [t.cpu() for t in batch]
+            out = TP.nerf_pipeline_forward(P[0], P[1], TP.Args(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine),
+                                           TP.PositionalEncoder(Lp, idp), TP.PositionalEncoder(Ld, idd), cb,
+                                           net_kw=dict(n_layers=depth, positions_dim=3 * pe.output_dim, directions_dim=3 * de.output_dim,
+                                                       skips=tuple(skips), use_directional_input=use_dir))
+            lt = torch.nn.functional.mse_loss(out[0], cb[-1]) + torch.nn.functional.mse_loss(out[1], cb[-1])
+            lt.backward()
+            ref = [v.grad for p_ in P for v in p_.values()]
+            top = max(float(r.norm()) for r in ref if r is not None) if any(r is not None for r in ref) else 0.0
+            et = 0.0
+            for a, r in zip(ga, ref):
+                if r is None or a is None:
+                    continue
+                et = max(et, float((a.cpu() - r).norm()) / max(float(r.norm()), 1e-3 * top, 1e-12))
+            lt = float(lt.detach())
+            if not (abs(la - lt) <= 3e-4 * abs(lt) + 1e-7 and et <= 2e-2):     # (a fine sample may sit on the other side of a bin edge)
+                err = max(err, 1.0)      # flag the case
         ok = abs(la - lb) <= 2e-6 * abs(lb) + 1e-8 and err <= (2e-4 if prec == "fp32" else 2e-3) and np.isfinite(la)
         bad += not ok
-        print(("ok  " if ok else "BAD ") + desc + f": loss {la:.6f} / {lb:.6f}, max rel grad err {err:.2e}", flush=True)
+        print(("ok  " if ok else "BAD ") + desc + f": loss {la:.6f} / {lb:.6f}, max rel grad err {err:.2e}" + (f", vs CPU torch: loss {lt:.6f}, grads {et:.2e}" if et >= 0 else ""), flush=True)
     except Exception as e:   # noqa: BLE001 - the sweep reports and goes on
         bad += 1
         print("EXC " + desc + f": {type(e).__name__}: {str(e)[:300]}", flush=True)
