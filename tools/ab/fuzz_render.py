@@ -9,13 +9,19 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import functools
+
 import numpy as np
 import torch
 
 from oracle import torch_cpu_path as TP
 from smpl_nerf_amd.nets import RenderRayNet
 from smpl_nerf_amd.ops import PositionalEncoder
-from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+from smpl_nerf_amd import synthetic as syn
+from smpl_nerf_amd.nets import WarpFieldNet
+from smpl_nerf_amd.pipelines import (AppendSmplParamsPipeline, AppendToNerfPipeline, NerfPipeline, PipelineArgs, SmplNerfPipeline)
+
+_tp_net = TP.render_ray_net
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -23,6 +29,9 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(seed)
 bad = 0
 for case in range(cases):
+    kind = str(rng.choice(["nerf", "nerf", "smpl_nerf", "append_smpl_params", "append_smpl_params_encoded", "append_to_nerf"]))
+    if os.environ.get("FUZZ_KIND"):
+        kind = os.environ["FUZZ_KIND"]
     depth = int(rng.integers(1, 13))
     width = int(rng.choice([16, 33, 64, 100, 128, 200, 256, 256, 256]))
     prec = str(rng.choice(["fp32", "fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
@@ -41,14 +50,18 @@ for case in range(cases):
     samples = (o[:, None, :] + d[:, None, :] * z[:, :, None]).astype(np.float32)
     gt = rng.uniform(0, 1, (B, 3)).astype(np.float32)
     cpu = [torch.from_numpy(np.ascontiguousarray(a)) for a in (samples, o, d, z, gt)]
+    add_dim = {"append_smpl_params": 69, "append_smpl_params_encoded": 69 * 20, "append_to_nerf": 2}.get(kind, 0)
+    if kind != "nerf":
+        use_dir = 1 if kind == "smpl_nerf" else use_dir
+        cpu = cpu[:4] + [torch.from_numpy(syn.human_poses()[np.arange(B) % 10].astype(np.float32)), cpu[4]]
     batch = [t.to(dev) for t in cpu]
-    desc = f"{prec} depth {depth} width {width} skips {skips} B {B} Nc {Nc} Nf {Nf} wb {wb} dir {use_dir} L {Lp}/{Ld} id {idp}/{idd}"
+    desc = f"{kind} {prec} depth {depth} width {width} skips {skips} B {B} Nc {Nc} Nf {Nf} wb {wb} dir {use_dir} L {Lp}/{Ld} id {idp}/{idd}"
     try:
         torch.manual_seed(2000 + case)
         pe, de = PositionalEncoder(Lp, idp), PositionalEncoder(Ld, idd)
         nets = []
         for _ in range(2):
-            m = RenderRayNet(depth, width, 3 * pe.output_dim, 3 * de.output_dim, skips=list(skips), use_directional_input=use_dir)
+            m = RenderRayNet(depth, width, 3 * pe.output_dim, 3 * de.output_dim, add_dim, skips=list(skips), use_directional_input=use_dir)
             with torch.no_grad():
                 m.sigma_out_layer.weight.mul_(20.0)
             m.precision = prec
@@ -56,14 +69,34 @@ for case in range(cases):
         P = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in nets]
         nets = [m.to(dev).eval() for m in nets]
         args = PipelineArgs(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine, strict_cumsum=1)
-        pipe = NerfPipeline(nets[0], nets[1], args, pe, de)
+        net_kw = dict(n_layers=depth, positions_dim=3 * pe.output_dim, directions_dim=3 * de.output_dim, skips=tuple(skips),
+                      use_directional_input=use_dir)
+        targs = TP.Args(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine)
+        tpe, tde, the = TP.PositionalEncoder(Lp, idp), TP.PositionalEncoder(Ld, idd), TP.PositionalEncoder(10, 0)
+        TP.render_ray_net = functools.partial(_tp_net, **net_kw)          # the pipelines below call it with their own defaults
+        if kind == "nerf":
+            pipe = NerfPipeline(nets[0], nets[1], args, pe, de)
+            ref_fn = lambda: TP.nerf_pipeline_forward(P[0], P[1], targs, tpe, tde, cpu)
+        elif kind == "smpl_nerf":
+            mw = WarpFieldNet(int(2 + case % 7), int([256, 128, 100][case % 3]), 3 * pe.output_dim, 40)
+            with torch.no_grad():
+                for q in mw.parameters():
+                    q.mul_(0.3)
+            Pw = {k: v.detach().clone() for k, v in mw.state_dict().items()}
+            mw.precision = prec if mw.width == 256 else "fp32"
+            pipe = SmplNerfPipeline(nets[0], nets[1], mw.to(dev).eval(), args, pe, de, PositionalEncoder(10, 0))
+            ref_fn = lambda: TP.smpl_nerf_pipeline_forward(P[0], P[1], Pw, targs, tpe, tde, the, cpu)
+        else:
+            args.human_pose_encoding = targs.human_pose_encoding = 1 if kind.endswith("encoded") else 0
+            cls = AppendToNerfPipeline if kind == "append_to_nerf" else AppendSmplParamsPipeline
+            pipe = cls(nets[0], nets[1], args, pe, de, PositionalEncoder(10, 0))
+            ref_fn = lambda: TP.append_pose_pipeline_forward(P[0], P[1], targs, tpe, tde, the, cpu, two_joints=kind == "append_to_nerf")
         with torch.no_grad():
             out = pipe(batch)
-            ref = TP.nerf_pipeline_forward(P[0], P[1], TP.Args(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine),
-                                           TP.PositionalEncoder(Lp, idp), TP.PositionalEncoder(Ld, idd), cpu,
-                                           net_kw=dict(n_layers=depth, positions_dim=3 * pe.output_dim, directions_dim=3 * de.output_dim,
-                                                       skips=tuple(skips), use_directional_input=use_dir))
+            ref = ref_fn()
         tol = 2e-5 if prec == "fp32" else 3e-4
+        if kind == "smpl_nerf":
+            tol *= 100          # the warp net's round-off passes through two 2^9 encoders before it reaches a colour
         ec = (out[0].cpu() - ref[0]).abs().max(-1).values
         ef = (out[1].cpu() - ref[1]).abs().max(-1).values
         flips = int((ef > 10 * tol).sum())
