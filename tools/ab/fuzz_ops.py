@@ -1,0 +1,107 @@
+"""Randomised sweep of the stand-alone operators against the numpy oracle: the hierarchical sampler (bit-exact: indices, samples,
+merged depths, points), compositing (1e-6), searchsorted (bit-exact, every dtype of the reference's dispatch, both sides, row
+broadcast), positional encoding.  Random row counts / lengths / weight patterns (zeros, spikes, ties).  Not part of the suite.
+
+    python tools/ab/fuzz_ops.py [cases] [seed]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from oracle import nerf_oracle as O
+from smpl_nerf_amd import ops
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(seed)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+N = lambda t: t.detach().cpu().numpy()
+bad = 0
+
+
+def weights_pattern(B, n):
+    kind = rng.integers(0, 5)
+    w = rng.uniform(0, 1, (B, n)).astype(np.float32)
+    if kind == 1:
+        w[:] = 0                                         # nothing hit: uniform pdf from the 1e-5 floor
+    elif kind == 2:
+        w[:] = 0
+        w[np.arange(B), rng.integers(0, n, B)] = 1      # one spike
+    elif kind == 3:
+        w = (w > 0.7).astype(np.float32)                # plateaus: ties in the cdf
+    elif kind == 4:
+        w *= np.float32(1e-6)                           # below the floor
+    return w
+
+
+for case in range(cases):
+    what = ["sampler", "composite", "searchsorted", "posenc"][case % 4]
+    try:
+        if what == "sampler":
+            B, Nc, Nf = int(rng.choice([1, 3, 64, 257, 1000])), int(rng.choice([3, 4, 5, 17, 64, 100, 255, 1024])), int(rng.choice([1, 2, 7, 64, 128, 333, 1024]))
+            z = np.sort(rng.uniform(1, 4, (B, Nc)).astype(np.float32), -1)
+            if rng.integers(0, 3) == 0:
+                z[:, Nc // 2] = z[:, Nc // 2 - 1]                  # a repeated depth
+            w = weights_pattern(B, Nc)
+            o = rng.normal(0, 1, (B, 3)).astype(np.float32)
+            d = rng.normal(0, 1, (B, 3)).astype(np.float32)
+            u = N(ops.uniform_u(Nf, dev))
+            r = ops.hierarchical_samples(T(o), T(d), T(z), T(w), Nf, want_inds=True, want_samples=True)
+            zmid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+            det = O.sample_pdf_detail(zmid, w[:, 1:-1], Nf, u=u)
+            zf, pts = O.fine_sampling(o, d, z, w, Nf, u=u)
+            ok = np.array_equal(N(r["inds"]), det["inds"]) and np.array_equal(N(r["z_samples"]), det["samples"]) and \
+                np.array_equal(N(r["z_fine"]), zf) and np.array_equal(N(r["pts"]), pts)
+            desc = f"sampler B {B} Nc {Nc} Nf {Nf}"
+        elif what == "composite":
+            B, n = int(rng.choice([1, 5, 64, 300, 1025])), int(rng.choice([1, 2, 3, 64, 100, 192, 256, 500]))
+            raw = rng.normal(0, 2, (B, n, 4)).astype(np.float32)
+            raw[..., 3] *= rng.choice([1, 20, 200])
+            z = np.sort(rng.uniform(1, 4, (B, n)).astype(np.float32), -1)
+            d = rng.normal(0, 1, (B, 3)).astype(np.float32)
+            wb = int(rng.integers(0, 2))
+            noise = rng.normal(0, 1, (B, n)).astype(np.float32) if rng.integers(0, 2) else None
+            rgb, wt, al = ops.composite(T(raw), T(z), T(d), bool(wb), noise=None if noise is None else T(noise), want_weights=True, want_alpha=True)
+            er, ew, ea = O.raw2outputs(raw, z, np.broadcast_to(d[:, None, :], (B, n, 3)), wb, noise)
+            err = max(np.abs(N(rgb) - er).max(), np.abs(N(wt) - ew).max(), np.abs(N(al) - ea).max())
+            ok = err <= 2e-6
+            desc = f"composite B {B} N {n} wb {wb} noise {noise is not None}: max err {err:.2e}"
+        elif what == "searchsorted":
+            dt = rng.choice([np.float32, np.float64, np.int32, np.int64, np.int16, np.int8, np.uint8])
+            ra, rv = int(rng.choice([1, 1, 7, 100])), int(rng.choice([1, 7, 100]))
+            if ra != rv and ra != 1 and rv != 1:
+                rv = ra
+            na, nv = int(rng.choice([1, 2, 33, 128, 1000, 5000])), int(rng.choice([1, 5, 64, 129, 2000]))
+            if np.issubdtype(dt, np.floating):
+                a = np.sort(rng.normal(0, 1, (ra, na)).astype(dt), -1)
+                v = rng.normal(0, 1.2, (rv, nv)).astype(dt)
+                v[:, ::3] = rng.choice(a[0], size=v[:, ::3].shape)         # exact hits: the two sides differ there
+            else:
+                hi = min(50, np.iinfo(dt).max)
+                a = np.sort(rng.integers(0, hi, (ra, na)).astype(dt), -1)      # many ties
+                v = rng.integers(0, hi, (rv, nv)).astype(dt)
+            side = str(rng.choice(["left", "right"]))
+            out = ops.searchsorted(T(a), T(v), side=side)
+            ok = np.array_equal(N(out), O.searchsorted(a, v, side))
+            desc = f"searchsorted {np.dtype(dt).name} a {a.shape} v {v.shape} {side}"
+        else:
+            L, ident = int(rng.choice([0, 1, 4, 10, 16])), int(rng.integers(0, 2))
+            if L == 0 and not ident:
+                ident = 1
+            shape = tuple(int(v) for v in rng.choice([1, 3, 17, 200], int(rng.integers(1, 3)))) + (int(rng.choice([2, 3])),)
+            x = rng.normal(0, 1.5, shape).astype(np.float32)
+            got = N(ops.PositionalEncoder(L, ident).encode(T(x)))
+            ref = O.PositionalEncoder(L, ident).encode(x)
+            err = float(np.abs(got - ref).max()) if got.shape == ref.shape else float("inf")
+            ok = err <= 1e-6
+            desc = f"posenc L {L} ident {ident} x {shape}: max err {err:.2e}"
+        bad += not ok
+        print(("ok  " if ok else "BAD ") + desc, flush=True)
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print(f"EXC {what}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+print(f"{cases - bad} of {cases} cases agree")
