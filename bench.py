@@ -413,6 +413,15 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
                 batches[-1][4].requires_grad_(True)           # d loss / d goal_pose (69 per-ray columns)
         next_batch = lambda i: batches[i % 4]
     losses = []
+    # warm-up: a quarter of a second of render passes, then two steps - after the CPU legs of this script the GPU has
+    # been idle for tens of seconds and comes back at idle clocks; a 64-ray step (0.9 ms) measured right then ran at 8 ms
+    # (profiles/r04: seen in one of two runs of the smpl_nerf line before this)
+    # (inference passes, not steps: their number may differ between ranks, and they contain no collective)
+    t_warm = time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t_warm < 0.25:
+            pipe([t[:4096].contiguous() for t in data] if data[0].shape[0] > 4096 else data)
+            torch.cuda.synchronize()
     for i in range(2):
         losses.append(tr.step(next_batch(i)))
     barrier(dev)

@@ -55,6 +55,8 @@ for case in range(cases):
         use_dir = 1 if kind == "smpl_nerf" else use_dir
         cpu = cpu[:4] + [torch.from_numpy(syn.human_poses()[np.arange(B) % 10].astype(np.float32)), cpu[4]]
     batch = [t.to(dev) for t in cpu]
+    if os.environ.get("FUZZ_MISALIGN"):      # every input 4 bytes off a 16-byte boundary (a view one float into its storage)
+        batch = [torch.cat([t.new_zeros(1), t.reshape(-1)])[1:].view(t.shape) for t in batch]
     desc = f"{kind} {prec} depth {depth} width {width} skips {skips} B {B} Nc {Nc} Nf {Nf} wb {wb} dir {use_dir} L {Lp}/{Ld} id {idp}/{idd}"
     try:
         torch.manual_seed(2000 + case)

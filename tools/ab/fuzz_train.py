@@ -50,6 +50,8 @@ for case in range(cases):
         from smpl_nerf_amd import synthetic as syn
         pose = torch.from_numpy(syn.human_poses()[np.arange(B) % 10].astype(np.float32)).to(dev)
         batch = batch[:4] + [pose, batch[4]]
+    if os.environ.get("FUZZ_MISALIGN"):      # every input 4 bytes off a 16-byte boundary (a view one float into its storage)
+        batch = [torch.cat([t.new_zeros(1), t.reshape(-1)])[1:].view(t.shape) for t in batch]
     desc = f"{kind} {prec} depth {depth} width {width} skips {skips} B {B} Nc {Nc} Nf {Nf} chunk {chunk} wb {wb} dir {use_dir} L {Lp}/{Ld} id {idp}/{idd}"
     try:
         runs = []
@@ -96,7 +98,7 @@ for case in range(cases):
             if b is None or a is None:
                 continue
             err = max(err, float((a - b).norm()) / (float(b.norm()) + 1e-12)) if float(b.norm()) > 1e-9 else err
-        et, lt = -1.0, 0.0
+        et, et_fine, lt = -1.0, 0.0, 0.0
         if kind == "nerf" and prec == "fp32" and os.environ.get("FUZZ_VS_TORCH", "1") != "0":
             # the same step on the CPU torch restatement of the reference (oracle/torch_cpu_path.py), from the same initial weights
             from oracle import torch_cpu_path as TP
@@ -116,17 +118,25 @@ for case in range(cases):
             lt.backward()
             ref = [v.grad for p_ in P for v in p_.values()]
             top = max(float(r.norm()) for r in ref if r is not None) if any(r is not None for r in ref) else 0.0
-            et = 0.0
-            for a, r in zip(ga, ref):
+            # the coarse net's gradient does not depend on the fine samples (they are detached): tight.  The fine net's does, and
+            # the reference's sampler is discontinuous where a bin's mass sits at its 1e-5 threshold (utils.py:224: nearly opaque
+            # rays) - there a last-bit difference of the coarse weights moves samples: loose.
+            et = et_fine = 0.0
+            n_coarse = len(P[0])
+            for i, (a, r) in enumerate(zip(ga, ref)):
                 if r is None or a is None:
                     continue
-                et = max(et, float((a.cpu() - r).norm()) / max(float(r.norm()), 1e-3 * top, 1e-12))
+                e = float((a.cpu() - r).norm()) / max(float(r.norm()), 1e-3 * top, 1e-12)
+                if i < n_coarse:
+                    et = max(et, e)
+                else:
+                    et_fine = max(et_fine, e)
             lt = float(lt.detach())
-            if not (abs(la - lt) <= 3e-4 * abs(lt) + 1e-7 and et <= 2e-2):     # (a fine sample may sit on the other side of a bin edge)
+            if not (abs(la - lt) <= 2e-3 * abs(lt) + 1e-7 and et <= 1e-2 and et_fine <= 2e-1):
                 err = max(err, 1.0)      # flag the case
         ok = abs(la - lb) <= 2e-6 * abs(lb) + 1e-8 and err <= (2e-4 if prec == "fp32" else 2e-3) and np.isfinite(la)
         bad += not ok
-        print(("ok  " if ok else "BAD ") + desc + f": loss {la:.6f} / {lb:.6f}, max rel grad err {err:.2e}" + (f", vs CPU torch: loss {lt:.6f}, grads {et:.2e}" if et >= 0 else ""), flush=True)
+        print(("ok  " if ok else "BAD ") + desc + f": loss {la:.6f} / {lb:.6f}, max rel grad err {err:.2e}" + (f", vs CPU torch: loss {lt:.6f}, grads coarse {et:.2e} fine {et_fine:.2e}" if et >= 0 else ""), flush=True)
     except Exception as e:   # noqa: BLE001 - the sweep reports and goes on
         bad += 1
         print("EXC " + desc + f": {type(e).__name__}: {str(e)[:300]}", flush=True)
