@@ -323,7 +323,7 @@ static int fork_join_events(hipEvent_t &fork, hipEvent_t &join) {
     return SNERF_OK;
 }
 
-static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t chunk, int Nc, int Nf, TrainWs &w) {
+static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t chunk, int Nc, int Nf, TrainWs &w, bool two_streams = true) {
     const int64_t N = Nc + Nf;
     int64_t act_c = 0, dy_c = 0, gp_c = 0, act_f = 0, dy_f = 0, gp_f = 0;
     int rc;
@@ -348,7 +348,7 @@ static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t 
     w.dy = take(dy_c > dy_f ? dy_c : dy_f);
     w.gpart = take(gp_c > gp_f ? gp_c : gp_f);
     w.loss_acc = take(4);
-    w.concurrent = Nf > 0 && chunk * N <= CONCURRENT_MAX_FINE_SAMPLES;
+    w.concurrent = two_streams && Nf > 0 && chunk * N <= CONCURRENT_MAX_FINE_SAMPLES;
     w.d_raw2 = take(w.concurrent ? chunk * Nc * 4 : 0);
     w.dy2 = take(w.concurrent ? dy_c : 0);
     w.gpart2 = take(w.concurrent ? gp_c : 0);
@@ -508,7 +508,8 @@ struct SmplTrainWs {
 static int smpl_train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, const snerf_warp_desc *dw, int64_t chunk, int Nc, int Nf,
                          SmplTrainWs &w) {
     int rc;
-    if ((rc = train_ws(dc, df, chunk, Nc, Nf, w.base))) return rc;
+    // (the two backward passes of this step run in sequence - both end in the warp net's gradient: no second scratch set)
+    if ((rc = train_ws(dc, df, chunk, Nc, Nf, w.base, false))) return rc;
     const int64_t N = Nc + Nf, nmax = chunk * (Nf > 0 ? N : Nc);
     int64_t act_c = 0, act_f = 0, dy_c = 0, dy_f = 0, gp_c = 0, gp_f = 0;
     if ((rc = snerf_warp_train_sizes(dw, chunk * Nc, &act_c, &dy_c, nullptr, &gp_c))) return rc;
