@@ -1,0 +1,98 @@
+"""Randomised sweep of the input-gradient contractions (snerf_dy_contract_f32 behind nets._extra_input_grads): d loss / d goal_pose of
+the pose-conditioned pipelines (per-ray additional inputs, raw or encoded, 2 / 69 / 1380 columns) and d loss / d encoded rows
+of RenderRayNet.forward, against CPU torch autograd on the restatement of the reference.  Random depth / width / skips / ray
+and sample counts.  Not part of the suite.
+
+    python tools/ab/fuzz_input_grads.py [cases] [seed]
+"""
+import functools
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from oracle import torch_cpu_path as TP
+from smpl_nerf_amd import synthetic as syn
+from smpl_nerf_amd.nets import RenderRayNet
+from smpl_nerf_amd.ops import PositionalEncoder
+from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline, PipelineArgs
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(seed)
+_tp_net = TP.render_ray_net
+bad = 0
+for case in range(cases):
+    kind = str(rng.choice(["append_smpl_params", "append_smpl_params_encoded", "append_to_nerf", "encoded_rows"]))
+    depth = int(rng.integers(1, 11))
+    width = int(rng.choice([33, 64, 128, 200, 256, 256]))
+    skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
+    prec = str(rng.choice(["fp32", "fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
+    B = int(rng.choice([1, 3, 31, 64, 100, 257, 700]))
+    Nc = int(rng.choice([3, 7, 16, 64, 100]))
+    Nf = int(rng.choice([0, 5, 64, 128]))
+    desc = f"{kind} {prec} depth {depth} width {width} skips {skips} B {B} Nc {Nc} Nf {Nf}"
+    try:
+        torch.manual_seed(3000 + case)
+        if kind == "encoded_rows":
+            n = B * Nc
+            net = RenderRayNet(depth, width, 60, 24, skips=list(skips))
+            with torch.no_grad():
+                net.sigma_out_layer.weight.mul_(5.0)
+            P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            net.precision = prec
+            net = net.to(dev).train()
+            rows = torch.randn(n, 84)
+            xg = rows.clone().to(dev).requires_grad_(True)
+            xc = rows.clone().requires_grad_(True)
+            wgt = torch.randn(n, 4)
+            (net(xg) * wgt.to(dev)).sum().backward()
+            (TP.render_ray_net(P, xc, n_layers=depth, skips=tuple(skips)) * wgt).sum().backward()
+            got, ref = xg.grad.cpu(), xc.grad
+        else:
+            add_dim = {"append_smpl_params": 69, "append_smpl_params_encoded": 69 * 20, "append_to_nerf": 2}[kind]
+            o = rng.normal(0, 0.2, (B, 3)).astype(np.float32) + np.array([0, 0, 2.4], np.float32)
+            d = rng.normal(0, 0.3, (B, 3)).astype(np.float32) + np.array([0, 0, -1], np.float32)
+            z = np.sort(rng.uniform(1.0, 4.0, (B, Nc)).astype(np.float32), -1)
+            samples = (o[:, None, :] + d[:, None, :] * z[:, :, None]).astype(np.float32)
+            gt = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+            pose = syn.human_poses()[np.arange(B) % 10].astype(np.float32) * np.float32(0.5)
+            cpu = [torch.from_numpy(np.ascontiguousarray(a)) for a in (samples, o, d, z, pose, gt)]
+            nets = []
+            for _ in range(2):
+                m = RenderRayNet(depth, width, 60, 24, add_dim, skips=list(skips))
+                with torch.no_grad():
+                    m.sigma_out_layer.weight.mul_(20.0)
+                nets.append(m)
+            P = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in nets]
+            for m in nets:
+                m.precision = prec
+            nets = [m.to(dev).train() for m in nets]
+            enc = kind.endswith("encoded")
+            args = PipelineArgs(number_fine_samples=max(Nf, 1), run_fine=1 if Nf else 0, human_pose_encoding=1 if enc else 0)
+            cls = AppendToNerfPipeline if kind == "append_to_nerf" else AppendSmplParamsPipeline
+            pipe = cls(nets[0], nets[1], args, PositionalEncoder(10, 0), PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+            batch = [t.to(dev) for t in cpu]
+            batch[4] = batch[4].clone().requires_grad_(True)
+            out = pipe(batch)
+            (torch.nn.functional.mse_loss(out[0], batch[-1]) + torch.nn.functional.mse_loss(out[1], batch[-1])).backward()
+            got = batch[4].grad.cpu()
+            cpu[4] = cpu[4].clone().requires_grad_(True)
+            TP.render_ray_net = functools.partial(_tp_net, n_layers=depth, skips=tuple(skips))
+            targs = TP.Args(number_fine_samples=max(Nf, 1), run_fine=1 if Nf else 0, human_pose_encoding=1 if enc else 0)
+            ro = TP.append_pose_pipeline_forward(P[0], P[1], targs, TP.PositionalEncoder(10, 0), TP.PositionalEncoder(4, 0),
+                                                 TP.PositionalEncoder(10, 0), cpu, two_joints=kind == "append_to_nerf")
+            (torch.nn.functional.mse_loss(ro[0], cpu[-1]) + torch.nn.functional.mse_loss(ro[1], cpu[-1])).backward()
+            ref = cpu[4].grad
+        err = float((got - ref).norm()) / max(float(ref.norm()), 1e-12)
+        tol = (2e-4 if kind == "encoded_rows" else 5e-2) * (1 if prec == "fp32" else 5)
+        ok = bool(torch.isfinite(got).all()) and (err <= tol or float(ref.norm()) < 1e-9)
+        bad += not ok
+        print(("ok  " if ok else "BAD ") + desc + f": rel err {err:.2e} (|ref| {float(ref.norm()):.2e})", flush=True)
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print("EXC " + desc + f": {type(e).__name__}: {str(e)[:300]}", flush=True)
+print(f"{cases - bad} of {cases} cases agree")
