@@ -153,7 +153,8 @@ int snerf_composite_bwd_all_f32(const float *raw, const float *z, const float *d
  * (passed in so that the caller controls its bits, see oracle/nerf_oracle.py:linspace01),
  * o, d [B, 3].  Outputs (each nullable): inds int64 [B, Nf] (searchsorted(cdf,u,'right')),
  * z_samples [B, Nf], z_fine [B, Nc+Nf] ascending, pts [B, Nc+Nf, 3] = o + d * z_fine.
- * 3 <= Nc <= 1024, 1 <= Nf <= 1024. */
+ * 3 <= Nc <= 1024, 1 <= Nf <= 1024 (with fewer than three coarse samples there is no interior weight: the reference's own
+ * sample_pdf builds an empty cdf and its gather raises, utils.py:200-221). */
 int snerf_sample_pdf_f32(const float *z, const float *weights, const float *u,
                          const float *o, const float *d, int64_t B, int Nc, int Nf,
                          int64_t *inds, float *z_samples, float *z_fine, float *pts,

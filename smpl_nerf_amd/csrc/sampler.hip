@@ -346,7 +346,8 @@ static int snerf::launch_sample_pdf(bool direct, const float *z, const float *we
                                     float *z_samples, float *z_fine, float *pts, snerf_stream_t stream) {
     if (B < 0) return fail(SNERF_E_BADARG, "sample_pdf: negative B");
     if (Nc < 3 || Nc > 1024 || Nf < 1 || Nf > 1024)
-        return fail(SNERF_E_BADARG, "sample_pdf: need 3 <= Nc <= 1024 and 1 <= Nf <= 1024 (got %d, %d)", Nc, Nf);
+        return fail(SNERF_E_BADARG, "sample_pdf: need 3 <= Nc <= 1024 and 1 <= Nf <= 1024 (got %d, %d; below three coarse samples the "
+                                    "reference's own sample_pdf raises: empty cdf)", Nc, Nf);
     if (B == 0) return SNERF_OK;
     if (!z || !weights || !u) return fail(SNERF_E_BADARG, "sample_pdf: z/weights/u is null");
     if (pts && (!o || !d)) return fail(SNERF_E_BADARG, "sample_pdf: pts requested but o/d is null");
