@@ -39,7 +39,7 @@ def weights_pattern(B, n):
 
 
 for case in range(cases):
-    what = ["sampler", "composite", "searchsorted", "posenc"][case % 4]
+    what = ["sampler", "composite", "searchsorted", "posenc", "raygen"][case % 5]
     try:
         if what == "sampler":
             B, Nc, Nf = int(rng.choice([1, 3, 64, 257, 1000])), int(rng.choice([3, 4, 5, 17, 64, 100, 255, 1024])), int(rng.choice([1, 2, 7, 64, 128, 333, 1024]))
@@ -88,6 +88,38 @@ for case in range(cases):
             out = ops.searchsorted(T(a), T(v), side=side)
             ok = np.array_equal(N(out), O.searchsorted(a, v, side))
             desc = f"searchsorted {np.dtype(dt).name} a {a.shape} v {v.shape} {side}"
+        elif what == "raygen":
+            from smpl_nerf_amd.raygen import RayGenerator
+            H, W = int(rng.choice([1, 7, 64, 128, 200])), int(rng.choice([1, 9, 64, 128, 333]))
+            F, Nc = int(rng.choice([1, 3, 10])), int(rng.choice([1, 2, 3, 64, 100]))
+            near, far = float(rng.uniform(0.1, 2.0)), float(rng.uniform(2.5, 8.0))
+            ang = float(rng.uniform(0.3, 2.0))
+            poses = np.tile(np.eye(4), (F, 1, 1))
+            for f in range(F):
+                q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+                poses[f, :3, :3] = q
+                poses[f, :3, 3] = rng.normal(0, 2, 3)
+            gen = RayGenerator(poses, H, W, ang, near, far, Nc, dev)
+            Bq = int(rng.choice([1, 5, 257, 4096]))
+            idx = rng.integers(0, F * H * W, Bq)
+            jit = rng.uniform(0, 1, Bq)
+            got = [N(t) for t in gen.batch(T(idx.astype(np.int64)), T(jit))[:4]]
+            focal = .5 * W / np.tan(.5 * ang)
+            exp = [[], [], [], []]
+            fr, pix = idx // (H * W), idx % (H * W)
+            for f in np.unique(fr):
+                o_all, d_all = O.get_rays(H, W, focal, poses[f])
+                sel = fr == f
+                r = O.coarse_sampling(o_all.reshape(-1, 3)[pix[sel]], d_all.reshape(-1, 3)[pix[sel]], near, far, Nc, jit[sel])
+                for k in range(4):
+                    exp[k].append((np.nonzero(sel)[0], r[k]))
+            ok = True
+            for k in range(4):
+                full = np.empty_like(got[k])
+                for where, val in exp[k]:
+                    full[where] = val
+                ok = ok and np.array_equal(full, got[k])
+            desc = f"raygen {F} frames {H}x{W} Nc {Nc} B {Bq}"
         else:
             L, ident = int(rng.choice([0, 1, 4, 10, 16])), int(rng.integers(0, 2))
             if L == 0 and not ident:
