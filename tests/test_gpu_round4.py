@@ -743,6 +743,20 @@ def test_randomised_sweeps_agree(dev, tool, count, seed):
     assert r.stdout.strip().splitlines()[-1] == f"{count} of {count} cases agree", r.stdout[-3000:]
 
 
+def test_gradients_do_not_depend_on_how_the_samples_are_chunked(dev):
+    """tools/ab/chunk_consistency.py: the parameter gradients of one backward over n samples equal the sum of two backwards over
+    an uneven split of them, for n from 5 to a million (every chunk-count rule and small-call kernel variant of the wgrad /
+    dgrad launchers), in the three precisions and for the warp net."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab", "chunk_consistency.py")], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == "bad: 0", r.stdout[-3000:]
+
+
 def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
     """After one-call steps the pipeline's inference (forward and the single-call render) reads the streams the step kept
     current - the warp net's are re-packed inside the call - and equals a pipeline built from the new parameters."""
