@@ -36,6 +36,19 @@ for prec in ("fp32", "bf16x6", "f16x3"):
         ok = worst <= tol and all(bool(torch.isfinite(f).all()) for f in full)
         bad += not ok
         print(("ok  " if ok else "BAD ") + f"{prec} n {n}: worst relative difference {worst:.2e}", flush=True)
+# inference: a sample's output does not depend on how many samples the call has or where in the call it sits - bit for bit
+# (persistent workgroups, wrap-around of the weight stream, ragged last tiles, the small-call tile size)
+for prec in ("fp32", "bf16x6", "f16x3", "bf16x3"):
+    net = RenderRayNet(8, 256, 60, 24, skips=[4]).to(dev).eval()
+    net.precision = prec
+    x = torch.randn(300007, 84, device=dev)
+    with torch.no_grad():
+        full = net(x)
+        for n, h in ((37, 5), (4097, 129), (16385, 16000), (65537, 1), (300007, 131072)):
+            parts = torch.cat([net(x[:h].contiguous()), net(x[h:n].contiguous())])
+            ok = torch.equal(parts, full[:n])
+            bad += not ok
+            print(("ok  " if ok else "BAD ") + f"inference {prec} n {n} split at {h}: {'bit-identical' if ok else 'DIFFERS'}", flush=True)
 # the warp net (linear1 -> relu -> linear2 on [encoded position | encoded pose] rows): its own dgrad / wgrad chunking
 from smpl_nerf_amd.nets import WarpFieldNet
 for width in (256, 128, 100):
