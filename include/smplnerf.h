@@ -65,13 +65,14 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 104 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+#define SNERF_VERSION 105 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
                              snerf_composite_bwd_all_f32; composite forward accepts any N
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
                              folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
                              0.1.4: + the training step as one call (snerf_nerf_train_step_f32 / _grads_f32, snerf_adam_step_f32,
                              snerf_mlp_stream_slots), snerf_dy_contract_f32; the per-ray fold tables moved from stream-ordered allocations inside
-                             the library to caller workspaces (snerf_mlp_fwd_ws_f32, snerf_warp_fwd_ws_f32): the library allocates nothing */
+                             the library to caller workspaces (snerf_mlp_fwd_ws_f32, snerf_warp_fwd_ws_f32): the library allocates nothing
+                             0.1.5: + snerf_render_rays_add_f32 (the single-call render for nets with per-ray additional inputs) */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -427,6 +428,21 @@ int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_
                           const float *u, const float *noise_coarse, const float *noise_fine, int64_t B, int Nc,
                           int Nf, int white_background, void *workspace, float *rgb, float *rgb_fine,
                           float *samples_fine, float *densities_fine, snerf_stream_t stream);
+
+/* ---- 8(f)-4: the same for nets with per-ray additional inputs (models/append_smpl_params_pipeline.py:14-91,
+ * append_to_nerf_pipeline.py:14-90 - the paper's headline model) ------------------------------------------------------
+ * snerf_render_rays_f32 with additional [B, add_dim] = the pose row of each ray (raw or encoded, :29-37), read by both nets as
+ * their `add` input (descriptors with add_dim > 0, add_first as the pipeline has it).  In fp32 the rows are folded into one
+ * vector per ray and layer inside the call (snerf_mlp_fwd_ws_f32) - the fold table lives in the workspace:
+ * snerf_render_rays_add_workspace_bytes(...) bytes, 16-byte aligned. */
+int64_t snerf_render_rays_add_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B, int Nc,
+                                              int Nf);
+int snerf_render_rays_add_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const snerf_mlp_desc *desc_fine,
+                              const void *packed_fine, int precision, const float *ray_samples, const float *rays_o,
+                              const float *rays_d, const float *z_vals, const float *additional, const float *u,
+                              const float *noise_coarse, const float *noise_fine, int64_t B, int Nc, int Nf, int white_background,
+                              void *workspace, float *rgb, float *rgb_fine, float *samples_fine, float *densities_fine,
+                              snerf_stream_t stream);
 
 /* ---- a7: the whole SmplNerfPipeline.forward for inference in one call (models/smpl_nerf_pipeline.py:16-100) ------
  * snerf_render_rays_f32 with the warp stage in front of both nets: warp(samples) -> x' = x + warp, per-sample directions

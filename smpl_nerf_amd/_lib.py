@@ -113,6 +113,9 @@ SIGNATURES = {
     "snerf_render_rays_smpl_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "snerf_render_rays_smpl_f32": (c_int, [POINTER(MlpDesc), _P, POINTER(MlpDesc), _P, POINTER(WarpDesc), _P, c_int, _P, _P, _P, _P,
                                            _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "snerf_render_rays_add_workspace_bytes": (c_int64, [POINTER(MlpDesc), POINTER(MlpDesc), c_int64, c_int, c_int]),
+    "snerf_render_rays_add_f32": (c_int, [POINTER(MlpDesc), _P, POINTER(MlpDesc), _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int64,
+                                          c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "snerf_render_rays_f32": (c_int, [POINTER(MlpDesc), _P, POINTER(MlpDesc), _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64,
                                       c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "snerf_mlp_fold_workspace_bytes": (c_int64, [POINTER(MlpDesc), c_int64, c_int]),

@@ -24,11 +24,18 @@ static RenderWs render_ws(int64_t B, int Nc, int Nf) {
     return w;
 }
 
+// add: per-ray additional inputs [n / spr, add_dim] or null; fold_ws / fold_bytes: room for the per-ray fold of the fp32
+// kernel (snerf_mlp_fold_workspace_bytes; 0 bytes = the per-sample form)
 static int mlp(const snerf_mlp_desc *desc, const void *packed, int precision, const float *x, const float *dirs,
-               int64_t n, int spr, float *raw, snerf_stream_t stream) {
-    if (precision == 0)
-        return snerf_mlp_fwd_f32(desc, reinterpret_cast<const float *>(packed), x, dirs, 0, nullptr, n, spr, raw, stream);
-    return snerf_mlp_fwd_bf16_f32(desc, packed, precision, x, dirs, 0, nullptr, n, spr, raw, stream);
+               int64_t n, int spr, float *raw, snerf_stream_t stream, const float *add = nullptr, void *fold_ws = nullptr,
+               int64_t fold_bytes = 0) {
+    if (precision == 0) {
+        if (add && fold_bytes > 0)
+            return snerf_mlp_fwd_ws_f32(desc, reinterpret_cast<const float *>(packed), x, dirs, 0, add, n, spr, raw, fold_ws, fold_bytes,
+                                        stream);
+        return snerf_mlp_fwd_f32(desc, reinterpret_cast<const float *>(packed), x, dirs, 0, add, n, spr, raw, stream);
+    }
+    return snerf_mlp_fwd_bf16_f32(desc, packed, precision, x, dirs, 0, add, n, spr, raw, stream);
 }
 
 static int mlp_per_sample_dirs(const snerf_mlp_desc *desc, const void *packed, int precision, const float *x,
@@ -72,6 +79,22 @@ extern "C" int64_t snerf_render_rays_workspace_bytes(int64_t B, int Nc, int Nf) 
     return render_ws(B, Nc, Nf).total;
 }
 
+namespace snerf {
+static int render_rays_impl(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const snerf_mlp_desc *desc_fine,
+                            const void *packed_fine, int precision, const float *ray_samples, const float *rays_o,
+                            const float *rays_d, const float *z_vals, const float *additional, const float *u,
+                            const float *noise_coarse, const float *noise_fine, int64_t B, int Nc, int Nf, int white_background,
+                            void *workspace, float *rgb, float *rgb_fine, float *samples_fine, float *densities_fine,
+                            snerf_stream_t stream);
+// fold tables of the two passes of snerf_render_rays_add_f32 (they are not live at the same time: one region, the larger)
+static int64_t add_fold_bytes(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t B, int Nc, int Nf, int64_t &fc, int64_t &ff) {
+    fc = snerf_mlp_fold_workspace_bytes(dc, B * Nc, Nc);
+    ff = Nf > 0 ? snerf_mlp_fold_workspace_bytes(df, B * (Nc + Nf), Nc + Nf) : 0;
+    if (fc < 0 || ff < 0) return -1;
+    return fc > ff ? fc : ff;
+}
+}  // namespace snerf
+
 extern "C" int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
                                      const snerf_mlp_desc *desc_fine, const void *packed_fine, int precision,
                                      const float *ray_samples, const float *rays_o, const float *rays_d,
@@ -79,6 +102,48 @@ extern "C" int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const vo
                                      const float *noise_fine, int64_t B, int Nc, int Nf, int white_background,
                                      void *workspace, float *rgb, float *rgb_fine, float *samples_fine,
                                      float *densities_fine, snerf_stream_t stream) {
+    using namespace snerf;
+    if (desc_coarse && Nf >= 0 && ((desc_coarse->add_dim) || (Nf > 0 && desc_fine && desc_fine->add_dim)))
+        return fail(SNERF_E_BADARG, "render_rays: nets with additional inputs go through snerf_render_rays_add_f32");
+    return render_rays_impl(desc_coarse, packed_coarse, desc_fine, packed_fine, precision, ray_samples, rays_o, rays_d, z_vals, nullptr, u,
+                            noise_coarse, noise_fine, B, Nc, Nf, white_background, workspace, rgb, rgb_fine, samples_fine,
+                            densities_fine, stream);
+}
+
+extern "C" int64_t snerf_render_rays_add_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B,
+                                                         int Nc, int Nf) {
+    using namespace snerf;
+    if (!desc_coarse || (Nf > 0 && !desc_fine) || B < 0 || Nc < 1 || Nf < 0)
+        return fail(SNERF_E_BADARG, "render_rays_add_workspace_bytes: bad arguments");
+    int64_t fc, ff;
+    const int64_t fold = add_fold_bytes(desc_coarse, desc_fine, B, Nc, Nf, fc, ff);
+    if (fold < 0) return SNERF_E_BADARG;
+    return align16(render_ws(B, Nc, Nf).total) + align16(fold);
+}
+
+extern "C" int snerf_render_rays_add_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+                                         const snerf_mlp_desc *desc_fine, const void *packed_fine, int precision,
+                                         const float *ray_samples, const float *rays_o, const float *rays_d, const float *z_vals,
+                                         const float *additional, const float *u, const float *noise_coarse,
+                                         const float *noise_fine, int64_t B, int Nc, int Nf, int white_background, void *workspace,
+                                         float *rgb, float *rgb_fine, float *samples_fine, float *densities_fine,
+                                         snerf_stream_t stream) {
+    using namespace snerf;
+    if (!desc_coarse || (Nf > 0 && !desc_fine)) return fail(SNERF_E_BADARG, "render_rays_add: null descriptor");
+    if (!desc_coarse->add_dim || (Nf > 0 && desc_fine->add_dim != desc_coarse->add_dim))
+        return fail(SNERF_E_BADARG, "render_rays_add: both nets must read the same per-ray additional inputs (add_dim > 0)");
+    if (!additional && B > 0) return fail(SNERF_E_BADARG, "render_rays_add: additional is null");
+    return render_rays_impl(desc_coarse, packed_coarse, desc_fine, packed_fine, precision, ray_samples, rays_o, rays_d, z_vals, additional,
+                            u, noise_coarse, noise_fine, B, Nc, Nf, white_background, workspace, rgb, rgb_fine, samples_fine,
+                            densities_fine, stream);
+}
+
+static int snerf::render_rays_impl(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const snerf_mlp_desc *desc_fine,
+                                   const void *packed_fine, int precision, const float *ray_samples, const float *rays_o,
+                                   const float *rays_d, const float *z_vals, const float *additional, const float *u,
+                                   const float *noise_coarse, const float *noise_fine, int64_t B, int Nc, int Nf,
+                                   int white_background, void *workspace, float *rgb, float *rgb_fine, float *samples_fine,
+                                   float *densities_fine, snerf_stream_t stream) {
     using namespace snerf;
     if (precision != 0 && precision != 2 && precision != 3 && precision != SNERF_SPLIT_F16X3)
         return fail(SNERF_E_BADARG, "render_rays: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
@@ -89,18 +154,23 @@ extern "C" int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const vo
         return fail(SNERF_E_BADARG, "render_rays: null pointer");
     if (Nf > 0 && (!desc_fine || !packed_fine || !rays_o || !u))
         return fail(SNERF_E_BADARG, "render_rays: the fine pass needs desc_fine, packed_fine, rays_o and u");
-    if ((desc_coarse->add_dim) || (Nf > 0 && desc_fine->add_dim))
-        return fail(SNERF_E_BADARG, "render_rays: nets with additional inputs go through snerf_mlp_fwd_* directly");
     if (!aligned(workspace, 16)) return fail(SNERF_E_ALIGN, "render_rays: workspace must be 16-byte aligned");
     const RenderWs w = render_ws(B, Nc, Nf);
     char *ws = reinterpret_cast<char *>(workspace);
+    int64_t fold_c = 0, fold_f = 0;
+    void *fold_ws = nullptr;
+    if (additional) {
+        if (add_fold_bytes(desc_coarse, desc_fine, B, Nc, Nf, fold_c, fold_f) < 0) return SNERF_E_BADARG;
+        fold_ws = ws + align16(w.total);
+    }
     float *raw_c = reinterpret_cast<float *>(ws + w.raw_c), *weights_c = reinterpret_cast<float *>(ws + w.weights_c);
     float *alpha_c = reinterpret_cast<float *>(ws + w.alpha_c), *z_samples = reinterpret_cast<float *>(ws + w.z_samples);
     float *z_fine = reinterpret_cast<float *>(ws + w.z_fine), *raw_f = reinterpret_cast<float *>(ws + w.raw_f);
     hipStream_t s = (hipStream_t)stream;
     int rc;
     // coarse net on the given samples, then compositing (:29-42)
-    if ((rc = mlp(desc_coarse, packed_coarse, precision, ray_samples, rays_d, B * Nc, Nc, raw_c, stream))) return rc;
+    if ((rc = mlp(desc_coarse, packed_coarse, precision, ray_samples, rays_d, B * Nc, Nc, raw_c, stream, additional, fold_ws, fold_c)))
+        return rc;
     if (Nf == 0) {  // run_fine = 0 (:43-44): (rgb, rgb, ray_samples, alpha)
         if ((rc = snerf_composite_fwd_f32(raw_c, z_vals, rays_d, 0, noise_coarse, B, Nc, white_background, rgb, weights_c,
                                           densities_fine, stream)))
@@ -118,7 +188,7 @@ extern "C" int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const vo
                                    samples_fine, stream)))
         return rc;
     const int N = Nc + Nf;
-    if ((rc = mlp(desc_fine, packed_fine, precision, samples_fine, rays_d, B * N, N, raw_f, stream))) return rc;
+    if ((rc = mlp(desc_fine, packed_fine, precision, samples_fine, rays_d, B * N, N, raw_f, stream, additional, fold_ws, fold_f))) return rc;
     return snerf_composite_fwd_f32(raw_f, z_fine, rays_d, 0, noise_fine, B, N, white_background, rgb_fine, nullptr,
                                    densities_fine, stream);
 }

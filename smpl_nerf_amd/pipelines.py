@@ -329,6 +329,50 @@ class AppendSmplParamsPipeline(NerfPipeline):
         return rgb, rgb_fine, ray_samples_fine, densities_fine                                         # :91
 
 
+    def render_rays(self, data):
+        """forward(data) for inference through the single C-ABI call snerf_render_rays_add_f32 (include/smplnerf.h): the pose
+        rows as the nets' per-ray additional inputs, folded per ray inside the call in fp32.  Same outputs as forward()."""
+        from . import _lib
+        from ._lib import check, ptr, current_stream
+        ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
+        args = self.args
+        B, Nc = z_vals.shape
+        Nf = int(args.number_fine_samples) if args.run_fine else 0
+        N = Nc + Nf
+        dev = ray_samples.device
+        mc, mf = self.model_coarse, self.model_fine
+        if mc.precision != mf.precision:
+            raise RuntimeError("render_rays: both nets must use the same precision mode")
+        prec = {"fp32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": _lib.SPLIT_F16X3}[mc.precision]
+        if mc.width != 256 or mf.width != 256:
+            prec = 0
+        goal_pose = self._select(goal_pose).contiguous()
+        pose = self.human_pose_encoder.encode(goal_pose) if args.human_pose_encoding else goal_pose
+        pose = pose.reshape(B, -1).contiguous().float()
+        descs, packed = [], []
+        for m in (mc, mf):
+            d = m.desc_for_encoders(self.position_encoder, self.direction_encoder, True)
+            descs.append(d)
+            packed.append(m.packed_weights(d) if prec == 0 else m.packed_weights_bf16(d, prec))
+        lib = _lib.load()
+        f32 = dict(device=dev, dtype=torch.float32)
+        need = int(lib.snerf_render_rays_add_workspace_bytes(descs[0], descs[1], B, Nc, Nf))
+        if need < 0:
+            check(need, "snerf_render_rays_add_workspace_bytes")
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        rgb, rgb_fine = torch.empty((B, 3), **f32), torch.empty((B, 3), **f32)
+        samples_fine, dens = torch.empty((B, N, 3), **f32), torch.empty((B, N), **f32)
+        u = ops.uniform_u(Nf, dev) if Nf else None
+        nc, nf = self._noise((B, Nc), dev), (self._noise((B, N), dev) if Nf else None)
+        x, o, d, z = (t.contiguous() for t in (ray_samples, ray_translation, ray_direction, z_vals))
+        with torch.cuda.device(dev), _lib.timed(f"render_rays_add[B={B}]"):
+            check(lib.snerf_render_rays_add_f32(descs[0], ptr(packed[0]), descs[1], ptr(packed[1]), prec, ptr(x), ptr(o), ptr(d),
+                                                ptr(z), ptr(pose), ptr(u), ptr(nc), ptr(nf), B, Nc, Nf,
+                                                1 if args.white_background else 0, ptr(ws), ptr(rgb), ptr(rgb_fine),
+                                                ptr(samples_fine), ptr(dens), current_stream()), "snerf_render_rays_add_f32")
+        return rgb, rgb_fine, samples_fine, dens
+
+
 class AppendToNerfPipeline(AppendSmplParamsPipeline):
     """models/append_to_nerf_pipeline.py:7-90 drop-in: the same with only joints 38 and 41 of the pose (:26)."""
 

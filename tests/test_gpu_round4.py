@@ -819,6 +819,38 @@ def test_pose_conditioned_pipelines_one_call_step_equals_the_autograd_step(dev, 
         assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("kind", ["append_smpl_params", "append_smpl_params_encoded", "append_to_nerf"])
+def test_pose_conditioned_pipelines_render_in_one_call(dev, prec, kind):
+    """snerf_render_rays_add_f32 (8(f)-4, the paper's headline model): the single-call render with the pose rows as per-ray
+    additional inputs equals forward() bit for bit - rgb, rgb_fine, the fine samples and densities - also with run_fine = 0,
+    white background and a ragged ray count."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, AppendToNerfPipeline, PipelineArgs
+    enc = kind.endswith("encoded")
+    add_dim = {"append_smpl_params": 69, "append_smpl_params_encoded": 69 * 20, "append_to_nerf": 2}[kind]
+    nets = []
+    for seed in (301, 303):
+        m = RenderRayNet(8, 256, 60, 24, add_dim, skips=[4])
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scene_net_params(seed, add_first=True, additional_input_dim=add_dim).items()})
+        m.precision = prec
+        nets.append(m.to(dev).eval())
+    cls = AppendToNerfPipeline if kind == "append_to_nerf" else AppendSmplParamsPipeline
+    for B, cfg in ((257, dict()), (64, dict(run_fine=0)), (100, dict(white_background=1, number_fine_samples=37))):
+        pipe = cls(nets[0], nets[1], PipelineArgs(human_pose_encoding=1 if enc else 0, **cfg), PositionalEncoder(10, 0),
+                   PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+        batch = _smpl_batch(dev, B)
+        with torch.no_grad():
+            a, b = pipe(batch), pipe.render_rays(batch)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y)
+    # plain nets are refused by this entry, posed nets by the plain one
+    lib = _lib.load()
+    d = nets[0].desc_for_encoders(PositionalEncoder(10, 0), PositionalEncoder(4, 0), True)
+    assert lib.snerf_render_rays_workspace_bytes(16, 64, 128) < lib.snerf_render_rays_add_workspace_bytes(d, d, 16, 64, 128) or prec != "fp32"
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
 def test_append_vertices_one_call_step_equals_the_autograd_step(dev, prec):
     """a8 / configs[4]: AppendVerticesPipeline with a frozen estimator and body model (the vertex floats the nets read are
