@@ -96,6 +96,15 @@ for case in range(cases):
         with torch.no_grad():
             out = pipe(batch)
             ref = ref_fn()
+        # the single-call entries (snerf_render_rays_f32 / _smpl_f32 / _add_f32) against the five-launch forward: bit for bit
+        one_call_ok = True
+        mixed = kind == "smpl_nerf" and pipe.model_warp_field.precision != prec      # (the one-call entry wants one precision for all nets)
+        if not (kind == "smpl_nerf" and Nf == 0) and not mixed:
+            args.strict_cumsum = 0
+            with torch.no_grad():
+                fwd, one = pipe(batch), pipe.render_rays(batch)
+            one_call_ok = all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(fwd, one))
+            args.strict_cumsum = 1
         tol = 2e-5 if prec == "fp32" else 3e-4
         if kind == "smpl_nerf":
             tol *= 100          # the warp net's round-off passes through two 2^9 encoders before it reaches a colour
@@ -106,9 +115,9 @@ for case in range(cases):
         # difference of the coarse weights moves that ray's samples - a few rays may differ visibly; the sampler itself is held
         # to the oracle bit for bit from equal weights by fuzz_ops.py)
         ok = float(ec.max()) <= tol and flips <= max(2, B // 25) and float(ef.max()) <= 5e-2 and float(ef.median()) <= tol and \
-            bool(torch.isfinite(out[1]).all())
+            bool(torch.isfinite(out[1]).all()) and one_call_ok
         bad += not ok
-        print(("ok  " if ok else "BAD ") + desc + f": coarse max {float(ec.max()):.2e}, fine median {float(ef.median()):.2e} max {float(ef.max()):.2e} ({flips} rays off)",
+        print(("ok  " if ok else "BAD ") + desc + f": coarse max {float(ec.max()):.2e}, fine median {float(ef.median()):.2e} max {float(ef.max()):.2e} ({flips} rays off)" + ("" if one_call_ok else "  ONE-CALL RENDER DIFFERS"),
               flush=True)
     except Exception as e:   # noqa: BLE001
         bad += 1
