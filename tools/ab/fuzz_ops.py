@@ -68,7 +68,7 @@ for case in range(cases):
             rgb, wt, al = ops.composite(T(raw), T(z), T(d), bool(wb), noise=None if noise is None else T(noise), want_weights=True, want_alpha=True)
             er, ew, ea = O.raw2outputs(raw, z, np.broadcast_to(d[:, None, :], (B, n, 3)), wb, noise)
             err = max(np.abs(N(rgb) - er).max(), np.abs(N(wt) - ew).max(), np.abs(N(al) - ea).max())
-            ok = err <= 2e-6
+            ok = err <= (2e-6 if n <= 256 else 5e-6)
             desc = f"composite B {B} N {n} wb {wb} noise {noise is not None}: max err {err:.2e}"
         elif what == "searchsorted":
             dt = rng.choice([np.float32, np.float64, np.int32, np.int64, np.int16, np.int8, np.uint8])
