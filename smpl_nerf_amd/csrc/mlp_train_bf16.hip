@@ -398,7 +398,12 @@ __global__ __launch_bounds__(WB_THREADS) void mlp_wgrad_bf16_kernel(Plan P, Trai
     const int nstages = begin < end ? (int)((end - begin + WB_STAGE - 1) / WB_STAGE) : 0;
     float sx = 1.f, sy = 1.f, unscale = 1.f;   // f16x3: operand scales of the job and the scale of its result
     if constexpr (F16) {
-        const int ex = 14 - min(max(A.xstat[l], -100), 100), ey = 14 - min(max(A.ystat[l], -100), 100);
+        // X scale: the statistic of THIS segment (xstat_index: the layer's hidden input, or the encoder / additional-input
+        // columns).  r04: this read xstat[l] - the hidden input's - for every wide job of the layer; with encoded pose columns
+        // (1380 of them: wide jobs of their own) layer 0 has no hidden input, its statistic is unset and the scale was 2^114
+        // (found by tools/ab/fuzz_train.py in chunked f16x3 steps)
+        const int xi = xstat_index(P, l, s);
+        const int ex = 14 - (xi < 0 ? 0 : min(max(A.xstat[xi], -100), 100)), ey = 14 - min(max(A.ystat[l], -100), 100);
         sx = __builtin_ldexpf(1.f, ex);
         sy = __builtin_ldexpf(1.f, ey);
         unscale = __builtin_ldexpf(1.f, -(ex + ey));
@@ -729,7 +734,8 @@ __global__ __launch_bounds__(WC_THREADS) void mlp_wgrad_f16_kernel(Plan P, Train
     const int64_t end = min(n, begin + A.chunk);
     const int nstages = begin < end ? (int)((end - begin + WC_STAGE - 1) / WC_STAGE) : 0;
     // operand scales of the job (per layer, over all samples) and the scale of its result
-    const int ex = 14 - min(max(A.xstat[l], -100), 100), ey = 14 - min(max(A.ystat[l], -100), 100);
+    const int xi = xstat_index(P, l, s);   // (the statistic of this segment, not of the layer's hidden input - see mlp_wgrad_bf16_kernel)
+    const int ex = 14 - (xi < 0 ? 0 : min(max(A.xstat[xi], -100), 100)), ey = 14 - min(max(A.ystat[l], -100), 100);
     const float sx = __builtin_ldexpf(1.f, ex), sy = __builtin_ldexpf(1.f, ey), unscale = __builtin_ldexpf(1.f, -(ex + ey));
 
     // ---- stage loader: this wave brings (and later converts) tile-rows 4*wave .. 4*wave+3 (rows 0..15 = dY, 16..31 =
