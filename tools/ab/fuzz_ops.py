@@ -39,7 +39,7 @@ def weights_pattern(B, n):
 
 
 for case in range(cases):
-    what = ["sampler", "composite", "searchsorted", "posenc", "raygen"][case % 5]
+    what = ["sampler", "composite", "searchsorted", "posenc", "raygen", "encoded_forward"][case % 6]
     try:
         if what == "sampler":
             B, Nc, Nf = int(rng.choice([1, 3, 64, 257, 1000])), int(rng.choice([3, 4, 5, 17, 64, 100, 255, 1024])), int(rng.choice([1, 2, 7, 64, 128, 333, 1024]))
@@ -120,6 +120,30 @@ for case in range(cases):
                     full[where] = val
                 ok = ok and np.array_equal(full, got[k])
             desc = f"raygen {F} frames {H}x{W} Nc {Nc} B {Bq}"
+        elif what == "encoded_forward":
+            # RenderRayNet.forward(x) on already-encoded rows (models/render_ray_net.py:42-61) - any positions_dim / directions_dim /
+            # additional_input_dim, the three precisions - against the CPU torch restatement
+            from oracle import torch_cpu_path as TP
+            from smpl_nerf_amd.nets import RenderRayNet
+            depth, width = int(rng.integers(1, 11)), int(rng.choice([16, 64, 100, 128, 256, 256]))
+            pd, dd, ad = int(rng.choice([60, 63, 30, 7, 100])), int(rng.choice([24, 27, 12, 3])), int(rng.choice([0, 0, 5, 69, 300]))
+            skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
+            use_dir = int(rng.integers(0, 4) != 0)
+            prec = str(rng.choice(["fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
+            n = int(rng.choice([1, 17, 128, 1000, 20001]))
+            torch.manual_seed(4000 + case)
+            net = RenderRayNet(depth, width, pd, dd, ad, skips=list(skips), use_directional_input=use_dir)
+            P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            net.precision = prec
+            net = net.to(dev).eval()
+            x = torch.randn(n, pd + ad + dd)
+            with torch.no_grad():
+                got = net(x.to(dev)).cpu()
+                ref = TP.render_ray_net(P, x, n_layers=depth, positions_dim=pd, directions_dim=dd, additional_input_dim=ad, skips=tuple(skips),
+                                        use_directional_input=use_dir)
+            err = float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+            ok = err <= (2e-5 if prec == "fp32" else 2e-4) and bool(torch.isfinite(got).all())
+            desc = f"encoded_forward {prec} depth {depth} width {width} skips {skips} dims {pd}/{ad}/{dd} dir {use_dir} n {n}: max err {err:.2e}"
         else:
             L, ident = int(rng.choice([0, 1, 4, 10, 16])), int(rng.integers(0, 2))
             if L == 0 and not ident:
