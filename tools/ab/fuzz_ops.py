@@ -39,7 +39,7 @@ def weights_pattern(B, n):
 
 
 for case in range(cases):
-    what = ["sampler", "composite", "searchsorted", "posenc", "raygen", "encoded_forward"][case % 6]
+    what = ["sampler", "composite", "searchsorted", "posenc", "raygen", "encoded_forward", "warp_rows"][case % 7]
     try:
         if what == "sampler":
             B, Nc, Nf = int(rng.choice([1, 3, 64, 257, 1000])), int(rng.choice([3, 4, 5, 17, 64, 100, 255, 1024])), int(rng.choice([1, 2, 7, 64, 128, 333, 1024]))
@@ -144,6 +144,33 @@ for case in range(cases):
             err = float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
             ok = err <= (2e-5 if prec == "fp32" else 2e-4) and bool(torch.isfinite(got).all())
             desc = f"encoded_forward {prec} depth {depth} width {width} skips {skips} dims {pd}/{ad}/{dd} dir {use_dir} n {n}: max err {err:.2e}"
+        elif what == "warp_rows":
+            # WarpFieldNet.forward(rows) (models/warp_field_net.py:17-21) with its backward (rows and parameters) against torch
+            from oracle import torch_cpu_path as TP
+            from smpl_nerf_amd.nets import WarpFieldNet
+            width = int(rng.choice([7, 64, 100, 128, 200, 256]))
+            pd, qd = int(rng.choice([60, 63, 3, 33])), int(rng.choice([40, 2, 24]))
+            n = int(rng.choice([1, 19, 128, 5000, 70001]))
+            torch.manual_seed(5000 + case)
+            mw = WarpFieldNet(8, width, pd, qd)
+            P = {k: v.detach().clone().requires_grad_(True) for k, v in mw.state_dict().items()}
+            mw = mw.to(dev).train()
+            x, w = torch.randn(n, pd + qd), torch.randn(n, 3)
+            xg, xc = x.clone().to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+            out = mw(xg)
+            (out * w.to(dev)).sum().backward()
+            ref = TP.warp_field_net(P, xc)
+            (ref * w).sum().backward()
+            errs = [float((out.detach().cpu() - ref.detach()).abs().max()) / max(1.0, float(ref.abs().max())),
+                    float((xg.grad.cpu() - xc.grad).norm()) / max(float(xc.grad.norm()), 1e-12)]
+            errs += [float((p.grad.cpu() - P[k].grad).norm()) / max(float(P[k].grad.norm()), 1e-12) for k, p in mw.named_parameters()]
+            err = max(errs)
+            # the output is continuous in the pre-activations; the gradients are not: a sample within rounding of a ReLU kink
+            # takes the other side in one of the two fp32 evaluations (checked against fp64: sometimes the GPU's, sometimes
+            # torch's) and moves a sum over n samples by ~1/sqrt(n) of itself
+            ok = errs[0] <= 2e-5 and err <= (2e-5 if n < 1000 else 2e-3)
+            names = ["out", "d rows"] + [k for k, _ in mw.named_parameters()]
+            desc = f"warp_rows width {width} dims {pd}+{qd} n {n}: max err {err:.2e} ({names[errs.index(err)]})"
         else:
             L, ident = int(rng.choice([0, 1, 4, 10, 16])), int(rng.integers(0, 2))
             if L == 0 and not ident:
