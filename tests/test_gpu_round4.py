@@ -757,6 +757,34 @@ def test_gradients_do_not_depend_on_how_the_samples_are_chunked(dev):
     assert r.stdout.strip().splitlines()[-1] == "bad: 0", r.stdout[-3000:]
 
 
+def test_smpl_nerf_one_call_step_in_a_hip_graph(dev):
+    """snerf_smpl_nerf_train_step_f32 (warp stage, both nets, Adam, the warp net's re-pack) captured into a HIP graph and
+    replayed walks the trajectory of eager steps - like test_one_call_step_in_a_hip_graph for the plain pipeline."""
+    tr, _ = _smpl_trainer(dev, lr=1e-4)
+    eager, _ = _smpl_trainer(dev, lr=1e-4)
+    batch = _smpl_batch(dev, 64)
+    for _ in range(2):
+        tr.step(batch), eager.step(batch)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tr.step(batch)
+        eager.step(batch)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        loss = tr.step(batch)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        want = eager.step(batch)
+    assert tr._one_call_state() is not None and float(loss) == float(want)
+    for a, b in zip(tr.params, eager.params):
+        assert torch.equal(a, b)
+
+
 def test_smpl_nerf_one_call_step_keeps_inference_current(dev):
     """After one-call steps the pipeline's inference (forward and the single-call render) reads the streams the step kept
     current - the warp net's are re-packed inside the call - and equals a pipeline built from the new parameters."""
