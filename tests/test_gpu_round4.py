@@ -879,6 +879,45 @@ def test_pose_conditioned_pipelines_render_in_one_call(dev, prec, kind):
     assert lib.snerf_render_rays_workspace_bytes(16, 64, 128) < lib.snerf_render_rays_add_workspace_bytes(d, d, 16, 64, 128) or prec != "fp32"
 
 
+@pytest.mark.parametrize("chunk", [0, 7])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6"])
+def test_split_precision_steps_with_encoded_pose_columns_follow_the_fp32_step(dev, prec, chunk):
+    """Regression (found by tools/ab/fuzz_train.py): with the ENCODED pose (69 x 20 = 1380 per-ray columns) the additional
+    inputs are wide weight-gradient jobs of their own; the f16 wide kernels scaled them by the statistic of the layer's hidden
+    input - unset at layer 0, a chunk's accident at the skip layer - and returned 1 % / 29 % errors there.  The gradients of a
+    split-precision step (whole batch and ray chunks, encoders with identity columns) against the fp32 step's, relative to the
+    largest gradient tensor."""
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, PipelineArgs
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    batch = _smpl_batch(dev, 31)
+
+    def grads(precision, rays_per_chunk):
+        torch.manual_seed(1438)
+        pe, de = PositionalEncoder(10, 1), PositionalEncoder(4, 1)
+        nets = []
+        for _ in range(2):
+            m = RenderRayNet(5, 256, 3 * pe.output_dim, 3 * de.output_dim, 69 * 20, skips=[3]).to(dev).train()
+            with torch.no_grad():
+                m.sigma_out_layer.weight.mul_(20.0)
+            m.precision = precision
+            nets.append(m)
+        pipe = AppendSmplParamsPipeline(nets[0], nets[1], PipelineArgs(number_fine_samples=5, human_pose_encoding=1), pe, de,
+                                        PositionalEncoder(10, 0))
+        tr = DataParallelTrainer(pipe, nets, lr=1e-6)
+        tr.rays_per_chunk = rays_per_chunk
+        tr.step(batch)
+        assert tr._one_call_state() is not None
+        return [p.grad.clone() for p in nets[0].parameters()]      # the coarse net: independent of the fine samples
+
+    ref = grads("fp32", 0)
+    top = max(float(r.norm()) for r in ref)
+    assert top > 0
+    for g, r in zip(grads(prec, chunk), ref):
+        assert bool(torch.isfinite(g).all()) and float((g - r).norm()) <= 1e-4 * top
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
 def test_append_vertices_one_call_step_equals_the_autograd_step(dev, prec):
     """a8 / configs[4]: AppendVerticesPipeline with a frozen estimator and body model (the vertex floats the nets read are
