@@ -32,8 +32,10 @@ for case in range(cases):
     kind = str(rng.choice(["nerf", "nerf", "smpl_nerf", "append_smpl_params", "append_smpl_params_encoded", "append_to_nerf"]))
     if os.environ.get("FUZZ_KIND"):
         kind = os.environ["FUZZ_KIND"]
-    depth = int(rng.integers(1, 13))
+    depth = int(rng.integers(1, 13)) if not os.environ.get("FUZZ_EDGES") else int(rng.choice([1, 2, 15, 16]))     # FUZZ_EDGES=1: the limits
     width = int(rng.choice([16, 33, 64, 100, 128, 200, 256, 256, 256]))
+    if os.environ.get("FUZZ_EDGES"):
+        width = int(rng.choice([2, 3, 15, 17, 63, 65, 127, 129, 255, 256]))
     prec = str(rng.choice(["fp32", "fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
     skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
     B = int(rng.choice([1, 2, 5, 31, 64, 100, 129, 257, 600, 2049]))
