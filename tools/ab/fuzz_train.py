@@ -34,7 +34,11 @@ for case in range(cases):
     B = int(rng.choice([1, 2, 5, 31, 64, 100, 129, 257, 600]))
     Nc = int(rng.choice([3, 4, 7, 16, 33, 64, 100]))   # the sampler needs 3 coarse samples (one interior weight)
     Nf = int(rng.choice([0, 1, 5, 64, 128, 150]))
+    if os.environ.get("FUZZ_LARGE"):      # FUZZ_LARGE=1: the sizes of real steps (use with FUZZ_VS_TORCH=0)
+        B, Nc, Nf = int(rng.choice([2048, 3001, 4096])), 64, 128
     chunk = int(rng.choice([0, 1, 17, 64, 200]))
+    if os.environ.get("FUZZ_LARGE"):
+        chunk = int(rng.choice([0, 1000, 2048]))
     wb = int(rng.integers(0, 2))
     use_dir = int(rng.integers(0, 4) != 0)
     Lp, Ld = int(rng.choice([10, 10, 6, 3])), int(rng.choice([4, 4, 2]))
