@@ -24,7 +24,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 data = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in bench.frame_inputs("nerf", 128, 0)]
 FLOP = 3 * 2 * 607872 * 256
-for rays in [int(v) for v in a.rays.split(",")]:
+for rays in [min(int(v), data[0].shape[0]) for v in a.rays.split(",")]:      # (at most the frame's 16 384 rays)
     for mode in (["one_call"] + (["autograd"] if a.autograd else [])):
         for chunk in ([int(v) for v in a.chunks.split(",")] if mode == "one_call" else [0]):
             pipe, _, models = bench.build_pipeline(dev, a.precision, "nerf")
