@@ -314,8 +314,9 @@ def test_one_call_step_in_a_hip_graph(dev):
     assert int(tr.optim.steps[0]) == 6
 
 
+@pytest.mark.parametrize("rays", [64, 800])
 @pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
-def test_small_batches_run_the_coarse_backward_on_the_auxiliary_stream(dev, prec, monkeypatch):
+def test_small_batches_run_the_coarse_backward_on_the_auxiliary_stream(dev, prec, rays, monkeypatch):
     """Chunks of <= 262 144 samples (up to 1024 rays; the README's 64-ray batches): the coarse net's backward runs beside the fine net's on
     the trainer's second stream (include/smplnerf.h: aux_stream) - the same kernels on their own scratch buffers, so the
     trajectory equals the single-stream one bit for bit."""
@@ -324,7 +325,7 @@ def test_small_batches_run_the_coarse_backward_on_the_auxiliary_stream(dev, prec
     for aux in ("1", "0"):
         monkeypatch.setenv("SNERF_TRAIN_AUX_STREAM", aux)
         tr, pipe, mc, mf = _trainer(dev, prec, lr=1e-3)
-        batch = _batch(dev, 64)
+        batch = _batch(dev, rays)
         losses = [float(tr.step(batch)) for _ in range(4)]
         assert (tr._oc["aux"] is not None) == (aux == "1")
         finals.append((losses, [p.detach().clone() for p in tr.params]))
