@@ -257,7 +257,39 @@ def cpu_baseline(workload, params, data_np, n_rays, run_fine=1):
                       f"restated op for op on PyTorch-CPU fp32, torch.set_num_threads({threads}) = the fastest of the probed "
                       f"counts",
             "calibration_vs_reference_in_build_container": _calibration()}
+    inds = T.LAST.get("inds") if (run_fine and workload == "nerf") else None
+    info["_sampler_inds"] = None if inds is None else inds.numpy()
     return info, [o.numpy() for o in out]
+
+
+def quality_keys(out, ref, gt, n, cpu_inds, pipe, data):
+    """The quality half of BASELINE's metric ("...; PSNR vs ref"), on the CPU-baseline subset and outside the timed region:
+    PSNR (util/scores.py:47-48: -10 ln(mse) / ln 10 over all pixels and channels) of the HIP render and of the CPU
+    reference path's render against the same ground truth, their difference (north_star: within 0.01 dB), the PSNR between
+    the two renders, and the fraction of (ray, u) pairs for which the HIP sampler picked the same searchsorted index as the
+    CPU path (end to end from each side's own coarse weights, default - non-strict - normalising sum)."""
+    import numpy as np
+    import torch
+    from smpl_nerf_amd import ops
+    from smpl_nerf_amd.io import img2psnr
+    q = {}
+    k = 1 if len(ref) > 1 else 0
+    hip, cpu = out[k][:n].float().cpu().numpy(), ref[k]
+    q["psnr_db"] = img2psnr(hip, gt[:n])
+    q["psnr_db_cpu_reference_path"] = img2psnr(cpu, gt[:n])
+    q["psnr_delta_db_vs_oracle"] = q["psnr_db"] - q["psnr_db_cpu_reference_path"]
+    q["psnr_db_hip_vs_cpu_reference_render"] = img2psnr(hip, cpu) if np.any(hip != cpu) else None   # (None: bit-identical)
+    q["psnr_note"] = ("util/scores.py:47-48 on the fine colours of the CPU-baseline subset (%d rays) against the synthetic scene's "
+                      "rgb_truth; tolerance of north_star: |delta| <= 0.01 dB" % n)
+    if cpu_inds is not None:
+        with torch.no_grad():
+            sub = [t[:n] for t in data]
+            B, Nc = sub[3].shape
+            raw = pipe.model_coarse.forward_fused(sub[0], sub[2], Nc, pipe.position_encoder, pipe.direction_encoder)
+            _, weights, _ = ops.composite(raw.view(B, Nc, 4), sub[3], sub[2], bool(pipe.args.white_background), None)
+            hs = ops.hierarchical_samples(sub[1], sub[2], sub[3], weights, pipe.args.number_fine_samples, want_inds=True)
+        q["sampler_index_equal_frac"] = float((hs["inds"].cpu().numpy() == cpu_inds).mean())
+    return q
 
 
 def cpu_train_baseline(workload, params, data_np, n_rays, threads, lr):
@@ -870,7 +902,10 @@ def main():
             # (append_vertices: the reference materialises 83 KB per sample - a far smaller sample fills the time budget)
             n = min(a.cpu_rays if a.workload != "append_vertices" else min(a.cpu_rays, 64), rays)
             info, ref = cpu_baseline(a.workload, params, data_np, n, run_fine)
+            cpu_inds = info.pop("_sampler_inds", None)
             line["cpu_baseline"] = info
+            if a.workload != "append_vertices":     # (its CPU figure is the coarse pass only)
+                line.update(quality_keys(out, ref, data_np[-1], n, cpu_inds, pipe, data))
             if (isinstance(train, dict) and "error" not in train and a.cpu_train_rays > 0 and run_fine
                     and a.workload in ("nerf", "smpl_nerf")):
                 train["cpu_baseline"] = cpu_train_baseline(a.workload, params, data_np, min(a.cpu_train_rays, rays),

@@ -25,7 +25,7 @@
  * State.  The library keeps no caller-visible state between calls.  What it does keep, process-wide:
  *   - the error text of the last failure, per thread (snerf_last_error_string);
  *   - two HIP events per host thread and device, created at the first training call that is given an auxiliary stream
- *     (fork / join of the concurrent backward; never destroyed);
+ *     (fork / join of the concurrent backward; snerf_shutdown() destroys them);
  *   - per HIP device ordinal (up to 64 devices): the CU count and, per kernel, whether its dynamic-LDS limit was
  *     raised (hipFuncSetAttribute is per device) - so one process may drive several GPUs through the library;
  *   - tuning knobs: the environment variables below are read ONCE, at the first call that consults them.  They choose
@@ -65,14 +65,15 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 105 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+#define SNERF_VERSION 106 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
                              snerf_composite_bwd_all_f32; composite forward accepts any N
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
                              folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
                              0.1.4: + the training step as one call (snerf_nerf_train_step_f32 / _grads_f32, snerf_adam_step_f32,
                              snerf_mlp_stream_slots), snerf_dy_contract_f32; the per-ray fold tables moved from stream-ordered allocations inside
                              the library to caller workspaces (snerf_mlp_fwd_ws_f32, snerf_warp_fwd_ws_f32): the library allocates nothing
-                             0.1.5: + snerf_render_rays_add_f32 (the single-call render for nets with per-ray additional inputs) */
+                             0.1.5: + snerf_render_rays_add_f32 (the single-call render for nets with per-ray additional inputs)
+                             0.1.6: + snerf_shutdown; hidden visibility: the entry points of this header are the only dynamic symbols */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -82,10 +83,22 @@ extern "C" {
 
 typedef void *snerf_stream_t; /* hipStream_t */
 
-int snerf_version(void);
-const char *snerf_last_error_string(void);
+/* The library is built with -fvisibility=hidden: the entry points declared here are its only dynamic symbols
+ * (tests/test_abi.py: `nm -D --defined-only` lists nothing but snerf_*). */
+#if defined(__GNUC__) || defined(__clang__)
+#define SNERF_API __attribute__((visibility("default")))
+#else
+#define SNERF_API
+#endif
+
+SNERF_API int snerf_version(void);
+SNERF_API const char *snerf_last_error_string(void);
 /* Number of visible HIP devices (0 when none); never fails. */
-int snerf_device_count(void);
+SNERF_API int snerf_device_count(void);
+/* Releases what the library holds process-wide (section "State"): the fork / join events of every host thread and device.
+ * Optional - a process may simply exit; for hosts that unload the library or count HIP objects.  Must not run concurrently
+ * with another call into the library; the next training call creates its events again.  Returns SNERF_OK. */
+SNERF_API int snerf_shutdown(void);
 
 /* ---- a6: batched searchsorted --------------------------------------------------------------
  * out[r, c] = #{ k : a[ra, k] <  v[rv, c] }   (side_left != 0, numpy side='left')
@@ -93,7 +106,7 @@ int snerf_device_count(void);
  * rows of `a` must be sorted ascending.  ra = 0 if nrow_a == 1 else r (same for rv): the
  * reference's row broadcast (searchsorted_cpu_wrapper.cpp:109-110).  nrow_a and nrow_v must be
  * equal or one of them 1 (searchsorted.py:23-28).  out: int64 [max(nrow_a,nrow_v), ncol_v]. */
-int snerf_searchsorted_f32(const float *a, int64_t nrow_a, int64_t ncol_a,
+SNERF_API int snerf_searchsorted_f32(const float *a, int64_t nrow_a, int64_t ncol_a,
                            const float *v, int64_t nrow_v, int64_t ncol_v,
                            int64_t *out, int side_left, snerf_stream_t stream);
 
@@ -106,17 +119,17 @@ int snerf_searchsorted_f32(const float *a, int64_t nrow_a, int64_t ncol_a,
 #define SNERF_DTYPE_I16 4
 #define SNERF_DTYPE_I8 5
 #define SNERF_DTYPE_U8 6
-int snerf_searchsorted(int dtype, const void *a, int64_t nrow_a, int64_t ncol_a, const void *v, int64_t nrow_v,
+SNERF_API int snerf_searchsorted(int dtype, const void *a, int64_t nrow_a, int64_t ncol_a, const void *v, int64_t nrow_v,
                        int64_t ncol_v, int64_t *out, int side_left, snerf_stream_t stream);
 
 /* ---- a1: positional encoding ----------------------------------------------------------------
  * x [n, c] -> out [n, c*(identity + 2*L)], frequency-major: [x] [sin(2^0 x) cos(2^0 x)] ...
  * (utils.py:116-131; no pi factor). */
-int snerf_posenc_f32(const float *x, int64_t n, int c, int L, int identity, float *out,
+SNERF_API int snerf_posenc_f32(const float *x, int64_t n, int c, int L, int identity, float *out,
                      snerf_stream_t stream);
 
 /* Backward of the encoding: d_out [n, c*(identity + 2*L)] -> d_x [n, c] (autograd through utils.py:123-131). */
-int snerf_posenc_bwd_f32(const float *x, const float *d_out, int64_t n, int c, int L, int identity, float *d_x,
+SNERF_API int snerf_posenc_bwd_f32(const float *x, const float *d_out, int64_t n, int c, int L, int identity, float *d_x,
                          snerf_stream_t stream);
 
 /* ---- a4: alpha compositing --------------------------------------------------------------------
@@ -126,7 +139,7 @@ int snerf_posenc_bwd_f32(const float *x, const float *d_out, int64_t n, int c, i
  * rgb [B, 3], weights [B, N], alpha [B, N] (any of the three may be NULL to skip the store).
  * N == 1 reproduces the reference's early return (utils.py:168-169): weights = alpha = 1.  Any N >= 1 (the backward
  * entry points take N <= 4096). */
-int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+SNERF_API int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
                             const float *noise, int64_t B, int N, int white_background,
                             float *rgb, float *weights, float *alpha, snerf_stream_t stream);
 
@@ -134,7 +147,7 @@ int snerf_composite_fwd_f32(const float *raw, const float *z, const float *dirs,
  * forward call; autograd through utils.py:161-191).  weights/alpha are treated as outputs without
  * gradient (the pipeline detaches what it derives from them, utils.py:260).  N <= 4096.  A per-sample direction of
  * norm 0 gets d_dirs = 0 (torch.norm's subgradient). */
-int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+SNERF_API int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
                             const float *noise, int64_t B, int N, int white_background,
                             const float *d_rgb, float *d_raw, float *d_dirs /* nullable, [B,N,3]: only with per-sample
                             directions (dists are scaled by their norm, utils.py:165) */, snerf_stream_t stream);
@@ -144,7 +157,7 @@ int snerf_composite_bwd_f32(const float *raw, const float *z, const float *dirs,
  * to the directions (d_dirs: [B,N,3] with per-sample directions, [B,3] otherwise; dists are scaled by their norm,
  * utils.py:165) and to the depths (d_z [B,N]; the last interval is the constant 1e10, utils.py:164).  N <= 4096.  N == 1:
  * weights and alpha are constants, d_dirs = d_z = 0. */
-int snerf_composite_bwd_all_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
+SNERF_API int snerf_composite_bwd_all_f32(const float *raw, const float *z, const float *dirs, int dirs_per_sample,
                                 const float *noise, int64_t B, int N, int white_background, const float *d_rgb,
                                 const float *d_weights, const float *d_alpha, float *d_raw, float *d_dirs /* nullable */,
                                 float *d_z /* nullable */, snerf_stream_t stream);
@@ -156,7 +169,7 @@ int snerf_composite_bwd_all_f32(const float *raw, const float *z, const float *d
  * z_samples [B, Nf], z_fine [B, Nc+Nf] ascending, pts [B, Nc+Nf, 3] = o + d * z_fine.
  * 3 <= Nc <= 1024, 1 <= Nf <= 1024 (with fewer than three coarse samples there is no interior weight: the reference's own
  * sample_pdf builds an empty cdf and its gather raises, utils.py:200-221). */
-int snerf_sample_pdf_f32(const float *z, const float *weights, const float *u,
+SNERF_API int snerf_sample_pdf_f32(const float *z, const float *weights, const float *u,
                          const float *o, const float *d, int64_t B, int Nc, int Nf,
                          int64_t *inds, float *z_samples, float *z_fine, float *pts,
                          snerf_stream_t stream);
@@ -166,22 +179,22 @@ int snerf_sample_pdf_f32(const float *z, const float *weights, const float *u,
  * host's SIMD width, and a 1-ulp difference in it moves ~0.15 % of the indices.  `tot` [B] = that sum as the reference's
  * host evaluated it (e.g. (weights[:, 1:-1] + 1e-5).sum(-1) with torch on the CPU); every other step is independent of
  * the evaluation order, so cdf, inds and the samples are then bit-identical to the reference's. */
-int snerf_sample_pdf_strict_f32(const float *z, const float *weights, const float *u, const float *o, const float *d,
+SNERF_API int snerf_sample_pdf_strict_f32(const float *z, const float *weights, const float *u, const float *o, const float *d,
                                 const float *tot, int64_t B, int Nc, int Nf, int64_t *inds, float *z_samples,
                                 float *z_fine, float *pts, snerf_stream_t stream);
-int snerf_sample_pdf_bins_strict_f32(const float *bins, const float *weights, const float *u, const float *tot, int64_t B,
+SNERF_API int snerf_sample_pdf_bins_strict_f32(const float *bins, const float *weights, const float *u, const float *tot, int64_t B,
                                      int Nb, int Nf, int64_t *inds, float *z_samples, snerf_stream_t stream);
 
 /* The literal sample_pdf(bins, weights, args) convention (utils.py:194-228): bins [B, Nb] (coarse
  * midpoints), weights [B, Nb-1] (interior coarse weights) -> inds int64 [B, Nf] (nullable),
  * z_samples [B, Nf].  2 <= Nb <= 1023. */
-int snerf_sample_pdf_bins_f32(const float *bins, const float *weights, const float *u, int64_t B,
+SNERF_API int snerf_sample_pdf_bins_f32(const float *bins, const float *weights, const float *u, int64_t B,
                               int Nb, int Nf, int64_t *inds, float *z_samples, snerf_stream_t stream);
 
 /* Backward of sample_pdf(bins, weights, args) (utils.py:194-228 under autograd; fine_sampling detaches its result,
  * utils.py:260, so no pipeline needs it): d_z_samples [B, Nf] -> d_bins [B, Nb], d_weights [B, Nb-1], with the forward's
  * searchsorted indices `inds` [B, Nf] held fixed (integers carry no gradient in the reference either). */
-int snerf_sample_pdf_bins_bwd_f32(const float *bins, const float *weights, const float *u, const int64_t *inds,
+SNERF_API int snerf_sample_pdf_bins_bwd_f32(const float *bins, const float *weights, const float *u, const int64_t *inds,
                                   const float *tot /* nullable [B]: the strict forward's normalising sums */,
                                   const float *d_z_samples, int64_t B, int Nb, int Nf, float *d_bins, float *d_weights,
                                   snerf_stream_t stream);
@@ -211,11 +224,11 @@ typedef struct snerf_mlp_desc {
 
 /* Number of floats in the flat parameter vector: weights and biases in state_dict order
  * (positions_pose_input.weight, .bias, positional_net.0.weight, ... rgb_out_layer.bias). */
-int64_t snerf_mlp_param_floats(const snerf_mlp_desc *desc);
+SNERF_API int64_t snerf_mlp_param_floats(const snerf_mlp_desc *desc);
 /* Number of floats of the MFMA-ordered weight stream produced by snerf_mlp_pack_f32. */
-int64_t snerf_mlp_packed_floats(const snerf_mlp_desc *desc);
+SNERF_API int64_t snerf_mlp_packed_floats(const snerf_mlp_desc *desc);
 /* params_flat -> packed (both device).  Run once per weight update. */
-int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed,
+SNERF_API int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed,
                        snerf_stream_t stream);
 
 /* Fused positional encoding + MLP.  x [n, 3] sample positions; directions dirs: [n/samples_per_ray, 3]
@@ -227,7 +240,7 @@ int snerf_mlp_pack_f32(const snerf_mlp_desc *desc, const float *params_flat, flo
  * order of snerf_mlp_fwd_train_f32 (whose `raw` the call then reproduces bit for bit). */
 #define SNERF_FWD_DIRS_PER_SAMPLE 1
 #define SNERF_FWD_NO_RAY_FOLD 2
-int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
+SNERF_API int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                       const float *dirs, int dirs_per_sample, const float *add,
                       int64_t n, int samples_per_ray, float *raw, snerf_stream_t stream);
 
@@ -237,8 +250,8 @@ int snerf_mlp_fwd_f32(const snerf_mlp_desc *desc, const float *packed, const flo
  * the accumulators; their k-blocks are skipped (same values up to the summation order of those columns).  workspace NULL
  * (= snerf_mlp_fwd_f32): the per-sample form.  A workspace smaller than needed is SNERF_E_BADARG - the library allocates
  * nothing and never switches form silently.  16-byte aligned. */
-int64_t snerf_mlp_fold_workspace_bytes(const snerf_mlp_desc *desc, int64_t n, int samples_per_ray);
-int snerf_mlp_fwd_ws_f32(const snerf_mlp_desc *desc, const float *packed, const float *x, const float *dirs,
+SNERF_API int64_t snerf_mlp_fold_workspace_bytes(const snerf_mlp_desc *desc, int64_t n, int samples_per_ray);
+SNERF_API int snerf_mlp_fwd_ws_f32(const snerf_mlp_desc *desc, const float *packed, const float *x, const float *dirs,
                          int dirs_per_sample, const float *add, int64_t n, int samples_per_ray, float *raw, void *workspace,
                          int64_t workspace_bytes, snerf_stream_t stream);
 
@@ -255,17 +268,17 @@ int snerf_mlp_fwd_ws_f32(const snerf_mlp_desc *desc, const float *packed, const 
  * taken from the exponents the f16x3 training forward leaves behind the rows of `act` and the f16x3 dgrad behind those
  * of `dy`: an f16x3 backward therefore needs the `act` of an f16x3 training forward). */
 #define SNERF_SPLIT_F16X3 16
-int64_t snerf_mlp_packed_bf16_bytes(const snerf_mlp_desc *desc, int nsplit);
-int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed, int nsplit,
+SNERF_API int64_t snerf_mlp_packed_bf16_bytes(const snerf_mlp_desc *desc, int nsplit);
+SNERF_API int snerf_mlp_pack_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed, int nsplit,
                         snerf_stream_t stream);
-int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
+SNERF_API int snerf_mlp_fwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
                            const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                            int samples_per_ray, float *raw, snerf_stream_t stream);
 /* The same forward for training: additionally saves every layer input into `act`, in exactly the layout
  * snerf_mlp_fwd_train_f32 writes (act_floats of snerf_mlp_train_sizes), so that snerf_mlp_bwd_f32 /
  * snerf_mlp_bwd_inputs_f32 run on it unchanged (any mix of fp32 / split-bf16 forward and backward works: the buffers are
  * fp32 - except that the f16x3 backward needs the f16x3 forward, see SNERF_SPLIT_F16X3). */
-int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
+SNERF_API int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed, int nsplit, const float *x,
                                  const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                                  int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
 
@@ -273,13 +286,13 @@ int snerf_mlp_fwd_train_bf16_f32(const snerf_mlp_desc *desc, const void *packed,
  * and fp32 stored d Y, and the wide wgrad GEMMs (the 256x256 and 128x256 layers) with both operands split the same
  * way; the narrow wgrad jobs and the reduction are exact fp32 (SNERF_WGRAD_BF16=0: all of wgrad in fp32).  Same buffers as snerf_mlp_bwd_f32 / _bwd_inputs_f32
  * (sizes from snerf_mlp_train_sizes) except the transposed weight stream, which comes from snerf_mlp_pack_t_bf16. */
-int64_t snerf_mlp_packed_t_bf16_bytes(const snerf_mlp_desc *desc, int nsplit, int input_grad);
-int snerf_mlp_pack_t_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed_t, int nsplit,
+SNERF_API int64_t snerf_mlp_packed_t_bf16_bytes(const snerf_mlp_desc *desc, int nsplit, int input_grad);
+SNERF_API int snerf_mlp_pack_t_bf16(const snerf_mlp_desc *desc, const float *params_flat, void *packed_t, int nsplit,
                           int input_grad, snerf_stream_t stream);
-int snerf_mlp_bwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+SNERF_API int snerf_mlp_bwd_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
                            const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
                            snerf_stream_t stream);
-int snerf_mlp_bwd_inputs_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
+SNERF_API int snerf_mlp_bwd_inputs_bf16_f32(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act,
                                   const float *d_raw, const float *x, const float *dirs, int dirs_per_sample,
                                   int samples_per_ray, int64_t n, float *dy, float *gpart, float *flat_grad,
                                   float *d_x, float *d_dirs, snerf_stream_t stream);
@@ -287,7 +300,7 @@ int snerf_mlp_bwd_inputs_bf16_f32(const snerf_mlp_desc *desc, const void *packed
 /* ---- a2 backward (training) ------------------------------------------------------------------------
  * Buffer sizes for n samples: activations saved by the forward, per-layer output gradients, the
  * transposed weight stream, the split-K partial gradients (gpart_count chunks). */
-int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
+SNERF_API int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
                           int64_t *packed_t_floats, int64_t *gpart_floats, int32_t *gpart_count);
 /* Where the backward leaves the per-layer output gradients in `dy` (an output, not only scratch: gradients w.r.t.
  * per-ray additional inputs and w.r.t. already-encoded input rows are contractions of these with weight columns, see
@@ -296,7 +309,7 @@ int snerf_mlp_train_sizes(const snerf_mlp_desc *desc, int64_t n, int64_t *act_fl
  * SNERF_MAX_MLP_LAYERS entries, each nullable.  d Y_l[s, f] (sample s of n, output feature f < n_out[l]) is the float at
  *     dy[((first_row[l] + f / 16) * n + s) * 16 + f % 16]                                   (tile-row-major) */
 #define SNERF_MAX_MLP_LAYERS 21
-int snerf_mlp_dy_layout(const snerf_mlp_desc *desc, int32_t *n_layers, int32_t *first_row, int32_t *n_out, int32_t *n_in);
+SNERF_API int snerf_mlp_dy_layout(const snerf_mlp_desc *desc, int32_t *n_layers, int32_t *first_row, int32_t *n_out, int32_t *n_in);
 /* Gradients w.r.t. inputs that enter a layer through plain weight columns - per-ray additional inputs, already-encoded input
  * rows, the pose rows of the warp net - as contractions of a stored d Y_l with those columns (what autograd leaves in the
  * .grad of x when y = x W^T; models/render_ray_net.py:43-50, models/append_vertices_pipeline.py:30-58):
@@ -307,28 +320,28 @@ int snerf_mlp_dy_layout(const snerf_mlp_desc *desc, int32_t *n_layers, int32_t *
  * are summed (the pipelines expand one input row per ray over its samples), out [n / samples_per_ray, out_stride];
  * scratch: snerf_dy_contract_scratch_floats(n, ncols, samples_per_ray) floats.  accumulate != 0: out += (several layers
  * read the same inputs: layer 0 and every skip layer). */
-int64_t snerf_dy_contract_scratch_floats(int64_t n, int ncols, int samples_per_ray);
-int snerf_dy_contract_f32(const float *dy, int64_t n, int first_row, int n_feat, const float *w, int w_stride, int col0,
+SNERF_API int64_t snerf_dy_contract_scratch_floats(int64_t n, int ncols, int samples_per_ray);
+SNERF_API int snerf_dy_contract_f32(const float *dy, int64_t n, int first_row, int n_feat, const float *w, int w_stride, int col0,
                           int ncols, int samples_per_ray, float *out, int64_t out_stride, int out_col0, int accumulate,
                           float *scratch, snerf_stream_t stream);
 
 /* snerf_mlp_fwd_f32 that also saves every layer input into `act` (act_floats): fp32 tile-rows, followed by one
  * sign bit per ReLU output (the masks the split-bf16 dgrad reads instead of the activation rows). */
-int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
+SNERF_API int snerf_mlp_fwd_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x,
                             const float *dirs, int dirs_per_sample, const float *add, int64_t n,
                             int samples_per_ray, float *raw, float *act, snerf_stream_t stream);
 /* The same for already-encoded rows (RenderRayNet.forward(x) under autograd). */
-int snerf_mlp_fwd_encoded_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
+SNERF_API int snerf_mlp_fwd_encoded_train_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
                                     int64_t n, int64_t row_floats, float *raw, float *act,
                                     snerf_stream_t stream);
 /* params_flat -> transposed weight stream for the dgrad kernel (once per weight update).  input_grad != 0
  * adds the encoder-column transposes snerf_mlp_bwd_inputs_f32 consumes (a different stream: pack one per use). */
-int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed_t,
+SNERF_API int snerf_mlp_pack_t_f32(const snerf_mlp_desc *desc, const float *params_flat, float *packed_t,
                          int input_grad, snerf_stream_t stream);
 /* d_raw [n,4] -> flat_grad (snerf_mlp_param_floats floats, state_dict order, OVERWRITTEN): what
  * autograd leaves in .grad of the 26 parameter tensors after (raw * d_raw).sum().backward().
  * dy, gpart: scratch (snerf_mlp_train_sizes).  Three launches: dgrad, split-K wgrad, reduce. */
-int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
+SNERF_API int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
                       const float *d_raw, int64_t n, float *dy, float *gpart, float *flat_grad,
                       snerf_stream_t stream);
 
@@ -338,7 +351,7 @@ int snerf_mlp_bwd_f32(const snerf_mlp_desc *desc, const float *packed_t, const f
  * Encoders of up to 8 position / 8 direction k-blocks of 16 slots (identity columns, up to 16 frequencies); the
  * split-precision variant (snerf_mlp_bwd_inputs_bf16_f32) takes the default-sized ones (<= 4 / 2 k-blocks: L = 10 / 4
  * without identity columns, or smaller). */
-int snerf_mlp_bwd_inputs_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
+SNERF_API int snerf_mlp_bwd_inputs_f32(const snerf_mlp_desc *desc, const float *packed_t, const float *act,
                              const float *d_raw, const float *x, const float *dirs, int dirs_per_sample,
                              int samples_per_ray, int64_t n, float *dy, float *gpart, float *flat_grad,
                              float *d_x, float *d_dirs, snerf_stream_t stream);
@@ -346,7 +359,7 @@ int snerf_mlp_bwd_inputs_f32(const snerf_mlp_desc *desc, const float *packed_t, 
 /* Same network on already-encoded rows x_enc [n, row_floats] (the literal RenderRayNet.forward(x)
  * signature): positions_pose = x[:, :positions_dim+add_dim], directions = x[:, -directions_dim:]
  * (models/render_ray_net.py:42-43). */
-int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
+SNERF_API int snerf_mlp_fwd_encoded_f32(const snerf_mlp_desc *desc, const float *packed, const float *x_enc,
                               int64_t n, int64_t row_floats, float *raw, snerf_stream_t stream);
 
 /* ---- a7: WarpFieldNet fused with x' = x + warp and the per-sample view direction ---------------------
@@ -358,47 +371,47 @@ typedef struct snerf_warp_desc {
     int32_t pos_identity; /* 0 */
     int32_t pose_dim;     /* 40 = encoded pose of the two joints (models/smpl_nerf_pipeline.py:28-30) */
 } snerf_warp_desc;
-int64_t snerf_warp_param_floats(const snerf_warp_desc *desc); /* linear1.weight, .bias, linear2.weight, .bias */
-int64_t snerf_warp_packed_floats(const snerf_warp_desc *desc);
-int snerf_warp_pack_f32(const snerf_warp_desc *desc, const float *params_flat, float *packed,
+SNERF_API int64_t snerf_warp_param_floats(const snerf_warp_desc *desc); /* linear1.weight, .bias, linear2.weight, .bias */
+SNERF_API int64_t snerf_warp_packed_floats(const snerf_warp_desc *desc);
+SNERF_API int snerf_warp_pack_f32(const snerf_warp_desc *desc, const float *params_flat, float *packed,
                         snerf_stream_t stream);
 /* x [n,3], pose_enc [n/samples_per_ray, pose_dim], o [n/samples_per_ray, 3] ->
  * warp [n,3] = net([PE(x) | pose_enc]) (models/warp_field_net.py:17-21),
  * warped [n,3] = x + warp (models/smpl_nerf_pipeline.py:49), sdirs [n,3] = warped - o (:52-53).
  * warped / sdirs nullable.  With pos_freqs = pos_identity = 0 the net reads only pose_enc rows
  * (x may be NULL): the literal WarpFieldNet.forward(x_rows) with samples_per_ray = 1. */
-int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
+SNERF_API int snerf_warp_fwd_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
                        const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
                        float *warp, float *warped, float *sdirs, snerf_stream_t stream);
 
 /* With a caller-allocated workspace of snerf_warp_fold_workspace_bytes(desc, n, samples_per_ray) bytes (0: the fold does not
  * apply) the pose columns of linear1 - per-ray constants - are folded into one vector per ray; NULL (= snerf_warp_fwd_f32):
  * the per-sample form; too small: SNERF_E_BADARG.  Same contract as snerf_mlp_fwd_ws_f32. */
-int64_t snerf_warp_fold_workspace_bytes(const snerf_warp_desc *desc, int64_t n, int samples_per_ray);
-int snerf_warp_fwd_ws_f32(const snerf_warp_desc *desc, const float *packed, const float *x, const float *pose_enc,
+SNERF_API int64_t snerf_warp_fold_workspace_bytes(const snerf_warp_desc *desc, int64_t n, int samples_per_ray);
+SNERF_API int snerf_warp_fwd_ws_f32(const snerf_warp_desc *desc, const float *packed, const float *x, const float *pose_enc,
                           const float *o, int64_t n, int samples_per_ray, float *warp, float *warped, float *sdirs,
                           void *workspace, int64_t workspace_bytes, snerf_stream_t stream);
 
 /* The same forward on the bf16 matrix cores (split-bf16, always three parts / six products: fp32-class accuracy - the warp
  * moves the sample in front of the 2^9 band of the position encoding).  packed from snerf_warp_pack_bf16
  * (snerf_warp_packed_bf16_bytes bytes).  Fused mode only (x given); width 256. */
-int64_t snerf_warp_packed_bf16_bytes(const snerf_warp_desc *desc);
-int snerf_warp_pack_bf16(const snerf_warp_desc *desc, const float *params_flat, void *packed, snerf_stream_t stream);
-int snerf_warp_fwd_bf16_f32(const snerf_warp_desc *desc, const void *packed, const float *x, const float *pose_enc,
+SNERF_API int64_t snerf_warp_packed_bf16_bytes(const snerf_warp_desc *desc);
+SNERF_API int snerf_warp_pack_bf16(const snerf_warp_desc *desc, const float *params_flat, void *packed, snerf_stream_t stream);
+SNERF_API int snerf_warp_fwd_bf16_f32(const snerf_warp_desc *desc, const void *packed, const float *x, const float *pose_enc,
                             const float *o, int64_t n, int samples_per_ray, float *warp, float *warped, float *sdirs,
                             snerf_stream_t stream);
 
 /* Training of the warp net: forward that saves [PE(x) | pose | h] tile-rows, the transposed head, and the
  * backward d_warp [n,3] (= d loss / d warp, the sum of what arrives through warp, warped and sdirs) ->
  * flat_grad (snerf_warp_param_floats floats, state_dict order, overwritten).  Sizes as snerf_mlp_train_sizes. */
-int snerf_warp_train_sizes(const snerf_warp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
+SNERF_API int snerf_warp_train_sizes(const snerf_warp_desc *desc, int64_t n, int64_t *act_floats, int64_t *dy_floats,
                            int64_t *packed_t_floats, int64_t *gpart_floats);
-int snerf_warp_fwd_train_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
+SNERF_API int snerf_warp_fwd_train_f32(const snerf_warp_desc *desc, const float *packed, const float *x,
                              const float *pose_enc, const float *o, int64_t n, int samples_per_ray,
                              float *warp, float *warped, float *sdirs, float *act, snerf_stream_t stream);
-int snerf_warp_pack_t_f32(const snerf_warp_desc *desc, const float *params_flat, float *packed_t,
+SNERF_API int snerf_warp_pack_t_f32(const snerf_warp_desc *desc, const float *params_flat, float *packed_t,
                           snerf_stream_t stream);
-int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *packed_t, const float *act,
+SNERF_API int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *packed_t, const float *act,
                        const float *d_warp, int64_t n, float *dy, float *gpart, float *flat_grad,
                        snerf_stream_t stream);
 
@@ -408,7 +421,7 @@ int snerf_warp_bwd_f32(const snerf_warp_desc *desc, const float *packed_t, const
  * jitter fp64 [B] = the per-ray np.random.rand() scalar; lower/span fp64 [Nc] = the bin tables of
  * CoarseSampling (lower, upper - lower).  fp64 arithmetic in the reference's order, one rounding to fp32:
  * bit-identical to the numpy path.  Outputs: samples [B,Nc,3], o [B,3], d [B,3], z [B,Nc] fp32. */
-int snerf_raygen_f64(const double *poses, int64_t n_frames, int H, int W, double focal, const double *lower,
+SNERF_API int snerf_raygen_f64(const double *poses, int64_t n_frames, int H, int W, double focal, const double *lower,
                      const double *span, int Nc, const int64_t *ray_index, const double *jitter, int64_t B,
                      float *samples, float *o, float *d, float *z, snerf_stream_t stream);
 
@@ -421,8 +434,8 @@ int snerf_raygen_f64(const double *poses, int64_t n_frames, int H, int W, double
  * utils.py:171-173).  Nf == 0 is run_fine = 0: the fine outputs are copies of the coarse ones (:43-44).
  * workspace: snerf_render_rays_workspace_bytes(B, Nc, Nf) bytes, 16-byte aligned.  Outputs: rgb [B,3],
  * rgb_fine [B,3], samples_fine [B,Nc+Nf,3], densities_fine [B,Nc+Nf] (the `alpha` of utils.py:169). */
-int64_t snerf_render_rays_workspace_bytes(int64_t B, int Nc, int Nf);
-int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+SNERF_API int64_t snerf_render_rays_workspace_bytes(int64_t B, int Nc, int Nf);
+SNERF_API int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
                           const snerf_mlp_desc *desc_fine, const void *packed_fine, int precision,
                           const float *ray_samples, const float *rays_o, const float *rays_d, const float *z_vals,
                           const float *u, const float *noise_coarse, const float *noise_fine, int64_t B, int Nc,
@@ -435,9 +448,9 @@ int snerf_render_rays_f32(const snerf_mlp_desc *desc_coarse, const void *packed_
  * their `add` input (descriptors with add_dim > 0, add_first as the pipeline has it).  In fp32 the rows are folded into one
  * vector per ray and layer inside the call (snerf_mlp_fwd_ws_f32) - the fold table lives in the workspace:
  * snerf_render_rays_add_workspace_bytes(...) bytes, 16-byte aligned. */
-int64_t snerf_render_rays_add_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B, int Nc,
+SNERF_API int64_t snerf_render_rays_add_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B, int Nc,
                                               int Nf);
-int snerf_render_rays_add_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const snerf_mlp_desc *desc_fine,
+SNERF_API int snerf_render_rays_add_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const snerf_mlp_desc *desc_fine,
                               const void *packed_fine, int precision, const float *ray_samples, const float *rays_o,
                               const float *rays_d, const float *z_vals, const float *additional, const float *u,
                               const float *noise_coarse, const float *noise_fine, int64_t B, int Nc, int Nf, int white_background,
@@ -452,8 +465,8 @@ int snerf_render_rays_add_f32(const snerf_mlp_desc *desc_coarse, const void *pac
  * packed_warp from snerf_warp_pack_f32 / snerf_warp_pack_bf16 accordingly).  Nf >= 1.  workspace:
  * snerf_render_rays_smpl_workspace_bytes bytes.  Outputs: rgb [B,3], rgb_fine [B,3], warp_fine / samples_fine /
  * warped_fine [B,Nc+Nf,3], densities_fine [B,Nc+Nf]. */
-int64_t snerf_render_rays_smpl_workspace_bytes(int64_t B, int Nc, int Nf);
-int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+SNERF_API int64_t snerf_render_rays_smpl_workspace_bytes(int64_t B, int Nc, int Nf);
+SNERF_API int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
                                const snerf_mlp_desc *desc_fine, const void *packed_fine,
                                const snerf_warp_desc *desc_warp, const void *packed_warp, int precision,
                                const float *ray_samples, const float *rays_o, const float *rays_d, const float *z_vals,
@@ -477,7 +490,7 @@ int snerf_render_rays_smpl_f32(const snerf_mlp_desc *desc_coarse, const void *pa
  * transposed stream that holds parameter i of params_flat, or -1 (biases do not appear in the transposed stream).
  * input_grad selects WHICH transposed stream (snerf_mlp_pack_t_f32's input_grad: 0 for snerf_nerf_train_*, 1 for
  * snerf_smpl_nerf_train_*).  Every parameter occupies at most one float of each stream. */
-int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, int input_grad, snerf_stream_t stream);
+SNERF_API int snerf_mlp_stream_slots(const snerf_mlp_desc *desc, int32_t *slot_fwd, int32_t *slot_t, int input_grad, snerf_stream_t stream);
 
 /* torch.optim.Adam(params, lr, betas, eps, weight_decay) (amsgrad = False) over ONE flat fp32 parameter buffer - the
  * statements of torch's single-tensor update in their order (solver/nerf_solver.py:11-14, 31-33, 87). */
@@ -509,7 +522,7 @@ typedef struct snerf_adam_net {
     const int32_t *slot_fwd, *slot_t; /* snerf_mlp_stream_slots (precision 0 only) */
 } snerf_adam_net;
 /* One optimiser step on the ranges (HOST array, at most 32) with the streams of at most 8 nets (HOST array) kept current. */
-int snerf_adam_step_f32(const snerf_adam_state *state, const snerf_adam_range *ranges_host, int n_ranges,
+SNERF_API int snerf_adam_step_f32(const snerf_adam_state *state, const snerf_adam_range *ranges_host, int n_ranges,
                         const snerf_adam_net *nets_host, int n_nets, snerf_stream_t stream);
 
 /* The batch as the Solver hands it to the pipeline (solver/nerf_solver.py:77-81) plus what utils.py draws inside. */
@@ -541,16 +554,16 @@ typedef struct snerf_nerf_batch {
  * hierarchical samples being detached (utils.py:260) - is enqueued on aux_stream beside it (forked from and joined back into
  * `stream` with events, also under graph capture).  NULL: everything on `stream`.  Same results either way.
  * workspace: snerf_nerf_train_workspace_bytes(...) bytes, 256-byte aligned. */
-int64_t snerf_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B, int Nc,
+SNERF_API int64_t snerf_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine, int64_t B, int Nc,
                                          int Nf, int64_t rays_per_chunk);
-int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+SNERF_API int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                                const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
                                const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
                                float *grad_fine, float *loss, float *rgb, float *rgb_fine, snerf_stream_t stream,
                                snerf_stream_t aux_stream);
 /* snerf_nerf_train_grads_f32 followed by snerf_adam_step_f32 (single-GPU step; a data-parallel trainer calls the two halves
  * with its gradient all-reduce in between). */
-int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+SNERF_API int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                               const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
                               const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
                               float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
@@ -569,15 +582,15 @@ int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *pac
  * here - run those nets with precision 0 (the Python trainer takes its autograd path, which routes that dgrad to fp32).  grad_warp: snerf_warp_param_floats floats.  Ray chunks, workspace, loss, rgb as in snerf_nerf_train_grads_f32.
  * The step variant runs snerf_adam_step_f32 and then re-packs the warp net's two streams (packed_warp from snerf_warp_pack_f32,
  * packed_t_warp from snerf_warp_pack_t_f32) from its parameters at params + warp_param_offset. */
-int64_t snerf_smpl_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine,
+SNERF_API int64_t snerf_smpl_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_coarse, const snerf_mlp_desc *desc_fine,
                                               const snerf_warp_desc *desc_warp, int64_t B, int Nc, int Nf, int64_t rays_per_chunk);
-int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+SNERF_API int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                                     const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
                                     const snerf_warp_desc *desc_warp, const float *packed_warp, const float *packed_t_warp,
                                     int precision, const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk,
                                     void *workspace, float *grad_coarse, float *grad_fine, float *grad_warp, float *loss, float *rgb,
                                     float *rgb_fine, snerf_stream_t stream);
-int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+SNERF_API int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                                    const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
                                    const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,
                                    const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk, void *workspace,
@@ -586,7 +599,7 @@ int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void
                                    const snerf_adam_net *nets_host, int n_nets, int64_t warp_param_offset, snerf_stream_t stream);
 /* packed_warp / packed_t_warp (each nullable) from the warp net's parameters at params + warp_param_offset: what a
  * data-parallel caller runs behind snerf_adam_step_f32. */
-int snerf_warp_repack_f32(const snerf_warp_desc *desc_warp, const float *params, int64_t n_params, int64_t warp_param_offset,
+SNERF_API int snerf_warp_repack_f32(const snerf_warp_desc *desc_warp, const float *params, int64_t n_params, int64_t warp_param_offset,
                           float *packed_warp, float *packed_t_warp, snerf_stream_t stream);
 
 #ifdef __cplusplus

@@ -113,6 +113,9 @@ def raw2outputs(raw, z_vals, samples_directions, args):
     return rgb, weights, density
 
 
+LAST = {}      # the searchsorted indices of the most recent sample_pdf call (a reference to the tensor, no copy)
+
+
 def sample_pdf(bins, weights, args):
     """utils.py:194-228."""
     weights = weights + 1e-5
@@ -123,6 +126,7 @@ def sample_pdf(bins, weights, args):
     u = u.expand(list(cdf.shape[:-1]) + [args.number_fine_samples])
     u = u.contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
+    LAST["inds"] = inds          # (checker's tap: bench.py compares the HIP sampler's indices with these)
     below = torch.max(torch.zeros_like(inds - 1), inds - 1)
     above = torch.min(cdf.shape[-1] - 1 * torch.ones_like(inds), inds)
     inds_g = torch.stack([below, above], -1)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "snerf_version": (c_int, []),
     "snerf_last_error_string": (c_char_p, []),
     "snerf_device_count": (c_int, []),
+    "snerf_shutdown": (c_int, []),
     "snerf_searchsorted_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
     "snerf_searchsorted": (c_int, [c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
     "snerf_posenc_bwd_f32": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P]),

@@ -98,6 +98,13 @@ const Tuning &tuning() {
 
 extern "C" int snerf_version(void) { return SNERF_VERSION; }
 extern "C" const char *snerf_last_error_string(void) { return snerf::err_buf(); }
+namespace snerf {
+void destroy_fork_join_events();   // train_step.hip
+}
+extern "C" int snerf_shutdown(void) {
+    snerf::destroy_fork_join_events();
+    return SNERF_OK;
+}
 extern "C" int snerf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

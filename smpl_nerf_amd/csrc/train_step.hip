@@ -16,6 +16,10 @@
 // summed over the chunks in chunk order - and the saved layer inputs / d Y buffers (21 KB per sample) are sized by the
 // chunk, not by the batch.  Nothing is recomputed (the autograd form needs the whole forward before any backward; the
 // reference keeps 2.6 MB per ray alive).
+#include <mutex>
+#include <thread>
+#include <vector>
+
 #include "mlp_device.h"
 
 namespace snerf {
@@ -308,19 +312,56 @@ struct TrainWs {
 #endif
 constexpr int64_t CONCURRENT_MAX_FINE_SAMPLES = SNERF_CONCURRENT_MAX_FINE_SAMPLES;
 
-// fork / join events of the concurrent backward: one pair per host thread and device (include/smplnerf.h "State")
+// fork / join events of the concurrent backward: one pair per host thread and device (include/smplnerf.h "State"), kept in a
+// registry so that snerf_shutdown() can destroy them
+struct EventPair {
+    std::thread::id tid;
+    int dev;
+    hipEvent_t ev[2];
+};
+static std::mutex &event_mutex() {
+    static std::mutex m;
+    return m;
+}
+static std::vector<EventPair> &event_registry() {
+    static std::vector<EventPair> v;
+    return v;
+}
 static int fork_join_events(hipEvent_t &fork, hipEvent_t &join) {
-    static thread_local hipEvent_t ev[MAX_DEVICES][2] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return fail(SNERF_E_LAUNCH, "nerf_train: cannot query the current device");
+    const std::thread::id me = std::this_thread::get_id();
+    std::lock_guard<std::mutex> lock(event_mutex());
+    for (const EventPair &p : event_registry())
+        if (p.tid == me && p.dev == dev) {
+            fork = p.ev[0];
+            join = p.ev[1];
+            return SNERF_OK;
+        }
+    EventPair p{me, dev, {nullptr, nullptr}};
     for (int k = 0; k < 2; ++k)
-        if (!ev[dev][k] && hipEventCreateWithFlags(&ev[dev][k], hipEventDisableTiming) != hipSuccess) {
-            ev[dev][k] = nullptr;
+        if (hipEventCreateWithFlags(&p.ev[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (k == 1) (void)hipEventDestroy(p.ev[0]);
             return fail(SNERF_E_LAUNCH, "nerf_train: cannot create an event");
         }
-    fork = ev[dev][0];
-    join = ev[dev][1];
+    event_registry().push_back(p);
+    fork = p.ev[0];
+    join = p.ev[1];
     return SNERF_OK;
+}
+void destroy_fork_join_events() {
+    std::lock_guard<std::mutex> lock(event_mutex());
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (const EventPair &p : event_registry()) {
+        (void)hipSetDevice(p.dev);
+        (void)hipEventDestroy(p.ev[0]);
+        (void)hipEventDestroy(p.ev[1]);
+    }
+    event_registry().clear();
+    if (have_cur) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
 }
 
 static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t chunk, int Nc, int Nf, TrainWs &w, bool two_streams = true) {

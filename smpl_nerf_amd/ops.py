@@ -327,7 +327,9 @@ class _SamplePdfGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bins, weights, zs, inds, u, tot):
-        ctx.save_for_backward(bins.detach(), weights.detach(), inds, u, tot)
+        # dense copies: the backward kernel walks [B, Nb] / [B, Nb - 1] rows by pointer, and the reference's own caller passes a
+        # strided view (`weights[..., 1:-1]`, utils.py:259)
+        ctx.save_for_backward(bins.detach().contiguous(), weights.detach().contiguous(), inds, u, tot)
         return zs
 
     @staticmethod
@@ -335,7 +337,8 @@ class _SamplePdfGrad(torch.autograd.Function):
         bins, weights, inds, u, tot = ctx.saved_tensors
         B, Nb = bins.shape
         d_zs = d_zs.contiguous().float()
-        gb, gw = torch.empty_like(bins), torch.empty_like(weights)
+        gb = torch.empty(bins.shape, device=bins.device, dtype=torch.float32)
+        gw = torch.empty(weights.shape, device=bins.device, dtype=torch.float32)
         lib = _lib.load()
         with torch.cuda.device(bins.device):
             check(lib.snerf_sample_pdf_bins_bwd_f32(ptr(bins), ptr(weights), ptr(u), ptr(inds), ptr(tot), ptr(d_zs), B, Nb, inds.shape[1],

@@ -31,9 +31,19 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.snerf_version() == 105
+    assert lib.snerf_version() == 106
     assert isinstance(lib.snerf_last_error_string(), bytes)
     assert lib.snerf_device_count() >= 0
+
+
+def test_only_the_header_symbols_are_exported(lib):
+    """-fvisibility=hidden + SNERF_API: `nm -D --defined-only` of the library lists the header's entry points and nothing else
+    (no C++ symbols of namespace snerf, no template instantiations a host's own code could collide with)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert names == header_symbols(), sorted(set(names) ^ set(header_symbols()))
+    assert lib.snerf_shutdown() == 0 and lib.snerf_shutdown() == 0          # idempotent, nothing to destroy on a CPU box
 
 
 def test_argument_validation_happens_on_the_host(lib):

@@ -181,3 +181,24 @@ def test_committed_r04_bench_lines_are_self_consistent():
     for wl in ("append_vertices", "append_smpl_params"):
         a = J(f"r04_bench_{wl}_input_grads.json.log")["train"]
         assert a["input_gradients"] and any(k.startswith("dy_contract") for k in a["kernels_ms_per_step"])
+
+
+def test_quality_keys_of_the_bench_line():
+    """The quality half of BASELINE's metric in the JSON line: PSNR by util/scores.py:47-48 of the HIP render and of the CPU
+    reference path's render against the same ground truth, their difference, the PSNR between the two renders (the sampler
+    key needs the GPU and is covered by the -m gpu bench test)."""
+    import torch
+    rng = np.random.default_rng(0)
+    gt = rng.random((64, 3)).astype(np.float32)
+    cpu = (gt + 0.05 * rng.standard_normal((64, 3))).astype(np.float32)
+    hip = cpu + np.float32(1e-5)
+    out = [torch.zeros(64, 3), torch.from_numpy(hip)]
+    q = bench.quality_keys(out, [np.zeros((64, 3), np.float32), cpu], gt, 64, None, None, None)
+    mse = np.mean((hip.astype(np.float64) - gt) ** 2)
+    assert abs(q["psnr_db"] - (-10.0 * np.log(mse) / np.log(10.0))) < 1e-9
+    assert abs(q["psnr_delta_db_vs_oracle"] - (q["psnr_db"] - q["psnr_db_cpu_reference_path"])) < 1e-12
+    assert abs(q["psnr_delta_db_vs_oracle"]) < 0.01 and q["psnr_db_hip_vs_cpu_reference_render"] > 90
+    assert "sampler_index_equal_frac" not in q
+    same = bench.quality_keys([out[0], torch.from_numpy(cpu)], [cpu, cpu], gt, 64, None, None, None)
+    assert same["psnr_db_hip_vs_cpu_reference_render"] is None and same["psnr_delta_db_vs_oracle"] == 0.0
+    json.dumps(same)
