@@ -392,6 +392,12 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
         if (rc != 1) return rc;
     }
     if (tuning().fwd_waves == 4) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
+    // Calls of a few 16-sample tiles per CU (the README's 64-ray batches, inference.py's 800 rays): the latency-class kernels
+    // (mlp_lat.hip: a tile's output features split over the waves of a workgroup; bit-identical results)
+    if constexpr (!ENCODED) {
+        const int rc = launch_fwd_lat<TRAIN>(P, A, s);
+        if (rc != 1) return rc;
+    }
     // Small calls (the README's 64-ray batches: 4096 + 12 288 samples): while 64-sample tiles still fit one round of the chip,
     // the 4-wave form finishes in half the time of a 128-sample tile's pass through the weight stream - a call of up to
     // 64 x CUs samples is one tile's latency, not throughput (same per-sample arithmetic: bit-identical results).

@@ -1,0 +1,468 @@
+// Latency-class forward and dgrad of the fused RenderRayNet for small calls (mlp_lat_device.h has the design): the reference's own
+// operating points - README.md:23 trains at --batchsize=64 (4096 coarse + 12 288 fine samples per step), inference.py:231 renders 800
+// rays per call - are below one 128-sample tile per CU, where the throughput kernels of mlp.hip / mlp_train.hip are one wave's serial
+// pass through the weight stream.  Same C-ABI entry points, same packed streams, same activation / dY / mask buffers, bit-identical
+// results: launch_fwd (mlp.hip) and launch_bwd (mlp_train.hip) route here by size.
+//
+// Replaces, like they do: RenderRayNet.forward (models/render_ray_net.py:42-61) + the encoders feeding it
+// (models/nerf_pipeline.py:29-39, :49-57), and loss.backward() through it (solver/nerf_solver.py:83-87).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "mlp_lat_device.h"
+
+namespace snerf {
+
+struct LatLds {   // byte offsets into the dynamic LDS of a workgroup
+    int act[2];   // two activation buffers, S x 16 KiB each
+    // forward: the encoder k-blocks of a sample tile, pe_stride bytes each: [position k-blocks][zero k-blocks up to a multiple of LAT_PF]
+    // [direction k-blocks][zero k-blocks: 16 + dir_nkb up to a multiple of LAT_PF]; dgrad: the d rgb operand + 3 zero k-blocks
+    int pe, pe_stride, pe_dir;   // pe_dir: offset of the direction k-blocks inside a tile's region
+    int aux, aux_stride;         // dgrad: the ReLU sign-mask words of the pass, S x n_mask x 512 B (forward: unused)
+    int total;
+};
+static inline int lat_pad(int nkb) { return (nkb + LAT_PF - 1) / LAT_PF * LAT_PF; }
+static inline LatLds lat_lds(int S, int pos_nkb, int dir_nkb, int aux_bytes) {
+    LatLds o;
+    o.act[0] = 0;
+    o.act[1] = S * LAT_ACT_BYTES;
+    o.pe = 2 * S * LAT_ACT_BYTES;
+    o.pe_dir = lat_pad(pos_nkb) * 1024;
+    o.pe_stride = o.pe_dir + (lat_pad(16 + dir_nkb) - 16) * 1024;
+    o.aux = o.pe + S * o.pe_stride;
+    o.aux_stride = aux_bytes;
+    o.total = o.aux + S * aux_bytes;
+    return o;
+}
+// forward: sigma of a sample travels from the sigma head's wave to the rgb head's through the last KiB of the sample tile's
+// directional-branch buffer (a 128-wide layer fills half of the 16 KiB)
+constexpr int LAT_SIG_OFF = 15 * 1024;
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int S, bool TRAIN>
+__global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_in_kernarg, FwdArgs A, LatGeom G, LatLds Lo) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const LatTabPtr tab = lat_table_ptr();   // = &tab_in_kernarg, read in place (mlp_lat_device.h)
+    const int tid = threadIdx.x;
+    LatWave W;
+    W.start(tab, A.packed, tid, G.passes);
+    const int lane = W.lane, wave = W.wave, g = lane >> 4;
+    const int enc_nkb = A.pos_nkb + A.dir_nkb;
+    const unsigned n32 = (unsigned)A.n;
+    const __amdgpu_buffer_rsrc_t act_rs = lat_rsrc(TRAIN ? A.act : A.raw, LAT_STORE_RANGE);   // (TRAIN only)
+    const __amdgpu_buffer_rsrc_t raw_rs = lat_rsrc(A.raw, LAT_STORE_RANGE);
+    const int n_layers = tab->n;
+
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < G.passes; ++pass) {
+        const int64_t tile0 = G.tile_off + ((int64_t)blockIdx.x * G.passes + pass) * S;
+        // sample of this lane in sample tile s (clamped for loads; `okay` gates every store)
+        auto sample_of = [&](int s) { return (tile0 + s) * 16 + (lane & 15); };
+        auto okay = [&](int s) { return tile0 + s < G.tile_end && sample_of(s) < A.n; };
+        // TRAIN: byte offset of this lane's tile in row `row` of the activation buffer, out of range for a masked sample
+        auto act_off = [&](int s, int row) { return okay(s) ? lat_tile_off(row, n32, (unsigned)sample_of(s), g) : LAT_OOB; };
+
+        // ---- phase 0: the encoder k-blocks of the pass, one (tile, k-block) unit per wave at a time -> LDS ---------------
+        if (pass == 0) {   // the zero k-blocks behind them (padding steps of layers whose k-block count is not a multiple of LAT_PF)
+            const int zp = Lo.pe_dir / 1024 - A.pos_nkb, zd = (Lo.pe_stride - Lo.pe_dir) / 1024 - A.dir_nkb;
+            for (int u = wave; u < S * (zp + zd); u += LAT_NW) {
+                const int s = u / (zp + zd), k = u - s * (zp + zd);
+                const int off = k < zp ? (A.pos_nkb + k) * 1024 : Lo.pe_dir + (A.dir_nkb + k - zp) * 1024;
+                *reinterpret_cast<f4 *>(lds + Lo.pe + s * Lo.pe_stride + off + W.voff) = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        for (int u = wave; u < S * enc_nkb; u += LAT_NW) {
+            const int s = u / enc_nkb, k = u - s * enc_nkb;
+            const bool is_dir = k >= A.pos_nkb;
+            const int kb = is_dir ? k - A.pos_nkb : k;
+            const int64_t smp = sample_of(s), sc = min(smp, A.n - 1);
+            SampleCtx c;
+            c.g = g;
+            c.enc = nullptr;
+            c.add = nullptr;
+            c.px = c.py = c.pz = c.dx = c.dy = c.dz = 0.f;
+            if (is_dir) {
+                const float *dp = A.dirs + (A.dirs_per_sample ? sc : sc / A.spr) * 3;
+                const float ux = dp[0], uy = dp[1], uz = dp[2];
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ux, ux), __fmul_rn(uy, uy)), __fmul_rn(uz, uz)));
+                c.dx = __fdiv_rn(ux, nrm);  // models/nerf_pipeline.py:33-34
+                c.dy = __fdiv_rn(uy, nrm);
+                c.dz = __fdiv_rn(uz, nrm);
+            } else {
+                c.px = A.x[sc * 3 + 0];
+                c.py = A.x[sc * 3 + 1];
+                c.pz = A.x[sc * 3 + 2];
+            }
+            const f4 b = pe_operand<false>(c, is_dir, is_dir ? A.dir_L : A.pos_L, is_dir ? A.dir_id : A.pos_id, kb, 0);
+            *reinterpret_cast<f4 *>(lds + Lo.pe + s * Lo.pe_stride + (is_dir ? Lo.pe_dir + kb * 1024 : kb * 1024) + W.voff) = b;
+            if (TRAIN) lat_store_f4(act_rs, act_off(s, (is_dir ? A.act_dpe : A.act_pe) + kb), b);
+        }
+        __syncthreads();
+
+        // ---- the layers of the table (host: lat_table_fwd), one site for all of them ---------------------------------------
+#pragma clang loop unroll(disable)
+        for (int l = 0; l < n_layers; ++l) {
+            const LatLayer Ly = lat_layer_at(tab, l);
+            const int w0 = Ly.wave0, t_out = Ly.t_out, op = Ly.op;
+            if (wave >= w0 && wave < w0 + ((t_out + 1) >> 1)) {
+                const int tile = 2 * (wave - w0);
+                f4 acc[S][2];
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[s][0] = W.aux[0], acc[s][1] = W.aux[1];
+                lat_run_layer<S>(W, tab, lds, Ly, acc);
+                // (a head: out_base is the directional-branch buffer, whose last KiB per sample tile carries sigma)
+                float *sig = reinterpret_cast<float *>(lds + Ly.out_base + LAT_SIG_OFF);
+                if (op & LAT_HEAD_SIGMA) {          // sigma_out_layer (:52): row 0 of the padded tile (lanes 0..15 hold it)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sig[s * (LAT_ACT_BYTES / 4) + lane] = acc[s][0][0];
+                } else if (op & LAT_HEAD_RGB) {     // rgb_out_layer (:60): rows 0..2, and the [rgb | sigma] store (:61)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const f4 o = f4{acc[s][0][0], acc[s][0][1], acc[s][0][2], sig[s * (LAT_ACT_BYTES / 4) + (lane & 15)]};
+                        lat_store_f4(raw_rs, (lane < 16 && okay(s)) ? (unsigned)sample_of(s) * 16u : LAT_OOB, o);
+                    }
+                } else {
+                    // a wide layer: activation -> LDS in B-operand layout; TRAIN: the tiles into rows store_row + tile .. of the
+                    // activation buffer and this wave's byte of the sign-mask word (store_mask, mlp_device.h: tiles 2w, 2w+1 are
+                    // byte w of the 64-bit word)
+                    const bool relu = op & LAT_RELU;
+                    const int out_base = Ly.out_base, store_row = Ly.store_row, mask_idx = Ly.mask_idx;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        f4 v[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[t][r] = relu ? fmaxf(acc[s][t][r], 0.f) : acc[s][t][r];
+                        f4 *dst = reinterpret_cast<f4 *>(lds + out_base + s * LAT_ACT_BYTES + tile * 1024 + W.voff);
+                        dst[0] = v[0];
+                        dst[64] = v[1];
+                        if (TRAIN) {
+                            lat_store_f4(act_rs, act_off(s, store_row + tile), v[0]);
+                            lat_store_f4(act_rs, act_off(s, store_row + tile + 1), v[1]);
+                            unsigned m = 0;
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) m |= (unsigned)min(max(__float_as_int(v[t][r]), 0), 1) << (4 * t + r);
+                            // (always issued: a layer without a mask stores out of range - see lat_store_f4)
+                            const unsigned mo = (mask_idx >= 0 && okay(s)) ? lat_mask_off(A.act_mask, mask_idx, n32, (unsigned)sample_of(s), g) + (unsigned)(tile >> 1) : LAT_OOB;
+                            lat_store_b8(act_rs, mo, m);
+                            lat_store_b8(act_rs, (mo != LAT_OOB && (op & LAT_HALF_WORD)) ? mo + 4u : LAT_OOB, 0u);
+                        }
+                    }
+                }
+            }
+            if (op & LAT_BARRIER) __syncthreads();
+        }
+        // (the next pass's phase 0 writes the encoder region only, and its barrier stands between this pass's rgb reads and the
+        // first activation write of the next pass)
+    }
+}
+
+static void lat_layer_stream(LatLayer &o, int first_slab, int nkb, int t_out) {
+    o.soff = first_slab * SLAB_BYTES;
+    o.nkb = nkb;
+    o.t_out = t_out;
+    int kps = SLAB_TILES / t_out, sh = 0;
+    while ((1 << sh) < kps) ++sh;
+    o.kps_shift = sh;
+}
+
+// the forward stream of `P` as the latency kernels walk it: layers in plan order (mlp_plan.h: make_plan)
+static void lat_table_fwd(const Plan &P, const TrainLayout &L, const LatLds &Lo, LatTable &T) {
+    T.n = P.nlayers;
+    T.stream_bytes = (P.total_slabs + SLAB_PAD) * SLAB_BYTES;
+    const int nh = P.n_hidden;
+    const int o_buf = Lo.act[(nh + 1) & 1], h_buf = Lo.act[nh & 1];
+    const int NONE = 1 << 20;   // "every k-block comes from the first region"
+    for (int l = 0; l < P.nlayers; ++l) {
+        const Layer &Ly = P.layer[l];
+        LatLayer &o = T.l[l];
+        lat_layer_stream(o, Ly.first_slab, Ly.nkb, Ly.t_out);
+        o.wave0 = 0;
+        o.b_base1 = o.b_stride1 = 0;
+        o.out_base = -1;
+        o.store_row = o.mask_idx = -1;
+        o.pad_[0] = o.pad_[1] = 0;
+        if (l == 0) {                 // positions_pose_input + relu (:45): reads the position encoding
+            o.b_base0 = Lo.pe, o.b_stride0 = Lo.pe_stride, o.b_n0 = NONE;
+        } else if (l <= nh + 1) {     // positional_net[l - 1] + relu (:46-50): the previous output and, as a skip layer, the encoding behind
+            o.b_base0 = Lo.act[(l + 1) & 1], o.b_stride0 = LAT_ACT_BYTES, o.b_n0 = 16;   // it; additional_linear_layer (:51): no activation
+            o.b_base1 = Lo.pe, o.b_stride1 = Lo.pe_stride;
+        }
+        if (l <= nh + 1) {
+            o.out_base = Lo.act[l & 1];
+            o.op = (l <= nh ? LAT_RELU : 0) | LAT_BARRIER;
+            o.store_row = l <= nh ? L.x[1] + l * 16 : L.o;
+            o.mask_idx = l <= nh ? l : -1;
+        } else if (l == nh + 2) {     // sigma_out_layer (:52) on wave 4, beside directional_input
+            o.wave0 = 4;
+            o.b_base0 = o_buf, o.b_stride0 = LAT_ACT_BYTES, o.b_n0 = NONE;
+            o.out_base = h_buf;   // (sigma goes into its last KiB)
+            o.op = LAT_HEAD_SIGMA;
+        } else if (l == nh + 3) {     // directional_input, no activation (:54-57): o and the direction encoding
+            o.b_base0 = o_buf, o.b_stride0 = LAT_ACT_BYTES, o.b_n0 = 16;
+            o.b_base1 = Lo.pe + Lo.pe_dir, o.b_stride1 = Lo.pe_stride;
+            o.out_base = h_buf;
+            o.op = LAT_BARRIER;
+            o.store_row = L.h1;
+        } else if (l == nh + 4) {     // directional_net[0] + relu (:58-59)
+            o.b_base0 = h_buf, o.b_stride0 = LAT_ACT_BYTES, o.b_n0 = NONE;
+            o.out_base = o_buf;
+            o.op = LAT_RELU | LAT_BARRIER | LAT_HALF_WORD;
+            o.store_row = L.h2;
+            o.mask_idx = nh + 1;
+        } else {                      // rgb_out_layer (:60) on wave 5
+            o.wave0 = 5;
+            o.b_base0 = o_buf, o.b_stride0 = LAT_ACT_BYTES, o.b_n0 = NONE;
+            o.out_base = h_buf;
+            o.op = LAT_HEAD_RGB;
+        }
+    }
+    lat_table_finish(T);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dgrad: the forward pass of the transposed network on d raw (mlp_train.hip: mlp_bwd_kernel), through the same interpreter
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(LAT_THREADS) void mlp_bwd_lat_kernel(LatTable tab_in_kernarg, BwdArgs A, LatGeom G, LatLds Lo) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const LatTabPtr tab = lat_table_ptr();
+    const int tid = threadIdx.x;
+    LatWave W;
+    W.start(tab, A.packed_t, tid, G.passes);
+    const int lane = W.lane, wave = W.wave, g = lane >> 4;
+    const unsigned n32 = (unsigned)A.n;
+    const __amdgpu_buffer_rsrc_t dy_rs = lat_rsrc(A.dy, LAT_STORE_RANGE);
+    const int n_layers = tab->n, n_mask = A.n_hidden + 2;
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < G.passes; ++pass) {
+        const int64_t tile0 = G.tile_off + ((int64_t)blockIdx.x * G.passes + pass) * S;
+        auto sample_of = [&](int s) { return (tile0 + s) * 16 + (lane & 15); };
+        auto okay = [&](int s) { return tile0 + s < G.tile_end && sample_of(s) < A.n; };
+        auto dy_off = [&](int s, int row) { return okay(s) ? lat_tile_off(row, n32, (unsigned)sample_of(s), g) : LAT_OOB; };
+
+        // ---- phase 0: d raw of this lane's samples; the d rgb operand of the first layer (+ three k-blocks of zeros behind it: the
+        // layer has one k-block) into the second activation buffer, which nobody uses yet; the head gradients as tile-rows for the
+        // wgrad kernel (rows 0..2 = rgb, row 0 = sigma); the ReLU sign-mask words of the pass -> LDS ------------------------------
+        f4 dr[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) dr[s] = *reinterpret_cast<const f4 *>(A.d_raw + min(sample_of(s), A.n - 1) * 4);
+        for (int s = wave; s < S; s += LAT_NW) {
+            f4 *blk = reinterpret_cast<f4 *>(lds + Lo.act[1] + s * LAT_ACT_BYTES + W.voff);
+            const f4 drgb = g == 0 ? f4{dr[0][0], dr[0][1], dr[0][2], 0.f} : zero, dsig = g == 0 ? f4{dr[0][3], 0.f, 0.f, 0.f} : zero;
+            f4 v = drgb, w = dsig;
+#pragma unroll
+            for (int q = 1; q < S; ++q)
+                if (s == q) v = g == 0 ? f4{dr[q][0], dr[q][1], dr[q][2], 0.f} : zero, w = g == 0 ? f4{dr[q][3], 0.f, 0.f, 0.f} : zero;
+            blk[0] = v;
+            blk[64] = zero;
+            blk[128] = zero;
+            blk[192] = zero;
+            lat_store_f4(dy_rs, dy_off(s, A.dy_rgb), v);
+            lat_store_f4(dy_rs, dy_off(s, A.dy_sig), w);
+        }
+        for (int u = wave; u < S * n_mask; u += LAT_NW) {
+            const int s = u / n_mask, idx = u - s * n_mask;
+            const int64_t sc = min(sample_of(s), A.n - 1);
+            *reinterpret_cast<uint2 *>(lds + Lo.aux + s * Lo.aux_stride + idx * 512 + lane * 8) = *mask_ptr(A.act, A.act_mask, idx, A.n, sc, g);
+        }
+        __syncthreads();
+
+#pragma clang loop unroll(disable)
+        for (int l = 0; l < n_layers; ++l) {
+            const LatLayer Ly = lat_layer_at(tab, l);
+            const int w0 = Ly.wave0, t_out = Ly.t_out, op = Ly.op;
+            if (wave >= w0 && wave < w0 + ((t_out + 1) >> 1)) {
+                const int tile = 2 * (wave - w0);
+                f4 acc[S][2];
+                const bool scale = op & LAT_SCALE_AUX;   // d o = directional_input[:, :W]^T d h1 + sigma_out_layer^T d sigma (:51-52)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[s][t][r] = scale ? W.aux[t][r] * dr[s][3] : W.aux[t][r];
+                lat_run_layer<S>(W, tab, lds, Ly, acc);
+                const bool mask = op & LAT_MASK_BITS;
+                const int out_base = Ly.out_base, store_row = Ly.store_row;
+                const int mask_at = Lo.aux + (Ly.mask_idx < 0 ? 0 : Ly.mask_idx) * 512 + lane * 8 + (tile >> 1);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    // d X masked with X > 0 gives d Y of the layer below: the forward's sign bits, this wave's byte of the word
+                    const unsigned m = mask ? *reinterpret_cast<const unsigned char *>(lds + mask_at + s * Lo.aux_stride) : 0xffu;
+                    f4 v[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[t][r] = ((m >> (4 * t + r)) & 1u) ? acc[s][t][r] : 0.f;
+                    if (out_base >= 0) {
+                        f4 *dst = reinterpret_cast<f4 *>(lds + out_base + s * LAT_ACT_BYTES + tile * 1024 + W.voff);
+                        dst[0] = v[0];
+                        dst[64] = v[1];
+                    }
+                    lat_store_f4(dy_rs, dy_off(s, store_row + tile), v[0]);
+                    lat_store_f4(dy_rs, dy_off(s, store_row + tile + 1), v[1]);
+                }
+            }
+            if (op & LAT_BARRIER) __syncthreads();
+        }
+    }
+}
+
+// the transposed stream (mlp_plan.h: make_bwd_plan without the encoder-column transposes) as the latency kernel walks it
+static void lat_table_bwd(const Plan &P, const BwdPlan &B, const TrainLayout &L, const LatLds &Lo, LatTable &T) {
+    T.n = B.nl;
+    T.stream_bytes = (B.total_slabs + SLAB_PAD) * SLAB_BYTES;
+    const int nh = P.n_hidden;
+    for (int bi = 0; bi < B.nl; ++bi) {
+        const BwdLayer &Bl = B.layer[bi];
+        LatLayer &o = T.l[bi];
+        lat_layer_stream(o, Bl.first_slab, Bl.nkb, Bl.t_out);
+        o.wave0 = 0;
+        o.b_base0 = bi == 0 ? Lo.act[1] : Lo.act[(bi + 1) & 1];   // (bi = 0: the d rgb operand phase 0 leaves in the second buffer)
+        o.b_stride0 = LAT_ACT_BYTES;
+        o.b_n0 = 1 << 20;
+        o.b_base1 = o.b_stride1 = 0;
+        o.out_base = bi + 1 < B.nl ? Lo.act[bi & 1] : -1;
+        o.pad_[0] = o.pad_[1] = 0;
+        // forward layer whose d Y this layer produces (mlp_train.hip: mlp_bwd_kernel)
+        const int fl = bi == 0 ? nh + 4 : bi == 1 ? nh + 3 : bi == 2 ? nh + 1 : nh - (bi - 3);
+        o.store_row = L.dy[fl];
+        o.mask_idx = bi == 0 ? nh + 1 : bi >= 3 ? fl : -1;
+        o.op = LAT_BARRIER | (o.mask_idx >= 0 ? LAT_MASK_BITS : 0) | (bi == 2 ? LAT_SCALE_AUX : 0);
+    }
+    lat_table_finish(T);
+}
+
+bool lat_enabled() {
+    static const bool on = [] { const char *e = getenv("SNERF_LAT"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+// calls of up to this many 16-sample tiles per CU take the latency kernels (SNERF_LAT_MAX_TILES_PER_CU)
+int lat_max_tiles_per_cu() {
+    static const int v = [] { const char *e = getenv("SNERF_LAT_MAX_TILES_PER_CU"); return e ? atoi(e) : 8; }();
+    return v;
+}
+
+// Splits n16 tiles into a main launch (n_cu workgroups x passes x S tiles) and a remainder launch of one pass; returns the number of
+// launches (1 or 2).  The makespan is passes * S + S' tile units against the ideal n16 / n_cu: at most one unit above it.
+struct LatLaunch {
+    int S, grid, passes;
+    int64_t tile_off, tile_end;
+};
+static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2]) {
+    int k = 0;
+    int64_t done = 0;
+    const int S = (int)std::min<int64_t>(s_max, (n16 + n_cu - 1) / n_cu);
+    const int64_t per_round = (int64_t)S * n_cu;
+    const int passes = (int)(n16 / per_round);
+    if (passes > 0) {
+        out[k++] = LatLaunch{S, n_cu, passes, 0, per_round * passes};
+        done = per_round * passes;
+    }
+    const int64_t r = n16 - done;
+    if (r > 0) {
+        const int S2 = (int)std::min<int64_t>(s_max, (r + n_cu - 1) / n_cu);
+        out[k++] = LatLaunch{S2, (int)((r + S2 - 1) / S2), 1, done, n16};
+    }
+    return k;
+}
+
+static LatLds lat_lds_fwd(int S, const Plan &P) { return lat_lds(S, P.pos_nkb, P.dir_nkb, 0); }
+
+template <int S, bool TRAIN>
+static int launch_fwd_lat_s(const Plan &P, const TrainLayout &L, const FwdArgs &A, const LatLaunch &Q, hipStream_t s) {
+    const LatLds Lo = lat_lds_fwd(S, P);
+    LatTable T;
+    lat_table_fwd(P, L, Lo, T);
+    static LdsRaised raised;   // per device, per instantiation
+    if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_fwd_lat_kernel<S, TRAIN>), Lo.total, raised, "mlp_fwd_lat")) return rc;
+    const LatGeom G{Q.tile_off, Q.tile_end, Q.passes};
+    hipLaunchKernelGGL((mlp_fwd_lat_kernel<S, TRAIN>), dim3((unsigned)Q.grid), dim3(LAT_THREADS), Lo.total, s, T, A, G, Lo);
+    return check_launch("mlp_fwd_lat");
+}
+
+// 0 = launched; 1 = this call is not for the latency kernels (the caller runs the throughput form); < 0 = error
+template <bool TRAIN>
+int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s) {
+    if (!lat_enabled() || P.width != 256 || P.add_dim != 0 || P.nlayers != P.n_hidden + 6) return 1;
+    const int n_cu = device_cu_count("mlp_fwd_lat");
+    if (n_cu < 1) return n_cu;
+    const int64_t n16 = (A.n + 15) / 16;
+    if (n16 > (int64_t)lat_max_tiles_per_cu() * n_cu) return 1;
+    int s_max = LAT_MAX_S;
+    while (s_max > 1 && lat_lds_fwd(s_max, P).total > 160 * 1024) --s_max;
+    if (lat_lds_fwd(s_max, P).total > 160 * 1024) return 1;
+    TrainLayout L;
+    make_train_layout(P, L);
+    // the masked stores go through 2 GiB buffer resources (mlp_lat_device.h: LAT_STORE_RANGE)
+    if ((int64_t)L.act_rows * A.n * 64 >= (int64_t)LAT_STORE_RANGE) return 1;
+    LatLaunch Q[2];
+    const int nq = lat_split(n16, n_cu, s_max, Q);
+    for (int i = 0; i < nq; ++i) {
+        int rc;
+        switch (Q[i].S) {
+            case 1: rc = launch_fwd_lat_s<1, TRAIN>(P, L, A, Q[i], s); break;
+            case 2: rc = launch_fwd_lat_s<2, TRAIN>(P, L, A, Q[i], s); break;
+            case 3: rc = launch_fwd_lat_s<3, TRAIN>(P, L, A, Q[i], s); break;
+            default: rc = launch_fwd_lat_s<4, TRAIN>(P, L, A, Q[i], s); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+template int launch_fwd_lat<false>(const Plan &, const FwdArgs &, hipStream_t);
+template int launch_fwd_lat<true>(const Plan &, const FwdArgs &, hipStream_t);
+
+template <int S>
+static int launch_bwd_lat_s(const Plan &P, const BwdPlan &B, const TrainLayout &L, const BwdArgs &A, const LatLaunch &Q, hipStream_t s) {
+    const LatLds Lo = lat_lds(S, 0, 0, (P.n_hidden + 2) * 512);
+    LatTable T;
+    lat_table_bwd(P, B, L, Lo, T);
+    static LdsRaised raised;
+    if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_lat_kernel<S>), Lo.total, raised, "mlp_bwd_lat")) return rc;
+    const LatGeom G{Q.tile_off, Q.tile_end, Q.passes};
+    hipLaunchKernelGGL((mlp_bwd_lat_kernel<S>), dim3((unsigned)Q.grid), dim3(LAT_THREADS), Lo.total, s, T, A, G, Lo);
+    return check_launch("mlp_bwd_lat");
+}
+
+// the dgrad of launch_bwd (mlp_train.hip) for small calls; 0 = launched, 1 = not a call for the latency kernel, < 0 = error
+int launch_bwd_lat(const Plan &P, const BwdArgs &A, bool input_grad, hipStream_t s) {
+    if (!lat_enabled() || input_grad || P.width != 256 || P.add_dim != 0 || P.nlayers != P.n_hidden + 6) return 1;
+    const int n_cu = device_cu_count("mlp_bwd_lat");
+    if (n_cu < 1) return n_cu;
+    const int64_t n16 = (A.n + 15) / 16;
+    if (n16 > (int64_t)lat_max_tiles_per_cu() * n_cu) return 1;
+    BwdPlan B;
+    make_bwd_plan(P, B, false);
+    if (B.nl > LAT_MAX_LAYERS) return 1;
+    TrainLayout L;
+    make_train_layout(P, L);
+    if ((int64_t)L.dy_rows * A.n * 64 >= (int64_t)LAT_STORE_RANGE) return 1;
+    int s_max = LAT_MAX_S;
+    while (s_max > 1 && lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024) --s_max;
+    if (lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024) return 1;
+    LatLaunch Q[2];
+    const int nq = lat_split(n16, n_cu, s_max, Q);
+    for (int i = 0; i < nq; ++i) {
+        int rc;
+        switch (Q[i].S) {
+            case 1: rc = launch_bwd_lat_s<1>(P, B, L, A, Q[i], s); break;
+            case 2: rc = launch_bwd_lat_s<2>(P, B, L, A, Q[i], s); break;
+            case 3: rc = launch_bwd_lat_s<3>(P, B, L, A, Q[i], s); break;
+            default: rc = launch_bwd_lat_s<4>(P, B, L, A, Q[i], s); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace snerf

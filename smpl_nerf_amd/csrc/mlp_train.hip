@@ -958,6 +958,11 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     if (n_cu < 1) return n_cu;
     const bool small = tuning().fwd_small_tiles && n <= (int64_t)64 * n_cu;
     const bool wide_pe = input_grad && bwd_pe_tiles(P).pos == 8;
+    // calls of a few 16-sample tiles per CU: the latency-class dgrad (mlp_lat.hip; bit-identical d Y)
+    if (const int lrc = launch_bwd_lat(P, A, input_grad, s); lrc != 1) {
+        if (lrc) return lrc;
+        return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);
+    }
     auto launch = [&](auto bw_c) -> int {
         constexpr int BW = decltype(bw_c)::value;
         const int64_t grid = (n + BW * 16 - 1) / (BW * 16);

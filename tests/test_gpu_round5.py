@@ -79,3 +79,84 @@ def test_shutdown_destroys_the_events_and_the_next_step_recreates_them(dev):
         losses.append(ls)
     assert losses[0] == losses[1]
     assert lib.snerf_shutdown() == 0 and lib.snerf_shutdown() == 0
+
+
+# ------------------------------------------------------------------------------------------ latency-class kernels (csrc/mlp_lat.hip)
+F32 = np.float32
+
+
+def _rnet(dev, n_layers=8, width=256, skips=(4,), pos=(10, 0), dirs=(4, 0), seed=5, use_dir=True):
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    pe, de = PositionalEncoder(*pos), PositionalEncoder(*dirs)
+    torch.manual_seed(seed)
+    net = RenderRayNet(n_layers, width, pe.output_dim if hasattr(pe, "output_dim") else 3 * (pos[1] + 2 * pos[0]),
+                       de.output_dim if hasattr(de, "output_dim") else 3 * (dirs[1] + 2 * dirs[0]), skips=list(skips),
+                       use_directional_input=use_dir) if not use_dir else \
+        RenderRayNet(n_layers, width, 3 * (pos[1] + 2 * pos[0]), 3 * (dirs[1] + 2 * dirs[0]), skips=list(skips))
+    return net.to(dev), pe, de
+
+
+@pytest.mark.parametrize("shape", [dict(), dict(n_layers=4, skips=(1,), pos=(6, 1), dirs=(4, 1)), dict(n_layers=2, skips=()),
+                                   dict(n_layers=10, skips=(2, 5, 7), pos=(10, 1), dirs=(2, 0))])
+def test_latency_kernels_equal_the_throughput_kernels_bit_for_bit(dev, shape):
+    """csrc/mlp_lat.hip: calls of a few 16-sample tiles per CU split a tile's output features over the waves of a workgroup.  Same
+    streams, same k-block order, same MFMA sequence per accumulator: the rows of a small call equal the same rows inside a
+    frame-sized call (throughput kernel) bit for bit - ragged sample counts, several tiles per pass, two launches (main +
+    remainder), other depths / skip masks / encoders."""
+    rng = np.random.default_rng(11)
+    net, pe, de = _rnet(dev, **shape)
+    Ns = 8
+    big = 16384                                                   # x 8 = 131 072 samples = 32 tiles per CU: the throughput kernel
+    pts = T(rng.uniform(-2, 2, (big, Ns, 3)).astype(F32), dev)
+    dirs = T(rng.normal(size=(big, 3)).astype(F32), dev)
+    with torch.no_grad():
+        full = net.forward_fused(pts, dirs, Ns, pe, de).reshape(big, Ns, 4)
+        for rays in (1, 2, 3, 31, 512, 513, 1536, 2000, 2501, 4096):          # 8 .. 32 768 samples
+            small = net.forward_fused(pts[:rays].contiguous(), dirs[:rays].contiguous(), Ns, pe, de).reshape(rays, Ns, 4)
+            assert torch.equal(small, full[:rays]), rays
+
+
+_GRAD_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+from test_gpu_round5 import _rnet
+dev = torch.device("cuda:0")
+out = {{}}
+for ci, shape in enumerate({shapes!r}):
+    net, pe, de = _rnet(dev, **shape)
+    rng = np.random.default_rng(3)
+    for rays in {rays!r}:
+        Ns = 8
+        pts = torch.from_numpy(rng.uniform(-2, 2, (rays, Ns, 3)).astype(np.float32)).to(dev)
+        dirs = torch.from_numpy(rng.normal(size=(rays, 3)).astype(np.float32)).to(dev)
+        gout = torch.from_numpy(rng.normal(size=(rays * Ns, 4)).astype(np.float32)).to(dev)
+        net.zero_grad(set_to_none=True)
+        raw = net.forward_fused(pts, dirs, Ns, pe, de).reshape(-1, 4)
+        (raw * gout).sum().backward()
+        out[f"raw_{{ci}}_{{rays}}"] = raw.detach().cpu().numpy()
+        out[f"grad_{{ci}}_{{rays}}"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+np.savez({path!r}, **out)
+"""
+
+
+def test_latency_training_kernels_give_the_throughput_kernels_gradients_bit_for_bit(dev, tmp_path):
+    """Training forward (stored layer inputs, sign masks) and dgrad of csrc/mlp_lat.hip: the same call evaluated by a process with
+    SNERF_LAT=0 (throughput kernels) and by one with the latency kernels - raw outputs AND the flat weight gradient (same
+    wgrad chunking: it depends on n only) are bit-identical, for ragged sample counts and several net shapes."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    shapes = [dict(), dict(n_layers=3, skips=(1,)), dict(n_layers=9, skips=(2, 6), dirs=(2, 0))]
+    rays = [1, 37, 512, 1537, 2500]
+    res = {}
+    for lat in ("0", "1"):
+        path = str(tmp_path / f"g{lat}.npz")
+        env = dict(os.environ, SNERF_LAT=lat)
+        subprocess.run([sys.executable, "-c", _GRAD_SCRIPT.format(root=ROOT, shapes=shapes, rays=rays, path=path)], check=True, env=env)
+        res[lat] = dict(np.load(path))
+    assert set(res["0"]) == set(res["1"]) and len(res["0"]) == 2 * len(shapes) * len(rays)
+    for k in res["0"]:
+        assert np.isfinite(res["0"][k]).all()
+        np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
