@@ -346,9 +346,10 @@ bool lat_enabled() {
     static const bool on = [] { const char *e = getenv("SNERF_LAT"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
-// calls of up to this many 16-sample tiles per CU take the latency kernels (SNERF_LAT_MAX_TILES_PER_CU)
-int lat_max_tiles_per_cu() {
-    static const int v = [] { const char *e = getenv("SNERF_LAT_MAX_TILES_PER_CU"); return e ? atoi(e) : 8; }();
+// SNERF_LAT_MAX_TILES_PER_CU=k (experiments): the latency kernels for every call of up to k 16-sample tiles per CU, whatever the
+// cost model below says; unset: the model decides
+static int lat_max_tiles_override() {
+    static const int v = [] { const char *e = getenv("SNERF_LAT_MAX_TILES_PER_CU"); return e ? atoi(e) : -1; }();
     return v;
 }
 
@@ -376,6 +377,24 @@ static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2]) {
     return k;
 }
 
+// Which form is faster for a call of n16 tiles?  Measured per launch on MI355X (r05, tools/ab/lat_trace.sh, microseconds):
+//   latency kernels    a launch costs `fixed` + per pass of S tiles 4 + per_tile * S: inference 21 / 41, training forward 22 / 43, dgrad 19 / 38
+//   throughput kernels one round of the chip: 64-sample tiles (calls of <= 64 x CUs samples) 178 / 191 / 170,
+//                      128-sample tiles 295 / 352 / 314 per round of 128 x CUs samples
+// (n = 4096: 62 against 178; 16 384: 185 / 182; 20 480: 247 / 295; 32 768: 370 / 295; 51 200 - inference.py's 800 rays, coarse -
+// 567 / 590; 153 600: 1611 / 1475.)  The latency form wins below two tiles of 128 per CU wherever the throughput form would run a
+// mostly empty round.
+enum LatKind { LAT_INFER = 0, LAT_TRAIN_FWD = 1, LAT_DGRAD = 2 };
+static bool lat_wins(LatKind kind, int64_t n, int64_t n16, int n_cu, const LatLaunch *Q, int nq) {
+    const int ovr = lat_max_tiles_override();
+    if (ovr >= 0) return n16 <= (int64_t)ovr * n_cu;
+    static const double fixed[3] = {21, 22, 19}, per_tile[3] = {41, 43, 38}, round64[3] = {178, 191, 170}, round128[3] = {295, 352, 314};
+    double t_lat = 0;
+    for (int i = 0; i < nq; ++i) t_lat += fixed[kind] + Q[i].passes * (4.0 + per_tile[kind] * Q[i].S);
+    const double t_thr = n <= (int64_t)64 * n_cu ? round64[kind] : (double)((n + (int64_t)128 * n_cu - 1) / ((int64_t)128 * n_cu)) * round128[kind];
+    return t_lat < t_thr;
+}
+
 static LatLds lat_lds_fwd(int S, const Plan &P) { return lat_lds(S, P.pos_nkb, P.dir_nkb, 0); }
 
 template <int S, bool TRAIN>
@@ -397,7 +416,7 @@ int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s) {
     const int n_cu = device_cu_count("mlp_fwd_lat");
     if (n_cu < 1) return n_cu;
     const int64_t n16 = (A.n + 15) / 16;
-    if (n16 > (int64_t)lat_max_tiles_per_cu() * n_cu) return 1;
+    if (n16 > (int64_t)64 * n_cu) return 1;
     int s_max = LAT_MAX_S;
     while (s_max > 1 && lat_lds_fwd(s_max, P).total > 160 * 1024) --s_max;
     if (lat_lds_fwd(s_max, P).total > 160 * 1024) return 1;
@@ -407,6 +426,7 @@ int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s) {
     if ((int64_t)L.act_rows * A.n * 64 >= (int64_t)LAT_STORE_RANGE) return 1;
     LatLaunch Q[2];
     const int nq = lat_split(n16, n_cu, s_max, Q);
+    if (!lat_wins(TRAIN ? LAT_TRAIN_FWD : LAT_INFER, A.n, n16, n_cu, Q, nq)) return 1;
     for (int i = 0; i < nq; ++i) {
         int rc;
         switch (Q[i].S) {
@@ -440,7 +460,7 @@ int launch_bwd_lat(const Plan &P, const BwdArgs &A, bool input_grad, hipStream_t
     const int n_cu = device_cu_count("mlp_bwd_lat");
     if (n_cu < 1) return n_cu;
     const int64_t n16 = (A.n + 15) / 16;
-    if (n16 > (int64_t)lat_max_tiles_per_cu() * n_cu) return 1;
+    if (n16 > (int64_t)64 * n_cu) return 1;
     BwdPlan B;
     make_bwd_plan(P, B, false);
     if (B.nl > LAT_MAX_LAYERS) return 1;
@@ -452,6 +472,7 @@ int launch_bwd_lat(const Plan &P, const BwdArgs &A, bool input_grad, hipStream_t
     if (lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024) return 1;
     LatLaunch Q[2];
     const int nq = lat_split(n16, n_cu, s_max, Q);
+    if (!lat_wins(LAT_DGRAD, A.n, n16, n_cu, Q, nq)) return 1;
     for (int i = 0; i < nq; ++i) {
         int rc;
         switch (Q[i].S) {

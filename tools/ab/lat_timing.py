@@ -17,7 +17,8 @@ net.load_state_dict({k: torch.from_numpy(v) for k, v in pc.items()})
 net = net.to(dev)
 pe, de = PositionalEncoder(10, 0), PositionalEncoder(4, 0)
 rng = np.random.default_rng(0)
-train = len(sys.argv) > 1 and sys.argv[1] == "train"
+train = len(sys.argv) > 1 and sys.argv[1] in ("train", "bwd")
+bwd = len(sys.argv) > 1 and sys.argv[1] == "bwd"      # forward + backward through autograd (run under rocprofv3 for the kernels' own times)
 sizes = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (4096, 12288, 16384, 32768, 51200, 65536, 153600, 262144, 524288)
 for n in sizes:
     rays = n // 64
@@ -32,7 +33,9 @@ for n in sizes:
         reps = 20
         e0.record()
         for _ in range(reps):
-            net.forward_fused(pts, d, 64, pe, de)
+            raw = net.forward_fused(pts, d, 64, pe, de)
+            if bwd:
+                raw.backward(torch.ones_like(raw))
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
