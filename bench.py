@@ -474,6 +474,23 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
     dt = max_over_ranks(dt, dev)
     ar = [e0.elapsed_time(e1) for e0, e1 in tr.timing.get("allreduce_events", [])]
     tr.timing = None
+    # The one-call data-parallel step (snerf_nerf_train_step_dp_f32) averages the gradients INSIDE the call: no event pair can
+    # bracket the collective there, so it is timed on its own - the same ncclAllReduce(ncclAvg) of the same flat buffer on the
+    # same communicator and stream, `steps` times back to back (outside the timed region above)
+    in_call = getattr(tr, "_comm", None) not in (None, False)
+    ar_calls_in_steps = getattr(tr, "collective_calls", 0)
+    if in_call:
+        scratch = torch.zeros_like(tr._flat_g)
+        tr._comm.allreduce_avg_(scratch)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            tr._comm.allreduce_avg_(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        ar = [e0.elapsed_time(e1) / steps] * steps
+        del scratch
     # the host cost a user pays: the same steps without the event pairs of the profile above
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -515,10 +532,18 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
                         "timed region)" if loader is not None else "4 resident batches drawn from this rank's frame"),
             "raygen_ms_per_step": (kern["raygen"][1] / steps if "raygen" in kern else None),
             "collective": (dict(collective_info(backend, sum(p.numel() for p in tr.params),
+                                                ("ncclAllReduce(ncclAvg, fp32) of the flat gradient buffer INSIDE the one C-ABI call of a "
+                                                 "step, on the compute stream between the backward and Adam (small chunks: the coarse "
+                                                 "net's bucket on the auxiliary stream beside the fine net's backward) - "
+                                                 "snerf_nerf_train_step_dp_f32, RCCL bound by the library") if in_call else
                                                 "one all-reduce (sum, then / world) of the flat fp32 gradient buffer per step"),
                                 allreduce_ms_per_step=(sum(ar) / len(ar) if ar else None), allreduce_calls=len(ar),
+                                allreduce_inside_the_step_call=bool(in_call),
+                                rccl_comm_world_rank=([tr._comm.world, tr._comm.rank] if in_call else None),
                                 broadcast_ms=tr.broadcast_ms,
-                                timing="HIP events on the compute stream around dist.sync (includes the / world)")
+                                timing=("HIP events around the same collective issued stand-alone on the same communicator, buffer and "
+                                        "stream (inside the step call it cannot be bracketed)" if in_call else
+                                        "HIP events on the compute stream around dist.sync (includes the / world)"))
                            if backend else "none (1 GPU, no process group)"),
             "per_rank": gather_per_rank({"rank": rank, "device": torch.cuda.get_device_name(dev),
                                          "arch": torch.cuda.get_device_properties(dev).gcnArchName, "device_index": dev.index,

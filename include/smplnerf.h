@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 106 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+#define SNERF_VERSION 107 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
                              snerf_composite_bwd_all_f32; composite forward accepts any N
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
                              folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
@@ -73,7 +73,9 @@ extern "C" {
                              snerf_mlp_stream_slots), snerf_dy_contract_f32; the per-ray fold tables moved from stream-ordered allocations inside
                              the library to caller workspaces (snerf_mlp_fwd_ws_f32, snerf_warp_fwd_ws_f32): the library allocates nothing
                              0.1.5: + snerf_render_rays_add_f32 (the single-call render for nets with per-ray additional inputs)
-                             0.1.6: + snerf_shutdown; hidden visibility: the entry points of this header are the only dynamic symbols */
+                             0.1.6: + snerf_shutdown; hidden visibility: the entry points of this header are the only dynamic symbols
+                             0.1.7: + snerf_comm_*, snerf_nerf_train_step_dp_f32, snerf_smpl_nerf_train_step_dp_f32 (RCCL inside the
+                             boundary); latency-class kernels behind the same entry points for small calls */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -601,6 +603,42 @@ SNERF_API int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, 
  * data-parallel caller runs behind snerf_adam_step_f32. */
 SNERF_API int snerf_warp_repack_f32(const snerf_warp_desc *desc_warp, const float *params, int64_t n_params, int64_t warp_param_offset,
                           float *packed_warp, float *packed_t_warp, snerf_stream_t stream);
+
+/* ---- 8(e): the data-parallel step as one call ---------------------------------------------------------------------------
+ * Rays of independent images shard over the GPUs of a node, one process per GPU; the only exchange of the path is the average of
+ * the replicated nets' gradients.  snerf_comm_t is an ncclComm_t of RCCL (bound at run time: librccl.so.1 is loaded by the first
+ * snerf_comm_* / *_dp_* call, the copy the process already holds if there is one).  A host with its own communicator passes it
+ * as is; one without creates it here: rank 0 calls snerf_comm_unique_id, hands the SNERF_COMM_ID_BYTES bytes to the other ranks
+ * by whatever channel it has (a file, MPI, torch.distributed's store), and every rank calls snerf_comm_init_rank - collective,
+ * with its HIP device current.  snerf_comm_destroy(NULL) is a no-op. */
+typedef void *snerf_comm_t; /* ncclComm_t */
+#define SNERF_COMM_ID_BYTES 128
+SNERF_API int snerf_comm_unique_id(void *id_host);
+SNERF_API int snerf_comm_init_rank(const void *id_host, int world_size, int rank, snerf_comm_t *comm);
+SNERF_API int snerf_comm_destroy(snerf_comm_t comm);
+SNERF_API int snerf_comm_info(snerf_comm_t comm, int32_t *world_size, int32_t *rank);
+/* buf[0 .. n) <- its average over the ranks, in place, enqueued on `stream` (ncclAllReduce, ncclAvg, fp32). */
+SNERF_API int snerf_comm_allreduce_avg_f32(snerf_comm_t comm, float *buf, int64_t n, snerf_stream_t stream);
+/* snerf_nerf_train_step_f32 / snerf_smpl_nerf_train_step_f32 with the gradient average between the backward and the optimiser:
+ * ... -> backward -> ncclAllReduce(ncclAvg) of adam->grads[0 .. adam->n_params) - the trainer's flat gradient buffer, which holds
+ * grad_coarse / grad_fine (/ grad_warp) as segments and is the same size on every rank - on `stream` -> Adam.  With an auxiliary
+ * stream and a chunk small enough for the concurrent backward (snerf_nerf_train_grads_f32), the coarse net's segment is averaged
+ * on aux_stream as soon as its backward is done, beside the fine net's backward, and the rest of the buffer behind the join.
+ * Nothing is synchronised; every rank must make the same calls in the same order (RCCL's rule).  Graph-capturable. */
+SNERF_API int snerf_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                 const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
+                                 const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
+                                 float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
+                                 const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
+                                 snerf_comm_t comm, snerf_stream_t stream, snerf_stream_t aux_stream);
+SNERF_API int snerf_smpl_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                      const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                      const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,
+                                      const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk, void *workspace,
+                                      float *grad_coarse, float *grad_fine, float *grad_warp, float *loss, float *rgb, float *rgb_fine,
+                                      const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
+                                      const snerf_adam_net *nets_host, int n_nets, int64_t warp_param_offset, snerf_comm_t comm,
+                                      snerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -140,6 +140,18 @@ SIGNATURES = {
                                            _P, _P, _P, _P, _P, _P, _P, _P]),
     "snerf_nerf_train_step_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
                                           _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P, _P]),
+    # 8(e): RCCL inside the boundary
+    "snerf_comm_unique_id": (c_int, [_P]),
+    "snerf_comm_init_rank": (c_int, [_P, c_int, c_int, POINTER(_P)]),
+    "snerf_comm_destroy": (c_int, [_P]),
+    "snerf_comm_info": (c_int, [_P, POINTER(ctypes.c_int32), POINTER(ctypes.c_int32)]),
+    "snerf_comm_allreduce_avg_f32": (c_int, [_P, _P, c_int64, _P]),
+    "snerf_nerf_train_step_dp_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
+                                             _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int,
+                                             _P, _P, _P]),
+    "snerf_smpl_nerf_train_step_dp_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, POINTER(WarpDesc), _P, _P, c_int,
+                                                  POINTER(NerfBatch), _P, c_int64, _P, _P, _P, _P, _P, _P, _P, POINTER(AdamState),
+                                                  POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, c_int64, _P, _P]),
 }
 
 _lib = None

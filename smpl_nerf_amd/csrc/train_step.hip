@@ -414,11 +414,20 @@ extern "C" int64_t snerf_nerf_train_workspace_bytes(const snerf_mlp_desc *desc_c
     return w.total;
 }
 
-extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
-                                          const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
-                                          int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
-                                          float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
-                                          snerf_stream_t stream, snerf_stream_t aux_stream) {
+namespace snerf {
+// dp_comm.hip
+int dp_allreduce_avg(snerf_comm_t comm, float *buf, int64_t begin, int64_t end, int64_t skip_begin, int64_t skip_end, hipStream_t stream,
+                     const char *what);
+}
+
+// comm != NULL (the data-parallel step): the flat gradient buffer flat_g[0 .. flat_n), which holds grad_coarse / grad_fine as
+// segments, is averaged over the ranks behind the last chunk's backward - the coarse net's segment on the auxiliary stream beside
+// the fine net's backward when the two run concurrently, the rest on `stream` behind the join
+static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                 const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                 int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                 float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                 snerf_stream_t stream, snerf_stream_t aux_stream, snerf_comm_t comm, float *flat_g, int64_t flat_n) {
     using namespace snerf;
     if (precision != 0 && !split_code(precision))
         return fail(SNERF_E_BADARG, "nerf_train_grads: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
@@ -454,6 +463,20 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
     if (concurrent && (rc = fork_join_events(ev_fork, ev_join))) return rc;
     float *d_raw_c = concurrent ? f(w.d_raw2) : d_raw, *dy_c = concurrent ? f(w.dy2) : dy, *gpart_c = concurrent ? f(w.gpart2) : gpart;
     const snerf_stream_t stream_c = concurrent ? aux_stream : stream;
+    // (data-parallel step) the coarse net's gradient as a segment [cb0, cb1) of the flat buffer
+    int64_t cb0 = 0, cb1 = 0;
+    bool coarse_bucket = false;
+    if (comm) {
+        if (!flat_g || flat_n < 1) return fail(SNERF_E_BADARG, "nerf_train_step_dp: no flat gradient buffer");
+        const int64_t pc = snerf_mlp_param_floats(desc_coarse);
+        cb0 = grad_coarse - flat_g;
+        cb1 = cb0 + pc;
+        coarse_bucket = pc > 0 && cb0 >= 0 && cb1 <= flat_n;
+        if (!coarse_bucket) return fail(SNERF_E_BADARG, "nerf_train_step_dp: grad_coarse must lie inside adam->grads[0 .. n_params)");
+        const int64_t pf = Nf > 0 ? snerf_mlp_param_floats(desc_fine) : 0;
+        if (Nf > 0 && (grad_fine - flat_g < 0 || grad_fine - flat_g + pf > flat_n))
+            return fail(SNERF_E_BADARG, "nerf_train_step_dp: grad_fine must lie inside adam->grads[0 .. n_params)");
+    }
     double *loss_acc = reinterpret_cast<double *>(ws + w.loss_acc);
     hipStream_t s = (hipStream_t)stream;
     const int wb = batch->white_background ? 1 : 0;
@@ -504,13 +527,47 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
         }
         if ((rc = snerf_composite_bwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, d_rgb_c, d_raw_c, nullptr, stream_c))) return rc;
         if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, d_raw_c, b * Nc, dy_c, gpart_c, grad_coarse, r0 > 0, stream_c))) return rc;
+        const bool last = r0 + b >= B;
+        if (comm && last && concurrent && coarse_bucket &&   // the coarse net's bucket, while the fine net's backward still runs
+            (rc = dp_allreduce_avg(comm, flat_g, cb0, cb1, 0, 0, (hipStream_t)aux_stream, "nerf_train_step_dp")))
+            return rc;
         if (concurrent && (hipEventRecord(ev_join, (hipStream_t)aux_stream) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess))
             return fail(SNERF_E_LAUNCH, "nerf_train_grads: cannot join the auxiliary stream");
+        if (comm && last &&
+            (rc = dp_allreduce_avg(comm, flat_g, 0, flat_n, concurrent && coarse_bucket ? cb0 : 0, concurrent && coarse_bucket ? cb1 : 0, s,
+                                   "nerf_train_step_dp")))
+            return rc;
     }
     if (Nf == 0 && rgb_fine != rgb &&
         hipMemcpyAsync(rgb_fine, rgb, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return fail(SNERF_E_LAUNCH, "nerf_train_grads: device copy failed");
     return SNERF_OK;
+}
+
+extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                          const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                          int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                          float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                          snerf_stream_t stream, snerf_stream_t aux_stream) {
+    return nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision, batch,
+                                 rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream, nullptr, nullptr, 0);
+}
+
+extern "C" int snerf_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                            const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                            int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                            float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                            const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
+                                            const snerf_adam_net *nets_host, int n_nets, snerf_comm_t comm, snerf_stream_t stream,
+                                            snerf_stream_t aux_stream) {
+    using namespace snerf;
+    if (!comm) return fail(SNERF_E_BADARG, "nerf_train_step_dp: comm is null (the single-GPU step is snerf_nerf_train_step_f32)");
+    if (!adam || !adam->grads || adam->n_params < 1) return fail(SNERF_E_BADARG, "nerf_train_step_dp: adam / adam->grads is null");
+    int rc = nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision, batch,
+                                   rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream, comm,
+                                   const_cast<float *>(adam->grads), adam->n_params);
+    if (rc) return rc;
+    return snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream);
 }
 
 extern "C" int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
@@ -709,6 +766,27 @@ extern "C" int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse,
     if ((rc = snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream))) return rc;
     return snerf_warp_repack_f32(desc_warp, adam ? adam->params : nullptr, adam ? adam->n_params : 0, warp_param_offset, packed_warp,
                                  packed_t_warp, stream);
+}
+
+extern "C" int snerf_smpl_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                                 const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                                 const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,
+                                                 const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk,
+                                                 void *workspace, float *grad_coarse, float *grad_fine, float *grad_warp, float *loss,
+                                                 float *rgb, float *rgb_fine, const snerf_adam_state *adam,
+                                                 const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host,
+                                                 int n_nets, int64_t warp_param_offset, snerf_comm_t comm, snerf_stream_t stream) {
+    using namespace snerf;
+    if (!comm) return fail(SNERF_E_BADARG, "smpl_nerf_train_step_dp: comm is null (the single-GPU step is snerf_smpl_nerf_train_step_f32)");
+    if (!adam || !adam->grads || adam->n_params < 1) return fail(SNERF_E_BADARG, "smpl_nerf_train_step_dp: adam / adam->grads is null");
+    int rc = snerf_smpl_nerf_train_grads_f32(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
+                                             packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
+                                             grad_fine, grad_warp, loss, rgb, rgb_fine, stream);
+    if (rc) return rc;
+    if ((rc = dp_allreduce_avg(comm, const_cast<float *>(adam->grads), 0, adam->n_params, 0, 0, (hipStream_t)stream, "smpl_nerf_train_step_dp")))
+        return rc;
+    if ((rc = snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream))) return rc;
+    return snerf_warp_repack_f32(desc_warp, adam->params, adam->n_params, warp_param_offset, packed_warp, packed_t_warp, stream);
 }
 
 extern "C" int snerf_warp_repack_f32(const snerf_warp_desc *desc_warp, const float *params, int64_t n_params, int64_t warp_param_offset,

@@ -113,3 +113,57 @@ def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         flat_grad.div_(dist.get_world_size())
     return flat_grad
+
+
+class RcclComm:
+    """An RCCL communicator of this process group, created through the library (include/smplnerf.h "8(e)": snerf_comm_unique_id on
+    rank 0, the 128 id bytes handed to the other ranks through torch.distributed - any backend - and snerf_comm_init_rank on every
+    rank with its device current).  `handle` is the ncclComm_t the one-call data-parallel steps take
+    (snerf_nerf_train_step_dp_f32 / snerf_smpl_nerf_train_step_dp_f32): the gradient average runs inside the call, on the
+    compute stream, between the backward and the optimiser - no torch.distributed call, no separate division, in the step."""
+
+    def __init__(self, device: torch.device):
+        import ctypes
+        from . import _lib
+        if device.type != "cuda":
+            raise RuntimeError("RcclComm: needs this rank's GPU")
+        self._lib = _lib
+        self.device = device
+        lib = _lib.load()
+        world, rank = world_rank()
+        ident = (ctypes.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(lib.snerf_comm_unique_id(ctypes.cast(ident, ctypes.c_void_p)), "snerf_comm_unique_id")
+        if is_dist() and world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.snerf_comm_init_rank(ctypes.cast(ident, ctypes.c_void_p), world, rank, ctypes.byref(handle)), "snerf_comm_init_rank")
+        self.handle = handle
+        w, r = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(lib.snerf_comm_info(handle, ctypes.byref(w), ctypes.byref(r)), "snerf_comm_info")
+        self.world, self.rank = int(w.value), int(r.value)      # as RCCL reports them
+
+    def allreduce_avg_(self, flat: torch.Tensor) -> torch.Tensor:
+        """In-place average over the ranks on the current stream (snerf_comm_allreduce_avg_f32)."""
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        with torch.cuda.device(flat.device):
+            self._lib.check(self._lib.load().snerf_comm_allreduce_avg_f32(self.handle, flat.data_ptr(), flat.numel(), self._lib.current_stream()),
+                            "snerf_comm_allreduce_avg_f32")
+        return flat
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            torch.cuda.synchronize(self.device)
+            self._lib.load().snerf_comm_destroy(self.handle)
+        self.handle = None
+
+
+def rccl_usable(device) -> bool:
+    """The in-library RCCL path applies when every rank has its own GPU (the group runs on the nccl backend, or there is no
+    group / a world of one on a GPU); ranks that share a GPU (the gloo dry runs) keep the host-staged torch path."""
+    if device is None or device.type != "cuda":
+        return False
+    return (not is_dist()) or dist.get_backend() == "nccl"

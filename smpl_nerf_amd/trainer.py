@@ -202,6 +202,7 @@ class DataParallelTrainer:
         # (bench.py on a 1-GPU box: the collective of the path on RCCL with nothing to exchange; the mean over one rank is the
         # identity)
         self._sync = self.world > 1 or (bool(sync_at_world_one) and sdist.is_dist())
+        self._comm = None      # dist.RcclComm of the one-call data-parallel step (created lazily; False: not usable here)
         # one flat parameter buffer and one flat gradient buffer for all nets (what is all-reduced is the flat
         # gradient the backward kernels wrote)
         self._flat_p, self._flat_g, self._segments, order = flatten_parameters_(self.models)
@@ -294,6 +295,19 @@ class DataParallelTrainer:
         for p, v in zip(self.params, self._views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v
+
+    def _rccl_comm(self, dev):
+        """The RCCL communicator of the one-call data-parallel step (dist.RcclComm), created at the first step that needs it;
+        None when the ranks cannot use it (they share a GPU: the gloo dry runs) or SNERF_DP_ONE_CALL=0 asks for the three-call
+        form (gradients, torch.distributed all-reduce, optimiser)."""
+        if self._comm is False:
+            return None
+        if self._comm is None:
+            if os.environ.get("SNERF_DP_ONE_CALL", "1") == "0" or not sdist.rccl_usable(dev) or self._flat_g is None:
+                self._comm = False
+                return None
+            self._comm = sdist.RcclComm(dev)
+        return self._comm
 
     def _allreduce_flat(self):
         """The one collective of a step, optionally between two HIP events (bench.py reads self.timing)."""
@@ -494,10 +508,22 @@ class DataParallelTrainer:
             name, tail = "snerf_nerf_train", (aux,)
             step_tail = lambda st, ranges, nr: (ctypes.byref(st), ranges, nr, nets_c, n_nets, stream(), aux)
         with torch.cuda.device(dev), _lib.timed(f"train_step{'_smpl' if W is not None else ''}[B={B}]"):
+            comm = self._rccl_comm(dev) if self._sync else None
             if not self._sync:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
                 _lib.check(getattr(lib, name + "_step_f32")(*head, *step_tail(st, ranges, nr)), name + "_step_f32")
+            elif comm is not None:
+                # more than one rank, one call all the same: the gradient average is RCCL's ncclAllReduce(ncclAvg) of the flat
+                # buffer inside the call, on the compute stream between the backward and Adam (include/smplnerf.h 8(e))
+                if not Nf:      # every rank contributes the same shape: zeros for the net that took no part
+                    self._flat_g[of_off:of_off + of_n].zero_()
+                ranges, nr = opt.c_ranges(flags)
+                st = opt.c_state()
+                t = step_tail(st, ranges, nr)
+                t = t[:-1] + (comm.handle, t[-1]) if W is not None else t[:-2] + (comm.handle,) + t[-2:]
+                _lib.check(getattr(lib, name + "_step_dp_f32")(*head, *t), name + "_step_dp_f32")
+                self.collective_calls = getattr(self, "collective_calls", 0) + 1
             else:
                 _lib.check(getattr(lib, name + "_grads_f32")(*head, stream(), *tail), name + "_grads_f32")
                 if not Nf:      # every rank contributes the same shape: zeros for the net that took no part

@@ -531,6 +531,9 @@ def test_bench_takes_its_rccl_branch_at_world_size_one():
     c = line["train"]["collective"]
     assert c["backend"] == "nccl (RCCL)" and c["bytes"] == 4 * 1220872 and c["allreduce_calls"] == 2
     assert 0 < c["allreduce_ms_per_step"] < 50 and len(line["train"]["per_rank"]) == 1
+    # r05: the grouped step is ONE C-ABI call with the all-reduce inside (snerf_nerf_train_step_dp_f32)
+    assert c["allreduce_inside_the_step_call"] and c["rccl_comm_world_rank"] == [1, 0]
+    assert line["train"]["c_abi_calls_per_step"] == 1.0
 
 
 def test_smpl_render_rays_covers_the_modes_without_a_one_call_entry(dev):

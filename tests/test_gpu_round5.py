@@ -160,3 +160,97 @@ def test_latency_training_kernels_give_the_throughput_kernels_gradients_bit_for_
     for k in res["0"]:
         assert np.isfinite(res["0"][k]).all()
         np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------ RCCL inside the boundary (8e)
+def _dp_worker(port, q):
+    """World-size-1 process group on the nccl backend (= RCCL): what every rank of an 8-GPU node runs, with nobody to exchange with."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dv = torch.device("cuda", 0)
+    torch.cuda.set_device(dv)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dv)
+    out = {}
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from test_gpu_round4 import _trainer, _batch
+        from smpl_nerf_amd import dist as sd
+        from smpl_nerf_amd.trainer import DataParallelTrainer
+        # the library's own communicator and the stand-alone collective
+        comm = sd.RcclComm(dv)
+        flat = torch.arange(1220872, device=dv, dtype=torch.float32)
+        ref = flat.clone()
+        comm.allreduce_avg_(flat)
+        torch.cuda.synchronize()
+        out["comm"] = (comm.world, comm.rank, bool(torch.equal(flat, ref)))
+        comm.close()
+
+        def make(sync):
+            import test_gpu_round4 as r4
+            tr, pipe, mc, mf = _trainer(dv)
+            if sync:
+                tr._sync = True            # (sync_at_world_one: the group has one rank)
+            return tr
+        batch = _batch(dv, 64)
+        single, dp = make(False), make(True)
+        calls = []
+        import smpl_nerf_amd._lib as L
+        losses_s = [float(single.step(batch)) for _ in range(3)]
+        with L.profile() as prof:
+            losses_d = [float(dp.step(batch)) for _ in range(3)]
+        out["calls"] = sorted(prof.summary().keys()) if hasattr(prof, "summary") else None
+        out["losses"] = (losses_s, losses_d)
+        out["params_equal"] = all(bool(torch.equal(a, b)) for a, b in zip(single.params, dp.params))
+        out["used_rccl"] = dp._comm not in (None, False) and getattr(dp, "collective_calls", 0) == 3
+        # the data-parallel step in a HIP graph: ncclAllReduce is captured with the kernels around it
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dp.step(batch), single.step(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            loss = dp.step(batch)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            want = single.step(batch)
+        out["graph"] = (float(loss) == float(want), all(bool(torch.equal(a, b)) for a, b in zip(single.params, dp.params)))
+        dp._comm.close()
+    except Exception as e:      # noqa: BLE001 - the parent asserts on the report
+        import traceback
+        out["error"] = traceback.format_exc()
+    finally:
+        q.put(out)
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_is_one_call_with_rccl_inside():
+    """with more than one rank the step stays ONE C-ABI call - snerf_nerf_train_step_dp_f32 takes an ncclComm_t and
+    averages the flat gradient with ncclAllReduce(ncclAvg) on the compute stream between the backward and Adam (coarse bucket on the
+    auxiliary stream beside the fine net's backward).  On the 1-GPU box: a world-size-1 RCCL communicator created through the
+    library (snerf_comm_unique_id / _init_rank), the trajectory equal to the single-process step bit for bit (the average over
+    one rank is the identity), and the step captured into a HIP graph and replayed."""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_dp_worker, args=(port, q))
+    p.start()
+    out = q.get()
+    p.join(300)
+    assert "error" not in out, out.get("error")
+    assert out["comm"] == (1, 0, True)
+    assert out["used_rccl"]
+    assert out["losses"][0] == out["losses"][1] and out["params_equal"]
+    assert out["graph"] == (True, True)
+    assert p.exitcode == 0
