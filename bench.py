@@ -520,6 +520,10 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
             "loss_first": losses[0], "loss_last": losses[-1], "rgb_fine_std_last_step": fine_std,
             "mlp_kernels_ms_per_step": mlp_ms, "mlp_algorithmic_tflops": tf, "mlp_peak_tflops": peak,
             "mlp_roofline_frac": tf / peak if tf else None,
+            # smpl_nerf: the warp net's own FLOPs (forward + dgrad + wgrad of 100 -> 256 -> 3 on every ray-sample) are executed inside the
+            # same call; with them in the numerator (VERDICT r04 #3 asks for this as a second key)
+            "mlp_plus_warp_roofline_frac": ((flop_step + 3 * WARP_FLOP_PER_EVAL * rays * 256) / (mlp_ms * 1e-3) / 1e12 / peak
+                                            if (tf and workload == "smpl_nerf" and one_call) else None),
             "step_entry": ((("snerf_smpl_nerf_train_step_f32" if any(k.startswith("train_step_smpl") for k in kern) else
                              "snerf_nerf_train_step_f32") + " (one C-ABI call per step; mlp_kernels_ms_per_step brackets the whole "
                             "call - for smpl_nerf that includes the warp net's kernels, which the FLOP count of the fraction leaves out)")

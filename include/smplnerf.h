@@ -572,6 +572,32 @@ SNERF_API int snerf_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const
                               const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
                               snerf_stream_t stream, snerf_stream_t aux_stream);
 
+/* The same with d loss / d batch->additional as one more output (nets with add_dim > 0): what autograd returns for the per-ray pose
+ * rows / vertex floats the pipelines expand over a ray's samples (models/append_smpl_params_pipeline.py:29-52,
+ * append_to_nerf_pipeline.py:26, append_vertices_pipeline.py:37-58) - the gradient AppendVerticesSolver's second parameter
+ * group (solver/append_vertices_solver.py: the pose estimator, lrate_pose) and a goal_pose that requires a gradient are trained
+ * from.  d_additional [B, add_dim] is OVERWRITTEN: the stored d Y of layer 0 and of every skip layer of both nets contracted with
+ * the weight columns that read the additional inputs (snerf_dy_contract_f32), summed over the samples of each ray.  params_*: the
+ * nets' parameters (snerf_mlp_param_floats floats, state_dict order - the weight columns are read from there); the step variant
+ * reads them before Adam updates them.  input_grads == NULL or d_additional == NULL: exactly snerf_nerf_train_grads_f32 / _step_f32.
+ * The workspace of snerf_nerf_train_workspace_bytes covers the contraction's scratch. */
+typedef struct snerf_input_grads {
+    float *d_additional;
+    const float *params_coarse;
+    const float *params_fine; /* unused with Nf == 0 */
+} snerf_input_grads;
+SNERF_API int snerf_nerf_train_grads_ig_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                  const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
+                                  const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
+                                  float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_input_grads *input_grads,
+                                  snerf_stream_t stream, snerf_stream_t aux_stream);
+SNERF_API int snerf_nerf_train_step_ig_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                 const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
+                                 const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
+                                 float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
+                                 const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
+                                 const snerf_input_grads *input_grads, snerf_stream_t stream, snerf_stream_t aux_stream);
+
 /* ---- a7 + a9: SmplNerfSolver.train's per-batch body as one call (solver/smpl_nerf_solver.py:76-89 with the default loss,
  * models/smpl_nerf_pipeline.py:16-100, human_pose_encoding = 1) ------------------------------------------------------
  * snerf_nerf_train_* with the warp stage in front of both nets and its backward behind them: warp forward (saving its rows)

@@ -139,8 +139,14 @@ def sample_pdf(bins, weights, args):
     return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
 
 
+FINE_OVERRIDE = None      # checker's tap: (z_vals_fine [B, Nc + Nf], ray_samples_fine [B, Nc + Nf, 3]) to use instead of this path's own
+                          # hierarchical samples - the HIP path's, so that the fine pass is compared on equal samples (tools/ab/fuzz_*)
+
+
 def fine_sampling(ray_translation, samples_directions, z_vals, weights, args):
     """utils.py:231-264."""
+    if FINE_OVERRIDE is not None:
+        return FINE_OVERRIDE
     z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
     z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], args).detach()
     z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)

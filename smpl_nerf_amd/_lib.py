@@ -56,6 +56,10 @@ class NerfBatch(ctypes.Structure):
                 ("white_background", c_int32)]
 
 
+class InputGrads(ctypes.Structure):      # snerf_input_grads
+    _fields_ = [("d_additional", _P), ("params_coarse", _P), ("params_fine", _P)]
+
+
 # name -> (restype, argtypes); must list every symbol include/smplnerf.h declares
 SIGNATURES = {
     "snerf_version": (c_int, []),
@@ -140,6 +144,11 @@ SIGNATURES = {
                                            _P, _P, _P, _P, _P, _P, _P, _P]),
     "snerf_nerf_train_step_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
                                           _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, _P, _P]),
+    "snerf_nerf_train_grads_ig_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
+                                              _P, _P, _P, _P, _P, _P, POINTER(InputGrads), _P, _P]),
+    "snerf_nerf_train_step_ig_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
+                                             _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int,
+                                             POINTER(InputGrads), _P, _P]),
     # 8(e): RCCL inside the boundary
     "snerf_comm_unique_id": (c_int, [_P]),
     "snerf_comm_init_rank": (c_int, [_P, c_int, c_int, POINTER(_P)]),

@@ -297,6 +297,7 @@ namespace snerf {
 struct TrainWs {
     int64_t raw_c, weights_c, z_fine, pts_f, raw_f, d_rgb_c, d_rgb_f, d_raw, act_c, act_f, dy, gpart, loss_acc;
     int64_t d_raw2, dy2, gpart2;   // second set for the coarse net's backward when it runs beside the fine net's (small chunks)
+    int64_t contract;              // scratch of the d loss / d additional-inputs contraction (nets with add_dim > 0)
     bool concurrent;
     int64_t total;
 };
@@ -393,7 +394,43 @@ static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t 
     w.d_raw2 = take(w.concurrent ? chunk * Nc * 4 : 0);
     w.dy2 = take(w.concurrent ? dy_c : 0);
     w.gpart2 = take(w.concurrent ? gp_c : 0);
+    // d loss / d additional inputs (snerf_*_ig_f32): the per-ray partial sums of the contraction (contract.hip)
+    int64_t cs = 0;
+    if (dc->add_dim > 0) {
+        cs = snerf_dy_contract_scratch_floats(chunk * Nc, dc->add_dim, Nc);
+        if (Nf > 0) {
+            const int64_t cf = snerf_dy_contract_scratch_floats(chunk * N, dc->add_dim, (int)N);
+            cs = cf > cs ? cf : cs;
+        }
+        if (cs < 0) return (int)cs;
+    }
+    w.contract = take(cs);
     w.total = off;
+    return SNERF_OK;
+}
+
+// d loss / d additional inputs of one net for one chunk: the stored d Y_l of layer 0 and of every skip layer contracted with the
+// weight columns that read the additional inputs, summed over the samples of a ray (contract.hip; what autograd does through
+// models/render_ray_net.py:43-50 and the `expand` of the pose rows, models/append_smpl_params_pipeline.py:29-52).  out: [rays, add_dim]
+// rows of this chunk; overwrite: the first contraction of the chunk overwrites, the others accumulate.
+static int contract_additional(const snerf_mlp_desc *desc, const float *params, const float *dy, int64_t n, int spr, float *out,
+                               bool overwrite, float *scratch, snerf_stream_t stream) {
+    Plan P;
+    const char *why;
+    if (make_plan(*desc, P, why) != 0) return fail(SNERF_E_BADARG, "nerf_train_grads: %s", why);
+    TrainLayout L;
+    make_train_layout(P, L);
+    bool first = overwrite;
+    for (int l = 0; l < P.nlayers; ++l)
+        for (int sg = 0; sg < P.layer[l].nseg; ++sg) {
+            const Seg &seg = P.layer[l].seg[sg];
+            if (seg.type != SEG_ADD) continue;
+            const Layer &Ly = P.layer[l];
+            const int rc = snerf_dy_contract_f32(dy, n, L.dy[l], Ly.n_out, params + Ly.w_off, Ly.n_in, seg.col_off, seg.ncols, spr, out,
+                                                 seg.ncols, 0, first ? 0 : 1, scratch, stream);
+            if (rc) return rc;
+            first = false;
+        }
     return SNERF_OK;
 }
 
@@ -427,7 +464,8 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
                                  const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
                                  int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
                                  float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
-                                 snerf_stream_t stream, snerf_stream_t aux_stream, snerf_comm_t comm, float *flat_g, int64_t flat_n) {
+                                 snerf_stream_t stream, snerf_stream_t aux_stream, snerf_comm_t comm, float *flat_g, int64_t flat_n,
+                                 const snerf_input_grads *ig = nullptr) {
     using namespace snerf;
     if (precision != 0 && !split_code(precision))
         return fail(SNERF_E_BADARG, "nerf_train_grads: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
@@ -445,6 +483,9 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
         return fail(SNERF_E_BADARG, "nerf_train_grads: both nets must read the same per-ray additional inputs (add_dim %d vs %d)", add_dim,
                     desc_fine->add_dim);
     if (add_dim && !batch->additional) return fail(SNERF_E_BADARG, "nerf_train_grads: the nets have additional inputs but batch->additional is null");
+    float *d_add = ig ? ig->d_additional : nullptr;
+    if (d_add && (!add_dim || !ig->params_coarse || (Nf > 0 && !ig->params_fine)))
+        return fail(SNERF_E_BADARG, "nerf_train_grads: d_additional needs nets with additional inputs and their parameters (params_coarse / params_fine)");
     if (!aligned(workspace, 256)) return fail(SNERF_E_ALIGN, "nerf_train_grads: workspace must be 256-byte aligned");
     if (precision != 0 && (desc_coarse->width != 256 || (Nf > 0 && desc_fine->width != 256)))
         return fail(SNERF_E_BADARG, "nerf_train_grads: the split-precision kernels exist for width 256");
@@ -456,7 +497,7 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
     auto f = [&](int64_t off) { return reinterpret_cast<float *>(ws + off); };
     float *raw_c = f(w.raw_c), *weights_c = f(w.weights_c), *z_fine = f(w.z_fine), *pts_f = f(w.pts_f), *raw_f = f(w.raw_f);
     float *d_rgb_c = f(w.d_rgb_c), *d_rgb_f = f(w.d_rgb_f), *d_raw = f(w.d_raw), *act_c = f(w.act_c), *act_f = f(w.act_f);
-    float *dy = f(w.dy), *gpart = f(w.gpart);
+    float *dy = f(w.dy), *gpart = f(w.gpart), *cscratch = f(w.contract);
     // small chunks with an auxiliary stream: the coarse net's backward beside the fine net's, on its own scratch buffers
     const bool concurrent = w.concurrent && aux_stream && aux_stream != stream;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -524,6 +565,7 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
         if (Nf > 0) {
             if ((rc = snerf_composite_bwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, d_rgb_f, d_raw, nullptr, stream))) return rc;
             if ((rc = bwd(desc_fine, packed_t_fine, act_f, d_raw, b * N, dy, gpart, grad_fine, r0 > 0, stream))) return rc;
+            if (d_add && (rc = contract_additional(desc_fine, ig->params_fine, dy, b * N, N, d_add + r0 * add_dim, true, cscratch, stream))) return rc;
         }
         if ((rc = snerf_composite_bwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, d_rgb_c, d_raw_c, nullptr, stream_c))) return rc;
         if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, d_raw_c, b * Nc, dy_c, gpart_c, grad_coarse, r0 > 0, stream_c))) return rc;
@@ -536,6 +578,10 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
         if (comm && last &&
             (rc = dp_allreduce_avg(comm, flat_g, 0, flat_n, concurrent && coarse_bucket ? cb0 : 0, concurrent && coarse_bucket ? cb1 : 0, s,
                                    "nerf_train_step_dp")))
+            return rc;
+        // the coarse net's share of d loss / d additional inputs: behind the join (the two backwards may have run side by side; the
+        // coarse net's d Y buffer is its own then), added to the fine net's
+        if (d_add && (rc = contract_additional(desc_coarse, ig->params_coarse, dy_c, b * Nc, Nc, d_add + r0 * add_dim, Nf == 0, cscratch, stream)))
             return rc;
     }
     if (Nf == 0 && rgb_fine != rgb &&
@@ -551,6 +597,31 @@ extern "C" int snerf_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, con
                                           snerf_stream_t stream, snerf_stream_t aux_stream) {
     return nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision, batch,
                                  rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream, nullptr, nullptr, 0);
+}
+
+extern "C" int snerf_nerf_train_grads_ig_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                             const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                             int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                             float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                             const snerf_input_grads *input_grads, snerf_stream_t stream, snerf_stream_t aux_stream) {
+    return nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision, batch,
+                                 rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream, nullptr, nullptr, 0,
+                                 input_grads);
+}
+
+extern "C" int snerf_nerf_train_step_ig_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                            const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                            int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                            float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                            const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
+                                            const snerf_adam_net *nets_host, int n_nets, const snerf_input_grads *input_grads,
+                                            snerf_stream_t stream, snerf_stream_t aux_stream) {
+    // (the contraction reads the parameters: it runs inside the gradient half, before Adam moves them)
+    int rc = nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision, batch,
+                                   rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream, nullptr, nullptr,
+                                   0, input_grads);
+    if (rc) return rc;
+    return snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream);
 }
 
 extern "C" int snerf_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,

@@ -83,6 +83,15 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def min_over_ranks(value: float, device=None) -> float:
+    if not is_dist():
+        return float(value)
+    on_host = device is None or device.type != "cuda" or dist.get_backend() == "gloo"
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """All-gather ragged per-rank row blocks (the inverse of shard_rays) - used to assemble a frame
     rendered cooperatively by several ranks (196 KiB of RGB per 128x128 frame)."""

@@ -254,8 +254,15 @@ class _FusedMlpFn(torch.autograd.Function):
         raw = torch.empty((n, 4), device=dev, dtype=torch.float32)
         group = 1 if per_sample == _ENCODED_ROWS else spr            # blocks are whole rays (per-ray directions / inputs)
         budget = getattr(net, "activation_budget_bytes", 0)
-        if budget is None:       # default: a share of what is free on THIS device right now (other nets, the optimiser, gpart live there too)
-            budget = int(0.25 * torch.cuda.mem_get_info(dev)[0])
+        if budget is None:
+            # default: a quarter of what this process can get on THIS device - free at the driver plus what torch's caching
+            # allocator holds without using (driver-free memory alone shrinks as the cache fills, so the same batch
+            # could flip between the stored and the block-wise backward) - decided ONCE per net and device, not per forward
+            cache = net.__dict__.setdefault("_activation_budget_cache", {})
+            budget = cache.get(dev.index)
+            if budget is None:
+                free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                budget = cache[dev.index] = int(0.25 * free)
         budget = int(budget or 0)
         ctx.block = 0
         if budget > 0 and 4 * (act_floats + dy_floats + gpart_floats) > budget and n > group:

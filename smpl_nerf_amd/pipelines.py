@@ -93,6 +93,7 @@ class NerfPipeline(nn.Module):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]
+        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
         N = z_fine.shape[1]
         raw_fine = self.model_fine.forward_fused(ray_samples_fine, ray_direction, N, self.position_encoder,
                                                  self.direction_encoder)
@@ -188,6 +189,7 @@ class SmplNerfPipeline(NerfPipeline):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :68
+        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
         N = z_fine.shape[1]
         warp_f, warped_f, _, raw_f = self._stage(self.model_fine, ray_samples_fine, ray_translation, pose_enc, N)
         rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
@@ -283,6 +285,7 @@ class AppendVerticesPipeline(NerfPipeline):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :70
+        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
         N = z_fine.shape[1]
         raw_f = self.model_fine.forward_rays(ray_inputs, ray_direction, N, B * N)
         rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
@@ -321,6 +324,7 @@ class AppendSmplParamsPipeline(NerfPipeline):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                              # :60
+        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
         N = z_fine.shape[1]
         raw_f = self.model_fine.forward_fused(ray_samples_fine, ray_direction, N, self.position_encoder,
                                               self.direction_encoder, additional=pose, add_first=True)  # :77-81

@@ -77,6 +77,7 @@ class HipAdam:
         self.exp_avg_sq = torch.zeros_like(flat_p)
         self.steps = torch.zeros(len(self.params), dtype=torch.int64, device=dev)     # torch: state[p]["step"]
         self._host_steps = [0] * len(self.params)      # mirror of `steps` (grouping only; the device counters are what the kernel reads)
+        self._pending = None
         self.scratch = torch.zeros(64, dtype=torch.float32, device=dev)
         self.offsets, off = [], 0
         for p in self.params:
@@ -97,7 +98,7 @@ class HipAdam:
 
     def c_ranges(self, has_grad):
         """(snerf_adam_range array, count) for the parameters flagged in `has_grad` (one bool per parameter tensor): runs
-        of adjacent tensors with equal step counts.  Advances the host mirror of the counters."""
+        of adjacent tensors with equal step counts.  commit_step() advances the host mirror of the counters once the call went through."""
         hs = self._host_steps
         key = (tuple(has_grad), tuple(hs[i] == hs[i - 1] for i in range(1, len(hs))))
         if self._range_cache[0] != key:
@@ -117,10 +118,17 @@ class HipAdam:
             for k, (a, b) in enumerate(runs):
                 arr[k] = _lib.AdamRange(self.offsets[a], self.offsets[b], self.steps.data_ptr() + 8 * a, b - a)
             self._range_cache = (key, arr, len(runs))
-        for i, h in enumerate(has_grad):
+        self._pending = tuple(has_grad)
+        return self._range_cache[1], self._range_cache[2]
+
+    def commit_step(self):
+        """Advance the host mirror of the step counters for the ranges c_ranges handed out last - called once the library call
+        that runs the update has returned SNERF_OK (advancing before the call left the mirror ahead of the device
+        counters when the call failed)."""
+        for i, h in enumerate(self._pending or ()):
             if h:
                 self._host_steps[i] += 1
-        return self._range_cache[1], self._range_cache[2]
+        self._pending = None
 
     # -- torch.optim.Optimizer surface -------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
@@ -153,6 +161,7 @@ class HipAdam:
         with torch.cuda.device(self.flat_p.device):
             _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, n, nets, n_nets, _lib.current_stream()),
                        "snerf_adam_step_f32")
+        self.commit_step()
 
     def state_dict(self):
         """torch.optim.Adam.state_dict()'s format (loads into a torch.optim.Adam over the same parameter list)."""
@@ -326,6 +335,11 @@ class DataParallelTrainer:
         NerfPipeline (snerf_nerf_train_step_f32) or a SmplNerfPipeline with the encoded pose (snerf_smpl_nerf_train_step_f32)
         over RenderRayNets without additional inputs (and the WarpFieldNet) that are exactly this trainer's models, the
         default MSE loss, the library's optimiser, every parameter trainable."""
+        # what the decision below depends on and a caller can change between steps (ADVICE r04: a later requires_grad_(False) or a
+        # swapped loss_func used to be ignored): decided again when it changes
+        sig = (tuple(p.requires_grad for p in self.params), type(self.loss_func), getattr(self.loss_func, "reduction", None), self.one_call)
+        if getattr(self, "_oc_sig", None) != sig:
+            self._oc, self._oc_sig = None, sig
         if self._oc is not None:
             return self._oc or None
         from .nets import AppendVerticesNet, RenderRayNet, WarpFieldNet
@@ -342,10 +356,14 @@ class DataParallelTrainer:
         want = AppendVerticesNet if verts else RenderRayNet
         if type(mc) is not want or type(mf) is not want or mc is mf:
             return None
-        if verts and any(p.requires_grad for m in (pipe.smpl_estimator, pipe.smpl_model) if isinstance(m, torch.nn.Module)
-                         for p in m.parameters()):
-            return None        # a trained estimator (AppendVerticesSolver's second group) needs d loss / d vertices: the autograd path
         mine = [mc, mf]
+        upstream = []      # trained modules in front of the nets (AppendVerticesSolver's second parameter group: the pose estimator,
+        if verts:          # solver/append_vertices_solver.py, lrate_pose): they receive d loss / d vertices from the call (r05)
+            upstream = [m for m in (pipe.smpl_estimator, pipe.smpl_model) if isinstance(m, torch.nn.Module)
+                        and any(p.requires_grad for p in m.parameters())]
+            mine = mine + [m for m in upstream if any(m is q for q in self.models)]
+            if len(mine) != 2 + len(upstream):
+                return None    # (a trained upstream module this trainer does not optimise: the autograd path leaves its .grad)
         if smpl:        # the fused warp stage with the encoded pose (human_pose_encoding = 1; the raw-pose mode's fine branch fails like
             mw = pipe.model_warp_field       # the reference's, quirk Q5, and stays on the autograd path)
             if type(mw) is not WarpFieldNet or not getattr(pipe.args, "human_pose_encoding", 0):
@@ -367,18 +385,22 @@ class DataParallelTrainer:
         if (not (posed or verts) and (mc.additional_input_dim or mf.additional_input_dim)) or \
                 not all(p.requires_grad for p in (self.params if not verts else [q for m in (mc, mf) for q in m._ordered_params()])):
             return None
+        if upstream and self._flat_g is None:
+            return None
         if posed and (not mc.additional_input_dim or mc.additional_input_dim != mf.additional_input_dim):
             return None
         seg = {id(m): (off, n) for m, off, n in self._segments}
         if any(id(m) not in seg for m in mine):
             return None
         lib = _lib.load()
-        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None, "posed": posed or verts, "verts": verts}
+        oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None, "posed": posed or verts, "verts": verts,
+              "upstream": upstream}
         # second stream for the coarse net's backward of small batches (include/smplnerf.h: aux_stream); SNERF_TRAIN_AUX_STREAM=0: none
         oc["aux"] = torch.cuda.Stream(self._flat_p.device) if os.environ.get("SNERF_TRAIN_AUX_STREAM", "1") != "0" else None
         # parameter tensors of each net (indices into self.params): the optimiser's has-grad flags of a step
         index = {id(p): i for i, p in enumerate(self.params)}
         oc["tensors"] = tuple(frozenset(index[id(p)] for p in m._ordered_params()) for m in (mc, mf))
+        oc["upstream_tensors"] = frozenset(index[id(p)] for m in upstream for p in m.parameters() if id(p) in index)
         if smpl:
             mw = pipe.model_warp_field
             oc["warp"] = {"net": mw, "seg": seg[id(mw)], "tensors": frozenset(index[id(p)] for p in mw._params()), "packed_t": None}
@@ -398,29 +420,62 @@ class DataParallelTrainer:
             oc["slots"][key] = hit
         return hit
 
-    @torch.no_grad()
     def _step_one_call(self, oc, batch):
+        # the per-ray rows the nets read, under autograd when something in front of them wants the gradient the call returns (a
+        # trained pose estimator, a goal_pose with requires_grad); everything else of the step records nothing
+        add_graph = None
+        with torch.set_grad_enabled(bool(oc["upstream"]) or (oc["posed"] and not oc["verts"] and batch[4].requires_grad)):
+            if oc["verts"] or oc["posed"]:
+                add_graph = self._additional_rows(oc, batch)
+        with torch.no_grad():
+            return self._step_one_call_impl(oc, batch, add_graph)
+
+    def _upstream_backward(self, oc, add_graph, d_add):
+        """torch autograd from the rows' gradient back into what produced them; the upstream modules' parameter gradients are
+        written into their views of the flat gradient buffer."""
+        ups = [self.params[i] for i in sorted(oc["upstream_tensors"])]
+        for p in ups:
+            p.grad = None
+        with torch.enable_grad():
+            add_graph.backward(d_add)
+        for i in sorted(oc["upstream_tensors"]):
+            p, v = self.params[i], self._views[i]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+
+    def _additional_rows(self, oc, batch):
+        pipe, args = self.pipeline, self.pipeline.args
+        if oc["verts"]:      # models/append_vertices_pipeline.py:30-58: estimator -> body model -> the vertex floats the nets read (Q7)
+            images, z_vals = batch[4], batch[3]
+            goal_poses, betas = pipe.smpl_estimator(images)
+            orient = torch.zeros([1, 3], device=z_vals.device).expand(z_vals.shape[0], -1)
+            vertices = pipe.smpl_model(betas=betas, return_verts=True, body_pose=goal_poses, global_orient=orient).vertices
+            return vertices.reshape(z_vals.shape[0], -1)[:, :oc["nets"][0].positions_dim].contiguous().float()
+        # models/append_smpl_params_pipeline.py:29-37 / append_to_nerf_pipeline.py:26: the pose rows the nets read
+        add = pipe._select(batch[4]).contiguous()
+        if args.human_pose_encoding:
+            add = pipe.human_pose_encoder.encode(add)
+        add = add.reshape(add.shape[0], -1).contiguous()
+        if add.shape[1] != oc["nets"][0].additional_input_dim:
+            raise RuntimeError("DataParallelTrainer: the pose rows do not match the nets' additional_input_dim")
+        return add.float()
+
+    def _step_one_call_impl(self, oc, batch, add_graph):
         from . import ops
         from .nets import _split_code
         lib = oc["lib"]
         pipe, args = self.pipeline, self.pipeline.args
         W = oc["warp"]
         goal_pose = add = None
-        if oc["verts"]:      # models/append_vertices_pipeline.py:30-58: estimator -> body model -> the vertex floats the nets read (Q7)
-            ray_samples, rays_o, rays_d, z_vals, images, rgb_truth = (t.contiguous() for t in batch)
-            goal_poses, betas = pipe.smpl_estimator(images)
-            orient = torch.zeros([1, 3], device=ray_samples.device).expand(z_vals.shape[0], -1)
-            vertices = pipe.smpl_model(betas=betas, return_verts=True, body_pose=goal_poses, global_orient=orient).vertices
-            add = vertices.reshape(z_vals.shape[0], -1)[:, :oc["nets"][0].positions_dim].contiguous().float()
-        elif oc["posed"]:    # models/append_smpl_params_pipeline.py:29-37 / append_to_nerf_pipeline.py:26: the pose rows the nets read
-            ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.contiguous() for t in batch)
-            add = pipe._select(goal_pose).contiguous()
-            if args.human_pose_encoding:
-                add = pipe.human_pose_encoder.encode(add)
-            add = add.reshape(add.shape[0], -1).contiguous()
-            if add.shape[1] != oc["nets"][0].additional_input_dim:
-                raise RuntimeError("DataParallelTrainer: the pose rows do not match the nets' additional_input_dim")
-            add = add.float()
+        want_d_add = add_graph is not None and add_graph.requires_grad
+        if oc["verts"]:
+            ray_samples, rays_o, rays_d, z_vals, images, rgb_truth = (t.detach().contiguous() for t in batch)
+            add = add_graph.detach()
+        elif oc["posed"]:
+            ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.detach().contiguous() for t in batch)
+            add = add_graph.detach()
         elif W is not None:
             ray_samples, rays_o, rays_d, z_vals, goal_pose, rgb_truth = (t.contiguous() for t in batch)
         else:
@@ -507,12 +562,25 @@ class DataParallelTrainer:
         else:
             name, tail = "snerf_nerf_train", (aux,)
             step_tail = lambda st, ranges, nr: (ctypes.byref(st), ranges, nr, nets_c, n_nets, stream(), aux)
+        ig = d_add = None
+        if want_d_add:      # d loss / d additional rows comes back from the call (include/smplnerf.h: snerf_input_grads)
+            d_add = torch.empty_like(add)
+            pc = self._flat_p.data_ptr() + 4 * oc_off
+            pf = self._flat_p.data_ptr() + 4 * of_off
+            ig = _lib.InputGrads(d_add.data_ptr(), pc, pf if Nf else None)
         with torch.cuda.device(dev), _lib.timed(f"train_step{'_smpl' if W is not None else ''}[B={B}]"):
-            comm = self._rccl_comm(dev) if self._sync else None
-            if not self._sync:
+            comm = self._rccl_comm(dev) if self._sync and ig is None else None
+            if not self._sync and ig is not None:
+                ranges, nr = opt.c_ranges(flags)
+                st = opt.c_state()
+                _lib.check(lib.snerf_nerf_train_step_ig_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets, ctypes.byref(ig), stream(), aux),
+                           "snerf_nerf_train_step_ig_f32")
+                opt.commit_step()
+            elif not self._sync:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
                 _lib.check(getattr(lib, name + "_step_f32")(*head, *step_tail(st, ranges, nr)), name + "_step_f32")
+                opt.commit_step()
             elif comm is not None:
                 # more than one rank, one call all the same: the gradient average is RCCL's ncclAllReduce(ncclAvg) of the flat
                 # buffer inside the call, on the compute stream between the backward and Adam (include/smplnerf.h 8(e))
@@ -523,18 +591,46 @@ class DataParallelTrainer:
                 t = step_tail(st, ranges, nr)
                 t = t[:-1] + (comm.handle, t[-1]) if W is not None else t[:-2] + (comm.handle,) + t[-2:]
                 _lib.check(getattr(lib, name + "_step_dp_f32")(*head, *t), name + "_step_dp_f32")
+                opt.commit_step()
                 self.collective_calls = getattr(self, "collective_calls", 0) + 1
             else:
-                _lib.check(getattr(lib, name + "_grads_f32")(*head, stream(), *tail), name + "_grads_f32")
+                if ig is not None:
+                    _lib.check(lib.snerf_nerf_train_grads_ig_f32(*head, ctypes.byref(ig), stream(), aux), "snerf_nerf_train_grads_ig_f32")
+                else:
+                    _lib.check(getattr(lib, name + "_grads_f32")(*head, stream(), *tail), name + "_grads_f32")
+                if ig is not None and oc["upstream"]:      # the upstream modules' gradients must be in the flat buffer before it is averaged
+                    self._upstream_backward(oc, add_graph, d_add)
                 if not Nf:      # every rank contributes the same shape: zeros for the net that took no part
                     self._flat_g[of_off:of_off + of_n].zero_()
                 self._allreduce_flat()
+                if ig is not None and oc["upstream"]:
+                    flags = [f or (i in oc["upstream_tensors"]) for i, f in enumerate(flags)]
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
                 _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, nr, nets_c, n_nets, stream()), "snerf_adam_step_f32")
+                opt.commit_step()
                 if W is not None:
                     _lib.check(lib.snerf_warp_repack_f32(wdesc, self._flat_p.data_ptr(), self._flat_p.numel(), w_off, packed_w.data_ptr(),
                                                          packed_t_w.data_ptr(), stream()), "snerf_warp_repack_f32")
+        if self._sync and not Nf and hasattr(mf, "mark_weights_changed"):
+            #  run_fine = 0 with more than one rank: the fine net's parameters are live in the ranges (zero gradients:
+            # weight decay and resumed moments still move them) but its streams were not among the nets the call refreshed
+            mf.mark_weights_changed()
+        if ig is not None and not (self._sync and oc["upstream"]):
+            # back through what produced the rows: a goal_pose that wants its gradient gets it here; a trained estimator's parameter
+            # gradients land in the flat buffer and its tensors take their optimiser step (a second, small C-ABI call)
+            self._upstream_backward(oc, add_graph, d_add)
+            if oc["upstream"]:
+                uflags = [i in oc["upstream_tensors"] for i in range(len(self.params))]
+                with torch.cuda.device(dev):
+                    ranges, nr = opt.c_ranges(uflags)
+                    if nr:
+                        st = opt.c_state()
+                        _lib.check(lib.snerf_adam_step_f32(ctypes.byref(st), ranges, nr, None, 0, stream()), "snerf_adam_step_f32")
+                        opt.commit_step()
+                flags = [a or b for a, b in zip(flags, uflags)]
+        elif ig is not None:
+            flags = [f or (i in oc["upstream_tensors"]) for i, f in enumerate(flags)]
         # p.grad = what autograd would have left: views of the flat gradient buffer (None for a net that took no part)
         for i, (p, v) in enumerate(zip(self.params, self._views)):
             want = v if flags[i] else None
@@ -548,9 +644,11 @@ class DataParallelTrainer:
         local loss tensor (not synchronised with the host)."""
         oc = self._one_call_state()
         if oc is not None and len(batch) == (6 if (oc["warp"] is not None or oc["posed"]) else 5) and \
-                all(t.is_cuda and not t.requires_grad and (t.dtype == torch.float32 or (oc["verts"] and i == 4))
-                    for i, t in enumerate(batch)) and \
-                not getattr(self.pipeline.args, "strict_cumsum", 0):      # (a batch tensor that wants a gradient: the autograd path)
+                all(t.is_cuda and (not t.requires_grad or (i == 4 and oc["posed"] and not oc["verts"])) and
+                    (t.dtype == torch.float32 or (oc["verts"] and i == 4)) for i, t in enumerate(batch)) and \
+                not getattr(self.pipeline.args, "strict_cumsum", 0):
+            # (a batch tensor that wants a gradient: the autograd path - except the pose rows of the pose-conditioned pipelines,
+            # whose gradient the call returns, r05)
             return self._step_one_call(oc, batch)
         self.optim.zero_grad(set_to_none=True)
         self._arm_grad_sinks()
@@ -655,8 +753,8 @@ class RayBatchLoader:
 
     shuffle = True (the reference's loader: DataLoader(shuffle=True, drop_last=False), train.py:100): an epoch is a random
     permutation of this rank's rays cut into batches of `batch_size` - every ray exactly once, the last batch short - with a
-    new permutation per epoch; `iterations` then caps the number of batches (None: the whole epoch).  Ranks whose shards
-    differ in size must agree on `iterations` (the gradient all-reduce of a step is collective).
+    new permutation per epoch; `iterations` then caps the number of batches (None: the whole epoch).  With more than one rank the
+    count is the minimum over the ranks (shards may differ by a frame; the gradient all-reduce of a step is collective).
     shuffle = False: `iterations` batches of uniformly drawn rays, with replacement (no epoch structure)."""
 
     def __init__(self, ray_generator, batch_size: int, iterations: int = None, seed: int = 0, shuffle: bool = False):
@@ -666,7 +764,11 @@ class RayBatchLoader:
             raise ValueError("RayBatchLoader: draws with replacement need `iterations`")
         full = -(-ray_generator.n_rays // self.batch_size)
         self.iterations = full if iterations is None else (min(int(iterations), full) if self.shuffle else int(iterations))
-        _, rank = sdist.world_rank()
+        world, rank = sdist.world_rank()
+        if world > 1 and self.shuffle:
+            # ranks with image shards of different sizes would run different numbers of steps and the per-step gradient
+            # all-reduce would hang: every rank runs the smallest count
+            self.iterations = int(sdist.min_over_ranks(self.iterations, ray_generator.device))
         self.rng = torch.Generator(device=ray_generator.device)
         self.rng.manual_seed(int(seed) + rank)
 

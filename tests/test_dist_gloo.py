@@ -228,3 +228,30 @@ def test_frames_are_sharded_by_image_across_ranks():
         assert [float(v) for v in g.images.view(g.n_frames, 16, 3)[:, 0, 0]] == [float(i) for i in g.frame_ids]  # ... and images
         seen += g.frame_ids
     assert sorted(seen) == list(range(10))
+
+
+def _loader_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smpl_nerf_amd.trainer import RayBatchLoader
+
+        class Gen:      # what the loader reads of a RayGenerator: this rank's ray count and device
+            n_rays = 1000 if rank == 0 else 1300
+            device = torch.device("cpu")
+        loader = RayBatchLoader(Gen(), 256, iterations=None, seed=1, shuffle=True)
+        q.put((rank, len(loader), sd.min_over_ranks(float(rank + 5))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shuffled_loader_runs_the_same_number_of_steps_on_every_rank():
+    """image shards of different sizes (1000 / 1300 rays -> 4 / 6 batches of 256) would leave the ranks with different
+    numbers of steps and the per-step gradient all-reduce would hang: the loader takes the minimum over the ranks."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_loader_worker, args=(2, port, q), nprocs=2, join=True)
+    got = sorted(q.get() for _ in range(2))
+    assert [g[1] for g in got] == [4, 4] and [g[2] for g in got] == [5.0, 5.0]

@@ -923,7 +923,7 @@ def test_split_precision_steps_with_encoded_pose_columns_follow_the_fp32_step(de
 def test_append_vertices_one_call_step_equals_the_autograd_step(dev, prec):
     """a8 / configs[4]: AppendVerticesPipeline with a frozen estimator and body model (the vertex floats the nets read are
     per-ray constants, quirk Q7) trains through snerf_nerf_train_step_f32 with batch.additional; the dead vertices_net
-    parameters get no gradient and are not updated, like in the reference; a TRAINED estimator keeps the autograd path."""
+    parameters get no gradient and are not updated, like in the reference."""
     from test_gpu_round2 import _av_pipeline
     from smpl_nerf_amd.trainer import DataParallelTrainer
     b = _batch(dev, 100, stride=53)
@@ -949,10 +949,12 @@ def test_append_vertices_one_call_step_equals_the_autograd_step(dev, prec):
         assert (ga is None) == (gb is None)
         if ga is not None:
             assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
+    # (r05: a TRAINED estimator stays on the one-call path too - d loss / d vertices comes back from the call:
+    # tests/test_gpu_round5.py::test_trained_estimator_and_pose_gradients_through_the_one_call_step)
     pipe, _ = _av_pipeline(dev, prec, n_poses=10, run_fine=1)
     pipe.smpl_estimator.goal_poses.requires_grad_(True)
     tr = DataParallelTrainer(pipe, [pipe.model_coarse, pipe.model_fine, pipe.smpl_estimator], lr=1e-4)
-    assert tr._one_call_state() is None
+    assert tr._one_call_state() is not None
     tr.step(batch)
     assert float(pipe.smpl_estimator.goal_poses.grad.abs().max()) > 0
 

@@ -254,3 +254,70 @@ def test_data_parallel_step_is_one_call_with_rccl_inside():
     assert out["losses"][0] == out["losses"][1] and out["params_equal"]
     assert out["graph"] == (True, True)
     assert p.exitcode == 0
+
+
+# ------------------------------------------------------------------------------------------ input gradients inside the one-call step
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+def test_trained_estimator_and_pose_gradients_through_the_one_call_step(dev, prec):
+    """d loss / d additional inputs is an output of the one-call step (snerf_nerf_train_step_ig_f32:
+    snerf_dy_contract_f32 per chunk and net, summed per ray), so AppendVerticesSolver's second parameter group (the pose
+    estimator, solver/append_vertices_solver.py) and a goal_pose that requires its gradient no longer fall back to the autograd
+    path.  Against the autograd form of the same steps: losses, the nets' gradients, the estimator's gradient and its updated
+    parameters (append_vertices, configs[4]); goal_pose.grad (append_smpl_params, raw and encoded pose columns)."""
+    from test_gpu_round2 import _av_pipeline
+    from test_gpu_round4 import _batch, _smpl_batch, close
+    from smpl_nerf_amd.nets import RenderRayNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, PipelineArgs
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    b = _batch(dev, 100, stride=53)
+    images = (torch.arange(100, device=dev) % 10)
+    batch = b[:4] + [images, b[4]]
+    runs = []
+    for one_call in (None, False):
+        pipe, _ = _av_pipeline(dev, prec, n_poses=10, run_fine=1)
+        pipe.smpl_estimator.goal_poses.requires_grad_(True)
+        nets = [pipe.model_coarse.train(), pipe.model_fine.train(), pipe.smpl_estimator]
+        tr = DataParallelTrainer(pipe, nets, lr=1e-4, one_call=one_call)
+        tr.rays_per_chunk = 64          # two chunks: the rows' gradient is written chunk by chunk
+        assert (tr._one_call_state() is not None) == (one_call is None)
+        losses = [float(tr.step(batch))]
+        grads = [None if p.grad is None else p.grad.clone() for p in tr.params]
+        g_est = pipe.smpl_estimator.goal_poses.grad.clone()
+        losses.append(float(tr.step(batch)))
+        runs.append((losses, grads, g_est, pipe.smpl_estimator.goal_poses.detach().clone()))
+    close(runs[0][0][:1], runs[1][0][:1], 2e-6, 1e-8)
+    close(runs[0][0][1:], runs[1][0][1:], 2e-4, 1e-8)
+    tol = 1e-4 if prec == "fp32" else 2e-3
+    for ga, gb in zip(runs[0][1], runs[1][1]):
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            assert float((ga - gb).norm()) <= tol * float(gb.norm()) + 1e-10
+    assert float(runs[1][2].abs().max()) > 0
+    assert float((runs[0][2] - runs[1][2]).norm()) <= tol * float(runs[1][2].norm())
+    assert float((runs[0][3] - runs[1][3]).abs().max()) <= 2e-4 * 1e-4 + tol * 1e-4      # two Adam steps of 1e-4 each
+    # a goal_pose that wants its gradient (bench.py --train-input-grads, append_smpl_params)
+    for encoded in (0, 1):
+        got = []
+        for one_call in (None, False):
+            torch.manual_seed(77)
+            pe, de = PositionalEncoder(10, 0), PositionalEncoder(4, 0)
+            nets = []
+            for _ in range(2):
+                m = RenderRayNet(6, 256, 3 * pe.output_dim, 3 * de.output_dim, 69 * (20 if encoded else 1), skips=[3]).to(dev).train()
+                with torch.no_grad():
+                    m.sigma_out_layer.weight.mul_(20.0)
+                m.precision = prec
+                nets.append(m)
+            pipe = AppendSmplParamsPipeline(nets[0], nets[1], PipelineArgs(number_fine_samples=32, human_pose_encoding=encoded), pe, de,
+                                            PositionalEncoder(10, 0))
+            tr = DataParallelTrainer(pipe, nets, lr=1e-5, one_call=one_call)
+            tr.rays_per_chunk = 20
+            sb = [t.clone() for t in _smpl_batch(dev, 50)]
+            sb[4].requires_grad_(True)
+            loss = float(tr.step(sb))
+            assert (tr._one_call_state() is not None) == (one_call is None)
+            got.append((loss, sb[4].grad.clone()))
+        close([got[0][0]], [got[1][0]], 2e-6, 1e-8)
+        assert float(got[1][1].abs().max()) > 0
+        assert float((got[0][1] - got[1][1]).norm()) <= (2e-4 if prec == "fp32" else 5e-3) * float(got[1][1].norm())

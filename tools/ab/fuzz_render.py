@@ -99,7 +99,15 @@ for case in range(cases):
             ref_fn = lambda: TP.append_pose_pipeline_forward(P[0], P[1], targs, tpe, tde, the, cpu, two_joints=kind == "append_to_nerf")
         with torch.no_grad():
             out = pipe(batch)
-            ref = ref_fn()
+            ref_own = ref_fn()          # the CPU path on its own hierarchical samples
+            # ... and on the HIP path's samples: the reference's sampler is discontinuous where a bin's mass sits at
+            # its 1e-5 threshold (utils.py:224), so a last-bit difference of the coarse weights moves a ray's samples - with equal
+            # samples the fine pass is held to the tolerance of the coarse one, no "rays off" allowance
+            TP.FINE_OVERRIDE = tuple(t.detach().cpu() for t in pipe.last_fine) if run_fine else None
+            try:
+                ref = ref_fn()
+            finally:
+                TP.FINE_OVERRIDE = None
         # the single-call entries (snerf_render_rays_f32 / _smpl_f32 / _add_f32) against the five-launch forward: bit for bit
         one_call_ok = True
         mixed = kind == "smpl_nerf" and pipe.model_warp_field.precision != prec      # (the one-call entry wants one precision for all nets)
@@ -114,15 +122,32 @@ for case in range(cases):
             tol *= 100          # the warp net's round-off passes through two 2^9 encoders before it reaches a colour
         ec = (out[0].cpu() - ref[0]).abs().max(-1).values
         ef = (out[1].cpu() - ref[1]).abs().max(-1).values
-        flips = int((ef > 10 * tol).sum())
-        # (the reference's sampler is discontinuous where a bin's mass sits at its 1e-5 threshold, utils.py:224: a last-bit
-        # difference of the coarse weights moves that ray's samples - a few rays may differ visibly; the sampler itself is held
-        # to the oracle bit for bit from equal weights by fuzz_ops.py)
-        ok = float(ec.max()) <= tol and flips <= max(2, B // 15) and float(ef.max()) <= 0.25 and float(ef.median()) <= tol and \
-            bool(torch.isfinite(out[1]).all()) and one_call_ok
+        # information only: rays whose fine colour differs visibly when the CPU path draws its OWN samples (the sampler itself is
+        # held to the oracle bit for bit from equal weights by fuzz_ops.py; the bench line reports sampler_index_equal_frac)
+        flips = int(((out[1].cpu() - ref_own[1]).abs().max(-1).values > 10 * tol).sum())
+        ok = float(ec.max()) <= tol and float(ef.max()) <= 3 * tol and bool(torch.isfinite(out[1]).all()) and one_call_ok
         bad += not ok
-        print(("ok  " if ok else "BAD ") + desc + f": coarse max {float(ec.max()):.2e}, fine median {float(ef.median()):.2e} max {float(ef.max()):.2e} ({flips} rays off)" + ("" if one_call_ok else "  ONE-CALL RENDER DIFFERS"),
+        print(("ok  " if ok else "BAD ") + desc + f": coarse max {float(ec.max()):.2e}, fine on equal samples median {float(ef.median()):.2e} max {float(ef.max()):.2e} (own samples: {flips} rays off)" + ("" if one_call_ok else "  ONE-CALL RENDER DIFFERS"),
               flush=True)
+        if not ok and os.environ.get("FUZZ_ADJUDICATE", "1") != "0":
+            # the flagged case in float64 on the CPU, same samples: who is further from the exact value?
+            try:
+                TP.FINE_OVERRIDE = tuple(t.detach().cpu().double() for t in pipe.last_fine) if run_fine else None
+                P64 = [{k: v.double() for k, v in p_.items()} for p_ in P]
+                cpu64 = [t.double() if t.is_floating_point() else t for t in cpu]
+                if kind == "nerf":
+                    r64 = TP.nerf_pipeline_forward(P64[0], P64[1], targs, tpe, tde, cpu64)
+                elif kind == "smpl_nerf":
+                    r64 = TP.smpl_nerf_pipeline_forward(P64[0], P64[1], {k: v.double() for k, v in Pw.items()}, targs, tpe, tde, the, cpu64)
+                else:
+                    r64 = TP.append_pose_pipeline_forward(P64[0], P64[1], targs, tpe, tde, the, cpu64, two_joints=kind == "append_to_nerf")
+                print(f"     fp64 adjudication (max abs error of the fine colours): HIP {float((out[1].cpu().double() - r64[1]).abs().max()):.2e}, "
+                      f"CPU fp32 restatement {float((ref[1].double() - r64[1]).abs().max()):.2e}; coarse: HIP {float((out[0].cpu().double() - r64[0]).abs().max()):.2e}, "
+                      f"CPU fp32 {float((ref[0].double() - r64[0]).abs().max()):.2e}", flush=True)
+            except Exception as e:      # noqa: BLE001
+                print(f"     fp64 adjudication failed: {type(e).__name__}: {str(e)[:200]}", flush=True)
+            finally:
+                TP.FINE_OVERRIDE = None
     except Exception as e:   # noqa: BLE001
         bad += 1
         print("EXC " + desc + f": {type(e).__name__}: {str(e)[:300]}", flush=True)

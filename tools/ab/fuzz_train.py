@@ -96,6 +96,10 @@ for case in range(cases):
                 pipe = NerfPipeline(nets[0], nets[1], args, pe, de)
             tr = DataParallelTrainer(pipe, nets, lr=1e-3, one_call=one_call)
             tr.rays_per_chunk = chunk
+            if len(runs) == 0 and run_fine:      # the HIP path's hierarchical samples at the initial weights (for the CPU comparison below)
+                with torch.no_grad():
+                    pipe(batch)
+                gpu_fine = tuple(t.detach().cpu() for t in pipe.last_fine)
             loss = float(tr.step(batch))
             # (split-precision smpl_nerf with identity columns / more frequencies: the trainer keeps the autograd path by design)
             by_design = kind == "smpl_nerf" and prec != "fp32" and (idp or Lp > 10)
@@ -131,10 +135,15 @@ for case in range(cases):
                     m.sigma_out_layer.weight.mul_(20.0)
                 P.append({k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()})
             cb = [t.cpu() for t in batch]
+            # on the HIP path's fine samples: the reference's sampler is discontinuous where a bin's mass sits at its 1e-5
+            # threshold (utils.py:224: nearly opaque rays), so a last-bit difference of the coarse weights would move samples - with
+            # equal samples the fine net's gradient is held as tightly as the coarse net's
+            TP.FINE_OVERRIDE = gpu_fine if run_fine else None
             out = TP.nerf_pipeline_forward(P[0], P[1], TP.Args(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine),
                                            TP.PositionalEncoder(Lp, idp), TP.PositionalEncoder(Ld, idd), cb,
                                            net_kw=dict(n_layers=depth, positions_dim=3 * pe.output_dim, directions_dim=3 * de.output_dim,
                                                        skips=tuple(skips), use_directional_input=use_dir))
+            TP.FINE_OVERRIDE = None
             lt = torch.nn.functional.mse_loss(out[0], cb[-1]) + torch.nn.functional.mse_loss(out[1], cb[-1])
             lt.backward()
             ref = [v.grad for p_ in P for v in p_.values()]
@@ -153,7 +162,7 @@ for case in range(cases):
                 else:
                     et_fine = max(et_fine, e)
             lt = float(lt.detach())
-            if not (abs(la - lt) <= 2e-3 * abs(lt) + 1e-7 and et <= 1e-2 and et_fine <= 5e-1):
+            if not (abs(la - lt) <= 2e-3 * abs(lt) + 1e-7 and et <= 1e-2 and et_fine <= 1e-2):
                 err = max(err, 1.0)      # flag the case
         # (a sample within rounding of a ReLU kink takes the other side in the other arithmetic: ~1 / sqrt(samples) of a gradient)
         if e32 > max(2e-4 if prec != "bf16x3" else 2e-2, 0.05 / np.sqrt(B * Nc)):
