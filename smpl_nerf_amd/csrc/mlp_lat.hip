@@ -110,8 +110,6 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_i
             if (wave >= w0 && wave < w0 + ((t_out + 1) >> 1)) {
                 const int tile = 2 * (wave - w0);
                 f4 acc[S][2];
-                lat_wait_loads();      // the aux pair of this layer: issued at the top of the wave's previous group, eight loads ago
-                asm volatile("" : "+v"(W.aux[0]), "+v"(W.aux[1]));
 #pragma unroll
                 for (int s = 0; s < S; ++s) acc[s][0] = W.aux[0], acc[s][1] = W.aux[1];
                 lat_run_layer<S>(W, tab, lds, Ly, acc);
@@ -286,8 +284,6 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_bwd_lat_kernel(LatTable tab_i
                 const int tile = 2 * (wave - w0);
                 f4 acc[S][2];
                 const bool scale = op & LAT_SCALE_AUX;   // d o = directional_input[:, :W]^T d h1 + sigma_out_layer^T d sigma (:51-52)
-                lat_wait_loads();      // the aux pair of this layer: issued at the top of the wave's previous group, eight loads ago
-                asm volatile("" : "+v"(W.aux[0]), "+v"(W.aux[1]));
 #pragma unroll
                 for (int s = 0; s < S; ++s)
 #pragma unroll

@@ -150,23 +150,9 @@ struct LatCursor {
     }
 };
 
-// The FIFO's loads and the waits for them are written by hand: two buffer loads per step into the slot the step just consumed, two
-// per group for the aux values, and `s_waitcnt vmcnt(LAT_INFLIGHT)` in front of every use - ten loads are in flight at that point
-// and the two oldest are the ones needed.  (Left to the compiler's wait-count insertion, the first step of every group waited for
-// all but three - i.e. for loads issued one step earlier: at one sample tile per pass a quarter of the kernel.)  The compiler does
-// not know these are loads: it must never move or copy a slot between its load and the wait - checked in the ISA (no v_mov of a
-// FIFO register), and the bit-for-bit tests against the throughput kernels would see a stale operand.  Other vector-memory
-// instructions in between (the compiler's own: stores of a training forward, phase-0 loads) only make the wait more conservative:
-// loads return in order, so whatever is older than the eight youngest has landed.
-constexpr int LAT_INFLIGHT = 2 * (LAT_PF - 1) + 2;   // younger loads at a step's wait: the other slots' and the group's aux pair
-typedef int lat_i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void lat_load_pair(f4 &d0, f4 &d1, lat_i4 rs, int voff, int soff, int soff1) {
-    asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %5 offen"
-                 : "=&v"(d0), "=&v"(d1)
-                 : "v"(voff), "s"(rs), "s"(soff), "s"(soff1)
-                 : "memory");
+__device__ __forceinline__ f4 lat_load_a(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
-__device__ __forceinline__ void lat_wait_loads() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAT_INFLIGHT) : "memory"); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lat_rsrc(const void *base, unsigned bytes) {
     const uint64_t b = reinterpret_cast<uint64_t>(base);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
@@ -195,7 +181,7 @@ __device__ __forceinline__ unsigned lat_mask_off(int mask_row, int idx, unsigned
 
 // The A-operand FIFO and the wave's place in the workgroup
 struct LatWave {
-    lat_i4 rs;      // buffer resource of the packed stream
+    __amdgpu_buffer_rsrc_t rs;
     int voff;       // lane * 16
     int gvoff;      // (lane >> 4) * 16: lane offset into an aux block
     int wave, lane;
@@ -205,22 +191,20 @@ struct LatWave {
 
     // the two loads of one step into its slot
     __device__ __forceinline__ void fetch(int so, f4 (&slot)[2]) {
-        lat_load_pair(slot[0], slot[1], rs, voff, so, so + 1024);   // (a one-tile layer: the KiB behind its tile, inside the slab; unused)
+        slot[0] = lat_load_a(rs, voff, so);
+        slot[1] = lat_load_a(rs, voff, so + 1024);   // (a one-tile layer: the KiB behind its tile, inside the slab; unused)
     }
     __device__ __forceinline__ void fetch_aux() {
         const int so = cur.aux_offset();
-        lat_load_pair(aux[0], aux[1], rs, gvoff, so, so + 64);      // (a one-tile layer: the next 16 floats of the aux block; unused)
+        aux[0] = lat_load_a(rs, gvoff, so);
+        aux[1] = lat_load_a(rs, gvoff, so + 64);     // (a one-tile layer: the next 16 floats of the aux block; unused)
     }
     __device__ __forceinline__ void start(LatTabPtr tab, const float *packed, int tid, int passes) {
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         voff = lane * 16;
         gvoff = (lane >> 4) * 16;
-        {   // raw buffer resource of the stream: {base[31:0], base[47:32] (stride 0), bytes, 0x00020000} - lat_rsrc's words
-            const uint64_t b = reinterpret_cast<uint64_t>(packed);
-            rs = lat_i4{(int)__builtin_amdgcn_readfirstlane((uint32_t)b), (int)(__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) & 0xffffu),
-                        (int)__builtin_amdgcn_readfirstlane((uint32_t)tab->stream_bytes), 0x00020000};
-        }
+        rs = lat_rsrc(packed, (unsigned)tab->stream_bytes);
         cur.passes_left = passes;
         cur.enter(tab, wave, 0);
         fetch_aux();
@@ -230,6 +214,11 @@ struct LatWave {
     }
 };
 
+// (r05, measured and withdrawn: the FIFO's loads and their `s_waitcnt vmcnt(8)` written by hand as inline asm - the compiler's own
+// wait-count insertion makes the first step of every group wait for all but three of the ten loads in flight, i.e. for loads issued
+// one step earlier.  The compiler does not know the asm outputs are still in flight: under register pressure it parks FIFO registers
+// in other registers around address arithmetic (v_mov out, v_mov back) and the late-landing load is overwritten by the stale copy -
+// wrong gradients and memory faults in two-trainer runs.  The loads stay builtins.)
 // two MFMAs on two accumulators, in place (tied operands: the builtin form lets the compiler accumulate out of place and copy back)
 __device__ __forceinline__ void lat_mfma2(f4 &c0, f4 &c1, float a0, float a1, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, %3, %4, %1" : "+v"(c0), "+v"(c1) : "v"(a0), "v"(a1), "v"(b));
@@ -272,7 +261,6 @@ __device__ __forceinline__ void lat_run_layer(LatWave &W, LatTabPtr tab, const c
             for (int s = 0; s < S; ++s)
                 b[(j + 1) & 1][s] = j + 1 < LAT_PF ? *reinterpret_cast<const f4 *>(p + (j + 1) * 1024 + s * st)
                                                    : *reinterpret_cast<const f4 *>(p_next + s * st_next);
-            lat_wait_loads();      // slot j has landed
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll

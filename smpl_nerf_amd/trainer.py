@@ -390,8 +390,8 @@ class DataParallelTrainer:
         if posed and (not mc.additional_input_dim or mc.additional_input_dim != mf.additional_input_dim):
             return None
         seg = {id(m): (off, n) for m, off, n in self._segments}
-        if any(id(m) not in seg for m in mine):
-            return None
+        if any(id(m) not in seg for m in mine if not any(m is u for u in upstream)):
+            return None        # (the nets need their segment of the flat buffers; an upstream module's gradients are copied into its views)
         lib = _lib.load()
         oc = {"nets": (mc, mf), "seg": (seg[id(mc)], seg[id(mf)]), "slots": {}, "ws": None, "lib": lib, "warp": None, "posed": posed or verts, "verts": verts,
               "upstream": upstream}
@@ -400,7 +400,7 @@ class DataParallelTrainer:
         # parameter tensors of each net (indices into self.params): the optimiser's has-grad flags of a step
         index = {id(p): i for i, p in enumerate(self.params)}
         oc["tensors"] = tuple(frozenset(index[id(p)] for p in m._ordered_params()) for m in (mc, mf))
-        oc["upstream_tensors"] = frozenset(index[id(p)] for m in upstream for p in m.parameters() if id(p) in index)
+        oc["upstream_tensors"] = frozenset(index[id(p)] for m in upstream for p in m.parameters() if id(p) in index and p.requires_grad)
         if smpl:
             mw = pipe.model_warp_field
             oc["warp"] = {"net": mw, "seg": seg[id(mw)], "tensors": frozenset(index[id(p)] for p in mw._params()), "packed_t": None}

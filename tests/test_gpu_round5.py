@@ -246,8 +246,13 @@ def test_data_parallel_step_is_one_call_with_rccl_inside():
     q = ctx.SimpleQueue()
     p = ctx.Process(target=_dp_worker, args=(port, q))
     p.start()
+    p.join(420)          # (join first: a worker that died before reporting must not leave this test waiting on the queue)
+    if p.is_alive():
+        p.kill()
+        p.join(10)
+        pytest.fail("the RCCL worker did not finish within 420 s")
+    assert not q.empty(), f"the RCCL worker exited with code {p.exitcode} without a report"
     out = q.get()
-    p.join(300)
     assert "error" not in out, out.get("error")
     assert out["comm"] == (1, 0, True)
     assert out["used_rccl"]
