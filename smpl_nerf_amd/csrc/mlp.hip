@@ -324,10 +324,10 @@ __global__ __launch_bounds__(256) void mlp_add_fold_kernel(Plan P, const float *
 }
 
 template <int NW, bool ENCODED, bool TRAIN, bool FOLD = false>
-static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s) {
+static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t n_limit = -1) {
     const int64_t tile = NW * 16;
     FwdArgs B = A;
-    B.n_tiles = (A.n + tile - 1) / tile;
+    B.n_tiles = ((n_limit >= 0 ? n_limit : A.n) + tile - 1) / tile;   // (n_limit: only the first n_limit samples - the others are another launch's)
     B.total_slabs = P.total_slabs;
     if (B.n_tiles > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd: n too large");
     const int n_cu = device_cu_count("mlp_fwd");  // one persistent workgroup per CU
@@ -395,8 +395,12 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // Calls of a few 16-sample tiles per CU (the README's 64-ray batches, inference.py's 800 rays): the latency-class kernels
     // (mlp_lat.hip: a tile's output features split over the waves of a workgroup; bit-identical results)
     if constexpr (!ENCODED) {
-        const int rc = launch_fwd_lat<TRAIN>(P, A, s);
-        if (rc != 1) return rc;
+        const LatChoice c = lat_choose_fwd<TRAIN>(P, A.n);
+        if (c.mode == 1) return launch_fwd_lat<TRAIN>(P, A, s, 0);
+        if (c.mode == 2) {      // whole rounds of 128-sample tiles on the throughput kernel, the rest on the latency kernels
+            if (int rc = launch_fwd_nw<FWD_WAVES, ENCODED, TRAIN>(P, A, s, c.n_main)) return rc;
+            return launch_fwd_lat<TRAIN>(P, A, s, c.n_main);
+        }
     }
     // Small calls (the README's 64-ray batches: 4096 + 12 288 samples): while 64-sample tiles still fit one round of the chip,
     // the 4-wave form finishes in half the time of a 128-sample tile's pass through the weight stream - a call of up to

@@ -24,13 +24,21 @@ int launch_warp_bwd(const snerf_warp_desc *desc, const float *packed_t, const fl
 int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int nsplit, const float *act, const float *d_raw, int64_t n,
                     float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample, int spr,
                     float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate = false);
-// defined in mlp_lat.hip: the latency-class kernels of small calls.  0 = launched, 1 = not a call for them (run the throughput form),
-// < 0 = error.
+// defined in mlp_lat.hip: the latency-class kernels of small calls, and which form a call takes (mode 0: the throughput kernel alone,
+// 1: the latency kernels alone, 2: the throughput kernel on the first n_main samples - whole rounds of the chip - and the latency
+// kernels on the rest)
+struct LatChoice {
+    int mode;
+    int64_t n_main;
+};
 struct FwdArgs;
-template <bool TRAIN>
-int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s);
 struct BwdArgs;
-int launch_bwd_lat(const Plan &P, const BwdArgs &A, bool input_grad, hipStream_t s);
+template <bool TRAIN>
+LatChoice lat_choose_fwd(const Plan &P, int64_t n);
+template <bool TRAIN>
+int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t first_sample);
+LatChoice lat_choose_bwd(const Plan &P, int64_t n, bool input_grad);
+int launch_bwd_lat(const Plan &P, const BwdArgs &A, hipStream_t s, int64_t first_sample);
 // defined in mlp.hip: packs params_flat into the slab stream described by `P` (any plan)
 int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStream_t s, const char *what);
 

@@ -16,19 +16,23 @@ namespace snerf {
 
 struct LatLds {   // byte offsets into the dynamic LDS of a workgroup
     int act[2];   // two activation buffers, S x 16 KiB each
-    // forward: the encoder k-blocks of a sample tile, pe_stride bytes each: [position k-blocks][zero k-blocks up to a multiple of LAT_PF]
-    // [direction k-blocks][zero k-blocks: 16 + dir_nkb up to a multiple of LAT_PF]; dgrad: the d rgb operand + 3 zero k-blocks
+    // forward: the input k-blocks of a sample tile that are not a layer's output, pe_stride bytes per tile: [position-encoding and
+    // per-ray additional-input k-blocks in the column order of the weight matrix][zero k-blocks up to a multiple of LAT_PF]
+    // [direction-encoding k-blocks][zero k-blocks: 16 + dir_nkb up to a multiple of LAT_PF]; dgrad: unused
     int pe, pe_stride, pe_dir;   // pe_dir: offset of the direction k-blocks inside a tile's region
+    int pe_pos, pe_add;          // offsets of the position-encoding / additional-input k-blocks inside the first block
     int aux, aux_stride;         // dgrad: the ReLU sign-mask words of the pass, S x n_mask x 512 B (forward: unused)
     int total;
 };
 static inline int lat_pad(int nkb) { return (nkb + LAT_PF - 1) / LAT_PF * LAT_PF; }
-static inline LatLds lat_lds(int S, int pos_nkb, int dir_nkb, int aux_bytes) {
+static inline LatLds lat_lds(int S, int pos_nkb, int dir_nkb, int aux_bytes, int add_nkb = 0, int add_first = 0) {
     LatLds o;
     o.act[0] = 0;
     o.act[1] = S * LAT_ACT_BYTES;
     o.pe = 2 * S * LAT_ACT_BYTES;
-    o.pe_dir = lat_pad(pos_nkb) * 1024;
+    o.pe_pos = add_first ? add_nkb * 1024 : 0;
+    o.pe_add = add_first ? 0 : pos_nkb * 1024;
+    o.pe_dir = lat_pad(pos_nkb + add_nkb) * 1024;
     o.pe_stride = o.pe_dir + (lat_pad(16 + dir_nkb) - 16) * 1024;
     o.aux = o.pe + S * o.pe_stride;
     o.aux_stride = aux_bytes;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_i
     LatWave W;
     W.start(tab, A.packed, tid, G.passes);
     const int lane = W.lane, wave = W.wave, g = lane >> 4;
-    const int enc_nkb = A.pos_nkb + A.dir_nkb;
+    const int in_nkb = A.pos_nkb + A.add_nkb, enc_nkb = in_nkb + A.dir_nkb;
     const unsigned n32 = (unsigned)A.n;
     const __amdgpu_buffer_rsrc_t act_rs = lat_rsrc(TRAIN ? A.act : A.raw, LAT_STORE_RANGE);   // (TRAIN only)
     const __amdgpu_buffer_rsrc_t raw_rs = lat_rsrc(A.raw, LAT_STORE_RANGE);
@@ -67,38 +71,45 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_i
 
         // ---- phase 0: the encoder k-blocks of the pass, one (tile, k-block) unit per wave at a time -> LDS ---------------
         if (pass == 0) {   // the zero k-blocks behind them (padding steps of layers whose k-block count is not a multiple of LAT_PF)
-            const int zp = Lo.pe_dir / 1024 - A.pos_nkb, zd = (Lo.pe_stride - Lo.pe_dir) / 1024 - A.dir_nkb;
+            const int zp = Lo.pe_dir / 1024 - in_nkb, zd = (Lo.pe_stride - Lo.pe_dir) / 1024 - A.dir_nkb;
             for (int u = wave; u < S * (zp + zd); u += LAT_NW) {
                 const int s = u / (zp + zd), k = u - s * (zp + zd);
-                const int off = k < zp ? (A.pos_nkb + k) * 1024 : Lo.pe_dir + (A.dir_nkb + k - zp) * 1024;
+                const int off = k < zp ? (in_nkb + k) * 1024 : Lo.pe_dir + (A.dir_nkb + k - zp) * 1024;
                 *reinterpret_cast<f4 *>(lds + Lo.pe + s * Lo.pe_stride + off + W.voff) = f4{0.f, 0.f, 0.f, 0.f};
             }
         }
         for (int u = wave; u < S * enc_nkb; u += LAT_NW) {
             const int s = u / enc_nkb, k = u - s * enc_nkb;
-            const bool is_dir = k >= A.pos_nkb;
-            const int kb = is_dir ? k - A.pos_nkb : k;
+            const bool is_dir = k >= in_nkb, is_add = !is_dir && k >= A.pos_nkb;
+            const int kb = is_dir ? k - in_nkb : is_add ? k - A.pos_nkb : k;
             const int64_t smp = sample_of(s), sc = min(smp, A.n - 1);
             SampleCtx c;
             c.g = g;
             c.enc = nullptr;
             c.add = nullptr;
             c.px = c.py = c.pz = c.dx = c.dy = c.dz = 0.f;
-            if (is_dir) {
-                const float *dp = A.dirs + (A.dirs_per_sample ? sc : sc / A.spr) * 3;
-                const float ux = dp[0], uy = dp[1], uz = dp[2];
-                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ux, ux), __fmul_rn(uy, uy)), __fmul_rn(uz, uz)));
-                c.dx = __fdiv_rn(ux, nrm);  // models/nerf_pipeline.py:33-34
-                c.dy = __fdiv_rn(uy, nrm);
-                c.dz = __fdiv_rn(uz, nrm);
+            f4 b;
+            if (is_add) {      // per-ray additional inputs (the pose rows of models/append_smpl_params_pipeline.py:29-52): this sample's ray's row
+                c.add = A.add + (sc / A.spr) * A.add_dim;
+                b = add_operand(c, A.add_dim, kb);
             } else {
-                c.px = A.x[sc * 3 + 0];
-                c.py = A.x[sc * 3 + 1];
-                c.pz = A.x[sc * 3 + 2];
+                if (is_dir) {
+                    const float *dp = A.dirs + (A.dirs_per_sample ? sc : sc / A.spr) * 3;
+                    const float ux = dp[0], uy = dp[1], uz = dp[2];
+                    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ux, ux), __fmul_rn(uy, uy)), __fmul_rn(uz, uz)));
+                    c.dx = __fdiv_rn(ux, nrm);  // models/nerf_pipeline.py:33-34
+                    c.dy = __fdiv_rn(uy, nrm);
+                    c.dz = __fdiv_rn(uz, nrm);
+                } else {
+                    c.px = A.x[sc * 3 + 0];
+                    c.py = A.x[sc * 3 + 1];
+                    c.pz = A.x[sc * 3 + 2];
+                }
+                b = pe_operand<false>(c, is_dir, is_dir ? A.dir_L : A.pos_L, is_dir ? A.dir_id : A.pos_id, kb, 0);
             }
-            const f4 b = pe_operand<false>(c, is_dir, is_dir ? A.dir_L : A.pos_L, is_dir ? A.dir_id : A.pos_id, kb, 0);
-            *reinterpret_cast<f4 *>(lds + Lo.pe + s * Lo.pe_stride + (is_dir ? Lo.pe_dir + kb * 1024 : kb * 1024) + W.voff) = b;
-            if (TRAIN) lat_store_f4(act_rs, act_off(s, (is_dir ? A.act_dpe : A.act_pe) + kb), b);
+            const int off = is_dir ? Lo.pe_dir + kb * 1024 : (is_add ? Lo.pe_add : Lo.pe_pos) + kb * 1024;
+            *reinterpret_cast<f4 *>(lds + Lo.pe + s * Lo.pe_stride + off + W.voff) = b;
+            if (TRAIN) lat_store_f4(act_rs, act_off(s, (is_dir ? A.act_dpe : is_add ? A.act_add : A.act_pe) + kb), b);
         }
         __syncthreads();
 
@@ -348,6 +359,12 @@ bool lat_enabled() {
 }
 // SNERF_LAT_MAX_TILES_PER_CU=k (experiments): the latency kernels for every call of up to k 16-sample tiles per CU, whatever the
 // cost model below says; unset: the model decides
+// SNERF_LAT_FWD=0 / SNERF_LAT_BWD=0 (A/B measurements): the throughput kernels for every forward / every dgrad
+static bool lat_dir_enabled(bool bwd) {
+    static const bool f = [] { const char *e = getenv("SNERF_LAT_FWD"); return e ? atoi(e) != 0 : true; }();
+    static const bool b = [] { const char *e = getenv("SNERF_LAT_BWD"); return e ? atoi(e) != 0 : true; }();
+    return bwd ? b : f;
+}
 static int lat_max_tiles_override() {
     static const int v = [] { const char *e = getenv("SNERF_LAT_MAX_TILES_PER_CU"); return e ? atoi(e) : -1; }();
     return v;
@@ -385,17 +402,49 @@ static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2]) {
 // 567 / 590; 153 600: 1611 / 1475.)  The latency form wins below two tiles of 128 per CU wherever the throughput form would run a
 // mostly empty round.
 enum LatKind { LAT_INFER = 0, LAT_TRAIN_FWD = 1, LAT_DGRAD = 2 };
-static bool lat_wins(LatKind kind, int64_t n, int64_t n16, int n_cu, const LatLaunch *Q, int nq) {
+static double lat_cost(LatKind kind, int64_t n16, int n_cu, int s_max) {
+    static const double fixed[3] = {21, 22, 19}, per_tile[3] = {41, 43, 38};
+    LatLaunch Q[2];
+    const int nq = lat_split(n16, n_cu, s_max, Q);
+    double t = 0;
+    for (int i = 0; i < nq; ++i) t += fixed[kind] + Q[i].passes * (4.0 + per_tile[kind] * Q[i].S);
+    return t;
+}
+// 0: the throughput kernel alone; 1: the latency kernels alone; 2: the throughput kernel on the first n_main samples - whole rounds of
+// 128-sample tiles on every CU - and the latency kernels on the rest (a call of 2.3 rounds is two full rounds + 0.3 of one at the
+// latency kernels' granularity of 16 samples instead of a third, mostly empty round: inference.py's 800 rays, 153 600 fine samples =
+// 4.69 rounds)
+// The dgrad is different: inside a training step the coarse net's backward runs beside the fine net's on a second stream (chunks of up
+// to 1024 rays), and the partly empty rounds of one net's throughput dgrad are filled by the other's workgroups - while a latency
+// kernel takes a whole CU's LDS.  Measured on whole steps (profiles/r05_lat_step_ab.txt: 128 rays 1.237 ms with the throughput dgrad
+// / 1.261 with the latency dgrad, 800 rays 6.527 / 6.606; 64 rays 0.90 / 0.72): the latency dgrad pays up to four tiles per CU
+// (the README's 64-ray batches), and never as the remainder of a throughput launch.
+LatChoice lat_choose(int kind_i, int64_t n, int n_cu, int s_max) {
+    const LatKind kind = (LatKind)kind_i;
+    const int64_t max_tiles = kind == LAT_DGRAD ? 4 : 64;
+    static const double round64[3] = {178, 191, 170}, round128[3] = {295, 352, 314};
+    const int64_t n16 = (n + 15) / 16, per_round = (int64_t)128 * n_cu;
     const int ovr = lat_max_tiles_override();
-    if (ovr >= 0) return n16 <= (int64_t)ovr * n_cu;
-    static const double fixed[3] = {21, 22, 19}, per_tile[3] = {41, 43, 38}, round64[3] = {178, 191, 170}, round128[3] = {295, 352, 314};
-    double t_lat = 0;
-    for (int i = 0; i < nq; ++i) t_lat += fixed[kind] + Q[i].passes * (4.0 + per_tile[kind] * Q[i].S);
-    const double t_thr = n <= (int64_t)64 * n_cu ? round64[kind] : (double)((n + (int64_t)128 * n_cu - 1) / ((int64_t)128 * n_cu)) * round128[kind];
-    return t_lat < t_thr;
+    if (ovr >= 0) return LatChoice{n16 <= (int64_t)ovr * n_cu ? 1 : 0, 0};
+    const double t_thr = n <= (int64_t)64 * n_cu ? round64[kind] : (double)((n + per_round - 1) / per_round) * round128[kind];
+    LatChoice best{0, 0};
+    double t_best = t_thr;
+    if (n16 <= max_tiles * n_cu) {
+        const double t = lat_cost(kind, n16, n_cu, s_max);
+        if (t < t_best) t_best = t, best = LatChoice{1, 0};
+    }
+    const int64_t rounds = n / per_round, rem = n - rounds * per_round;
+    if (kind != LAT_DGRAD && rounds >= 1 && rem > 0 && rounds <= 64) {
+        const double t = rounds * round128[kind] + lat_cost(kind, (rem + 15) / 16, n_cu, s_max);
+        if (t < 0.98 * t_best) best = LatChoice{2, rounds * per_round};
+    }
+    return best;
 }
 
-static LatLds lat_lds_fwd(int S, const Plan &P) { return lat_lds(S, P.pos_nkb, P.dir_nkb, 0); }
+static LatLds lat_lds_fwd(int S, const Plan &P) {
+    const bool add_first = P.add_dim && P.layer[0].seg[0].type == SEG_ADD;
+    return lat_lds(S, P.pos_nkb, P.dir_nkb, 0, P.add_nkb, add_first ? 1 : 0);
+}
 
 template <int S, bool TRAIN>
 static int launch_fwd_lat_s(const Plan &P, const TrainLayout &L, const FwdArgs &A, const LatLaunch &Q, hipStream_t s) {
@@ -410,24 +459,43 @@ static int launch_fwd_lat_s(const Plan &P, const TrainLayout &L, const FwdArgs &
 }
 
 // 0 = launched; 1 = this call is not for the latency kernels (the caller runs the throughput form); < 0 = error
-template <bool TRAIN>
-int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s) {
-    if (!lat_enabled() || P.width != 256 || P.add_dim != 0 || P.nlayers != P.n_hidden + 6) return 1;
-    const int n_cu = device_cu_count("mlp_fwd_lat");
-    if (n_cu < 1) return n_cu;
-    const int64_t n16 = (A.n + 15) / 16;
-    if (n16 > (int64_t)64 * n_cu) return 1;
+static int lat_s_max_fwd(const Plan &P) {
     int s_max = LAT_MAX_S;
     while (s_max > 1 && lat_lds_fwd(s_max, P).total > 160 * 1024) --s_max;
-    if (lat_lds_fwd(s_max, P).total > 160 * 1024) return 1;
+    return lat_lds_fwd(s_max, P).total > 160 * 1024 ? 0 : s_max;
+}
+// plain RenderRayNet plans of width 256; per-ray additional inputs of up to 128 k-blocks (what fits the LDS beside one sample tile)
+static bool lat_covers(const Plan &P) { return lat_enabled() && P.width == 256 && P.add_nkb <= 100 && P.nlayers == P.n_hidden + 6; }
+
+template <bool TRAIN>
+LatChoice lat_choose_fwd(const Plan &P, int64_t n) {
+    if (!lat_covers(P) || !lat_dir_enabled(false)) return LatChoice{0, 0};
+    const int n_cu = device_cu_count("mlp_fwd_lat"), s_max = lat_s_max_fwd(P);
+    if (n_cu < 1 || !s_max) return LatChoice{0, 0};
     TrainLayout L;
     make_train_layout(P, L);
     // the masked stores go through 2 GiB buffer resources (mlp_lat_device.h: LAT_STORE_RANGE)
-    if ((int64_t)L.act_rows * A.n * 64 >= (int64_t)LAT_STORE_RANGE) return 1;
+    if ((TRAIN ? (int64_t)L.act_rows * 64 : 16) * n >= (int64_t)LAT_STORE_RANGE) return LatChoice{0, 0};
+    return lat_choose(TRAIN ? LAT_TRAIN_FWD : LAT_INFER, n, n_cu, s_max);
+}
+template LatChoice lat_choose_fwd<false>(const Plan &, int64_t);
+template LatChoice lat_choose_fwd<true>(const Plan &, int64_t);
+
+// the latency kernels on samples [first_sample, A.n) (first_sample a multiple of 16)
+template <bool TRAIN>
+int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t first_sample) {
+    const int n_cu = device_cu_count("mlp_fwd_lat");
+    if (n_cu < 1) return n_cu;
+    const int s_max = lat_s_max_fwd(P);
+    if (!lat_covers(P) || !s_max || first_sample % 16) return fail(SNERF_E_BADARG, "mlp_fwd_lat: not a call for the latency kernels");
+    TrainLayout L;
+    make_train_layout(P, L);
+    const int64_t t0 = first_sample / 16, n16 = (A.n + 15) / 16 - t0;
     LatLaunch Q[2];
     const int nq = lat_split(n16, n_cu, s_max, Q);
-    if (!lat_wins(TRAIN ? LAT_TRAIN_FWD : LAT_INFER, A.n, n16, n_cu, Q, nq)) return 1;
     for (int i = 0; i < nq; ++i) {
+        Q[i].tile_off += t0;
+        Q[i].tile_end += t0;
         int rc;
         switch (Q[i].S) {
             case 1: rc = launch_fwd_lat_s<1, TRAIN>(P, L, A, Q[i], s); break;
@@ -439,8 +507,8 @@ int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s) {
     }
     return 0;
 }
-template int launch_fwd_lat<false>(const Plan &, const FwdArgs &, hipStream_t);
-template int launch_fwd_lat<true>(const Plan &, const FwdArgs &, hipStream_t);
+template int launch_fwd_lat<false>(const Plan &, const FwdArgs &, hipStream_t, int64_t);
+template int launch_fwd_lat<true>(const Plan &, const FwdArgs &, hipStream_t, int64_t);
 
 template <int S>
 static int launch_bwd_lat_s(const Plan &P, const BwdPlan &B, const TrainLayout &L, const BwdArgs &A, const LatLaunch &Q, hipStream_t s) {
@@ -454,26 +522,39 @@ static int launch_bwd_lat_s(const Plan &P, const BwdPlan &B, const TrainLayout &
     return check_launch("mlp_bwd_lat");
 }
 
-// the dgrad of launch_bwd (mlp_train.hip) for small calls; 0 = launched, 1 = not a call for the latency kernel, < 0 = error
-int launch_bwd_lat(const Plan &P, const BwdArgs &A, bool input_grad, hipStream_t s) {
-    if (!lat_enabled() || input_grad || P.width != 256 || P.add_dim != 0 || P.nlayers != P.n_hidden + 6) return 1;
-    const int n_cu = device_cu_count("mlp_bwd_lat");
-    if (n_cu < 1) return n_cu;
-    const int64_t n16 = (A.n + 15) / 16;
-    if (n16 > (int64_t)64 * n_cu) return 1;
-    BwdPlan B;
-    make_bwd_plan(P, B, false);
-    if (B.nl > LAT_MAX_LAYERS) return 1;
-    TrainLayout L;
-    make_train_layout(P, L);
-    if ((int64_t)L.dy_rows * A.n * 64 >= (int64_t)LAT_STORE_RANGE) return 1;
+static int lat_s_max_bwd(const Plan &P) {
     int s_max = LAT_MAX_S;
     while (s_max > 1 && lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024) --s_max;
-    if (lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024) return 1;
+    return lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024 ? 0 : s_max;
+}
+LatChoice lat_choose_bwd(const Plan &P, int64_t n, bool input_grad) {
+    if (!lat_covers(P) || input_grad || !lat_dir_enabled(true)) return LatChoice{0, 0};
+    const int n_cu = device_cu_count("mlp_bwd_lat"), s_max = lat_s_max_bwd(P);
+    if (n_cu < 1 || !s_max) return LatChoice{0, 0};
+    BwdPlan B;
+    make_bwd_plan(P, B, false);
+    TrainLayout L;
+    make_train_layout(P, L);
+    if (B.nl > LAT_MAX_LAYERS || (int64_t)L.dy_rows * n * 64 >= (int64_t)LAT_STORE_RANGE) return LatChoice{0, 0};
+    return lat_choose(LAT_DGRAD, n, n_cu, s_max);
+}
+
+// the dgrad of launch_bwd (mlp_train.hip) on samples [first_sample, A.n) with the latency kernel
+int launch_bwd_lat(const Plan &P, const BwdArgs &A, hipStream_t s, int64_t first_sample) {
+    const int n_cu = device_cu_count("mlp_bwd_lat");
+    if (n_cu < 1) return n_cu;
+    const int s_max = lat_s_max_bwd(P);
+    if (!lat_covers(P) || !s_max || first_sample % 16) return fail(SNERF_E_BADARG, "mlp_bwd_lat: not a call for the latency kernel");
+    BwdPlan B;
+    make_bwd_plan(P, B, false);
+    TrainLayout L;
+    make_train_layout(P, L);
+    const int64_t t0 = first_sample / 16, n16 = (A.n + 15) / 16 - t0;
     LatLaunch Q[2];
     const int nq = lat_split(n16, n_cu, s_max, Q);
-    if (!lat_wins(LAT_DGRAD, A.n, n16, n_cu, Q, nq)) return 1;
     for (int i = 0; i < nq; ++i) {
+        Q[i].tile_off += t0;
+        Q[i].tile_end += t0;
         int rc;
         switch (Q[i].S) {
             case 1: rc = launch_bwd_lat_s<1>(P, B, L, A, Q[i], s); break;

@@ -958,14 +958,17 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     if (n_cu < 1) return n_cu;
     const bool small = tuning().fwd_small_tiles && n <= (int64_t)64 * n_cu;
     const bool wide_pe = input_grad && bwd_pe_tiles(P).pos == 8;
-    // calls of a few 16-sample tiles per CU: the latency-class dgrad (mlp_lat.hip; bit-identical d Y)
-    if (const int lrc = launch_bwd_lat(P, A, input_grad, s); lrc != 1) {
-        if (lrc) return lrc;
+    // calls of a few 16-sample tiles per CU: the latency-class dgrad (mlp_lat.hip; bit-identical d Y); a call of a few rounds and a
+    // fraction: whole rounds here, the fraction there
+    const LatChoice lc = lat_choose_bwd(P, n, input_grad);
+    if (lc.mode == 1) {
+        if (int lrc = launch_bwd_lat(P, A, s, 0)) return lrc;
         return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);
     }
+    const int64_t n_dgrad = lc.mode == 2 ? lc.n_main : n;   // samples of the throughput kernel below
     auto launch = [&](auto bw_c) -> int {
         constexpr int BW = decltype(bw_c)::value;
-        const int64_t grid = (n + BW * 16 - 1) / (BW * 16);
+        const int64_t grid = (n_dgrad + BW * 16 - 1) / (BW * 16);
         if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
         if (P.width == 256) {
             if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
@@ -985,6 +988,7 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     if (int lrc = small ? launch(std::integral_constant<int, 4>{}) : launch(std::integral_constant<int, 8>{})) return lrc;
     int rc = check_launch("mlp_bwd(dgrad)");
     if (rc) return rc;
+    if (lc.mode == 2 && (rc = launch_bwd_lat(P, A, s, lc.n_main))) return rc;
     return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);
 }
 }  // namespace snerf

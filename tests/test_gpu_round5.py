@@ -85,15 +85,12 @@ def test_shutdown_destroys_the_events_and_the_next_step_recreates_them(dev):
 F32 = np.float32
 
 
-def _rnet(dev, n_layers=8, width=256, skips=(4,), pos=(10, 0), dirs=(4, 0), seed=5, use_dir=True):
+def _rnet(dev, n_layers=8, width=256, skips=(4,), pos=(10, 0), dirs=(4, 0), seed=5, add=0):
     from smpl_nerf_amd.nets import RenderRayNet
     from smpl_nerf_amd.ops import PositionalEncoder
     pe, de = PositionalEncoder(*pos), PositionalEncoder(*dirs)
     torch.manual_seed(seed)
-    net = RenderRayNet(n_layers, width, pe.output_dim if hasattr(pe, "output_dim") else 3 * (pos[1] + 2 * pos[0]),
-                       de.output_dim if hasattr(de, "output_dim") else 3 * (dirs[1] + 2 * dirs[0]), skips=list(skips),
-                       use_directional_input=use_dir) if not use_dir else \
-        RenderRayNet(n_layers, width, 3 * (pos[1] + 2 * pos[0]), 3 * (dirs[1] + 2 * dirs[0]), skips=list(skips))
+    net = RenderRayNet(n_layers, width, 3 * (pos[1] + 2 * pos[0]), 3 * (dirs[1] + 2 * dirs[0]), add, skips=list(skips))
     return net.to(dev), pe, de
 
 
@@ -112,7 +109,9 @@ def test_latency_kernels_equal_the_throughput_kernels_bit_for_bit(dev, shape):
     dirs = T(rng.normal(size=(big, 3)).astype(F32), dev)
     with torch.no_grad():
         full = net.forward_fused(pts, dirs, Ns, pe, de).reshape(big, Ns, 4)
-        for rays in (1, 2, 3, 31, 512, 513, 1536, 2000, 2501, 4096):          # 8 .. 32 768 samples
+        # 8 .. 32 768 samples: latency kernels alone; 37 768 and 70 000: one / two whole rounds of 128-sample tiles on the throughput
+        # kernel + the rest on the latency kernels (csrc/mlp_lat.hip: lat_choose, mode 2)
+        for rays in (1, 2, 3, 31, 512, 513, 1536, 2000, 2501, 4096, 4721, 8750):
             small = net.forward_fused(pts[:rays].contiguous(), dirs[:rays].contiguous(), Ns, pe, de).reshape(rays, Ns, 4)
             assert torch.equal(small, full[:rays]), rays
 
@@ -124,6 +123,7 @@ from test_gpu_round5 import _rnet
 dev = torch.device("cuda:0")
 out = {{}}
 for ci, shape in enumerate({shapes!r}):
+    add_first = shape.pop("add_first", False)
     net, pe, de = _rnet(dev, **shape)
     rng = np.random.default_rng(3)
     for rays in {rays!r}:
@@ -132,7 +132,8 @@ for ci, shape in enumerate({shapes!r}):
         dirs = torch.from_numpy(rng.normal(size=(rays, 3)).astype(np.float32)).to(dev)
         gout = torch.from_numpy(rng.normal(size=(rays * Ns, 4)).astype(np.float32)).to(dev)
         net.zero_grad(set_to_none=True)
-        raw = net.forward_fused(pts, dirs, Ns, pe, de).reshape(-1, 4)
+        add = torch.from_numpy(rng.normal(size=(rays, shape.get("add", 0))).astype(np.float32)).to(dev) if shape.get("add") else None
+        raw = net.forward_fused(pts, dirs, Ns, pe, de, add, add_first).reshape(-1, 4)
         (raw * gout).sum().backward()
         out[f"raw_{{ci}}_{{rays}}"] = raw.detach().cpu().numpy()
         out[f"grad_{{ci}}_{{rays}}"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
@@ -148,8 +149,11 @@ def test_latency_training_kernels_give_the_throughput_kernels_gradients_bit_for_
     import subprocess
     import sys
     from conftest import ROOT
-    shapes = [dict(), dict(n_layers=3, skips=(1,)), dict(n_layers=9, skips=(2, 6), dirs=(2, 0))]
-    rays = [1, 37, 512, 1537, 2500]
+    # (the last two: nets with per-ray additional inputs - the 69 pose columns of models/append_smpl_params_pipeline.py behind the
+    # encoding, and 30 columns in front of it like append_to_nerf_pipeline.py's)
+    shapes = [dict(), dict(n_layers=3, skips=(1,)), dict(n_layers=9, skips=(2, 6), dirs=(2, 0)), dict(n_layers=5, skips=(2,), add=69),
+              dict(n_layers=4, skips=(1,), add=30, add_first=True, pos=(6, 1))]
+    rays = [1, 37, 512, 1537, 2500, 4721]       # (4721 x 8 = 37 768 samples: one whole round on the throughput kernels + the rest on the latency kernels)
     res = {}
     for lat in ("0", "1"):
         path = str(tmp_path / f"g{lat}.npz")

@@ -64,3 +64,10 @@ find $OUT/trace_train -name "*kernel_stats.csv" -exec cp {} $OUT/train_kernel_st
 # keep what travels back small: the raw per-dispatch counter CSVs are reduced above
 rm -rf $OUT/trace $OUT/trace_train $OUT/trace_smpl $OUT/pmcs_sq $OUT/pmcs_fetch $OUT/pmcs_write $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmct_sq $OUT/pmct_fetch $OUT/pmct_write
 ls -la $OUT
+# (j) round 5: the latency-class kernels of small calls - isolated per-launch times of forward / training forward / dgrad against the
+#     throughput kernels (SNERF_LAT=0), and their SQ counters
+( echo "# latency-class kernels (default selection)"; timeout 300 bash $ROOT/tools/ab/lat_trace.sh 4096,12288,16384,51200
+  echo "# throughput kernels (SNERF_LAT=0)"; SNERF_LAT=0 timeout 300 bash $ROOT/tools/ab/lat_trace.sh 4096,12288,16384,51200
+  echo "# inference, HIP events"; timeout 200 python $ROOT/tools/ab/lat_timing.py infer 4096,12288,16384,20480,32768,51200,65536,153600
+  SNERF_LAT=0 timeout 200 python $ROOT/tools/ab/lat_timing.py infer 4096,12288,16384,20480,32768,51200,65536,153600 ) 2>/dev/null | grep -v "amdgpu.ids\|simple_timer" > $OUT/lat_kernels.txt
+timeout 400 bash $ROOT/tools/ab/pmc_lat.sh infer 4096,16384 2>/dev/null | grep -v amdgpu.ids > $OUT/pmc_lat.txt
