@@ -524,7 +524,7 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
             # same call; with them in the numerator (VERDICT r04 #3 asks for this as a second key)
             "mlp_plus_warp_roofline_frac": ((flop_step + 3 * WARP_FLOP_PER_EVAL * rays * 256) / (mlp_ms * 1e-3) / 1e12 / peak
                                             if (tf and workload == "smpl_nerf" and one_call) else None),
-            "step_entry": ((("snerf_smpl_nerf_train_step_f32" if any(k.startswith("train_step_smpl") for k in kern) else
+            "step_entry": ((("snerf_smpl_nerf_train_step_aux_f32" if any(k.startswith("train_step_smpl") for k in kern) else
                              "snerf_nerf_train_step_f32") + " (one C-ABI call per step; mlp_kernels_ms_per_step brackets the whole "
                             "call - for smpl_nerf that includes the warp net's kernels, which the FLOP count of the fraction leaves out)")
                            if one_call else "autograd (torch.autograd.Function per kernel group) + HipAdam"),
@@ -580,6 +580,9 @@ def main():
     ap.add_argument("--points", default="64,800,2048",
                     help="comma-separated ray counts of the extra operating points (render; training at 2048 when among them); "
                          "empty = skip")
+    ap.add_argument("--netwidth-points", default="512",
+                    help="comma-separated --netwidth values above 256 (config_parser.py:20) measured as extra points of the nerf "
+                         "workload: one frame rendered, one training step, each with its fraction of the fp32 MFMA peak; empty = skip")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): one frame per rank; strong: ONE frame split by rows over the ranks (dist.shard_rays), the "
                          "rendered rows all-gathered into the frame on every rank (dist.gather_rows) inside the timed region")
@@ -756,6 +759,66 @@ def main():
         if 800 <= rays and run_fine:
             points.append(eval_without_no_grad(800))
 
+    def netwidth_point(width, steps=3):
+        """The nerf workload with RenderRayNets of `width` features (config_parser.py:20 --netwidth; the kernels of 320 / 384 / 448 /
+        512 features, csrc/mlp_plan.h): this rank's rays rendered per step, and one-call training steps of min(4096, rays) rays -
+        fractions of the fp32 MFMA peak on the ALGORITHMIC FLOPs of the unpadded nets, kernel times from HIP event pairs."""
+        from smpl_nerf_amd import synthetic as syn
+        from smpl_nerf_amd.nets import RenderRayNet
+        from smpl_nerf_amd.ops import PositionalEncoder
+        from smpl_nerf_amd.pipelines import NerfPipeline, PipelineArgs
+        from smpl_nerf_amd.trainer import DataParallelTrainer
+        wnets = []
+        for seed in (401, 403):
+            m = RenderRayNet(8, width, 60, 24, skips=[4])
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_render_ray_net_params(seed, 30.0, 10.0, width=width).items()})
+            wnets.append(m.to(dev).eval())
+        flop = 2 * sum(p.numel() for k, p in wnets[0].named_parameters() if k.endswith("weight"))
+        wargs = PipelineArgs(white_background=0, run_fine=1, number_fine_samples=128, sigma_noise_std=0.0)
+        wpipe = NerfPipeline(wnets[0], wnets[1], wargs, PositionalEncoder(10, 0), PositionalEncoder(4, 0))
+        sub = [t.contiguous() for t in data[:5]]
+        with torch.no_grad():
+            wpipe(sub)
+            torch.cuda.synchronize()
+            with _lib.profile() as pp:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    wpipe(sub)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+            k = pp.summary()
+        # the RenderRayNet launches' own time where the pipeline ran them as separate C-ABI calls; else the whole step
+        mlp_ms = sum(v[1] for n, v in k.items() if n.startswith("mlp_fwd")) / steps
+        tf = flop * rays * 256 / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None
+        tf_step = flop * rays * 256 / dt / 1e12
+        n_train = min(4096, rays)
+        for m in wnets:
+            m.train()
+        tr = DataParallelTrainer(wpipe, wnets, lr=5e-4)
+        tb = [t[:n_train].contiguous() for t in data[:5]]
+        tr.step(tb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(tb)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / steps
+        ttf = 3 * flop * n_train * 256 / dts / 1e12
+        return {"netwidth": width, "kernel_width": (width + 63) // 64 * 64, "flop_per_eval": flop, "rays_per_step": rays,
+                "render_ms_per_step": dt * 1e3, "render_ray_samples_per_s": rays * 256 / dt,
+                "render_mlp_kernels_ms_per_step": mlp_ms or None, "render_mlp_roofline_frac": tf / PEAK_F32_MFMA_TFLOPS if tf else None,
+                "render_roofline_frac_whole_step": tf_step / PEAK_F32_MFMA_TFLOPS,
+                "train_rays_per_step": n_train, "train_ms_per_step": dts * 1e3, "train_ray_samples_per_s": n_train * 256 / dts,
+                "train_step_roofline_frac_whole_step": ttf / PEAK_F32_MFMA_TFLOPS, "train_one_call": tr._one_call_state() is not None,
+                "peak_tflops": PEAK_F32_MFMA_TFLOPS, "dtype": "f32"}
+
+    width_points = None
+    if a.netwidth_points and world == 1 and not grouped and a.workload == "nerf" and run_fine and a.precision == "fp32":
+        try:
+            width_points = [netwidth_point(int(v)) for v in a.netwidth_points.split(",") if v.strip()]
+        except Exception as e:
+            width_points = [{"error": f"{type(e).__name__}: {e}"}]
+
     def mlp_launch_stats(k, steps):
         mlp = {n: v for n, v in k.items() if n.startswith("mlp_fwd")}
         calls = sum(v[0] for v in mlp.values())
@@ -923,6 +986,8 @@ def main():
                 "padded_flop_per_unit": wexec, "pose_columns_folded_per_ray": bool(folded)}
         if points:
             line["operating_points_render"] = points
+        if width_points:
+            line["netwidth_points"] = width_points
         if train is not None:
             line["train"] = train
         if train_alt:

@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 107 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+#define SNERF_VERSION 108 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
                              snerf_composite_bwd_all_f32; composite forward accepts any N
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
                              folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
@@ -75,7 +75,9 @@ extern "C" {
                              0.1.5: + snerf_render_rays_add_f32 (the single-call render for nets with per-ray additional inputs)
                              0.1.6: + snerf_shutdown; hidden visibility: the entry points of this header are the only dynamic symbols
                              0.1.7: + snerf_comm_*, snerf_nerf_train_step_dp_f32, snerf_smpl_nerf_train_step_dp_f32 (RCCL inside the
-                             boundary); latency-class kernels behind the same entry points for small calls */
+                             boundary); latency-class kernels behind the same entry points for small calls
+                             0.1.8: + snerf_smpl_nerf_train_grads_aux_f32, snerf_smpl_nerf_train_step_aux_f32 (the smpl_nerf step with an
+                             auxiliary stream: small chunks run the coarse chain beside the fine chain) */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -665,6 +667,29 @@ SNERF_API int snerf_smpl_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coars
                                       const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
                                       const snerf_adam_net *nets_host, int n_nets, int64_t warp_param_offset, snerf_comm_t comm,
                                       snerf_stream_t stream);
+
+/* The smpl_nerf step with an auxiliary stream (0.1.8).  As snerf_smpl_nerf_train_grads_f32 / _step_f32 / _step_dp_f32 with one more
+ * argument: aux_stream (may be NULL or == stream: then exactly those calls).  For chunks of at most 262144 fine-pass samples
+ * (snerf_smpl_nerf_train_workspace_bytes already counts the second scratch set under that rule) the coarse chain of the backward -
+ * compositing, coarse net dgrad + wgrad, the warp net's backward on the coarse samples - runs on aux_stream beside the fine chain on
+ * `stream`, forked and joined with events inside the call; the coarse chain's warp-net gradient is added behind the join in the order
+ * of the sequential form, so the results are bit-identical with and without aux_stream.  comm (step form; may be NULL): the flat
+ * gradient buffer adam->grads is averaged over the ranks (ncclAllReduce, ncclAvg) between the backward and Adam.
+ * Replaces: solver/smpl_nerf_solver.py:76-89 per batch, as the entry points it extends. */
+SNERF_API int snerf_smpl_nerf_train_grads_aux_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                        const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                        const snerf_warp_desc *desc_warp, const float *packed_warp, const float *packed_t_warp,
+                                        int precision, const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk,
+                                        void *workspace, float *grad_coarse, float *grad_fine, float *grad_warp, float *loss, float *rgb,
+                                        float *rgb_fine, snerf_stream_t stream, snerf_stream_t aux_stream);
+SNERF_API int snerf_smpl_nerf_train_step_aux_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                       const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                       const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,
+                                       const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk, void *workspace,
+                                       float *grad_coarse, float *grad_fine, float *grad_warp, float *loss, float *rgb, float *rgb_fine,
+                                       const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
+                                       const snerf_adam_net *nets_host, int n_nets, int64_t warp_param_offset, snerf_comm_t comm,
+                                       snerf_stream_t stream, snerf_stream_t aux_stream);
 
 #ifdef __cplusplus
 }

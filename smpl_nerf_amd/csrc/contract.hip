@@ -156,9 +156,16 @@ extern "C" int snerf_dy_contract_f32(const float *dy, int64_t n, int first_row, 
                                      int ncols, int samples_per_ray, float *out, int64_t out_stride, int out_col0, int accumulate,
                                      float *scratch, snerf_stream_t stream) {
     using namespace snerf;
+    if (n_feat > 256 && n_feat <= 512 && w_stride >= 1) {   // a 512-feature layer (--netwidth above 256): its two 16-tile halves, the second added
+        if (int rc = snerf_dy_contract_f32(dy, n, first_row, 256, w, w_stride, col0, ncols, samples_per_ray, out, out_stride, out_col0,
+                                           accumulate, scratch, stream))
+            return rc;
+        return snerf_dy_contract_f32(dy, n, first_row + 16, n_feat - 256, w ? w + (int64_t)256 * w_stride : w, w_stride, col0, ncols,
+                                     samples_per_ray, out, out_stride, out_col0, 1, scratch, stream);
+    }
     if (n < 0 || first_row < 0 || n_feat < 1 || n_feat > 256 || w_stride < 1 || col0 < 0 || ncols < 1 || col0 + ncols > w_stride ||
         samples_per_ray < 0 || out_stride < 1 || out_col0 < 0 || out_col0 + ncols > out_stride)
-        return fail(SNERF_E_BADARG, "dy_contract: bad shape arguments (n_feat <= 256, columns inside the weight / output rows)");
+        return fail(SNERF_E_BADARG, "dy_contract: bad shape arguments (n_feat <= 512, columns inside the weight / output rows)");
     if (samples_per_ray > 0 && n % samples_per_ray != 0) return fail(SNERF_E_BADARG, "dy_contract: n is not a multiple of samples_per_ray");
     if (n == 0) return SNERF_OK;
     if (!dy || !w || !out || (samples_per_ray > 0 && !scratch)) return fail(SNERF_E_BADARG, "dy_contract: null pointer");

@@ -228,7 +228,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
         relu_into(ind, accd);
         if (TRAIN && valid) {
             store_tiles(A.act, A.act_h2, A.n, sample, c.g, ind);
-            store_mask(A.act, A.act_mask, A.n_hidden + 1, A.n, sample, c.g, ind);
+            store_mask<TD, (T > 16)>(A.act, A.act_mask, A.n_hidden + 1, A.n, sample, c.g, ind);
         }
     }
     f4 rgb[1];
@@ -340,7 +340,16 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         else SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<64, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     } else {
-        if (P.width == 256) SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        if (P.width > 256) {   // one wave per SIMD (20 .. 32-tile chains need the whole register file): 4-wave workgroups only
+            if constexpr (NW == 4 && !FOLD) {
+                if (P.width == 320) SNERF_LAUNCH_RING((mlp_fwd_kernel<320, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+                else if (P.width == 384) SNERF_LAUNCH_RING((mlp_fwd_kernel<384, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+                else if (P.width == 448) SNERF_LAUNCH_RING((mlp_fwd_kernel<448, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+                else SNERF_LAUNCH_RING((mlp_fwd_kernel<512, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+            } else {
+                return fail(SNERF_E_BADARG, "mlp_fwd: widths above 256 run 4-wave workgroups");
+            }
+        } else if (P.width == 256) SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         else SNERF_LAUNCH_RING((mlp_fwd_kernel<64, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     }
@@ -350,7 +359,7 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
 // slots (layers with an additional-input segment) and bytes of the per-ray fold table of a call, 0 when the fold does not apply
 // (a fold pays when a ray's vector is reused: with fewer than 8 samples per ray the table costs more than it saves)
 static int64_t fold_table_bytes(const Plan &P, int64_t n, int spr, int *slots_out = nullptr) {
-    if (!P.add_dim || !tuning().mlp_fold || tuning().fwd_waves == 4 || spr < 8 || n <= 0 || n % spr != 0) return 0;
+    if (!P.add_dim || P.width > 256 || !tuning().mlp_fold || tuning().fwd_waves == 4 || spr < 8 || n <= 0 || n % spr != 0) return 0;
     int slots = 0;
     for (int l = 0; l < P.nlayers; ++l)
         for (int sg = 0; sg < P.layer[l].nseg; ++sg) slots += P.layer[l].seg[sg].type == SEG_ADD ? 1 : 0;
@@ -387,6 +396,7 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // 8 waves (128 samples) per workgroup = one workgroup per CU, 2 waves per SIMD (85.7 % of the fp32 MFMA
     // peak on the 128x128 frame); SNERF_FWD_WAVES=4 selects two independent 4-wave workgroups per CU instead
     // (83.1 %; twice the L2->LDS weight traffic).  Tuning knob, read once.
+    if (P.width > 256) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);   // (--netwidth above 256: mlp_plan.h make_plan)
     if (!ENCODED && !TRAIN && tuning().fwd_waves != 4) {   // per-ray additional inputs + a workspace: the folded form (8-wave tiles)
         const int rc = launch_fwd_folded<FWD_WAVES>(P, A, s);
         if (rc != 1) return rc;

@@ -103,11 +103,20 @@ __device__ __forceinline__ uint2 *mask_ptr(const float *buf, int mask_row, int i
     return reinterpret_cast<uint2 *>(const_cast<float *>(buf) + ((int64_t)(mask_row + (idx >> 1)) * n + sample) * 16 +
                                      (idx & 1) * 8 + 2 * g);
 }
-template <int N>
+// 32-tile layers (width 512): mask `idx` is tile-row mask_row + idx, 16 bytes per lane group
+__device__ __forceinline__ uint4 *mask_ptr4(const float *buf, int mask_row, int idx, int64_t n, int64_t sample, int g) {
+    return reinterpret_cast<uint4 *>(const_cast<float *>(buf) + ((int64_t)(mask_row + idx) * n + sample) * 16 + 4 * g);
+}
+// ROW_PER_MASK: the layout of a net with 32-tile layers (also for its 16-tile directional branch, which stores two words there)
+template <int N, bool ROW_PER_MASK = (N > 16)>
 __device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, int64_t n, int64_t sample, int g,
                                            const f4 (&tiles)[N]) {
-    static_assert(N <= 16, "one or two mask words");
-    unsigned w[2] = {0u, 0u};
+    static_assert(N <= 32, "up to four mask words");
+    static_assert(N <= 16 || ROW_PER_MASK, "four words need a tile-row of their own");
+    constexpr int NWORDS = N <= 16 ? 2 : 4;
+    unsigned w[NWORDS];
+#pragma unroll
+    for (int q = 0; q < NWORDS; ++q) w[q] = 0u;
 #pragma unroll
     for (int t = 0; t < N; ++t)
 #pragma unroll
@@ -118,11 +127,17 @@ __device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, in
         }
     // the address is formed here, not hoisted to the top of the tile (where it would cost two registers per layer)
     asm volatile("" : "+v"(sample));
+    if constexpr (N <= 16 && ROW_PER_MASK) {
+        *reinterpret_cast<uint2 *>(mask_ptr4(buf, mask_row, idx, n, sample, g)) = uint2{w[0], w[1]};
+    } else if constexpr (N <= 16) {
 #if SNERF_EXP_NOSTORE != 2   // (diagnostic build: without the sign-mask stores)
-    *mask_ptr(buf, mask_row, idx, n, sample, g) = uint2{w[0], w[1]};
+        *mask_ptr(buf, mask_row, idx, n, sample, g) = uint2{w[0], w[1]};
 #else
-    asm volatile("" ::"v"(w[0]), "v"(w[1]));
+        asm volatile("" ::"v"(w[0]), "v"(w[1]));
 #endif
+    } else {   // 32 tiles: four words per lane, one mask per tile-row (TrainLayout::mask)
+        *mask_ptr4(buf, mask_row, idx, n, sample, g) = uint4{w[0], w[1], w[2], w[3]};
+    }
 }
 
 // The 3-slot ring (99 KiB) is dynamic LDS: a launch gets 64 KiB unless the limit is raised per kernel once.
@@ -316,7 +331,12 @@ struct LayerRun {
     __device__ __forceinline__ void init(f4 (&acc)[T_OUT]) {
         const f4 *aux = reinterpret_cast<const f4 *>(slab + SLAB_A_FLOATS) + (lane >> 4);
 #pragma unroll
-        for (int to = 0; to < T_OUT; ++to) acc[to] = aux[to * 4];
+        for (int to = 0; to < (T_OUT < 16 ? T_OUT : 16); ++to) acc[to] = aux[to * 4];
+        if constexpr (T_OUT > 16) {   // tiles 16 .. : the bias block of the layer's second slab (resident: LayerRun above)
+            const f4 *aux2 = reinterpret_cast<const f4 *>(pipe.peek_next() + SLAB_A_FLOATS) + (lane >> 4);
+#pragma unroll
+            for (int to = 16; to < T_OUT; ++to) acc[to] = aux2[(to - 16) * 4];
+        }
     }
     __device__ __forceinline__ void step(f4 b, f4 (&acc)[T_OUT]) {
         const float *cur = slab + kbl * (T_OUT * 256);

@@ -35,6 +35,7 @@ constexpr int SLAB_A_FLOATS = SLAB_TILES * 256;
 constexpr int SLAB_AUX_FLOATS = 256;
 constexpr int SLAB_FLOATS = SLAB_A_FLOATS + SLAB_AUX_FLOATS;  // 8448 floats = 33 KiB
 constexpr int SLAB_PAD = 3;                                    // zero slabs after the stream (prefetch overrun)
+constexpr int MAX_WIDTH = 512;   // --netwidth (config_parser.py:20): trunks of 64, 128, 256 or 512 features (others run zero-padded)
 constexpr int MAX_LAYERS = 21;  // n_layers <= 16, + 5 fixed layers
 constexpr int STAT_INTS = 32;    // per-layer statistics behind the activation / dY rows of a training step (f16x3)
 
@@ -108,9 +109,8 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
     why = "";
     P.kw = kw;
     if (d.n_layers < 1 || d.n_layers > 16) { why = "n_layers must be in [1,16]"; return -1; }
-    if (d.width < 2 || d.width > 256) {
-        why = "width must be in [2, 256] (--netwidth above 256 is not supported: the layer chain lives in registers, two accumulator "
-              "sets of width x 16 samples per wave)";
+    if (d.width < 2 || d.width > MAX_WIDTH) {
+        why = "width must be in [2, 512] (the layer chain lives in registers: two accumulator sets of width x 16 samples per wave)";
         return -1;
     }
     if (d.pos_freqs < 0 || d.pos_freqs > 16 || d.dir_freqs < 0 || d.dir_freqs > 16) { why = "bad encoder frequencies"; return -1; }
@@ -120,7 +120,10 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
     // layer are zero padding like the rows 3 .. 15 of the rgb head (their activations are relu(0) = 0, nothing reads them,
     // no gradient is scattered from them), so the results are those of the unpadded network.
     const int W = d.width, WD = W / 2;
-    const int WK = W <= 64 ? 64 : W <= 128 ? 128 : 256, WDK = WK / 2;
+    // Above 256 (config_parser.py:20 --netwidth): kernels for 320, 384, 448 and 512 features (20 .. 32 tiles), one wave per SIMD
+    // with the whole 512-register file (two accumulator sets of up to 32 tiles); a slab then is one k-block of all output tiles
+    // (its other tiles are padding) and the bias block (256 floats per slab) of a layer spans its first two slabs.
+    const int WK = W <= 64 ? 64 : W <= 128 ? 128 : W <= 256 ? 256 : (W + 63) / 64 * 64, WDK = WK / 2;
     const int pid = d.pos_identity ? 1 : 0, did = d.dir_identity ? 1 : 0;
     P.width = WK;
     P.n_hidden = d.n_layers - 1;
@@ -190,6 +193,11 @@ inline int make_plan(const snerf_mlp_desc &d, Plan &P, const char *&why, int kw 
     P.nlayers = nl;
     P.total_slabs = slab;
     P.param_floats = off;
+    for (int l = 0; l < nl; ++l)
+        if (P.layer[l].t_out > 16 && P.layer[l].nslab < 2) {
+            why = "width above 256 needs at least 17 input columns (two k-blocks) in every layer";
+            return -1;
+        }
     return 0;
 }
 
@@ -234,8 +242,9 @@ __host__ __device__ inline int64_t fwd_slab_src(const Layer &Ly, int sl, int e) 
         }
         return -1;
     }
-    const int jj = e - SLAB_A_FLOATS;
-    return (sl == 0 && jj < Ly.n_out) ? Ly.b_off + jj : -1;
+    // bias block: 256 floats per slab - a layer of more than 16 output tiles continues in its second slab
+    const int jj = sl * SLAB_AUX_FLOATS + (e - SLAB_A_FLOATS);
+    return (sl < (Ly.t_out + 15) / 16 && jj < Ly.n_out) ? Ly.b_off + jj : -1;
 }
 
 // 32-wide counterpart of slot_to_col
@@ -269,6 +278,7 @@ struct TrainLayout {
     int x[18];           // x[i], i = 1..nh+1: input of positional_net[i-1] / additional (post-ReLU), T rows each
     int o, h1, h2;       // additional out (T), directional_input out (TD), directional_net[0] out post-ReLU (TD)
     int mask;            // ReLU sign masks, 8 bytes per (sample, lane group): x[1..nh+1] then h2, two per tile-row
+                         // (width 512: 16 bytes, one per tile-row)
     int act_rows;
     int dy[MAX_LAYERS];  // dY of forward layer l (plan order): t_out tile-rows
     int dy_rows;
@@ -289,7 +299,7 @@ inline void make_train_layout(const Plan &P, TrainLayout &L) {
     L.o = r; r += L.T;
     L.h1 = r; r += L.TD;
     L.h2 = r; r += L.TD;
-    L.mask = r; r += (L.nh + 2 + 1) / 2;
+    L.mask = r; r += L.T > 16 ? L.nh + 2 : (L.nh + 2 + 1) / 2;
     L.act_rows = r;
     int d = 0, g = 0;
     for (int l = 0; l < P.nlayers; ++l) {
@@ -415,9 +425,9 @@ __host__ __device__ inline int64_t bwd_slab_src(const Plan &P, const BwdLayer &B
         if (kbl < kps && kb < Bl.nkb && row < Ly.n_out && col >= 0) return Ly.w_off + (int64_t)row * Ly.n_in + col;
         return -1;
     }
-    if (sl == 0 && Bl.aux_fwd >= 0) {
+    if (sl < (Bl.t_out + 15) / 16 && Bl.aux_fwd >= 0) {   // (more than 16 tiles: continued in the second slab, like the bias block)
         const Layer &La = P.layer[Bl.aux_fwd];
-        const int jj = e - SLAB_A_FLOATS;
+        const int jj = sl * SLAB_AUX_FLOATS + (e - SLAB_A_FLOATS);
         if (jj < La.seg[0].ncols) return La.w_off + jj;  // row 0 of the sigma head
     }
     return -1;

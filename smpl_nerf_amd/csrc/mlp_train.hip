@@ -76,12 +76,26 @@ __device__ __forceinline__ void mask_into(f4 (&dst)[N], const f4 (&src)[N], cons
 // mlp_device.h): 8 bytes per lane and layer instead of a 1 KiB tile-row per 16 samples and tile - the dgrad then reads
 // 0.3 GB instead of 3.6 GB per 786 k-sample launch.  The word is fetched before the layer's MFMA run and used after it.
 template <int N>
-__device__ __forceinline__ void mask_bits_into(f4 (&dst)[N], const f4 (&src)[N], uint2 w) {
+__device__ __forceinline__ void mask_bits_into(f4 (&dst)[N], const f4 (&src)[N], uint4 w) {
 #pragma unroll
     for (int t = 0; t < N; ++t) {
-        const unsigned word = (t >> 3) ? w.y : w.x;
+        const unsigned word = (t >> 3) == 0 ? w.x : (t >> 3) == 1 ? w.y : (t >> 3) == 2 ? w.z : w.w;
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[t][r] = ((word >> (((t & 7) << 2) | r)) & 1u) ? src[t][r] : 0.f;
+    }
+}
+// the mask words of layer output `idx` (store_mask, mlp_device.h): two per lane for nets of up to 16 tiles, four (a tile-row per
+// mask) for the 32-tile nets - whose 16-tile directional branch has two words in that layout
+template <int NTILES, bool ROW_PER_MASK>
+__device__ __forceinline__ uint4 load_mask(const float *act, int mask_row, int idx, int64_t n, int64_t sample, int g) {
+    if constexpr (NTILES > 16) {
+        return *mask_ptr4(act, mask_row, idx, n, sample, g);
+    } else if constexpr (ROW_PER_MASK) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(mask_ptr4(act, mask_row, idx, n, sample, g));
+        return uint4{w.x, w.y, 0u, 0u};
+    } else {
+        const uint2 w = *mask_ptr(act, mask_row, idx, n, sample, g);
+        return uint4{w.x, w.y, 0u, 0u};
     }
 }
 
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
 
     f4 ind[TD], accd[TD];
     {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
-        const uint2 mw = *mask_ptr(A.act, A.act_mask, nh + 1, A.n, sc, g);
+        const uint4 mw = load_mask<TD, (T > 16)>(A.act, A.act_mask, nh + 1, A.n, sc, g);
         LayerRun<TD, NT> run(pipe, lane);
         run.init(accd);
         run.step(g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, accd);
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
     // additional^T, positional_net[nh-1]^T ... positional_net[0]^T: forward layer l+1 transposed yields
     // d X_{l+1}; masking with X_{l+1} > 0 gives d Y of forward layer l (:46-50)
     for (int l = nh; l >= 0; --l) {
-        const uint2 mw = *mask_ptr(A.act, A.act_mask, l, A.n, sc, g);   // lands behind the layer's MFMAs
+        const uint4 mw = load_mask<T, (T > 16)>(A.act, A.act_mask, l, A.n, sc, g);   // lands behind the layer's MFMAs
         LayerRun<T, NT> run(pipe, lane);
         run.init(acc);
 #pragma unroll
@@ -258,7 +272,7 @@ struct WgradFold {
 template <int TI, int TJ, bool FX = false, bool FY = false>
 __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const TrainLayout &L, const WgradArgs &A, float *ring,
                                            int l, int kb0, int jb, int n_rows_y, int n_rows_x, bool bias_job,
-                                           const float *const (&row_src)[2], const WgradFold &F, int wave, int lane) {
+                                           const float *const (&row_src)[2], const WgradFold &F, int wave, int lane, int ti0 = 0) {
     const int nbj = (n_rows_x + TJ - 1) / TJ, nbi = (n_rows_y + TI - 1) / TI;
     const int bi = wave / nbj, bj = wave - bi * nbj;
     const bool active = bi < nbi;
@@ -447,14 +461,14 @@ __device__ __forceinline__ void wgrad_wave(const Plan &P, const Layer &Ly, const
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             if (j >= n_tj) continue;
-            const int ti = TI * bi + i, tj = kb0 + 16 * jb + TJ * bj + j;
+            const int ti = ti0 + TI * bi + i, tj = kb0 + 16 * jb + TJ * bj + j;   // (ti0: the job's first output tile)
             *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
         }
         if (want_bias) {
             float v = bsum[i];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (TI * bi + i) * 16 + lane] = v;
+            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (ti0 + TI * bi + i) * 16 + lane] = v;
         }
         if (FX && fx)   // folded segment of the same layer: tile column ex_tj0 + bj
             *reinterpret_cast<f4 *>(part + ((int64_t)((TI * bi + i) * Ly.nkb + F.ex_tj0 + bj) * 64 + lane) * 4) = accx[i];
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
         bool found = false;
         kb0 = 0;
         for (s = 0; s < P.layer[l].nseg; ++s) {
-            const int cnt = wgrad_wide(P.layer[l], s) ? (P.layer[l].seg[s].nkb + 15) / 16 : 0;
+            const int cnt = wgrad_wide_jobs(P.layer[l], s);
             if (job < cnt) { found = true; break; }
             job -= cnt;
             kb0 += P.layer[l].seg[s].nkb;
@@ -491,8 +505,10 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
         if (found) break;
     }
     const Layer &Ly = P.layer[l];
-    const int jb = job;                                    // k-blocks 16*jb .. of the segment
-    const int n_rows_y = Ly.t_out, n_rows_x = min(16, Ly.seg[s].nkb - 16 * jb);
+    const int nkg = (Ly.seg[s].nkb + 15) / 16;
+    const int ib = job / nkg, jb = job - ib * nkg;         // output tiles 16*ib .., k-blocks 16*jb .. of the segment
+    const int ti0 = 16 * ib;
+    const int n_rows_y = min(16, Ly.t_out - ti0), n_rows_x = min(16, Ly.seg[s].nkb - 16 * jb);
     const int64_t n = A.n;
     int first_seg = 0;  // the bias sums ride with the first non-empty input segment of the layer
     while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
@@ -505,9 +521,9 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = 2 * wave + q;
-        int64_t grow = L.dy[l];
+        int64_t grow = L.dy[l] + ti0;
         if (r < 16) {
-            if (r < n_rows_y) grow = L.dy[l] + r;
+            if (r < n_rows_y) grow = L.dy[l] + ti0 + r;
             row_src[q] = A.dy + grow * n * 16;
         } else if (r - 16 < n_rows_x) {
             row_src[q] = A.act + (int64_t)(seg_act_row(P, L, l, s) + 16 * jb + (r - 16)) * n * 16;
@@ -517,7 +533,7 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     }
     // ---- what rides with this job (first group of the layer's first wide segment only) ------------------------------
     WgradFold F{0, 0, -1, nullptr};
-    if (A.fold && jb == 0 && s == wgrad_first_wide_seg(Ly)) {
+    if (A.fold && jb == 0 && ib == 0 && s == wgrad_first_wide_seg(Ly)) {
         const int xs = wgrad_fold_xseg(P, l, A.fold);
         if (xs >= 0) {
             F.ex = Ly.seg[xs].nkb;
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
     }
 #define SNERF_WG_CASE(TI_, TJ_)                                                                                       \
     if (ti == TI_ && tj == TJ_)                                                                                       \
-        return wgrad_wave<TI_, TJ_>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane);
+        return wgrad_wave<TI_, TJ_>(P, Ly, L, A, ring, l, kb0, jb, n_rows_y, n_rows_x, bias_job, row_src, F, wave, lane, ti0);
     SNERF_WG_CASE(4, 4)
     SNERF_WG_CASE(4, 2)
     SNERF_WG_CASE(4, 1)
@@ -956,7 +972,7 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     // passes in two thirds of the time (r04: 290 -> 190 us at 4096 samples)
     const int n_cu = device_cu_count("mlp_bwd");
     if (n_cu < 1) return n_cu;
-    const bool small = tuning().fwd_small_tiles && n <= (int64_t)64 * n_cu;
+    const bool small = P.width > 256 || (tuning().fwd_small_tiles && n <= (int64_t)64 * n_cu);
     const bool wide_pe = input_grad && bwd_pe_tiles(P).pos == 8;
     // calls of a few 16-sample tiles per CU: the latency-class dgrad (mlp_lat.hip; bit-identical d Y); a call of a few rounds and a
     // fraction: whole rounds here, the fraction there
@@ -970,7 +986,23 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
         constexpr int BW = decltype(bw_c)::value;
         const int64_t grid = (n_dgrad + BW * 16 - 1) / (BW * 16);
         if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
-        if (P.width == 256) {
+        if (P.width > 256) {   // one wave per SIMD, like the forward
+            if constexpr (BW == 4) {
+#define SNERF_BWD_WIDE(W_)                                                                                                          \
+    do {                                                                                                                            \
+        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<W_, 4, true, 8, 8>), dim3((unsigned)grid), dim3(256), s, A);                 \
+        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<W_, 4, true>), dim3((unsigned)grid), dim3(256), s, A);               \
+        else SNERF_LAUNCH_RING((mlp_bwd_kernel<W_, 4, false>), dim3((unsigned)grid), dim3(256), s, A);                              \
+    } while (0)
+                if (P.width == 320) SNERF_BWD_WIDE(320);
+                else if (P.width == 384) SNERF_BWD_WIDE(384);
+                else if (P.width == 448) SNERF_BWD_WIDE(448);
+                else SNERF_BWD_WIDE(512);
+#undef SNERF_BWD_WIDE
+            } else {
+                return fail(SNERF_E_BADARG, "mlp_bwd: widths above 256 run 4-wave workgroups");
+            }
+        } else if (P.width == 256) {
             if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
             else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
             else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);

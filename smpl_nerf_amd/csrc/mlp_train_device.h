@@ -125,11 +125,14 @@ __host__ __device__ inline int wgrad_kind(const Plan &P, int l, int s, int fold)
     }
     return 2;
 }
-__host__ __device__ inline int wgrad_jobs(const Plan &P) {  // wide jobs: groups of <= 16 input k-blocks
+// wide jobs of a pair: groups of <= 16 output tiles x groups of <= 16 input k-blocks (a 512 x 512 layer: 2 x 2 jobs)
+__host__ __device__ inline int wgrad_wide_jobs(const Layer &Ly, int s) {
+    return wgrad_wide(Ly, s) ? ((Ly.t_out + 15) / 16) * ((Ly.seg[s].nkb + 15) / 16) : 0;
+}
+__host__ __device__ inline int wgrad_jobs(const Plan &P) {
     int jobs = 0;
     for (int l = 0; l < P.nlayers; ++l)
-        for (int s = 0; s < P.layer[l].nseg; ++s)
-            if (wgrad_wide(P.layer[l], s)) jobs += (P.layer[l].seg[s].nkb + 15) / 16;
+        for (int s = 0; s < P.layer[l].nseg; ++s) jobs += wgrad_wide_jobs(P.layer[l], s);
     return jobs;
 }
 __host__ __device__ inline int wgrad_direct_jobs(const Plan &P, int fold = 0) {  // narrow jobs: 4x4-tile blocks

@@ -671,14 +671,23 @@ __global__ __launch_bounds__(256) void sum3_kernel(const float *__restrict__ a, 
 
 struct SmplTrainWs {
     TrainWs base;
-    int64_t warp_c, warped_c, sdirs_c, warp_f, warped_f, sdirs_f, act_wc, act_wf, d_x, d_dirs, d_cdirs, d_warp, dy_w, gpart_w, total;
+    int64_t warp_c, warped_c, sdirs_c, warp_f, warped_f, sdirs_f, act_wc, act_wf, d_x, d_dirs, d_cdirs, d_warp, dy_w, gpart_w;
+    int64_t d_x2, d_dirs2, d_warp2, dy_w2, gpart_w2, grad_warp2;   // the coarse chain's own set (base.concurrent)
+    int64_t total;
 };
+
+// a += b, element by element (the coarse chain's warp-net gradient joins the fine chain's in the order of the sequential form)
+__global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] = __fadd_rn(a[i], b[i]);
+}
 
 static int smpl_train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, const snerf_warp_desc *dw, int64_t chunk, int Nc, int Nf,
                          SmplTrainWs &w) {
     int rc;
-    // (the two backward passes of this step run in sequence - both end in the warp net's gradient: no second scratch set)
-    if ((rc = train_ws(dc, df, chunk, Nc, Nf, w.base, false))) return rc;
+    // small chunks: the coarse chain (compositing, net, warp net) has its own scratch set and may run beside the fine chain; both end
+    // in the warp net's gradient, so the coarse chain's goes to a buffer of its own that is added behind the join
+    if ((rc = train_ws(dc, df, chunk, Nc, Nf, w.base, true))) return rc;
     const int64_t N = Nc + Nf, nmax = chunk * (Nf > 0 ? N : Nc);
     int64_t act_c = 0, act_f = 0, dy_c = 0, dy_f = 0, gp_c = 0, gp_f = 0;
     if ((rc = snerf_warp_train_sizes(dw, chunk * Nc, &act_c, &dy_c, nullptr, &gp_c))) return rc;
@@ -703,6 +712,15 @@ static int smpl_train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, con
     w.d_warp = take(nmax * 3);
     w.dy_w = take(dy_c > dy_f ? dy_c : dy_f);
     w.gpart_w = take(gp_c > gp_f ? gp_c : gp_f);
+    const bool two = w.base.concurrent;
+    const int64_t nw = snerf_warp_param_floats(dw);
+    if (nw < 0) return (int)nw;
+    w.d_x2 = take(two ? chunk * Nc * 3 : 0);
+    w.d_dirs2 = take(two ? chunk * Nc * 3 : 0);
+    w.d_warp2 = take(two ? chunk * Nc * 3 : 0);
+    w.dy_w2 = take(two ? dy_c : 0);
+    w.gpart_w2 = take(two ? gp_c : 0);
+    w.grad_warp2 = take(two ? nw : 0);
     w.total = off;
     return SNERF_OK;
 }
@@ -720,12 +738,13 @@ extern "C" int64_t snerf_smpl_nerf_train_workspace_bytes(const snerf_mlp_desc *d
     return w.total;
 }
 
-extern "C" int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
-                                               const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
-                                               const snerf_warp_desc *desc_warp, const float *packed_warp, const float *packed_t_warp,
-                                               int precision, const snerf_nerf_batch *batch, const float *pose_enc,
-                                               int64_t rays_per_chunk, void *workspace, float *grad_coarse, float *grad_fine,
-                                               float *grad_warp, float *loss, float *rgb, float *rgb_fine, snerf_stream_t stream) {
+// aux_stream (may be NULL): small chunks run the coarse chain there beside the fine chain on `stream` - same results either way
+static int smpl_nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                      const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                      const snerf_warp_desc *desc_warp, const float *packed_warp, const float *packed_t_warp,
+                                      int precision, const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk,
+                                      void *workspace, float *grad_coarse, float *grad_fine, float *grad_warp, float *loss, float *rgb,
+                                      float *rgb_fine, snerf_stream_t stream, snerf_stream_t aux_stream) {
     using namespace snerf;
     if (precision != 0 && !split_code(precision))
         return fail(SNERF_E_BADARG, "smpl_nerf_train_grads: precision must be 0 (fp32), 2 (bf16x3), 3 (bf16x6) or 16 (f16x3)");
@@ -760,6 +779,17 @@ extern "C" int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse
     float *sdirs_f = f(w.sdirs_f), *act_wc = f(w.act_wc), *act_wf = f(w.act_wf), *d_x = f(w.d_x), *d_dirs = f(w.d_dirs);
     float *d_cdirs = f(w.d_cdirs), *d_warp = f(w.d_warp), *dy_w = f(w.dy_w), *gpart_w = f(w.gpart_w);
     hipStream_t s = (hipStream_t)stream;
+    // small chunks with an auxiliary stream: the coarse chain beside the fine chain, on its own scratch set
+    const bool concurrent = b0.concurrent && aux_stream && aux_stream != stream;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (concurrent && (rc = fork_join_events(ev_fork, ev_join))) return rc;
+    const snerf_stream_t stream_c = concurrent ? aux_stream : stream;
+    float *d_raw_c = concurrent ? f(b0.d_raw2) : d_raw, *dy_c = concurrent ? f(b0.dy2) : dy, *gpart_c = concurrent ? f(b0.gpart2) : gpart;
+    float *d_x_c = concurrent ? f(w.d_x2) : d_x, *d_dirs_c = concurrent ? f(w.d_dirs2) : d_dirs, *d_warp_c = concurrent ? f(w.d_warp2) : d_warp;
+    float *dy_w_c = concurrent ? f(w.dy_w2) : dy_w, *gpart_w_c = concurrent ? f(w.gpart_w2) : gpart_w;
+    float *grad_warp_c = concurrent ? f(w.grad_warp2) : grad_warp;
+    const int64_t n_warp = snerf_warp_param_floats(desc_warp);
+    if (n_warp < 0) return (int)n_warp;
     const int wb = batch->white_background ? 1 : 0;
     const float norm = (float)(2.0 / (3.0 * (double)B));
     const double inv_total = 1.0 / (3.0 * (double)B);
@@ -770,15 +800,16 @@ extern "C" int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse
             return snerf_mlp_fwd_train_f32(d, reinterpret_cast<const float *>(packed), x, sd, 1, nullptr, n, spr, raw, act, stream);
         return snerf_mlp_fwd_train_bf16_f32(d, packed, precision, x, sd, 1, nullptr, n, spr, raw, act, stream);
     };
-    auto bwd_inputs = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, const float *x, const float *sd, int64_t n,
-                          int spr, float *grad, bool accumulate) {
+    auto bwd_inputs = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, const float *d_raw_, const float *x,
+                          const float *sd, int64_t n, int spr, float *dy_, float *gpart_, float *grad, float *d_x_, float *d_dirs_,
+                          bool accumulate, snerf_stream_t st) {
         if (precision == 0)
-            return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw, n, dy, gpart, grad, x, sd, 1, spr, d_x, d_dirs,
-                              stream, accumulate);
-        return launch_bwd_bf16(d, packed_t, precision, act, d_raw, n, dy, gpart, grad, x, sd, 1, spr, d_x, d_dirs, stream, accumulate);
+            return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw_, n, dy_, gpart_, grad, x, sd, 1, spr, d_x_, d_dirs_,
+                              st, accumulate);
+        return launch_bwd_bf16(d, packed_t, precision, act, d_raw_, n, dy_, gpart_, grad, x, sd, 1, spr, d_x_, d_dirs_, st, accumulate);
     };
-    auto sum3 = [&](const float *a, const float *b, const float *c, int64_t n) {
-        hipLaunchKernelGGL(sum3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, c, n, d_warp);
+    auto sum3 = [&](const float *a, const float *b, const float *c, int64_t n, float *out, snerf_stream_t st) {
+        hipLaunchKernelGGL(sum3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, a, b, c, n, out);
         return check_launch("smpl_nerf_train_grads(sum)");
     };
     for (int64_t r0 = 0; r0 < B; r0 += chunk) {
@@ -802,24 +833,86 @@ extern "C" int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse
         hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(MSE_THREADS), 0, s, rgb_c, Nf > 0 ? rgb_fo : nullptr, gt, b * 3, norm,
                            d_rgb_c, d_rgb_f, loss_acc, r0 == 0 ? 1 : 0, r0 + b >= B ? 1 : 0, inv_total, loss);
         if ((rc = check_launch("smpl_nerf_train_grads(mse)"))) return rc;
+        if (concurrent && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent((hipStream_t)aux_stream, ev_fork, 0) != hipSuccess))
+            return fail(SNERF_E_LAUNCH, "smpl_nerf_train_grads: cannot fork onto the auxiliary stream");
         bool warp_acc = acc;
         if (Nf > 0) {   // fine: the compositing is scaled by the ray direction (an input), the net back-propagates into x' and x' - o
             if ((rc = snerf_composite_bwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, d_rgb_f, d_raw, nullptr, stream))) return rc;
-            if ((rc = bwd_inputs(desc_fine, packed_t_fine, act_f, warped_f, sdirs_f, b * N, N, grad_fine, acc))) return rc;
-            if ((rc = sum3(d_x, d_dirs, nullptr, b * N * 3))) return rc;
+            if ((rc = bwd_inputs(desc_fine, packed_t_fine, act_f, d_raw, warped_f, sdirs_f, b * N, N, dy, gpart, grad_fine, d_x, d_dirs, acc,
+                                 stream)))
+                return rc;
+            if ((rc = sum3(d_x, d_dirs, nullptr, b * N * 3, d_warp, stream))) return rc;
             if ((rc = launch_warp_bwd(desc_warp, packed_t_warp, act_wf, d_warp, b * N, dy_w, gpart_w, grad_warp, stream, warp_acc))) return rc;
             warp_acc = true;
         }
         // coarse: the compositing's distance scale |x' - o| depends on the warp as well (:63)
-        if ((rc = snerf_composite_bwd_f32(raw_c, z, sdirs_c, 1, nz_c, b, Nc, wb, d_rgb_c, d_raw, d_cdirs, stream))) return rc;
-        if ((rc = bwd_inputs(desc_coarse, packed_t_coarse, act_c, warped_c, sdirs_c, b * Nc, Nc, grad_coarse, acc))) return rc;
-        if ((rc = sum3(d_x, d_dirs, d_cdirs, b * Nc * 3))) return rc;
-        if ((rc = launch_warp_bwd(desc_warp, packed_t_warp, act_wc, d_warp, b * Nc, dy_w, gpart_w, grad_warp, stream, warp_acc))) return rc;
+        if ((rc = snerf_composite_bwd_f32(raw_c, z, sdirs_c, 1, nz_c, b, Nc, wb, d_rgb_c, d_raw_c, d_cdirs, stream_c))) return rc;
+        if ((rc = bwd_inputs(desc_coarse, packed_t_coarse, act_c, d_raw_c, warped_c, sdirs_c, b * Nc, Nc, dy_c, gpart_c, grad_coarse, d_x_c,
+                             d_dirs_c, acc, stream_c)))
+            return rc;
+        if ((rc = sum3(d_x_c, d_dirs_c, d_cdirs, b * Nc * 3, d_warp_c, stream_c))) return rc;
+        if ((rc = launch_warp_bwd(desc_warp, packed_t_warp, act_wc, d_warp_c, b * Nc, dy_w_c, gpart_w_c, grad_warp_c, stream_c,
+                                  concurrent ? false : warp_acc)))
+            return rc;
+        if (concurrent) {   // (concurrent implies Nf > 0: grad_warp holds the fine chain's sum by now)
+            if (hipEventRecord(ev_join, (hipStream_t)aux_stream) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess)
+                return fail(SNERF_E_LAUNCH, "smpl_nerf_train_grads: cannot join the auxiliary stream");
+            hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n_warp + 255) / 256)), dim3(256), 0, s, grad_warp, grad_warp_c, n_warp);
+            if ((rc = check_launch("smpl_nerf_train_grads(add)"))) return rc;
+        }
     }
     if (Nf == 0 && rgb_fine != rgb &&
         hipMemcpyAsync(rgb_fine, rgb, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return fail(SNERF_E_LAUNCH, "smpl_nerf_train_grads: device copy failed");
     return SNERF_OK;
+}
+
+extern "C" int snerf_smpl_nerf_train_grads_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                               const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                               const snerf_warp_desc *desc_warp, const float *packed_warp, const float *packed_t_warp,
+                                               int precision, const snerf_nerf_batch *batch, const float *pose_enc,
+                                               int64_t rays_per_chunk, void *workspace, float *grad_coarse, float *grad_fine,
+                                               float *grad_warp, float *loss, float *rgb, float *rgb_fine, snerf_stream_t stream) {
+    return smpl_nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
+                                      packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
+                                      grad_fine, grad_warp, loss, rgb, rgb_fine, stream, nullptr);
+}
+
+extern "C" int snerf_smpl_nerf_train_grads_aux_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse,
+                                                   const void *packed_t_coarse, const snerf_mlp_desc *desc_fine, const void *packed_fine,
+                                                   const void *packed_t_fine, const snerf_warp_desc *desc_warp, const float *packed_warp,
+                                                   const float *packed_t_warp, int precision, const snerf_nerf_batch *batch,
+                                                   const float *pose_enc, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
+                                                   float *grad_fine, float *grad_warp, float *loss, float *rgb, float *rgb_fine,
+                                                   snerf_stream_t stream, snerf_stream_t aux_stream) {
+    return smpl_nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
+                                      packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
+                                      grad_fine, grad_warp, loss, rgb, rgb_fine, stream, aux_stream);
+}
+
+// comm (may be NULL): the flat gradient buffer is averaged over the ranks between the backward and Adam
+extern "C" int snerf_smpl_nerf_train_step_aux_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                                  const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                                  const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,
+                                                  const snerf_nerf_batch *batch, const float *pose_enc, int64_t rays_per_chunk,
+                                                  void *workspace, float *grad_coarse, float *grad_fine, float *grad_warp, float *loss,
+                                                  float *rgb, float *rgb_fine, const snerf_adam_state *adam,
+                                                  const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host,
+                                                  int n_nets, int64_t warp_param_offset, snerf_comm_t comm, snerf_stream_t stream,
+                                                  snerf_stream_t aux_stream) {
+    using namespace snerf;
+    if (comm && (!adam || !adam->grads || adam->n_params < 1))
+        return fail(SNERF_E_BADARG, "smpl_nerf_train_step_aux: the data-parallel step needs adam->grads");
+    int rc = smpl_nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
+                                        packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
+                                        grad_fine, grad_warp, loss, rgb, rgb_fine, stream, aux_stream);
+    if (rc) return rc;
+    if (comm && (rc = dp_allreduce_avg(comm, const_cast<float *>(adam->grads), 0, adam->n_params, 0, 0, (hipStream_t)stream,
+                                       "smpl_nerf_train_step_aux")))
+        return rc;
+    if ((rc = snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream))) return rc;
+    return snerf_warp_repack_f32(desc_warp, adam ? adam->params : nullptr, adam ? adam->n_params : 0, warp_param_offset, packed_warp,
+                                 packed_t_warp, stream);
 }
 
 extern "C" int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,

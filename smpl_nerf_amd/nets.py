@@ -26,7 +26,8 @@ def _encoder_shape(dim: int):
 
 
 _ENCODED_ROWS = -1  # marker passed in the `per_sample` slot of _FusedMlpFn
-MAX_WIDTH = 256     # --netwidth limit of the fused kernels (csrc/mlp_plan.h: make_plan)
+MAX_WIDTH = 512     # --netwidth limit of the fused kernels (csrc/mlp_plan.h: make_plan; above 256: the 512-feature kernels, fp32)
+MAX_WARP_WIDTH = 256  # --netwidth_warp limit (csrc/mlp_plan.h: make_warp_plan)
 
 
 def _need_f32_cuda(what: str, *tensors):
@@ -732,8 +733,8 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
 
     def __init__(self, n_layers=8, width=256, positions_dim=60, pose_dim=24):
         super(WarpFieldNet, self).__init__()
-        if not 1 <= int(width) <= MAX_WIDTH:
-            raise ValueError(f"WarpFieldNet: width {width} not supported by the HIP kernels (1 <= --netwidth_warp <= {MAX_WIDTH})")
+        if not 1 <= int(width) <= MAX_WARP_WIDTH:
+            raise ValueError(f"WarpFieldNet: width {width} not supported by the HIP kernels (1 <= --netwidth_warp <= {MAX_WARP_WIDTH})")
         self.positions_dim = positions_dim
         self.direcions_dim = pose_dim  # (sic) reference attribute name, :12
         self.width = width

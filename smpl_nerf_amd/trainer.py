@@ -332,7 +332,7 @@ class DataParallelTrainer:
     # ------------------------------------------------------------------ the one-call step
     def _one_call_state(self):
         """Descriptors, segment offsets and slot tables of the one-call path, or None when it does not apply: a plain
-        NerfPipeline (snerf_nerf_train_step_f32) or a SmplNerfPipeline with the encoded pose (snerf_smpl_nerf_train_step_f32)
+        NerfPipeline (snerf_nerf_train_step_f32) or a SmplNerfPipeline with the encoded pose (snerf_smpl_nerf_train_step_aux_f32)
         over RenderRayNets without additional inputs (and the WarpFieldNet) that are exactly this trainer's models, the
         default MSE loss, the library's optimiser, every parameter trainable."""
         # what the decision below depends on and a caller can change between steps (ADVICE r04: a later requires_grad_(False) or a
@@ -557,8 +557,9 @@ class DataParallelTrainer:
             head = head[:6] + (wdesc, packed_w.data_ptr(), packed_t_w.data_ptr(), ns, ctypes.byref(cb), pose_enc.data_ptr(),
                                self.rays_per_chunk, oc["ws"].data_ptr(), g_c, g_f if Nf else None, g_w, loss.data_ptr(), rgb.data_ptr(),
                                rgb_fine.data_ptr())
-            name, tail = "snerf_smpl_nerf_train", ()
-            step_tail = lambda st, ranges, nr: (ctypes.byref(st), ranges, nr, nets_c, n_nets, w_off, stream())
+            # (the _aux_ forms, 0.1.8: small chunks run the coarse chain of the backward on the auxiliary stream; comm may be None)
+            name, tail = "snerf_smpl_nerf_train", (aux,)
+            step_tail = lambda st, ranges, nr, comm=None: (ctypes.byref(st), ranges, nr, nets_c, n_nets, w_off, comm, stream(), aux)
         else:
             name, tail = "snerf_nerf_train", (aux,)
             step_tail = lambda st, ranges, nr: (ctypes.byref(st), ranges, nr, nets_c, n_nets, stream(), aux)
@@ -579,7 +580,8 @@ class DataParallelTrainer:
             elif not self._sync:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
-                _lib.check(getattr(lib, name + "_step_f32")(*head, *step_tail(st, ranges, nr)), name + "_step_f32")
+                entry = name + ("_step_aux_f32" if W is not None else "_step_f32")
+                _lib.check(getattr(lib, entry)(*head, *step_tail(st, ranges, nr)), entry)
                 opt.commit_step()
             elif comm is not None:
                 # more than one rank, one call all the same: the gradient average is RCCL's ncclAllReduce(ncclAvg) of the flat
@@ -588,16 +590,20 @@ class DataParallelTrainer:
                     self._flat_g[of_off:of_off + of_n].zero_()
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
-                t = step_tail(st, ranges, nr)
-                t = t[:-1] + (comm.handle, t[-1]) if W is not None else t[:-2] + (comm.handle,) + t[-2:]
-                _lib.check(getattr(lib, name + "_step_dp_f32")(*head, *t), name + "_step_dp_f32")
+                if W is not None:
+                    t, entry = step_tail(st, ranges, nr, comm.handle), name + "_step_aux_f32"
+                else:
+                    t = step_tail(st, ranges, nr)
+                    t, entry = t[:-2] + (comm.handle,) + t[-2:], name + "_step_dp_f32"
+                _lib.check(getattr(lib, entry)(*head, *t), entry)
                 opt.commit_step()
                 self.collective_calls = getattr(self, "collective_calls", 0) + 1
             else:
                 if ig is not None:
                     _lib.check(lib.snerf_nerf_train_grads_ig_f32(*head, ctypes.byref(ig), stream(), aux), "snerf_nerf_train_grads_ig_f32")
                 else:
-                    _lib.check(getattr(lib, name + "_grads_f32")(*head, stream(), *tail), name + "_grads_f32")
+                    entry = name + ("_grads_aux_f32" if W is not None else "_grads_f32")
+                    _lib.check(getattr(lib, entry)(*head, stream(), *tail), entry)
                 if ig is not None and oc["upstream"]:      # the upstream modules' gradients must be in the flat buffer before it is averaged
                     self._upstream_backward(oc, add_graph, d_add)
                 if not Nf:      # every rank contributes the same shape: zeros for the net that took no part

