@@ -55,6 +55,7 @@ MODES = {
 }
 COARSE_ONLY = ("nerf {r}x{r} frame per GPU, coarse-only 64 samples/ray, run_fine=0, netdepth 8, width 256, skips [4], forward "
                "render (BASELINE configs[0], the reference's CPU-runnable case)")
+INPUT_DGRAD_FLOP_PER_EVAL = 2 * (60 * 256 * 2 + 24 * 128)   # encoder columns of layer 0 + the skip layer, and of directional_input
 WARP_FLOP_PER_EVAL = 2 * (256 * 100 + 3 * 256)      # WarpFieldNet 100 -> 256 -> 3: 52 736 FLOP (SURVEY.md 8d / BASELINE.md 3)
 WARP_FLOP_PADDED = 2 * (256 * 112 + 16 * 256)       # as executed: 7 k-blocks of 16 input slots, the 3-wide head in a 16-wide tile
 WARP_FLOP_FOLDED = 2 * (256 * 64 + 16 * 256)        # fp32 inference: the 3 pose k-blocks are one 256-vector per ray (csrc/warp.hip)
@@ -524,6 +525,12 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
             # same call; with them in the numerator (VERDICT r04 #3 asks for this as a second key)
             "mlp_plus_warp_roofline_frac": ((flop_step + 3 * WARP_FLOP_PER_EVAL * rays * 256) / (mlp_ms * 1e-3) / 1e12 / peak
                                             if (tf and workload == "smpl_nerf" and one_call) else None),
+            # ... and with the dgrad into the nets' inputs (d loss / d warped sample and d view direction through the encoder
+            # columns of layer 0, the skip layer and directional_input: models/smpl_nerf_pipeline.py:49-56 under autograd),
+            # which the nerf step does not compute: 2 x (60 x 256 x 2 + 24 x 128) FLOP per ray-sample
+            "mlp_plus_warp_plus_input_dgrad_roofline_frac": (
+                (flop_step + (3 * WARP_FLOP_PER_EVAL + INPUT_DGRAD_FLOP_PER_EVAL) * rays * 256) / (mlp_ms * 1e-3) / 1e12 / peak
+                if (tf and workload == "smpl_nerf" and one_call) else None),
             "step_entry": ((("snerf_smpl_nerf_train_step_aux_f32" if any(k.startswith("train_step_smpl") for k in kern) else
                              "snerf_nerf_train_step_f32") + " (one C-ABI call per step; mlp_kernels_ms_per_step brackets the whole "
                             "call - for smpl_nerf that includes the warp net's kernels, which the FLOP count of the fraction leaves out)")

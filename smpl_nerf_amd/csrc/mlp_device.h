@@ -199,12 +199,20 @@ struct SlabPipe {
     }
     __device__ __forceinline__ const float *acquire() const { return ring + rd * SLAB_FLOATS; }
     __device__ __forceinline__ const float *peek_next() const { return ring + (rd == 2 ? 0 : rd + 1) * SLAB_FLOATS; }
-    __device__ __forceinline__ void release() {
+    // the two halves of release(): stage() may run anywhere inside the current slab's MFMAs (slot `wr` has been free since the
+    // barrier that ended the previous slab), advance() ends the slab
+    __device__ __forceinline__ void stage() {
         store(wr);
         load();
+    }
+    __device__ __forceinline__ void advance() {
         __syncthreads();
         rd = rd == 2 ? 0 : rd + 1;
         wr = wr == 2 ? 0 : wr + 1;
+    }
+    __device__ __forceinline__ void release() {
+        stage();
+        advance();
     }
 };
 
@@ -269,9 +277,17 @@ __device__ __forceinline__ f4 add_operand(const SampleCtx &c, int add_dim, int k
 // next slab) is read during the last pair - so a wave never waits on an LDS read between MFMAs.  Tiles are
 // walked in pairs so that consecutive MFMAs never share an accumulator (dependent latency of 16x16x4 is 40
 // cycles vs 32 issue).  (pa0, pa1) carry the prefetched first pair from k-block to k-block.
-template <int T_OUT>
+// mid(): called once between two tile pairs early in the block (LayerRun: the staging of the slab after next, so that its LDS
+// writes and global loads issue between MFMAs instead of behind the slab's last one)
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+#ifndef SNERF_STAGE_MID
+#define SNERF_STAGE_MID 1   // 0: stage at the end of the slab (the form of rounds 1-4; A/B knob)
+#endif
+template <int T_OUT, class Mid = NoMid>
 __device__ __forceinline__ void kblock(const float *a_kb, const float *a_next, f4 b, f4 (&acc)[T_OUT], f4 &pa0, f4 &pa1,
-                                       int lane) {
+                                       int lane, Mid mid = Mid{}) {
     const f4 *ap = reinterpret_cast<const f4 *>(a_kb) + lane;
     const f4 *np = reinterpret_cast<const f4 *>(a_next) + lane;
     if constexpr (T_OUT == 1) {
@@ -306,6 +322,10 @@ __device__ __forceinline__ void kblock(const float *a_kb, const float *a_next, f
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (to == (T_OUT >= 8 ? 2 : 0)) {
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             a0 = n0;
             a1 = n1;
         }
@@ -341,11 +361,23 @@ struct LayerRun {
     __device__ __forceinline__ void step(f4 b, f4 (&acc)[T_OUT]) {
         const float *cur = slab + kbl * (T_OUT * 256);
         const float *nxt = (kbl + 1 < KPS) ? cur + T_OUT * 256 : pipe.peek_next();
-        kblock<T_OUT>(cur, nxt, b, acc, pipe.pa0, pipe.pa1, lane);
-        if (++kbl == KPS) {
-            pipe.release();
-            slab = pipe.acquire();
-            kbl = 0;
+        if constexpr (SNERF_STAGE_MID && T_OUT >= 8) {
+            const bool last = kbl + 1 == KPS;     // the slab's last k-block carries the staging between its MFMAs
+            kblock<T_OUT>(cur, nxt, b, acc, pipe.pa0, pipe.pa1, lane, [&]() __attribute__((always_inline)) {
+                if (last) pipe.stage();
+            });
+            if (++kbl == KPS) {
+                pipe.advance();
+                slab = pipe.acquire();
+                kbl = 0;
+            }
+        } else {
+            kblock<T_OUT>(cur, nxt, b, acc, pipe.pa0, pipe.pa1, lane);
+            if (++kbl == KPS) {
+                pipe.release();
+                slab = pipe.acquire();
+                kbl = 0;
+            }
         }
     }
     // a k-block of the stream that is not multiplied (FOLD: the additional-input columns arrive as a per-ray vector):

@@ -312,6 +312,13 @@ struct TrainWs {
 #define SNERF_CONCURRENT_MAX_FINE_SAMPLES (1024 * 256)
 #endif
 constexpr int64_t CONCURRENT_MAX_FINE_SAMPLES = SNERF_CONCURRENT_MAX_FINE_SAMPLES;
+// the same rule for the smpl_nerf step (its coarse chain carries the warp net's backward as well).  Measured r05 with the rule
+// lifted (coarse chain beside the fine chain at every chunk size): 4096 rays 34.00 -> 33.72 ms per step, 2048 rays the same
+// fraction, for 1.8 GB more workspace - both chains are bound by the matrix pipe there, nothing is left to fill.
+#ifndef SNERF_SMPL_CONCURRENT_MAX_FINE_SAMPLES
+#define SNERF_SMPL_CONCURRENT_MAX_FINE_SAMPLES SNERF_CONCURRENT_MAX_FINE_SAMPLES
+#endif
+constexpr int64_t SMPL_CONCURRENT_MAX_FINE_SAMPLES = SNERF_SMPL_CONCURRENT_MAX_FINE_SAMPLES;
 
 // fork / join events of the concurrent backward: one pair per host thread and device (include/smplnerf.h "State"), kept in a
 // registry so that snerf_shutdown() can destroy them
@@ -365,7 +372,8 @@ void destroy_fork_join_events() {
     (void)hipGetLastError();
 }
 
-static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t chunk, int Nc, int Nf, TrainWs &w, bool two_streams = true) {
+static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t chunk, int Nc, int Nf, TrainWs &w, bool two_streams = true,
+                    int64_t concurrent_max = CONCURRENT_MAX_FINE_SAMPLES) {
     const int64_t N = Nc + Nf;
     int64_t act_c = 0, dy_c = 0, gp_c = 0, act_f = 0, dy_f = 0, gp_f = 0;
     int rc;
@@ -390,7 +398,7 @@ static int train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, int64_t 
     w.dy = take(dy_c > dy_f ? dy_c : dy_f);
     w.gpart = take(gp_c > gp_f ? gp_c : gp_f);
     w.loss_acc = take(4);
-    w.concurrent = two_streams && Nf > 0 && chunk * N <= CONCURRENT_MAX_FINE_SAMPLES;
+    w.concurrent = two_streams && Nf > 0 && chunk * N <= concurrent_max;
     w.d_raw2 = take(w.concurrent ? chunk * Nc * 4 : 0);
     w.dy2 = take(w.concurrent ? dy_c : 0);
     w.gpart2 = take(w.concurrent ? gp_c : 0);
@@ -687,7 +695,7 @@ static int smpl_train_ws(const snerf_mlp_desc *dc, const snerf_mlp_desc *df, con
     int rc;
     // small chunks: the coarse chain (compositing, net, warp net) has its own scratch set and may run beside the fine chain; both end
     // in the warp net's gradient, so the coarse chain's goes to a buffer of its own that is added behind the join
-    if ((rc = train_ws(dc, df, chunk, Nc, Nf, w.base, true))) return rc;
+    if ((rc = train_ws(dc, df, chunk, Nc, Nf, w.base, true, SMPL_CONCURRENT_MAX_FINE_SAMPLES))) return rc;
     const int64_t N = Nc + Nf, nmax = chunk * (Nf > 0 ? N : Nc);
     int64_t act_c = 0, act_f = 0, dy_c = 0, dy_f = 0, gp_c = 0, gp_f = 0;
     if ((rc = snerf_warp_train_sizes(dw, chunk * Nc, &act_c, &dy_c, nullptr, &gp_c))) return rc;

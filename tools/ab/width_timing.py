@@ -39,9 +39,11 @@ for width in widths:
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     tf = n * flop / ms / 1e9
-    padded = 512 if width > 256 else 256 if width > 128 else 128
+    padded = (width + 63) // 64 * 64 if width > 256 else 256 if width > 128 else 128
     print(f"width {width:3d} (kernel width {padded}) inference {n} samples: {ms:8.3f} ms/launch  {tf:6.1f} TFLOP/s algorithmic = "
           f"{tf / PEAK:.3f} of the fp32 MFMA peak", flush=True)
+    if len(sys.argv) > 3 and sys.argv[3] == "infer":
+        continue
     # the one-call training step: 4096 rays x (64 + 192) samples, fwd + dgrad + wgrad of both nets
     B = 4096
     for m in nets:
