@@ -71,3 +71,8 @@ ls -la $OUT
   echo "# inference, HIP events"; timeout 200 python $ROOT/tools/ab/lat_timing.py infer 4096,12288,16384,20480,32768,51200,65536,153600
   SNERF_LAT=0 timeout 200 python $ROOT/tools/ab/lat_timing.py infer 4096,12288,16384,20480,32768,51200,65536,153600 ) 2>/dev/null | grep -v "amdgpu.ids\|simple_timer" > $OUT/lat_kernels.txt
 timeout 400 bash $ROOT/tools/ab/pmc_lat.sh infer 4096,16384 2>/dev/null | grep -v amdgpu.ids > $OUT/pmc_lat.txt
+# (k) round 5: --netwidth above 256 - per-launch times / fractions of the 320 .. 512 kernels, their SQ counters beside the 256 kernel,
+#     and what one wave per SIMD can issue (microbenchmark, built by tools/ab/micro/build.sh into csrc/build/)
+timeout 400 python $ROOT/tools/ab/width_timing.py 256,320,384,448,512 2>/dev/null | grep width > $OUT/width_timing.txt
+timeout 600 bash $ROOT/tools/ab/pmc_width.sh 256,320,512 524288 2>/dev/null | grep -v amdgpu.ids > $OUT/pmc_width.txt
+[ -x $ROOT/smpl_nerf_amd/csrc/build/mfma_issue ] && timeout 120 $ROOT/smpl_nerf_amd/csrc/build/mfma_issue > $OUT/mfma_issue.txt 2>/dev/null
