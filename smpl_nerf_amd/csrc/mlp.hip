@@ -68,7 +68,8 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     // Persistent workgroups: one per CU (the 99 KiB ring allows no more), each walking the sample tiles blockIdx.x,
     // blockIdx.x + gridDim.x, ...  The weight ring keeps rolling from one tile into the next (the stream wraps around),
     // so only the first tile of a workgroup pays the pipeline fill and no CU idles between two workgroups.
-    SlabPipe<NT> pipe;
+    using Pipe = PipeFor<WIDTH, NT>;
+    Pipe pipe;
     // raw inputs of a tile (positions, direction), fetched while the previous tile's last layers run so that a tile
     // never starts by waiting on HBM (inference variant; the training variant sits at the register limit)
     // The training variant (at the register limit: the persistent loop would spill) runs one workgroup per tile.
@@ -120,7 +121,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     f4 in[T], acc[T];
 
     // extra input segments [PE(x) | add] of layer 0 and of the skip layers
-    auto pe_segment = [&](LayerRun<T, NT> &run, bool first) {
+    auto pe_segment = [&](LayerRun<T, NT, Pipe> &run, bool first) {
         for (int kb = 0; kb < A.pos_nkb; ++kb) {
             const f4 b = pe_operand<ENCODED>(c, false, A.pos_L, A.pos_id, kb, enc_pos_off);
             if (TRAIN && first && valid) store_tile(A.act, A.act_pe + kb, A.n, sample, c.g, b);
@@ -128,7 +129,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
         }
     };
     int fold_slot = 0;
-    auto add_segment = [&](LayerRun<T, NT> &run, bool first) {
+    auto add_segment = [&](LayerRun<T, NT, Pipe> &run, bool first) {
         if (FOLD) {
             for (int kb = 0; kb < A.add_nkb; ++kb) run.skip();
             const f4 *row = reinterpret_cast<const f4 *>(A.fold + ((sc / A.spr) * A.fold_slots + fold_slot) * WIDTH) + c.g;
@@ -156,14 +157,14 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
         }
     };
     // extra input segments of layer 0 and of the skip layers, in the column order of the weight matrix
-    auto pos_segments = [&](LayerRun<T, NT> &run, bool first) {
+    auto pos_segments = [&](LayerRun<T, NT, Pipe> &run, bool first) {
         if (A.add_first) add_segment(run, first);
         pe_segment(run, first);
         if (!A.add_first) add_segment(run, first);
     };
 
     {  // positions_pose_input + relu (models/render_ray_net.py:45)
-        LayerRun<T, NT> run(pipe, lane);
+        LayerRun<T, NT, Pipe> run(pipe, lane);
         run.init(acc);
         pos_segments(run, true);
         run.finish();
@@ -174,7 +175,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
         }
     }
     for (int i = 0; i < A.n_hidden; ++i) {  // positional_net[i] + relu (:46-50)
-        LayerRun<T, NT> run(pipe, lane);
+        LayerRun<T, NT, Pipe> run(pipe, lane);
         run.init(acc);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], acc);
@@ -187,7 +188,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
         }
     }
     {  // additional_linear_layer, no activation (:51)
-        LayerRun<T, NT> run(pipe, lane);
+        LayerRun<T, NT, Pipe> run(pipe, lane);
         run.init(acc);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], acc);
@@ -197,7 +198,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     }
     f4 sig[1];
     {  // sigma_out_layer (:52): one padded tile, row 0 is sigma
-        LayerRun<1, NT> run(pipe, lane);
+        LayerRun<1, NT, Pipe> run(pipe, lane);
         run.init(sig);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], sig);
@@ -205,7 +206,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     }
     f4 ind[TD], accd[TD];
     {  // directional_input, no activation (:54-57)
-        LayerRun<TD, NT> run(pipe, lane);
+        LayerRun<TD, NT, Pipe> run(pipe, lane);
         run.init(accd);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], accd);
@@ -220,7 +221,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
         if (PREFETCH && tile + gridDim.x < A.n_tiles) load_raw(tile + gridDim.x);   // lands behind the last two layers
     }
     {  // directional_net[0] + relu (:58-59)
-        LayerRun<TD, NT> run(pipe, lane);
+        LayerRun<TD, NT, Pipe> run(pipe, lane);
         run.init(accd);
 #pragma unroll
         for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], accd);
@@ -233,7 +234,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     }
     f4 rgb[1];
     {  // rgb_out_layer (:60): rows 0..2
-        LayerRun<1, NT> run(pipe, lane);
+        LayerRun<1, NT, Pipe> run(pipe, lane);
         run.init(rgb);
 #pragma unroll
         for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], rgb);
@@ -323,6 +324,11 @@ __global__ __launch_bounds__(256) void mlp_add_fold_kernel(Plan P, const float *
     out[e] = sum;
 }
 
+#if SNERF_WIDE_DMA
+#define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING4
+#else
+#define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING
+#endif
 template <int NW, bool ENCODED, bool TRAIN, bool FOLD = false>
 static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t n_limit = -1) {
     const int64_t tile = NW * 16;
@@ -342,10 +348,10 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
     } else {
         if (P.width > 256) {   // one wave per SIMD (20 .. 32-tile chains need the whole register file): 4-wave workgroups only
             if constexpr (NW == 4 && !FOLD) {
-                if (P.width == 320) SNERF_LAUNCH_RING((mlp_fwd_kernel<320, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
-                else if (P.width == 384) SNERF_LAUNCH_RING((mlp_fwd_kernel<384, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
-                else if (P.width == 448) SNERF_LAUNCH_RING((mlp_fwd_kernel<448, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
-                else SNERF_LAUNCH_RING((mlp_fwd_kernel<512, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+                if (P.width == 320) SNERF_LAUNCH_WIDE((mlp_fwd_kernel<320, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+                else if (P.width == 384) SNERF_LAUNCH_WIDE((mlp_fwd_kernel<384, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+                else if (P.width == 448) SNERF_LAUNCH_WIDE((mlp_fwd_kernel<448, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
+                else SNERF_LAUNCH_WIDE((mlp_fwd_kernel<512, 4, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(256), s, B);
             } else {
                 return fail(SNERF_E_BADARG, "mlp_fwd: widths above 256 run 4-wave workgroups");
             }

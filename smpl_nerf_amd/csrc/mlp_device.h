@@ -2,6 +2,7 @@
 // the slab pipe (L2 -> registers -> 3-slot LDS ring), the k-block MFMA step, the layer walker and the
 // in-register positional-encoding operands.  See mlp_plan.h for the operand algebra.
 #pragma once
+#include <type_traits>
 #include "snerf_common.h"
 #include "mlp_plan.h"
 
@@ -140,8 +141,13 @@ __device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, in
     }
 }
 
+#ifdef SNERF_DMA_MIN_WIDTH
+#define SNERF_DMA_MIN_WIDTH_ SNERF_DMA_MIN_WIDTH
+#else
+#define SNERF_DMA_MIN_WIDTH_ 257
+#endif
 // The 3-slot ring (99 KiB) is dynamic LDS: a launch gets 64 KiB unless the limit is raised per kernel once.
-constexpr int RING_BYTES = 3 * SLAB_FLOATS * 4;
+constexpr int RING_BYTES = (SNERF_DMA_MIN_WIDTH_ <= 256 ? 4 : 3) * SLAB_FLOATS * 4;
 #define SNERF_LAUNCH_RING(kernel, grid, block, stream, ...)                                                            \
     do {                                                                                                               \
         static ::snerf::LdsRaised snerf_lds_raised_; /* per device (snerf_common.h) */                                 \
@@ -150,6 +156,23 @@ constexpr int RING_BYTES = 3 * SLAB_FLOATS * 4;
             return snerf_rc_;                                                                                          \
         hipLaunchKernelGGL(kernel, grid, block, ::snerf::RING_BYTES, stream, __VA_ARGS__);                             \
     } while (0)
+
+// ... the 4-slot ring of the LDS-DMA pipe (SlabPipeDma below: the widths above 256), 132 KiB
+constexpr int RING4_BYTES = 4 * SLAB_FLOATS * 4;
+#define SNERF_LAUNCH_RING4(kernel, grid, block, stream, ...)                                                           \
+    do {                                                                                                               \
+        static ::snerf::LdsRaised snerf_lds_raised_; /* per device (snerf_common.h) */                                 \
+        if (int snerf_rc_ = ::snerf::raise_dynamic_lds(reinterpret_cast<const void *>(kernel), ::snerf::RING4_BYTES,   \
+                                                       snerf_lds_raised_, #kernel))                                    \
+            return snerf_rc_;                                                                                          \
+        hipLaunchKernelGGL(kernel, grid, block, ::snerf::RING4_BYTES, stream, __VA_ARGS__);                            \
+    } while (0)
+#ifndef SNERF_WIDE_DMA
+#define SNERF_WIDE_DMA 1   // widths above 256: slabs global -> LDS by DMA into a 4-slot ring (0: the register-staged 3-slot ring)
+#endif
+#ifndef SNERF_DMA_MIN_WIDTH
+#define SNERF_DMA_MIN_WIDTH 257   // (A/B knob: 0 = every width on the DMA pipe; the launches then take the 4-slot ring's LDS)
+#endif
 
 // Streams the slab sequence global -> registers -> LDS ring (3 slots).
 template <int NT>
@@ -215,6 +238,79 @@ struct SlabPipe {
         advance();
     }
 };
+
+// The same interface with the slabs copied global -> LDS by DMA (`global_load_lds`, 16 B per lane: one instruction moves a 1 KiB
+// piece) into a 4-slot ring: no staging registers and half the instructions per slab of the register-staged pipe.  For the
+// kernels that run ONE wave per SIMD (widths above 256): there nobody issues MFMAs while a wave sits in its refill instructions
+// (each blocks the issuing wave for ~60 cycles, DESIGN_HISTORY 3.1), so their number is what the refill costs.
+// Ring: slab p consumed, p+1 resident and visible (as above), p+2 landing or landed, p+3 being issued into the slot slab p-1 left
+// at the last barrier.  A wave's pieces of a slab are complete before the barrier TWO slabs later (vmcnt leaves only the
+// newest slab's pieces in flight), i.e. a slab has two periods to arrive.
+template <int NT>
+struct SlabPipeDma {
+    static constexpr int NW = NT / 64;
+    static constexpr int PIECES = SLAB_A_FLOATS / 256;   // 1 KiB pieces of the A region (32); the aux block is one more (wave 0)
+    static constexpr int PPW = PIECES / NW;
+    static_assert(PIECES % NW == 0, "pieces divide over the waves");
+    const float *g, *g0;   // this lane's cursor in the stream (slab `src`, piece wave * PPW, lane's 16 B) and its position at slab 0
+    int src, total;
+    float *ring;
+    f4 pa0, pa1;
+    int tid, rd, wr;
+    bool w0;
+
+    __device__ __forceinline__ void issue(int slot) {
+        float *dst = ring + slot * SLAB_FLOATS + (tid >> 6) * PPW * 256;   // wave-uniform; the hardware adds lane * 16 B
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i * 256),
+                                             (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+        if (w0)   // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + SLAB_A_FLOATS),
+                                             (__attribute__((address_space(3))) void *)(ring + slot * SLAB_FLOATS + SLAB_A_FLOATS), 16, 0, 0);
+        g += SLAB_FLOATS;
+        if (++src == total) {
+            src = 0;
+            g = g0;
+        }
+    }
+    __device__ __forceinline__ void prologue(const float *packed, float *ring_, int tid_, int total_slabs = 0x7fffffff) {
+        ring = ring_;
+        tid = tid_;
+        w0 = __builtin_amdgcn_readfirstlane(tid_ >> 6) == 0;
+        g = g0 = packed + (tid_ >> 6) * PPW * 256 + (tid_ & 63) * 4;   // (wave 0: the slab's first byte + the lane's 16)
+        src = 0;
+        total = total_slabs;
+        issue(0);
+        issue(1);
+        issue(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rd = 0;
+        wr = 3;
+        __syncthreads();
+        const f4 *np = reinterpret_cast<const f4 *>(ring) + (tid & 63);
+        pa0 = np[0];
+        pa1 = np[64];
+    }
+    __device__ __forceinline__ const float *acquire() const { return ring + rd * SLAB_FLOATS; }
+    __device__ __forceinline__ const float *peek_next() const { return ring + ((rd + 1) & 3) * SLAB_FLOATS; }
+    __device__ __forceinline__ void stage() { issue(wr); }
+    __device__ __forceinline__ void advance() {
+        // everything but this wave's newest slab (PPW pieces, + 1 for wave 0) has landed: the slab issued one period ago is complete
+        if (w0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        __syncthreads();
+        rd = (rd + 1) & 3;
+        wr = (wr + 1) & 3;
+    }
+    __device__ __forceinline__ void release() {
+        stage();
+        advance();
+    }
+};
+// the pipe of a kernel of WIDTH features on NT threads
+template <int WIDTH, int NT>
+using PipeFor = std::conditional_t<(WIDTH >= SNERF_DMA_MIN_WIDTH && SNERF_WIDE_DMA), SlabPipeDma<NT>, SlabPipe<NT>>;
 
 // per-lane view of the sample this lane works for
 struct SampleCtx {
@@ -338,15 +434,15 @@ __device__ __forceinline__ void kblock(const float *a_kb, const float *a_next, f
 // next global loads issued, workgroup barrier) as soon as its last k-block has been issued; the first A
 // pair of the following slab was read before that barrier - legal because slab p+1 has been resident and
 // visible since the barrier that ended slab p-1 (the ring holds p, p+1 and the slot being filled with p+2).
-template <int T_OUT, int NT>
+template <int T_OUT, int NT, class PIPE = SlabPipe<NT>>
 struct LayerRun {
     static constexpr int KPS = SLAB_TILES / T_OUT;
-    SlabPipe<NT> &pipe;
+    PIPE &pipe;
     const float *slab;
     int kbl;  // k-block index inside the current slab
     int lane;
 
-    __device__ __forceinline__ LayerRun(SlabPipe<NT> &p, int lane_) : pipe(p), slab(p.acquire()), kbl(0), lane(lane_) {}
+    __device__ __forceinline__ LayerRun(PIPE &p, int lane_) : pipe(p), slab(p.acquire()), kbl(0), lane(lane_) {}
     // bias -> accumulator init (aux block of the layer's first slab: bias[16*to + 4*g + r])
     __device__ __forceinline__ void init(f4 (&acc)[T_OUT]) {
         const f4 *aux = reinterpret_cast<const f4 *>(slab + SLAB_A_FLOATS) + (lane >> 4);

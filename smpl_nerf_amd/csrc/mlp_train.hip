@@ -126,13 +126,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         store_tile(A.dy, A.dy_sig, A.n, sample, g, g == 0 ? f4{dr[3], 0.f, 0.f, 0.f} : zero);
     }
 
-    SlabPipe<NT> pipe;
+    using Pipe = PipeFor<WIDTH, NT>;
+    Pipe pipe;
     pipe.prologue(A.packed_t, ring, tid);
 
     f4 ind[TD], accd[TD];
     {  // rgb_out_layer^T, then the ReLU mask of directional_net[0] (models/render_ray_net.py:58-60)
         const uint4 mw = load_mask<TD, (T > 16)>(A.act, A.act_mask, nh + 1, A.n, sc, g);
-        LayerRun<TD, NT> run(pipe, lane);
+        LayerRun<TD, NT, Pipe> run(pipe, lane);
         run.init(accd);
         run.step(g == 0 ? f4{dr[0], dr[1], dr[2], 0.f} : zero, accd);
         run.finish();
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         if (valid) store_tiles(A.dy, A.dy_dn0, A.n, sample, g, ind);
     }
     {  // directional_net[0]^T; directional_input has no activation (:54-57)
-        LayerRun<TD, NT> run(pipe, lane);
+        LayerRun<TD, NT, Pipe> run(pipe, lane);
         run.init(accd);
 #pragma unroll
         for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], accd);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
     if (INPUT_GRAD && A.use_dir && A.dir_nkb > 0) {
         // d (direction encoding) = directional_input[:, W:]^T d h1, then encoder and normalisation backward
         f4 ddpe[TPD];
-        LayerRun<TPD, NT> run(pipe, lane);
+        LayerRun<TPD, NT, Pipe> run(pipe, lane);
         run.init(ddpe);
 #pragma unroll
         for (int kb = 0; kb < TD; ++kb) run.step(ind[kb], ddpe);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         if (!INPUT_GRAD || A.pos_nkb <= 0) return;
         if (!(l == 0 || ((A.skip_mask >> (l - 1)) & 1u))) return;
         f4 t[TPP];
-        LayerRun<TPP, NT> run(pipe, lane);
+        LayerRun<TPP, NT, Pipe> run(pipe, lane);
         run.init(t);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], t);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         for (int q = 0; q < TPP; ++q) dpe[q] += t[q];
     };
     {  // d o = directional_input[:, :W]^T d h1 + sigma_out_layer^T d sigma; additional layer has no activation (:51-52)
-        LayerRun<T, NT> run(pipe, lane);
+        LayerRun<T, NT, Pipe> run(pipe, lane);
         run.init(acc);  // aux block = sigma head weights
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
     // d X_{l+1}; masking with X_{l+1} > 0 gives d Y of forward layer l (:46-50)
     for (int l = nh; l >= 0; --l) {
         const uint4 mw = load_mask<T, (T > 16)>(A.act, A.act_mask, l, A.n, sc, g);   // lands behind the layer's MFMAs
-        LayerRun<T, NT> run(pipe, lane);
+        LayerRun<T, NT, Pipe> run(pipe, lane);
         run.init(acc);
 #pragma unroll
         for (int kb = 0; kb < T; ++kb) run.step(in[kb], acc);
@@ -988,11 +989,16 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
         if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
         if (P.width > 256) {   // one wave per SIMD, like the forward
             if constexpr (BW == 4) {
+#if SNERF_WIDE_DMA
+#define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING4
+#else
+#define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING
+#endif
 #define SNERF_BWD_WIDE(W_)                                                                                                          \
     do {                                                                                                                            \
-        if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<W_, 4, true, 8, 8>), dim3((unsigned)grid), dim3(256), s, A);                 \
-        else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<W_, 4, true>), dim3((unsigned)grid), dim3(256), s, A);               \
-        else SNERF_LAUNCH_RING((mlp_bwd_kernel<W_, 4, false>), dim3((unsigned)grid), dim3(256), s, A);                              \
+        if (wide_pe) SNERF_LAUNCH_WIDE((mlp_bwd_kernel<W_, 4, true, 8, 8>), dim3((unsigned)grid), dim3(256), s, A);                 \
+        else if (input_grad) SNERF_LAUNCH_WIDE((mlp_bwd_kernel<W_, 4, true>), dim3((unsigned)grid), dim3(256), s, A);               \
+        else SNERF_LAUNCH_WIDE((mlp_bwd_kernel<W_, 4, false>), dim3((unsigned)grid), dim3(256), s, A);                              \
     } while (0)
                 if (P.width == 320) SNERF_BWD_WIDE(320);
                 else if (P.width == 384) SNERF_BWD_WIDE(384);
