@@ -31,6 +31,8 @@ for case in range(cases):
     width = int(rng.choice([33, 64, 128, 200, 256, 256]))
     skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
     prec = str(rng.choice(["fp32", "fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
+    if os.environ.get("FUZZ_WIDE"):      # FUZZ_WIDE=1: --netwidth above 256 (the kernels of 320 / 384 / 448 / 512 features, fp32)
+        width, prec = [257, 300, 320, 352, 384, 400, 448, 500, 512][case % 9], "fp32"
     B = int(rng.choice([1, 3, 31, 64, 100, 257, 700]))
     Nc = int(rng.choice([3, 7, 16, 64, 100]))
     Nf = int(rng.choice([0, 5, 64, 128]))

@@ -130,6 +130,8 @@ for case in range(cases):
             skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
             use_dir = int(rng.integers(0, 4) != 0)
             prec = str(rng.choice(["fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
+            if os.environ.get("FUZZ_WIDE"):      # FUZZ_WIDE=1: --netwidth above 256 (the kernels of 320 / 384 / 448 / 512 features, fp32)
+                width, prec = [257, 300, 320, 352, 384, 400, 448, 500, 512][case % 9], "fp32"
             n = int(rng.choice([1, 17, 128, 1000, 20001]))
             torch.manual_seed(4000 + case)
             net = RenderRayNet(depth, width, pd, dd, ad, skips=list(skips), use_directional_input=use_dir)

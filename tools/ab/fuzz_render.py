@@ -39,6 +39,8 @@ for case in range(cases):
     prec = str(rng.choice(["fp32", "fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
     if os.environ.get("FUZZ_PREC") and width == 256:      # e.g. FUZZ_PREC=bf16x3
         prec = os.environ["FUZZ_PREC"]
+    if os.environ.get("FUZZ_WIDE"):      # FUZZ_WIDE=1: --netwidth above 256 (the kernels of 320 / 384 / 448 / 512 features, fp32)
+        width, prec = [257, 300, 320, 352, 384, 400, 448, 500, 512][case % 9], "fp32"
     skips = sorted(set(int(v) for v in rng.integers(0, depth, rng.integers(0, 3)))) if depth > 1 else []
     B = int(rng.choice([1, 2, 5, 31, 64, 100, 129, 257, 600, 2049]))
     Nc = int(rng.choice([3, 4, 7, 16, 33, 64, 100]))

@@ -29,6 +29,8 @@ for case in range(cases):
     prec = str(rng.choice(["fp32", "bf16x6", "f16x3"])) if width == 256 else "fp32"
     if os.environ.get("FUZZ_PREC") and width == 256:      # e.g. FUZZ_PREC=bf16x3
         prec = os.environ["FUZZ_PREC"]
+    if os.environ.get("FUZZ_WIDE"):      # FUZZ_WIDE=1: --netwidth above 256 (the kernels of 320 / 384 / 448 / 512 features, fp32)
+        width, prec = [257, 300, 320, 352, 384, 400, 448, 500, 512][case % 9], "fp32"
     kind = str(rng.choice(["nerf", "nerf", "smpl_nerf", "append_smpl_params", "append_smpl_params_encoded", "append_to_nerf"]))
     if os.environ.get("FUZZ_KIND"):
         kind = os.environ["FUZZ_KIND"]
