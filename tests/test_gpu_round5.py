@@ -440,3 +440,18 @@ def test_pose_conditioned_steps_with_widths_above_256(dev, kind, width):
     for ga, gb in zip(runs[0][1], runs[1][1]):
         assert float(gb.norm()) > 0
         assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-10
+
+
+@pytest.mark.parametrize("tool,count,seed", [("fuzz_train.py", 18, 5003), ("fuzz_render.py", 18, 5003)])
+def test_randomised_sweeps_agree_for_widths_above_256(dev, tool, count, seed):
+    """A fixed-seed slice of the FUZZ_WIDE=1 campaign (profiles/r05_fuzz_campaign.txt): every case draws its --netwidth from 257 ..
+    512 - the one-call step against the autograd form and the CPU torch restatement, inference of every pipeline against the CPU
+    torch restatement (config_parser.py:20)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab", tool), str(count), str(seed)], capture_output=True, text=True,
+                       timeout=900, cwd=root, env=dict(os.environ, FUZZ_WIDE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == f"{count} of {count} cases agree", r.stdout[-3000:]
