@@ -245,6 +245,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
         reinterpret_cast<f4 *>(A.raw)[sample] = o;
     }
     } while (PERSIST && (tile += gridDim.x) < A.n_tiles);
+    pipe.drain();
 }
 
 // the kernels: the body above with and without the per-ray fold (two kernel names: the profiles of the rounds key on the

@@ -237,6 +237,7 @@ struct SlabPipe {
         stage();
         advance();
     }
+    __device__ __forceinline__ void drain() {}   // (loads into registers: nothing of this pipe can land after the kernel)
 };
 
 // The same interface with the slabs copied global -> LDS by DMA (`global_load_lds`, 16 B per lane: one instruction moves a 1 KiB
@@ -307,6 +308,9 @@ struct SlabPipeDma {
         stage();
         advance();
     }
+    // end of the kernel: the slabs issued ahead of the last one consumed are still landing in this workgroup's LDS (s_endpgm waits
+    // for a wave's outstanding memory operations by itself; said here so that it does not rest on that)
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 // the pipe of a kernel of WIDTH features on NT threads
 template <int WIDTH, int NT>

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
             q[2] = gz;
         }
     }
+    pipe.drain();
 }
 
 // ------------------------------------------------------------------------------------------------
