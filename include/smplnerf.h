@@ -77,7 +77,8 @@ extern "C" {
                              0.1.7: + snerf_comm_*, snerf_nerf_train_step_dp_f32, snerf_smpl_nerf_train_step_dp_f32 (RCCL inside the
                              boundary); latency-class kernels behind the same entry points for small calls
                              0.1.8: + snerf_smpl_nerf_train_grads_aux_f32, snerf_smpl_nerf_train_step_aux_f32 (the smpl_nerf step with an
-                             auxiliary stream: small chunks run the coarse chain beside the fine chain) */
+                             auxiliary stream: small chunks run the coarse chain beside the fine chain); snerf_mlp_desc.width
+                             up to 512 */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -211,9 +212,10 @@ SNERF_API int snerf_sample_pdf_bins_bwd_f32(const float *bins, const float *weig
  * encoding (train.py:154-159). */
 typedef struct snerf_mlp_desc {
     int32_t n_layers;     /* 8 */
-    int32_t width;        /* 2 .. 256 (--netwidth, config_parser.py:20).  The kernels are built for trunks of 256, 128 and 64
-                             features; any other width runs zero-padded inside the next larger one (same results, the
-                             cost of that kernel).  The split-precision entry points take 256 only. */
+    int32_t width;        /* 2 .. 512 (--netwidth, config_parser.py:20).  The kernels are built for trunks of 64, 128, 256 and
+                             (0.1.8; one wave per SIMD) 320, 384, 448, 512 features; any other width runs zero-padded inside
+                             the next larger one (same results, the cost of that kernel).  The split-precision entry points
+                             take 256 only; a net above 256 needs at least 17 input columns in its first layer. */
     int32_t pos_freqs;    /* 10 */
     int32_t pos_identity; /* 0 */
     int32_t dir_freqs;    /* 4 */
