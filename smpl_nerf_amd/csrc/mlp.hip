@@ -68,13 +68,15 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     // Persistent workgroups: one per CU (the 99 KiB ring allows no more), each walking the sample tiles blockIdx.x,
     // blockIdx.x + gridDim.x, ...  The weight ring keeps rolling from one tile into the next (the stream wraps around),
     // so only the first tile of a workgroup pays the pipeline fill and no CU idles between two workgroups.
-    using Pipe = PipeFor<WIDTH, NT>;
+    // (SNERF_TRAIN_PERSIST: the training forward of the 256 kernel as persistent workgroups on the DMA pipe - its staging registers are
+    // what the persistent loop did not fit beside; A/B knob, mlp_device.h)
+    using Pipe = std::conditional_t<(TRAIN && SNERF_TRAIN_PERSIST && WIDTH == 256 && NWAVES == 8), SlabPipeDma<NT>, PipeFor<WIDTH, NT>>;
     Pipe pipe;
     // raw inputs of a tile (positions, direction), fetched while the previous tile's last layers run so that a tile
     // never starts by waiting on HBM (inference variant; the training variant sits at the register limit)
     // The training variant (at the register limit: the persistent loop would spill) runs one workgroup per tile.
-    constexpr bool PERSIST = !TRAIN;
-    constexpr bool PREFETCH = !ENCODED && PERSIST;
+    constexpr bool PERSIST = !TRAIN || (SNERF_TRAIN_PERSIST && WIDTH == 256 && NWAVES == 8);
+    constexpr bool PREFETCH = !ENCODED && PERSIST && !TRAIN;
     float raw_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto load_raw = [&](int64_t t) __attribute__((always_inline)) {
         const int64_t s0 = (t * NWAVES + wave) * 16 + (lane & 15);
@@ -341,7 +343,8 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
     if (n_cu < 1) return n_cu;
     // SNERF_FWD_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
     const bool persistent = tuning().fwd_persistent;
-    const int64_t grid = (!TRAIN && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
+    constexpr bool TRAIN_PERSIST = TRAIN && SNERF_TRAIN_PERSIST && NW == 8;   // (width 256 only: the others ignore total_slabs)
+    const int64_t grid = ((!TRAIN || (TRAIN_PERSIST && P.width == 256)) && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
     if constexpr (FOLD) {
         if (P.width == 256) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
@@ -356,7 +359,10 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
             } else {
                 return fail(SNERF_E_BADARG, "mlp_fwd: widths above 256 run 4-wave workgroups");
             }
-        } else if (P.width == 256) SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        } else if (P.width == 256) {
+            if constexpr (TRAIN_PERSIST) SNERF_LAUNCH_RING4((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+            else SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        }
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         else SNERF_LAUNCH_RING((mlp_fwd_kernel<64, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     }

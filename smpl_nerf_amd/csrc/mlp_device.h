@@ -170,6 +170,9 @@ constexpr int RING4_BYTES = 4 * SLAB_FLOATS * 4;
 #ifndef SNERF_WIDE_DMA
 #define SNERF_WIDE_DMA 1   // widths above 256: slabs global -> LDS by DMA into a 4-slot ring (0: the register-staged 3-slot ring)
 #endif
+#ifndef SNERF_TRAIN_PERSIST
+#define SNERF_TRAIN_PERSIST 0   // (A/B knob, mlp.hip: persistent training forward of the 256 kernel on the DMA pipe)
+#endif
 #ifndef SNERF_DMA_MIN_WIDTH
 #define SNERF_DMA_MIN_WIDTH 257   // (A/B knob: 0 = every width on the DMA pipe; the launches then take the 4-slot ring's LDS)
 #endif
