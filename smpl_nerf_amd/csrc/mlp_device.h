@@ -18,7 +18,8 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
 // snerf_mlp_bwd_inputs_f32 and their split-precision twins); accumulate: flat_grad += instead of = (train_step.hip)
 int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n, float *dy,
                float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample, int spr, float *d_x,
-               float *d_dirs, snerf_stream_t stream, bool accumulate = false);
+               float *d_dirs, snerf_stream_t stream, bool accumulate = false, bool beside_another_net = false);
+// (beside_another_net: the caller runs another net's backward on a second stream at the same time - train_step.hip)
 // defined in warp.hip: the body of snerf_warp_bwd_f32
 int launch_warp_bwd(const snerf_warp_desc *desc, const float *packed_t, const float *act, const float *d_warp, int64_t n, float *dy,
                     float *gpart, float *flat_grad, snerf_stream_t stream, bool accumulate = false);
@@ -38,7 +39,7 @@ template <bool TRAIN>
 LatChoice lat_choose_fwd(const Plan &P, int64_t n);
 template <bool TRAIN>
 int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t first_sample);
-LatChoice lat_choose_bwd(const Plan &P, int64_t n, bool input_grad);
+LatChoice lat_choose_bwd(const Plan &P, int64_t n, bool input_grad, bool beside_another_net = false);
 int launch_bwd_lat(const Plan &P, const BwdArgs &A, hipStream_t s, int64_t first_sample);
 // defined in mlp.hip: packs params_flat into the slab stream described by `P` (any plan)
 int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStream_t s, const char *what);

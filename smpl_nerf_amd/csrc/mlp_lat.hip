@@ -240,7 +240,12 @@ static void lat_table_fwd(const Plan &P, const TrainLayout &L, const LatLds &Lo,
 // ------------------------------------------------------------------------------------------------
 // dgrad: the forward pass of the transposed network on d raw (mlp_train.hip: mlp_bwd_kernel), through the same interpreter
 // ------------------------------------------------------------------------------------------------
-template <int S>
+// IG: with input gradients (smpl_nerf: the nets back-propagate into the warped samples and their view directions,
+// models/smpl_nerf_pipeline.py:49-56) for the default-sized encoders (4 position / 2 direction k-blocks: bwd_pe_tiles).  The
+// transposed encoder columns are layers of two / one wave(s): waves 0, 1 keep the running d (position encoding) tiles 0-1 / 2-3 of
+// the pass in registers, wave 0 finishes the direction columns on the spot; at the end of the pass wave 1 hands its tiles to wave 0
+// through LDS, which runs the encoder backward in the order of mlp_bwd_kernel (same bits).
+template <int S, bool IG = false>
 __global__ __launch_bounds__(LAT_THREADS) void mlp_bwd_lat_kernel(LatTable tab_in_kernarg, BwdArgs A, LatGeom G, LatLds Lo) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const LatTabPtr tab = lat_table_ptr();
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_bwd_lat_kernel(LatTable tab_i
     const int lane = W.lane, wave = W.wave, g = lane >> 4;
     const unsigned n32 = (unsigned)A.n;
     const __amdgpu_buffer_rsrc_t dy_rs = lat_rsrc(A.dy, LAT_STORE_RANGE);
+    const __amdgpu_buffer_rsrc_t dx_rs = lat_rsrc(IG ? A.d_x : A.dy, LAT_STORE_RANGE), dd_rs = lat_rsrc(IG ? A.d_dirs : A.dy, LAT_STORE_RANGE);
     const int n_layers = tab->n, n_mask = A.n_hidden + 2;
     const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
 
@@ -266,6 +272,22 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_bwd_lat_kernel(LatTable tab_i
         f4 dr[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) dr[s] = *reinterpret_cast<const f4 *>(A.d_raw + min(sample_of(s), A.n - 1) * 4);
+        // (IG) the forward inputs of this lane's samples and the running d (position encoding) tiles of this wave
+        float xin[IG ? S : 1][3], din[IG ? S : 1][3];
+        f4 dpe[IG ? S : 1][2];
+        if constexpr (IG) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int64_t sc = min(sample_of(s), A.n - 1);
+                const float *dp = A.dirs + (A.dirs_per_sample ? sc : sc / A.spr) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    xin[s][c] = A.x[sc * 3 + c];
+                    din[s][c] = A.use_dir ? dp[c] : 0.f;
+                }
+                dpe[s][0] = dpe[s][1] = zero;
+            }
+        }
         for (int s = wave; s < S; s += LAT_NW) {
             f4 *blk = reinterpret_cast<f4 *>(lds + Lo.act[1] + s * LAT_ACT_BYTES + W.voff);
             const f4 drgb = g == 0 ? f4{dr[0][0], dr[0][1], dr[0][2], 0.f} : zero, dsig = g == 0 ? f4{dr[0][3], 0.f, 0.f, 0.f} : zero;
@@ -302,6 +324,34 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_bwd_lat_kernel(LatTable tab_i
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[s][t][r] = scale ? W.aux[t][r] * dr[s][3] : W.aux[t][r];
                 lat_run_layer<S>(W, tab, lds, Ly, acc);
+                if (IG && (op & LAT_PE_POS)) {          // (waves 0, 1: k-blocks 2 wave, 2 wave + 1 of the position encoding)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) dpe[IG ? s : 0][t] += acc[s][t];
+                    continue;
+                }
+                if (IG && (op & LAT_PE_DIR)) {          // (wave 0: both k-blocks of the direction encoding)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float ux = din[IG ? s : 0][0], uy = din[IG ? s : 0][1], uz = din[IG ? s : 0][2];
+                        const float nrm = sqrtf(ux * ux + uy * uy + uz * uz);
+                        const float nx = ux / nrm, ny = uy / nrm, nz = uz / nrm;
+                        float gx = 0.f, gy = 0.f, gz = 0.f;
+                        const f4 dd[2] = {acc[s][0], acc[s][1]};
+                        pe_backward<2>(dd, A.dir_nkb, nx, ny, nz, A.dir_L, A.dir_id, g, gx, gy, gz);
+                        gx = sum_over_g(gx);
+                        gy = sum_over_g(gy);
+                        gz = sum_over_g(gz);
+                        // d (u/|u|) -> d u = (g - n (n.g)) / |u|   (models/smpl_nerf_pipeline.py:54-55)
+                        const float dot = nx * gx + ny * gy + nz * gz;
+                        const unsigned off = (okay(s) && g == 0) ? (unsigned)sample_of(s) * 12u : LAT_OOB;
+                        lat_store_b32(dd_rs, off, (gx - nx * dot) / nrm);
+                        lat_store_b32(dd_rs, off == LAT_OOB ? off : off + 4u, (gy - ny * dot) / nrm);
+                        lat_store_b32(dd_rs, off == LAT_OOB ? off : off + 8u, (gz - nz * dot) / nrm);
+                    }
+                    continue;
+                }
                 const bool mask = op & LAT_MASK_BITS;
                 const int out_base = Ly.out_base, store_row = Ly.store_row;
                 const int mask_at = Lo.aux + (Ly.mask_idx < 0 ? 0 : Ly.mask_idx) * 512 + lane * 8 + (tile >> 1);
@@ -325,31 +375,77 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_bwd_lat_kernel(LatTable tab_i
             }
             if (op & LAT_BARRIER) __syncthreads();
         }
+        if constexpr (IG) {
+            // d (position encoding): wave 1's tiles 2, 3 -> LDS -> wave 0, which holds tiles 0, 1; encoder backward in the order of
+            // mlp_bwd_kernel (pe_backward over k-blocks 0 .. 3, then the four lane groups)
+            __syncthreads();   // (every wave is through its last layer: the activation buffers are free)
+            if (wave == 1) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    f4 *blk = reinterpret_cast<f4 *>(lds + Lo.act[0] + s * LAT_ACT_BYTES + W.voff);
+                    blk[0] = dpe[s][0];
+                    blk[64] = dpe[s][1];
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const f4 *blk = reinterpret_cast<const f4 *>(lds + Lo.act[0] + s * LAT_ACT_BYTES + W.voff);
+                    const f4 d4[4] = {dpe[s][0], dpe[s][1], blk[0], blk[64]};
+                    float gx = 0.f, gy = 0.f, gz = 0.f;
+                    if (A.pos_nkb > 0) pe_backward<4>(d4, A.pos_nkb, xin[s][0], xin[s][1], xin[s][2], A.pos_L, A.pos_id, g, gx, gy, gz);
+                    gx = sum_over_g(gx);
+                    gy = sum_over_g(gy);
+                    gz = sum_over_g(gz);
+                    const unsigned off = (okay(s) && g == 0) ? (unsigned)sample_of(s) * 12u : LAT_OOB;
+                    lat_store_b32(dx_rs, off, gx);
+                    lat_store_b32(dx_rs, off == LAT_OOB ? off : off + 4u, gy);
+                    lat_store_b32(dx_rs, off == LAT_OOB ? off : off + 8u, gz);
+                }
+            }
+        }
     }
 }
 
-// the transposed stream (mlp_plan.h: make_bwd_plan without the encoder-column transposes) as the latency kernel walks it
+// the transposed stream (mlp_plan.h: make_bwd_plan, with the encoder-column transposes when B was built with input_grad) as the
+// latency kernel walks it
 static void lat_table_bwd(const Plan &P, const BwdPlan &B, const TrainLayout &L, const LatLds &Lo, LatTable &T) {
     T.n = B.nl;
     T.stream_bytes = (B.total_slabs + SLAB_PAD) * SLAB_BYTES;
     const int nh = P.n_hidden;
+    int n_chain = 0;   // layers of the chain proper (every layer but the encoder-column transposes)
+    for (int bi = 0; bi < B.nl; ++bi) n_chain += P.layer[B.layer[bi].fwd].seg[B.layer[bi].seg].type == SEG_PE ? 0 : 1;
+    int j = 0;         // chain layers seen so far
     for (int bi = 0; bi < B.nl; ++bi) {
         const BwdLayer &Bl = B.layer[bi];
         LatLayer &o = T.l[bi];
         lat_layer_stream(o, Bl.first_slab, Bl.nkb, Bl.t_out);
         o.wave0 = 0;
-        o.b_base0 = bi == 0 ? Lo.act[1] : Lo.act[(bi + 1) & 1];   // (bi = 0: the d rgb operand phase 0 leaves in the second buffer)
         o.b_stride0 = LAT_ACT_BYTES;
         o.b_n0 = 1 << 20;
         o.b_base1 = o.b_stride1 = 0;
-        o.out_base = bi + 1 < B.nl ? Lo.act[bi & 1] : -1;
         o.pad_[0] = o.pad_[1] = 0;
+        if (P.layer[Bl.fwd].seg[Bl.seg].type == SEG_PE) {
+            // encoder-column transposes: they contract the d Y the chain layer before them left in LDS (the same operand the next chain
+            // layer reads), on waves 0 .. t_out / 2 - 1; no output buffer, no barrier
+            o.b_base0 = Lo.act[(j - 1) & 1];
+            o.out_base = -1;
+            o.store_row = -1;
+            o.mask_idx = -1;
+            o.op = Bl.fwd == nh + 3 ? LAT_PE_DIR : LAT_PE_POS;
+            continue;
+        }
+        o.b_base0 = j == 0 ? Lo.act[1] : Lo.act[(j + 1) & 1];   // (j = 0: the d rgb operand phase 0 leaves in the second buffer)
+        o.out_base = bi + 1 < B.nl ? Lo.act[j & 1] : -1;        // (somebody - chain layer or encoder columns - reads it)
         // forward layer whose d Y this layer produces (mlp_train.hip: mlp_bwd_kernel)
-        const int fl = bi == 0 ? nh + 4 : bi == 1 ? nh + 3 : bi == 2 ? nh + 1 : nh - (bi - 3);
+        const int fl = j == 0 ? nh + 4 : j == 1 ? nh + 3 : j == 2 ? nh + 1 : nh - (j - 3);
         o.store_row = L.dy[fl];
-        o.mask_idx = bi == 0 ? nh + 1 : bi >= 3 ? fl : -1;
-        o.op = LAT_BARRIER | (o.mask_idx >= 0 ? LAT_MASK_BITS : 0) | (bi == 2 ? LAT_SCALE_AUX : 0);
+        o.mask_idx = j == 0 ? nh + 1 : j >= 3 ? fl : -1;
+        o.op = LAT_BARRIER | (o.mask_idx >= 0 ? LAT_MASK_BITS : 0) | (j == 2 ? LAT_SCALE_AUX : 0);
+        ++j;
     }
+    (void)n_chain;
     lat_table_finish(T);
 }
 
@@ -510,15 +606,15 @@ int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t first
 template int launch_fwd_lat<false>(const Plan &, const FwdArgs &, hipStream_t, int64_t);
 template int launch_fwd_lat<true>(const Plan &, const FwdArgs &, hipStream_t, int64_t);
 
-template <int S>
+template <int S, bool IG>
 static int launch_bwd_lat_s(const Plan &P, const BwdPlan &B, const TrainLayout &L, const BwdArgs &A, const LatLaunch &Q, hipStream_t s) {
     const LatLds Lo = lat_lds(S, 0, 0, (P.n_hidden + 2) * 512);
     LatTable T;
     lat_table_bwd(P, B, L, Lo, T);
     static LdsRaised raised;
-    if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_lat_kernel<S>), Lo.total, raised, "mlp_bwd_lat")) return rc;
+    if (int rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_bwd_lat_kernel<S, IG>), Lo.total, raised, "mlp_bwd_lat")) return rc;
     const LatGeom G{Q.tile_off, Q.tile_end, Q.passes};
-    hipLaunchKernelGGL((mlp_bwd_lat_kernel<S>), dim3((unsigned)Q.grid), dim3(LAT_THREADS), Lo.total, s, T, A, G, Lo);
+    hipLaunchKernelGGL((mlp_bwd_lat_kernel<S, IG>), dim3((unsigned)Q.grid), dim3(LAT_THREADS), Lo.total, s, T, A, G, Lo);
     return check_launch("mlp_bwd_lat");
 }
 
@@ -527,26 +623,42 @@ static int lat_s_max_bwd(const Plan &P) {
     while (s_max > 1 && lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024) --s_max;
     return lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024 ? 0 : s_max;
 }
-LatChoice lat_choose_bwd(const Plan &P, int64_t n, bool input_grad) {
-    if (!lat_covers(P) || input_grad || !lat_dir_enabled(true)) return LatChoice{0, 0};
+// input gradients: the default-sized encoders (4 position / 2 direction k-blocks; the kernel's waves 0, 1 hold two tiles each), nets
+// that read directions, and d_x / d_dirs within the store range; SNERF_LAT_BWD_IG=0: the throughput kernel (A/B)
+static bool lat_ig_covers(const Plan &P, int64_t n) {
+    static const bool on = [] { const char *e = getenv("SNERF_LAT_BWD_IG"); return e ? atoi(e) != 0 : true; }();
+    const PeTiles pt = bwd_pe_tiles(P);
+    return on && pt.pos == 4 && pt.dir == 2 && P.add_dim == 0 && n * 12 < (int64_t)LAT_STORE_RANGE;
+}
+// With input gradients inside a step whose two backward chains run side by side (smpl_nerf, small chunks): the throughput kernels of
+// the two nets pack - 64 rays are 64 + 192 workgroups of 64 samples, one round of the chip for both, 190 us - while each latency
+// kernel takes every CU's LDS and the two run one after the other (74 + 166 us; whole step 0.98 -> 1.02 ms, r05).  There the latency
+// form is kept for nets that leave room for the other one (up to 3/4 tile per CU); alone on the chip (autograd path, no auxiliary
+// stream: 189 -> 74 us at 4096 samples, 189 -> 166 at 12 288) the rule of the plain dgrad holds.
+LatChoice lat_choose_bwd(const Plan &P, int64_t n, bool input_grad, bool beside_another_net) {
+    if (!lat_covers(P) || (input_grad && !lat_ig_covers(P, n)) || !lat_dir_enabled(true)) return LatChoice{0, 0};
     const int n_cu = device_cu_count("mlp_bwd_lat"), s_max = lat_s_max_bwd(P);
     if (n_cu < 1 || !s_max) return LatChoice{0, 0};
+    if (input_grad && beside_another_net && lat_max_tiles_override() < 0 && (n + 15) / 16 > (int64_t)n_cu * 3 / 4) return LatChoice{0, 0};
     BwdPlan B;
-    make_bwd_plan(P, B, false);
+    make_bwd_plan(P, B, input_grad);
     TrainLayout L;
     make_train_layout(P, L);
     if (B.nl > LAT_MAX_LAYERS || (int64_t)L.dy_rows * n * 64 >= (int64_t)LAT_STORE_RANGE) return LatChoice{0, 0};
     return lat_choose(LAT_DGRAD, n, n_cu, s_max);
 }
 
-// the dgrad of launch_bwd (mlp_train.hip) on samples [first_sample, A.n) with the latency kernel
+// the dgrad of launch_bwd (mlp_train.hip) on samples [first_sample, A.n) with the latency kernel (A.d_x != NULL: with input gradients,
+// A.packed_t is then the input_grad stream)
 int launch_bwd_lat(const Plan &P, const BwdArgs &A, hipStream_t s, int64_t first_sample) {
     const int n_cu = device_cu_count("mlp_bwd_lat");
     if (n_cu < 1) return n_cu;
     const int s_max = lat_s_max_bwd(P);
-    if (!lat_covers(P) || !s_max || first_sample % 16) return fail(SNERF_E_BADARG, "mlp_bwd_lat: not a call for the latency kernel");
+    const bool ig = A.d_x != nullptr;
+    if (!lat_covers(P) || !s_max || first_sample % 16 || (ig && !lat_ig_covers(P, A.n)))
+        return fail(SNERF_E_BADARG, "mlp_bwd_lat: not a call for the latency kernel");
     BwdPlan B;
-    make_bwd_plan(P, B, false);
+    make_bwd_plan(P, B, ig);
     TrainLayout L;
     make_train_layout(P, L);
     const int64_t t0 = first_sample / 16, n16 = (A.n + 15) / 16 - t0;
@@ -556,11 +668,20 @@ int launch_bwd_lat(const Plan &P, const BwdArgs &A, hipStream_t s, int64_t first
         Q[i].tile_off += t0;
         Q[i].tile_end += t0;
         int rc;
-        switch (Q[i].S) {
-            case 1: rc = launch_bwd_lat_s<1>(P, B, L, A, Q[i], s); break;
-            case 2: rc = launch_bwd_lat_s<2>(P, B, L, A, Q[i], s); break;
-            case 3: rc = launch_bwd_lat_s<3>(P, B, L, A, Q[i], s); break;
-            default: rc = launch_bwd_lat_s<4>(P, B, L, A, Q[i], s); break;
+        if (ig) {
+            switch (Q[i].S) {
+                case 1: rc = launch_bwd_lat_s<1, true>(P, B, L, A, Q[i], s); break;
+                case 2: rc = launch_bwd_lat_s<2, true>(P, B, L, A, Q[i], s); break;
+                case 3: rc = launch_bwd_lat_s<3, true>(P, B, L, A, Q[i], s); break;
+                default: rc = launch_bwd_lat_s<4, true>(P, B, L, A, Q[i], s); break;
+            }
+        } else {
+            switch (Q[i].S) {
+                case 1: rc = launch_bwd_lat_s<1, false>(P, B, L, A, Q[i], s); break;
+                case 2: rc = launch_bwd_lat_s<2, false>(P, B, L, A, Q[i], s); break;
+                case 3: rc = launch_bwd_lat_s<3, false>(P, B, L, A, Q[i], s); break;
+                default: rc = launch_bwd_lat_s<4, false>(P, B, L, A, Q[i], s); break;
+            }
         }
         if (rc) return rc;
     }

@@ -43,6 +43,9 @@ enum LatOp : int {
     LAT_SCALE_AUX = 16,   // dgrad: the aux block is the sigma head's weight row, scaled by d sigma of the sample
     LAT_BARRIER = 32,     // a workgroup barrier follows the layer
     LAT_HALF_WORD = 64,   // forward: a 128-wide layer fills half of the mask word; the other half is zeroed
+    LAT_PE_POS = 128,     // dgrad with input gradients: transposed position-encoding columns of layer 0 / a skip layer - the result is
+                          // added to the wave's running d (position encoding) tiles, nothing is stored
+    LAT_PE_DIR = 256,     // ... the direction-encoding columns of directional_input: encoder + normalisation backward -> d_dirs
 };
 
 // one layer of a packed stream as the kernels walk it (32-bit fields: scalar loads from the kernarg segment)
@@ -166,6 +169,9 @@ constexpr unsigned LAT_STORE_RANGE = 0x80000000u, LAT_OOB = 0xfffffff0u;
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lat_store_f4(__amdgpu_buffer_rsrc_t rs, unsigned off, f4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, (int)off, 0, 0);
+}
+__device__ __forceinline__ void lat_store_b32(__amdgpu_buffer_rsrc_t rs, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)off, 0, 0);
 }
 __device__ __forceinline__ void lat_store_b8(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned v) {
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, rs, (int)off, 0, 0);

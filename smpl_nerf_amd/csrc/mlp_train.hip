@@ -920,7 +920,7 @@ namespace snerf {
 // accumulate: flat_grad += instead of = (one ray chunk of a larger batch, train_step.hip)
 int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n,
                float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample,
-               int spr, float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate) {
+               int spr, float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate, bool beside_another_net) {
     Plan P;
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "mlp_bwd: desc is null");
@@ -978,7 +978,7 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     const bool wide_pe = input_grad && bwd_pe_tiles(P).pos == 8;
     // calls of a few 16-sample tiles per CU: the latency-class dgrad (mlp_lat.hip; bit-identical d Y); a call of a few rounds and a
     // fraction: whole rounds here, the fraction there
-    const LatChoice lc = lat_choose_bwd(P, n, input_grad);
+    const LatChoice lc = lat_choose_bwd(P, n, input_grad, beside_another_net);
     if (lc.mode == 1) {
         if (int lrc = launch_bwd_lat(P, A, s, 0)) return lrc;
         return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);

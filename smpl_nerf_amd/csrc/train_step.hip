@@ -813,7 +813,7 @@ static int smpl_nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const v
                           bool accumulate, snerf_stream_t st) {
         if (precision == 0)
             return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw_, n, dy_, gpart_, grad, x, sd, 1, spr, d_x_, d_dirs_,
-                              st, accumulate);
+                              st, accumulate, concurrent);
         return launch_bwd_bf16(d, packed_t, precision, act, d_raw_, n, dy_, gpart_, grad, x, sd, 1, spr, d_x_, d_dirs_, st, accumulate);
     };
     auto sum3 = [&](const float *a, const float *b, const float *c, int64_t n, float *out, snerf_stream_t st) {

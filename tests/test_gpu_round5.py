@@ -455,3 +455,53 @@ def test_randomised_sweeps_agree_for_widths_above_256(dev, tool, count, seed):
                        timeout=900, cwd=root, env=dict(os.environ, FUZZ_WIDE="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip().splitlines()[-1] == f"{count} of {count} cases agree", r.stdout[-3000:]
+
+
+_IG_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+from test_gpu_round5 import _rnet
+dev = torch.device("cuda:0")
+out = {{}}
+for ci, shape in enumerate({shapes!r}):
+    net, pe, de = _rnet(dev, **shape)
+    rng = np.random.default_rng(5)
+    for rays in {rays!r}:
+        Ns = 8
+        pts = torch.from_numpy(rng.uniform(-2, 2, (rays * Ns, 3)).astype(np.float32)).to(dev).requires_grad_(True)
+        per_sample = rays % 2 == 1                 # per-sample view directions (smpl_nerf: x' - o) or per-ray ones
+        dirs = torch.from_numpy(rng.normal(size=(rays * Ns if per_sample else rays, 3)).astype(np.float32)).to(dev).requires_grad_(True)
+        gout = torch.from_numpy(rng.normal(size=(rays * Ns, 4)).astype(np.float32)).to(dev)
+        net.zero_grad(set_to_none=True)
+        raw = net.forward_fused(pts, dirs, Ns, pe, de).reshape(-1, 4)
+        (raw * gout).sum().backward()
+        out[f"dx_{{ci}}_{{rays}}"] = pts.grad.cpu().numpy()
+        out[f"dd_{{ci}}_{{rays}}"] = dirs.grad.cpu().numpy()
+        out[f"grad_{{ci}}_{{rays}}"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+np.savez({path!r}, **out)
+"""
+
+
+def test_latency_dgrad_with_input_gradients_is_bit_identical(dev, tmp_path):
+    """The latency-class dgrad with input gradients (csrc/mlp_lat.hip: mlp_bwd_lat_kernel<S, true>; the nets of SmplNerfPipeline
+    back-propagate into the warped samples and their per-sample view directions, models/smpl_nerf_pipeline.py:49-56): d loss / d
+    positions, d loss / d directions and the weight gradient of a process with SNERF_LAT_BWD_IG=0 (throughput kernel) equal those of
+    one with the latency kernel bit for bit - ragged sample counts, one to four sample tiles per pass, per-ray and per-sample
+    directions, other depths / skip masks (skip layers carry encoder columns of their own)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    shapes = [dict(), dict(n_layers=3, skips=(1,)), dict(n_layers=9, skips=(0, 2, 6)), dict(n_layers=2, skips=())]
+    rays = [1, 37, 512, 1025, 1537, 2048]
+    res = {}
+    for ig in ("0", "1"):
+        path = str(tmp_path / f"ig{ig}.npz")
+        env = dict(os.environ, SNERF_LAT_BWD_IG=ig)
+        subprocess.run([sys.executable, "-c", _IG_SCRIPT.format(root=ROOT, shapes=shapes, rays=rays, path=path)], check=True, env=env)
+        res[ig] = dict(np.load(path))
+    assert set(res["0"]) == set(res["1"]) and len(res["0"]) == 3 * len(shapes) * len(rays)
+    for k in res["0"]:
+        assert np.isfinite(res["0"][k]).all()
+        np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
+    assert any(np.abs(v).max() > 0 for k, v in res["1"].items() if k.startswith("dd_"))
