@@ -90,6 +90,7 @@ const Tuning &tuning() {
         k.wgrad_f16_split_per_wave = flag("SNERF_WGRAD_F16_SPLIT_PER_WAVE", false);
         const char *fo = getenv("SNERF_WGRAD_FOLD");
         k.wgrad_fold = fo ? (atoi(fo) != 0 ? 1 : 0) : 1;
+        k.wgrad_small_chunks = flag("SNERF_WGRAD_SMALL_CHUNKS", true);
         return k;
     }();
     return t;

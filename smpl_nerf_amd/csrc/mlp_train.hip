@@ -846,6 +846,9 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
         if (const int jobs_d = WGD_WHOLE_ROUNDS ? wgrad_direct_jobs(P, fold) : 0) {
             const int slots = 3 * n_cu;
             if ((int64_t)jobs_d * G_narrow > slots) G_narrow = min(G_narrow, max(1, (int)((int64_t)jobs_d * G_narrow / slots) * slots / jobs_d));
+            // small calls (the README's 64-ray batches): 1024-sample chunks would fill a fifth of the slots, each wave walking 256
+            // samples at the latency of its 4 k-steps in flight - shorter chunks (>= 64 samples), one round of the slots
+            else if (tuning().wgrad_small_chunks) G_narrow = max(G_narrow, min(min(wgrad_chunks(n), (int)((n + 63) / 64)), max(1, slots / jobs_d)));
         }
         const int jobs = wgrad_jobs(P);
         if (jobs > 0 && (int64_t)jobs * G > n_cu) {

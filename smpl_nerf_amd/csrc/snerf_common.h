@@ -55,6 +55,7 @@ struct Tuning {
     bool wgrad_narrow_f16;          // SNERF_WGRAD_NARROW_F16          (1)
     bool wgrad_f16_split_per_wave;  // SNERF_WGRAD_F16_SPLIT_PER_WAVE  (0)
     int wgrad_fold;                 // SNERF_WGRAD_FOLD                (1)
+    bool wgrad_small_chunks;        // SNERF_WGRAD_SMALL_CHUNKS=0      narrow wgrad jobs of small calls: 1024-sample chunks as for large ones
 };
 const Tuning &tuning();
 
