@@ -48,6 +48,14 @@
  *       SNERF_WGRAD_F16_SPLIT_PER_WAVE=1  f16x3 wide weight-gradient GEMMs: every wave converts its own operands
  *       SNERF_WGRAD_FOLD=0                fp32 steps: every narrow weight-gradient pair as its own job (default: the sigma head
  *                                         and the direction-encoding columns ride with directional_input's wide job)
+ *       SNERF_WGRAD_SMALL_CHUNKS=0        narrow weight-gradient jobs of small calls: 1024-sample chunks as for large calls (default:
+ *                                         chunks of >= 64 samples filling one round of the workgroup slots; changes the summation
+ *                                         order of those gradients like a different batch size does)
+ *       SNERF_LAT=0                       small calls: the throughput kernels everywhere (default: the latency-class kernels of
+ *                                         csrc/mlp_lat.hip where their cost model wins; bit-identical results).  SNERF_LAT_FWD=0 /
+ *                                         SNERF_LAT_BWD=0 / SNERF_LAT_BWD_IG=0: the same for the forwards / the dgrads / the dgrads
+ *                                         with input gradients only; SNERF_LAT_MAX_TILES_PER_CU=k: the latency kernels for every
+ *                                         call of up to k 16-sample tiles per CU, whatever the model says
  *       SNERF_DEBUG_POISON_LDS=1          debugging aid, not a tuning knob: every checked launch is followed by a kernel on the
  *                                         NULL stream that fills the LDS of every CU with NaNs (a kernel that reads LDS it has not
  *                                         written then computes with NaNs instead of its predecessor's leftovers); slow
