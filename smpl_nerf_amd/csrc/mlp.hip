@@ -70,7 +70,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     // so only the first tile of a workgroup pays the pipeline fill and no CU idles between two workgroups.
     // (SNERF_TRAIN_PERSIST: the training forward of the 256 kernel as persistent workgroups on the DMA pipe - its staging registers are
     // what the persistent loop did not fit beside; A/B knob, mlp_device.h)
-    using Pipe = std::conditional_t<(TRAIN && SNERF_TRAIN_PERSIST && WIDTH == 256 && NWAVES == 8), SlabPipeDma<NT>, PipeFor<WIDTH, NT>>;
+    using Pipe = std::conditional_t<((TRAIN ? SNERF_TRAIN_PERSIST : SNERF_INFER_DMA) && WIDTH == 256 && NWAVES == 8), SlabPipeDma<NT>, PipeFor<WIDTH, NT>>;
     Pipe pipe;
     // raw inputs of a tile (positions, direction), fetched while the previous tile's last layers run so that a tile
     // never starts by waiting on HBM (inference variant; the training variant sits at the register limit)
@@ -346,7 +346,10 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
     constexpr bool TRAIN_PERSIST = TRAIN && SNERF_TRAIN_PERSIST && NW == 8;   // (width 256 only: the others ignore total_slabs)
     const int64_t grid = ((!TRAIN || (TRAIN_PERSIST && P.width == 256)) && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
     if constexpr (FOLD) {
-        if (P.width == 256) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        if (P.width == 256) {
+            if constexpr (SNERF_INFER_DMA && NW == 8) SNERF_LAUNCH_RING4((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+            else SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+        }
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         else SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<64, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
     } else {
@@ -360,7 +363,7 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
                 return fail(SNERF_E_BADARG, "mlp_fwd: widths above 256 run 4-wave workgroups");
             }
         } else if (P.width == 256) {
-            if constexpr (TRAIN_PERSIST) SNERF_LAUNCH_RING4((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+            if constexpr (TRAIN_PERSIST || (!TRAIN && SNERF_INFER_DMA && NW == 8)) SNERF_LAUNCH_RING4((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
             else SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         }
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);

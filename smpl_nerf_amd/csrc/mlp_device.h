@@ -171,6 +171,11 @@ constexpr int RING4_BYTES = 4 * SLAB_FLOATS * 4;
 #ifndef SNERF_WIDE_DMA
 #define SNERF_WIDE_DMA 1   // widths above 256: slabs global -> LDS by DMA into a 4-slot ring (0: the register-staged 3-slot ring)
 #endif
+#ifndef SNERF_INFER_DMA
+#define SNERF_INFER_DMA 1   // the 8-wave inference kernel of width 256 on the DMA pipe (r05: 38.07 -> 37.70 ms per frame, three interleaved
+                          // pairs on one box; 0 = the register-staged 3-slot ring of rounds 1-4.  The training forward and the dgrad
+                          // measured no gain from it and keep the register-staged ring)
+#endif
 #ifndef SNERF_TRAIN_PERSIST
 #define SNERF_TRAIN_PERSIST 0   // (A/B knob, mlp.hip: persistent training forward of the 256 kernel on the DMA pipe)
 #endif

@@ -11,17 +11,17 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
 # (a) render only: every dispatch of a render kernel is one of the bench's frame launches (12 steps x {coarse, fine})
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-pmc --train-rays 0 --points= > $OUT/bench_under_rocprof.json.log 2> $OUT/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-pmc --train-rays 0 --points= --netwidth-points= > $OUT/bench_under_rocprof.json.log 2> $OUT/trace.err
 # (b) the training section (all precisions) behind a one-step render
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --cpu-rays 0 --points= > $OUT/train_under_rocprof.json.log 2> $OUT/trace_train.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --cpu-rays 0 --points= --netwidth-points= > $OUT/train_under_rocprof.json.log 2> $OUT/trace_train.err
 # (c) smpl_nerf: render + training rows of the warp kernels (warp_fwd_resident_kernel, warp_bwd_light_kernel) and the
 #     INPUT_GRAD dgrad variants; fp32 only, no CPU leg
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_smpl -- python $ROOT/bench.py --workload smpl_nerf --steps 10 --warmup 2 --no-pmc --no-alt --cpu-rays 0 --train-steps 10 --points= > $OUT/smpl_nerf_under_rocprof.json.log 2> $OUT/trace_smpl.err
 timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmcs_sq -- python $ROOT/bench.py --workload smpl_nerf --steps 3 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --no-alt --points= > $OUT/pmcs_sq.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcs_fetch -- python $ROOT/bench.py --workload smpl_nerf --steps 3 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --no-alt --points= > $OUT/pmcs_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcs_write -- python $ROOT/bench.py --workload smpl_nerf --steps 3 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --no-alt --points= > $OUT/pmcs_write.log 2>&1
-RENDER="--steps 3 --warmup 1 --cpu-rays 0 --train-rays 0 --no-pmc --points="
-TRAIN="--steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --points="
+RENDER="--steps 3 --warmup 1 --cpu-rays 0 --train-rays 0 --no-pmc --points= --netwidth-points="
+TRAIN="--steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --no-pmc --points= --netwidth-points="
 timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py $RENDER > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py $RENDER > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py $RENDER > $OUT/pmc_write.log 2>&1
@@ -40,7 +40,7 @@ timeout 600 python $ROOT/bench.py --workload append_smpl_params --no-pmc --no-al
 timeout 600 python $ROOT/bench.py > $OUT/bench_default.json.log 2>/dev/null
 # (f) round 4: the one-call training step at the README's 64-ray batch (kernel trace), the operating-point table with the ray-chunk
 #     sizes and the autograd form beside it, the input-gradient contraction against the r03 form
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train64 -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --no-alt --cpu-rays 0 --points= --train-rays 64 --train-steps 50 > $OUT/train64_under_rocprof.json.log 2> $OUT/trace_train64.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train64 -- python $ROOT/bench.py --steps 1 --warmup 1 --no-pmc --no-alt --cpu-rays 0 --points= --netwidth-points= --train-rays 64 --train-steps 50 > $OUT/train64_under_rocprof.json.log 2> $OUT/trace_train64.err
 find $OUT/trace_train64 -name "*kernel_stats.csv" -exec cp {} $OUT/train64_kernel_stats.csv \;
 rm -rf $OUT/trace_train64
 timeout 600 python $ROOT/tools/ab/train_points.py --autograd --chunks 0,1024,2048 --steps 20 2>/dev/null | grep rays > $OUT/train_points.txt
