@@ -176,6 +176,10 @@ constexpr int RING4_BYTES = 4 * SLAB_FLOATS * 4;
                           // pairs on one box; 0 = the register-staged 3-slot ring of rounds 1-4.  The training forward and the dgrad
                           // measured no gain from it and keep the register-staged ring)
 #endif
+#ifndef SNERF_DGRAD_DMA
+#define SNERF_DGRAD_DMA 0    // (A/B knob, mlp_train.hip: the 8-wave dgrad of width 256 on the DMA pipe - 4096-ray step 31.04 / 31.11 ms
+                            // without / with, three interleaved pairs: kept off)
+#endif
 #ifndef SNERF_TRAIN_PERSIST
 #define SNERF_TRAIN_PERSIST 0   // (A/B knob, mlp.hip: persistent training forward of the 256 kernel on the DMA pipe)
 #endif

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         store_tile(A.dy, A.dy_sig, A.n, sample, g, g == 0 ? f4{dr[3], 0.f, 0.f, 0.f} : zero);
     }
 
-    using Pipe = PipeFor<WIDTH, NT>;
+    using Pipe = std::conditional_t<(SNERF_DGRAD_DMA && WIDTH == 256 && NWAVES == 8), SlabPipeDma<NT>, PipeFor<WIDTH, NT>>;
     Pipe pipe;
     pipe.prologue(A.packed_t, ring, tid);
 
@@ -1013,9 +1013,15 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
                 return fail(SNERF_E_BADARG, "mlp_bwd: widths above 256 run 4-wave workgroups");
             }
         } else if (P.width == 256) {
-            if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-            else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-            else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            if constexpr (SNERF_DGRAD_DMA && BW == 8) {
+                if (wide_pe) SNERF_LAUNCH_RING4((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+                else if (input_grad) SNERF_LAUNCH_RING4((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+                else SNERF_LAUNCH_RING4((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            } else {
+                if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+                else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+                else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            }
         } else if (P.width == 128) {
             if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
             else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
