@@ -218,3 +218,35 @@ def test_pipeline_set_precision_reaches_every_net():
     assert {pipe.model_coarse.precision, pipe.model_fine.precision, pipe.model_warp_field.precision} == {"bf16x6"}
     with pytest.raises(ValueError):
         pipe.set_precision("fp16")
+
+
+def test_training_buffer_sizes_of_widths_above_256(lib):
+    """Host-side layout of the 320 .. 512 kernels (csrc/mlp_plan.h: make_train_layout): tile-rows of 16 features per layer input,
+    one tile-row per ReLU sign mask (four words per lane) instead of half a row, d Y rows per layer output; the transposed stream
+    of the dgrad; a width is laid out as the next kernel width above it (config_parser.py:20 --netwidth)."""
+    import ctypes
+
+    def sizes(width, n, depth=8, skip_mask=1 << 4):
+        d = _lib.MlpDesc(depth, width, 10, 0, 4, 0, 0, skip_mask, 1)
+        v = [ctypes.c_int64() for _ in range(4)]
+        cnt = ctypes.c_int32()
+        assert lib.snerf_mlp_train_sizes(d, n, *[ctypes.byref(x) for x in v], ctypes.byref(cnt)) == 0
+        return [x.value for x in v] + [cnt.value]
+
+    n = 1000
+    for width, T in ((512, 32), (500, 32), (448, 28), (384, 24), (330, 24), (320, 20), (257, 20)):
+        act, dy, pt, gp, cnt = sizes(width, n)
+        nh = 7
+        rows = 4 + 2 + (nh + 1) * T + T + T // 2 + T // 2 + (nh + 2)      # encoders, x[1..nh+1], o, h1, h2, one row per mask
+        assert act >= rows * n * 16 and act - rows * n * 16 <= 64, (width, act, rows)
+        dy_rows = (nh + 2) * T + 1 + T // 2 + T // 2 + 1                  # trunk layers + additional, sigma, directional x 2, rgb
+        assert dy >= dy_rows * n * 16 and dy - dy_rows * n * 16 <= 64, (width, dy, dy_rows)
+        assert cnt == 8 and gp % cnt == 0                                  # wgrad_chunks(1000) partials of one slot-ordered gradient
+        assert pt % 8448 == 0                                              # whole slabs
+    # the same description below 256 keeps two masks per tile-row
+    act256 = sizes(256, n)[0]
+    assert act256 >= (4 + 2 + 8 * 16 + 16 + 8 + 8 + 5) * n * 16 and act256 - (4 + 2 + 8 * 16 + 16 + 8 + 8 + 5) * n * 16 <= 64
+    # a 512-wide first layer needs two k-blocks of input: 3 identity columns alone are refused by name
+    tiny = _lib.MlpDesc(2, 512, 0, 1, 0, 1, 0, 0, 1)
+    assert lib.snerf_mlp_param_floats(tiny) < 0
+    assert lib.snerf_mlp_pack_f32(tiny, None, None, None) == -1 and b"two k-blocks" in lib.snerf_last_error_string()
