@@ -227,6 +227,17 @@ def _dp_worker(port, q):
             want = single.step(batch)
         out["graph"] = (float(loss) == float(want), all(bool(torch.equal(a, b)) for a, b in zip(single.params, dp.params)))
         dp._comm.close()
+        # the smpl_nerf step with the communicator (snerf_smpl_nerf_train_step_aux_f32: comm + auxiliary stream)
+        from test_gpu_round4 import _smpl_trainer, _smpl_batch
+        sb = _smpl_batch(dv, 64)
+        s1, _ = _smpl_trainer(dv)
+        s2, _ = _smpl_trainer(dv)
+        s2._sync = True
+        ls = [float(s1.step(sb)) for _ in range(3)]
+        ld = [float(s2.step(sb)) for _ in range(3)]
+        out["smpl"] = (ls == ld, all(bool(torch.equal(a, b)) for a, b in zip(s1.params, s2.params)),
+                       s2._comm not in (None, False) and getattr(s2, "collective_calls", 0) == 3)
+        s2._comm.close()
     except Exception as e:      # noqa: BLE001 - the parent asserts on the report
         import traceback
         out["error"] = traceback.format_exc()
@@ -262,6 +273,7 @@ def test_data_parallel_step_is_one_call_with_rccl_inside():
     assert out["used_rccl"]
     assert out["losses"][0] == out["losses"][1] and out["params_equal"]
     assert out["graph"] == (True, True)
+    assert out["smpl"] == (True, True, True)      # SmplNerfSolver's step with the communicator: same trajectory, RCCL inside the call
     assert p.exitcode == 0
 
 
