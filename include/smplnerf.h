@@ -73,7 +73,7 @@
 extern "C" {
 #endif
 
-#define SNERF_VERSION 108 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
+#define SNERF_VERSION 109 /* 0.1.2: + snerf_searchsorted (all scalar types), snerf_posenc_bwd_f32,
                              snerf_composite_bwd_all_f32; composite forward accepts any N
                              0.1.3: same entry points; descriptors accept any width <= 256 and n_layers >= 1; fp32 inference
                              folds per-ray inputs (dirs_per_sample bit 1 = SNERF_FWD_NO_RAY_FOLD keeps the per-sample form)
@@ -86,7 +86,9 @@ extern "C" {
                              boundary); latency-class kernels behind the same entry points for small calls
                              0.1.8: + snerf_smpl_nerf_train_grads_aux_f32, snerf_smpl_nerf_train_step_aux_f32 (the smpl_nerf step with an
                              auxiliary stream: small chunks run the coarse chain beside the fine chain); snerf_mlp_desc.width
-                             up to 512 */
+                             up to 512
+                             0.1.9: + snerf_nerf_train_step_dp_ig_f32; the data-parallel steps issue the same collectives on every
+                             rank whatever its batch size (B == 0 included); SNERF_RCCL_LIB */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -659,16 +661,32 @@ SNERF_API int snerf_comm_info(snerf_comm_t comm, int32_t *world_size, int32_t *r
 SNERF_API int snerf_comm_allreduce_avg_f32(snerf_comm_t comm, float *buf, int64_t n, snerf_stream_t stream);
 /* snerf_nerf_train_step_f32 / snerf_smpl_nerf_train_step_f32 with the gradient average between the backward and the optimiser:
  * ... -> backward -> ncclAllReduce(ncclAvg) of adam->grads[0 .. adam->n_params) - the trainer's flat gradient buffer, which holds
- * grad_coarse / grad_fine (/ grad_warp) as segments and is the same size on every rank - on `stream` -> Adam.  With an auxiliary
- * stream and a chunk small enough for the concurrent backward (snerf_nerf_train_grads_f32), the coarse net's segment is averaged
- * on aux_stream as soon as its backward is done, beside the fine net's backward, and the rest of the buffer behind the join.
- * Nothing is synchronised; every rank must make the same calls in the same order (RCCL's rule).  Graph-capturable. */
+ * grad_coarse / grad_fine (/ grad_warp) as segments and is the same size on every rank -> Adam.  The collectives of a nerf step
+ * are the same two on every rank whatever its batch size, chunking and streams (0.1.9): the coarse net's segment first - on
+ * aux_stream beside the fine net's backward when the chunk is small enough for the concurrent backward
+ * (snerf_nerf_train_grads_f32), on `stream` otherwise - then the rest of the buffer (one grouped launch) on `stream` behind the
+ * join; the smpl_nerf steps issue one all-reduce of the whole buffer on `stream`.  batch->B == 0 is valid here (a rank whose
+ * shard ran out): zero gradient, zero loss, the same collectives, the optimiser step.  Nothing is synchronised; every rank must
+ * make the same calls in the same order (RCCL's rule).  Graph-capturable.  SNERF_RCCL_LIB=<path> (read at the first call)
+ * names the library to bind instead of librccl.so.1. */
 SNERF_API int snerf_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                                  const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
                                  const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
                                  float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
                                  const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
                                  snerf_comm_t comm, snerf_stream_t stream, snerf_stream_t aux_stream);
+/* snerf_nerf_train_step_ig_f32 with the gradient average: the data-parallel step of the pose-conditioned pipelines whose
+ * estimator / goal_pose is trained too (BASELINE configs[4]; solver/append_vertices_solver.py:26-31, 77-82: the lrate_pose group).
+ * input_grads->d_additional [B, add_dim] holds THIS rank's rows (per-ray data: nothing to average); the caller continues its
+ * autograd from them into the estimator and averages that module's gradient segment with snerf_comm_allreduce_avg_f32 before
+ * its optimiser step.  Same collectives, in the same order, as snerf_nerf_train_step_dp_f32. */
+SNERF_API int snerf_nerf_train_step_dp_ig_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                    const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine, int precision,
+                                    const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace, float *grad_coarse,
+                                    float *grad_fine, float *loss, float *rgb, float *rgb_fine, const snerf_adam_state *adam,
+                                    const snerf_adam_range *ranges_host, int n_ranges, const snerf_adam_net *nets_host, int n_nets,
+                                    const snerf_input_grads *input_grads, snerf_comm_t comm, snerf_stream_t stream,
+                                    snerf_stream_t aux_stream);
 SNERF_API int snerf_smpl_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                                       const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
                                       const snerf_warp_desc *desc_warp, float *packed_warp, float *packed_t_warp, int precision,

@@ -158,6 +158,9 @@ SIGNATURES = {
     "snerf_nerf_train_step_dp_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
                                              _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int,
                                              _P, _P, _P]),
+    "snerf_nerf_train_step_dp_ig_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
+                                                _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int,
+                                                POINTER(InputGrads), _P, _P, _P]),
     "snerf_smpl_nerf_train_step_dp_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, POINTER(WarpDesc), _P, _P, c_int,
                                                   POINTER(NerfBatch), _P, c_int64, _P, _P, _P, _P, _P, _P, _P, POINTER(AdamState),
                                                   POINTER(AdamRange), c_int, POINTER(AdamNet), c_int, c_int64, _P, _P]),

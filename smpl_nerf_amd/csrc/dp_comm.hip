@@ -7,6 +7,7 @@
 // RCCL is bound at run time (dlopen / dlsym of librccl.so.1 - the copy the process already holds, e.g. PyTorch's, else the
 // system's): a host that never trains data-parallel never loads it, and the C hosts of the single-GPU entry points link as before.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -41,6 +42,15 @@ static const Rccl *rccl(const char *what) {
     static std::once_flag once;
     static char err[256] = "";
     std::call_once(once, [] {
+        // SNERF_RCCL_LIB=<path>: this library and no other (a site build of RCCL, or the recording communicator of
+        // tests/native/fake_rccl.cpp through which the GPU suite checks what the data-parallel steps reduce, and on which stream)
+        if (const char *path = getenv("SNERF_RCCL_LIB"); path && path[0]) {
+            r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) {
+                snprintf(err, sizeof err, "cannot load SNERF_RCCL_LIB=%s (%s)", path, dlerror());
+                return;
+            }
+        }
         const char *names[] = {"librccl.so.1", "librccl.so"};
         for (const char *n : names)   // the copy this process already holds (PyTorch ships one), if any
             if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);

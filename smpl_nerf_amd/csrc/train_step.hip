@@ -480,7 +480,21 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
     if (!batch) return fail(SNERF_E_BADARG, "nerf_train_grads: batch is null");
     const int64_t B = batch->B;
     const int Nc = batch->Nc, Nf = batch->Nf, N = Nc + Nf;
-    if (B < 1 || Nc < 1 || Nf < 0) return fail(SNERF_E_BADARG, "nerf_train_grads: need B >= 1, Nc >= 1, Nf >= 0");
+    if (B < (comm ? 0 : 1) || Nc < 1 || Nf < 0) return fail(SNERF_E_BADARG, "nerf_train_grads: need B >= 1, Nc >= 1, Nf >= 0");
+    if (comm && B == 0) {
+        // a rank whose shard ran out (RayBatchLoader allows unequal shards) still takes part in the step's collectives, in the
+        // order every other rank issues them, with a zero gradient
+        if (!flat_g || flat_n < 1 || !desc_coarse || !grad_coarse || !loss) return fail(SNERF_E_BADARG, "nerf_train_step_dp: null pointer");
+        const int64_t pc = snerf_mlp_param_floats(desc_coarse);
+        const int64_t c0 = grad_coarse - flat_g;
+        if (pc < 1 || c0 < 0 || c0 + pc > flat_n) return fail(SNERF_E_BADARG, "nerf_train_step_dp: grad_coarse must lie inside adam->grads[0 .. n_params)");
+        hipStream_t s0 = (hipStream_t)stream;
+        if (hipMemsetAsync(flat_g, 0, (size_t)flat_n * sizeof(float), s0) != hipSuccess ||
+            hipMemsetAsync(loss, 0, 3 * sizeof(float), s0) != hipSuccess)
+            return fail(SNERF_E_LAUNCH, "nerf_train_step_dp: memset failed");
+        if (int rc0 = dp_allreduce_avg(comm, flat_g, c0, c0 + pc, 0, 0, s0, "nerf_train_step_dp")) return rc0;
+        return dp_allreduce_avg(comm, flat_g, 0, flat_n, c0, c0 + pc, s0, "nerf_train_step_dp");
+    }
     if (!desc_coarse || !packed_coarse || !packed_t_coarse || !batch->ray_samples || !batch->rays_d || !batch->z_vals ||
         !batch->rgb_truth || !workspace || !grad_coarse || !loss || !rgb || !rgb_fine)
         return fail(SNERF_E_BADARG, "nerf_train_grads: null pointer");
@@ -577,16 +591,17 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
         }
         if ((rc = snerf_composite_bwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, d_rgb_c, d_raw_c, nullptr, stream_c))) return rc;
         if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, d_raw_c, b * Nc, dy_c, gpart_c, grad_coarse, r0 > 0, stream_c))) return rc;
+        // The collectives of the step are the same two on every rank, whatever its batch size, chunking and streams (RCCL matches
+        // collectives by issue order and size; ADVICE r05: the concurrent form depends on the rank's own B): first the coarse net's
+        // segment [cb0, cb1) - on the auxiliary stream while the fine net's backward still runs when the two run side by side, on
+        // `stream` otherwise - then the rest of the flat buffer behind the join.
         const bool last = r0 + b >= B;
-        if (comm && last && concurrent && coarse_bucket &&   // the coarse net's bucket, while the fine net's backward still runs
-            (rc = dp_allreduce_avg(comm, flat_g, cb0, cb1, 0, 0, (hipStream_t)aux_stream, "nerf_train_step_dp")))
+        if (comm && last &&
+            (rc = dp_allreduce_avg(comm, flat_g, cb0, cb1, 0, 0, concurrent ? (hipStream_t)aux_stream : s, "nerf_train_step_dp")))
             return rc;
         if (concurrent && (hipEventRecord(ev_join, (hipStream_t)aux_stream) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess))
             return fail(SNERF_E_LAUNCH, "nerf_train_grads: cannot join the auxiliary stream");
-        if (comm && last &&
-            (rc = dp_allreduce_avg(comm, flat_g, 0, flat_n, concurrent && coarse_bucket ? cb0 : 0, concurrent && coarse_bucket ? cb1 : 0, s,
-                                   "nerf_train_step_dp")))
-            return rc;
+        if (comm && last && (rc = dp_allreduce_avg(comm, flat_g, 0, flat_n, cb0, cb1, s, "nerf_train_step_dp"))) return rc;
         // the coarse net's share of d loss / d additional inputs: behind the join (the two backwards may have run side by side; the
         // coarse net's d Y buffer is its own then), added to the fine net's
         if (d_add && (rc = contract_additional(desc_coarse, ig->params_coarse, dy_c, b * Nc, Nc, d_add + r0 * add_dim, Nf == 0, cscratch, stream)))
@@ -645,6 +660,24 @@ extern "C" int snerf_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coarse, c
     int rc = nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision, batch,
                                    rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream, comm,
                                    const_cast<float *>(adam->grads), adam->n_params);
+    if (rc) return rc;
+    return snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream);
+}
+
+extern "C" int snerf_nerf_train_step_dp_ig_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
+                                               const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
+                                               int precision, const snerf_nerf_batch *batch, int64_t rays_per_chunk, void *workspace,
+                                               float *grad_coarse, float *grad_fine, float *loss, float *rgb, float *rgb_fine,
+                                               const snerf_adam_state *adam, const snerf_adam_range *ranges_host, int n_ranges,
+                                               const snerf_adam_net *nets_host, int n_nets, const snerf_input_grads *input_grads,
+                                               snerf_comm_t comm, snerf_stream_t stream, snerf_stream_t aux_stream) {
+    using namespace snerf;
+    if (!comm) return fail(SNERF_E_BADARG, "nerf_train_step_dp_ig: comm is null (the single-GPU step is snerf_nerf_train_step_ig_f32)");
+    if (!adam || !adam->grads || adam->n_params < 1) return fail(SNERF_E_BADARG, "nerf_train_step_dp_ig: adam / adam->grads is null");
+    // (the contraction reads the parameters and the stored d Y: inside the gradient half, before the average and before Adam)
+    int rc = nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, precision, batch,
+                                   rays_per_chunk, workspace, grad_coarse, grad_fine, loss, rgb, rgb_fine, stream, aux_stream, comm,
+                                   const_cast<float *>(adam->grads), adam->n_params, input_grads);
     if (rc) return rc;
     return snerf_adam_step_f32(adam, ranges_host, n_ranges, nets_host, n_nets, stream);
 }
@@ -898,6 +931,17 @@ extern "C" int snerf_smpl_nerf_train_grads_aux_f32(const snerf_mlp_desc *desc_co
                                       grad_fine, grad_warp, loss, rgb, rgb_fine, stream, aux_stream);
 }
 
+namespace snerf {
+// a rank of a data-parallel step whose shard ran out (B == 0): zero gradient, zero loss; the caller goes on to the collective
+static int dp_empty_batch(const snerf_adam_state *adam, float *loss, snerf_stream_t stream) {
+    if (!loss) return fail(SNERF_E_BADARG, "smpl_nerf_train_step_dp: loss is null");
+    if (hipMemsetAsync(const_cast<float *>(adam->grads), 0, (size_t)adam->n_params * sizeof(float), (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(loss, 0, 3 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return fail(SNERF_E_LAUNCH, "smpl_nerf_train_step_dp: memset failed");
+    return SNERF_OK;
+}
+}  // namespace snerf
+
 // comm (may be NULL): the flat gradient buffer is averaged over the ranks between the backward and Adam
 extern "C" int snerf_smpl_nerf_train_step_aux_f32(const snerf_mlp_desc *desc_coarse, const void *packed_coarse, const void *packed_t_coarse,
                                                   const snerf_mlp_desc *desc_fine, const void *packed_fine, const void *packed_t_fine,
@@ -911,9 +955,11 @@ extern "C" int snerf_smpl_nerf_train_step_aux_f32(const snerf_mlp_desc *desc_coa
     using namespace snerf;
     if (comm && (!adam || !adam->grads || adam->n_params < 1))
         return fail(SNERF_E_BADARG, "smpl_nerf_train_step_aux: the data-parallel step needs adam->grads");
-    int rc = smpl_nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
-                                        packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
-                                        grad_fine, grad_warp, loss, rgb, rgb_fine, stream, aux_stream);
+    int rc = (comm && batch && batch->B == 0)
+                 ? dp_empty_batch(adam, loss, stream)
+                 : smpl_nerf_train_grads_impl(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
+                                              packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
+                                              grad_fine, grad_warp, loss, rgb, rgb_fine, stream, aux_stream);
     if (rc) return rc;
     if (comm && (rc = dp_allreduce_avg(comm, const_cast<float *>(adam->grads), 0, adam->n_params, 0, 0, (hipStream_t)stream,
                                        "smpl_nerf_train_step_aux")))
@@ -951,9 +997,11 @@ extern "C" int snerf_smpl_nerf_train_step_dp_f32(const snerf_mlp_desc *desc_coar
     using namespace snerf;
     if (!comm) return fail(SNERF_E_BADARG, "smpl_nerf_train_step_dp: comm is null (the single-GPU step is snerf_smpl_nerf_train_step_f32)");
     if (!adam || !adam->grads || adam->n_params < 1) return fail(SNERF_E_BADARG, "smpl_nerf_train_step_dp: adam / adam->grads is null");
-    int rc = snerf_smpl_nerf_train_grads_f32(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
-                                             packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace, grad_coarse,
-                                             grad_fine, grad_warp, loss, rgb, rgb_fine, stream);
+    int rc = (batch && batch->B == 0)
+                 ? dp_empty_batch(adam, loss, stream)
+                 : snerf_smpl_nerf_train_grads_f32(desc_coarse, packed_coarse, packed_t_coarse, desc_fine, packed_fine, packed_t_fine, desc_warp,
+                                                   packed_warp, packed_t_warp, precision, batch, pose_enc, rays_per_chunk, workspace,
+                                                   grad_coarse, grad_fine, grad_warp, loss, rgb, rgb_fine, stream);
     if (rc) return rc;
     if ((rc = dp_allreduce_avg(comm, const_cast<float *>(adam->grads), 0, adam->n_params, 0, 0, (hipStream_t)stream, "smpl_nerf_train_step_dp")))
         return rc;

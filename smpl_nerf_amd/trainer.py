@@ -211,7 +211,7 @@ class DataParallelTrainer:
         # (bench.py on a 1-GPU box: the collective of the path on RCCL with nothing to exchange; the mean over one rank is the
         # identity)
         self._sync = self.world > 1 or (bool(sync_at_world_one) and sdist.is_dist())
-        self._comm = None      # dist.RcclComm of the one-call data-parallel step (created lazily; False: not usable here)
+        self._comm = False     # dist.RcclComm of the one-call data-parallel step (_init_comm; False: not usable here)
         # one flat parameter buffer and one flat gradient buffer for all nets (what is all-reduced is the flat
         # gradient the backward kernels wrote)
         self._flat_p, self._flat_g, self._segments, order = flatten_parameters_(self.models)
@@ -265,6 +265,39 @@ class DataParallelTrainer:
         self._oc = None            # state of the one-call path (descriptors, slot tables, workspace)
         self.last_outputs = None   # (rgb, rgb_fine) of the last one-call step
         self.timing = None         # optional dict: HIP-event pairs around the gradient all-reduce (bench.py)
+        self._init_comm()
+
+    def _init_comm(self):
+        """The RCCL communicator of the one-call data-parallel step (dist.RcclComm), created HERE - its construction is a collective
+        (broadcast of the id, ncclCommInitRank), so it must not hang on a per-step, per-rank condition - and only when
+        EVERY rank can use it: the ranks agree once (a MIN all-reduce of the local verdict) between the one-call form with RCCL
+        inside the call and the three-call form (gradients, torch.distributed all-reduce, optimiser).  False: not usable here (the
+        ranks share a GPU - the gloo dry runs -, SNERF_DP_ONE_CALL=0, one_call=False, parameters not flattened / not on a GPU)."""
+        self._comm = False
+        if not self._sync:
+            return
+        dev = self._flat_p.device if self._flat_p is not None else None
+        ok = (os.environ.get("SNERF_DP_ONE_CALL", "1") != "0" and self.one_call is not False and self._flat_g is not None
+              and isinstance(self.optim, HipAdam) and sdist.rccl_usable(dev))
+        if sdist.is_dist() and self.world > 1:
+            on_dev = dev is not None and dev.type == "cuda" and sdist.dist.get_backend() == "nccl"
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
+            sdist.dist.all_reduce(flag, op=sdist.dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        if ok:
+            self._comm = sdist.RcclComm(dev)
+
+    def close(self):
+        """Destroys the communicator (ncclCommDestroy); the trainer keeps working on the three-call form afterwards."""
+        comm, self._comm = getattr(self, "_comm", None), False
+        if comm:
+            comm.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def loss(self, rgb, rgb_fine, rgb_truth):
         return self.loss_func(rgb, rgb_truth) + self.loss_func(rgb_fine, rgb_truth)  # nerf_solver.py:48-52
@@ -306,17 +339,8 @@ class DataParallelTrainer:
                 p.grad = v
 
     def _rccl_comm(self, dev):
-        """The RCCL communicator of the one-call data-parallel step (dist.RcclComm), created at the first step that needs it;
-        None when the ranks cannot use it (they share a GPU: the gloo dry runs) or SNERF_DP_ONE_CALL=0 asks for the three-call
-        form (gradients, torch.distributed all-reduce, optimiser)."""
-        if self._comm is False:
-            return None
-        if self._comm is None:
-            if os.environ.get("SNERF_DP_ONE_CALL", "1") == "0" or not sdist.rccl_usable(dev) or self._flat_g is None:
-                self._comm = False
-                return None
-            self._comm = sdist.RcclComm(dev)
-        return self._comm
+        """The communicator _init_comm created, or None: the three-call form (gradients, torch.distributed all-reduce, optimiser)."""
+        return self._comm or None
 
     def _allreduce_flat(self):
         """The one collective of a step, optionally between two HIP events (bench.py reads self.timing)."""
@@ -570,7 +594,7 @@ class DataParallelTrainer:
             pf = self._flat_p.data_ptr() + 4 * of_off
             ig = _lib.InputGrads(d_add.data_ptr(), pc, pf if Nf else None)
         with torch.cuda.device(dev), _lib.timed(f"train_step{'_smpl' if W is not None else ''}[B={B}]"):
-            comm = self._rccl_comm(dev) if self._sync and ig is None else None
+            comm = self._rccl_comm(dev) if self._sync else None
             if not self._sync and ig is not None:
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
@@ -590,12 +614,18 @@ class DataParallelTrainer:
                     self._flat_g[of_off:of_off + of_n].zero_()
                 ranges, nr = opt.c_ranges(flags)
                 st = opt.c_state()
-                if W is not None:
-                    t, entry = step_tail(st, ranges, nr, comm.handle), name + "_step_aux_f32"
+                if ig is not None:
+                    # ... and with d loss / d additional rows coming back (r06: snerf_nerf_train_step_dp_ig_f32; the rows are this
+                    # rank's own rays - the estimator's gradient is averaged below, behind its autograd)
+                    _lib.check(lib.snerf_nerf_train_step_dp_ig_f32(*head, ctypes.byref(st), ranges, nr, nets_c, n_nets, ctypes.byref(ig),
+                                                                   comm.handle, stream(), aux), "snerf_nerf_train_step_dp_ig_f32")
                 else:
-                    t = step_tail(st, ranges, nr)
-                    t, entry = t[:-2] + (comm.handle,) + t[-2:], name + "_step_dp_f32"
-                _lib.check(getattr(lib, entry)(*head, *t), entry)
+                    if W is not None:
+                        t, entry = step_tail(st, ranges, nr, comm.handle), name + "_step_aux_f32"
+                    else:
+                        t = step_tail(st, ranges, nr)
+                        t, entry = t[:-2] + (comm.handle,) + t[-2:], name + "_step_dp_f32"
+                    _lib.check(getattr(lib, entry)(*head, *t), entry)
                 opt.commit_step()
                 self.collective_calls = getattr(self, "collective_calls", 0) + 1
             else:
@@ -622,12 +652,21 @@ class DataParallelTrainer:
             #  run_fine = 0 with more than one rank: the fine net's parameters are live in the ranges (zero gradients:
             # weight decay and resumed moments still move them) but its streams were not among the nets the call refreshed
             mf.mark_weights_changed()
-        if ig is not None and not (self._sync and oc["upstream"]):
+        if ig is not None and not (self._sync and comm is None and oc["upstream"]):
             # back through what produced the rows: a goal_pose that wants its gradient gets it here; a trained estimator's parameter
             # gradients land in the flat buffer and its tensors take their optimiser step (a second, small C-ABI call)
             self._upstream_backward(oc, add_graph, d_add)
             if oc["upstream"]:
                 uflags = [i in oc["upstream_tensors"] for i in range(len(self.params))]
+                if comm is not None:      # more than one rank: the upstream tensors' stretches of the flat gradient, averaged
+                    idx = sorted(oc["upstream_tensors"])
+                    k = 0
+                    while k < len(idx):
+                        j = k
+                        while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1:
+                            j += 1
+                        comm.allreduce_avg_(self._flat_g[opt.offsets[idx[k]]:opt.offsets[idx[j] + 1]])
+                        k = j + 1
                 with torch.cuda.device(dev):
                     ranges, nr = opt.c_ranges(uflags)
                     if nr:

@@ -31,7 +31,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.snerf_version() == 108
+    assert lib.snerf_version() == 109
     assert isinstance(lib.snerf_last_error_string(), bytes)
     assert lib.snerf_device_count() >= 0
 

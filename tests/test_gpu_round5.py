@@ -198,6 +198,7 @@ def _dp_worker(port, q):
             tr, pipe, mc, mf = _trainer(dv)
             if sync:
                 tr._sync = True            # (sync_at_world_one: the group has one rank)
+                tr._init_comm()            # (r06: the communicator is created with the trainer, not at the first step)
             return tr
         batch = _batch(dv, 64)
         single, dp = make(False), make(True)
@@ -233,6 +234,7 @@ def _dp_worker(port, q):
         s1, _ = _smpl_trainer(dv)
         s2, _ = _smpl_trainer(dv)
         s2._sync = True
+        s2._init_comm()
         ls = [float(s1.step(sb)) for _ in range(3)]
         ld = [float(s2.step(sb)) for _ in range(3)]
         out["smpl"] = (ls == ld, all(bool(torch.equal(a, b)) for a, b in zip(s1.params, s2.params)),
