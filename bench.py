@@ -730,14 +730,19 @@ def main():
             k = pp.summary()
             # the same steps without the per-call event pairs of the profile: the host cost a user pays
             torch.cuda.synchronize()
+            calls0 = _lib.CALLS
             t0 = time.perf_counter()
             for _ in range(steps):
                 pipe(sub)
             th_plain = time.perf_counter() - t0
             torch.cuda.synchronize()
             dt_plain = time.perf_counter() - t0
+            calls_plain = (_lib.CALLS - calls0) / steps
+        # c_abi_calls_per_step: of the plain loop - what inference.py:251-252's `pipeline(data)` under no_grad costs (r06: the single-call
+        # render entry); under the profile above the pipeline keeps one call per kernel so that every launch has its event pair
         return {"rays_per_step": n, "ms_per_step": dt_plain / steps * 1e3, "host_enqueue_ms_per_step": th_plain / steps * 1e3,
-                "ray_samples_per_s": n * per_ray * steps / dt_plain, "c_abi_calls_per_step": sum(v[0] for v in k.values()) / steps,
+                "ray_samples_per_s": n * per_ray * steps / dt_plain, "c_abi_calls_per_step": calls_plain,
+                "c_abi_calls_per_step_under_the_launch_profile": sum(v[0] for v in k.values()) / steps,
                 "gpu_kernels_ms_per_step": sum(v[1] for v in k.values()) / steps,
                 "ms_per_step_with_event_pairs": dt / steps * 1e3, "host_ms_with_event_pairs": th / steps * 1e3}
 

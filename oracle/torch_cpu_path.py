@@ -140,7 +140,27 @@ def sample_pdf(bins, weights, args):
 
 
 FINE_OVERRIDE = None      # checker's tap: (z_vals_fine [B, Nc + Nf], ray_samples_fine [B, Nc + Nf, 3]) to use instead of this path's own
-                          # hierarchical samples - the HIP path's, so that the fine pass is compared on equal samples (tools/ab/fuzz_*)
+                          # hierarchical samples - the HIP path's, so that the fine pass is compared on equal samples (tools/ab/fuzz_*).
+                          # Set it through fine_override() only: a leftover value would make every later run of this path reuse
+                          # those samples and mask a sampler divergence; tests/conftest.py asserts it is None.
+
+
+class fine_override:
+    """with fine_override((z_fine, pts)): ...   - the tap above for the duration of the block, always reset."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __enter__(self):
+        global FINE_OVERRIDE
+        assert FINE_OVERRIDE is None, "fine_override does not nest"
+        FINE_OVERRIDE = self.value
+        return self
+
+    def __exit__(self, *exc):
+        global FINE_OVERRIDE
+        FINE_OVERRIDE = None
+        return False
 
 
 def fine_sampling(ray_translation, samples_directions, z_vals, weights, args):

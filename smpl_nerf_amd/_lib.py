@@ -246,13 +246,18 @@ class profile:
         return out
 
 
+CALLS = 0      # C-ABI launches made through timed() since import (bench.py: calls per step of an unprofiled loop)
+
+
 class timed:
-    """with timed("mlp_fwd"): lib.snerf_...(...)  - no-op unless a profile() is active."""
+    """with timed("mlp_fwd"): lib.snerf_...(...)  - counts the call; records an event pair when a profile() is active."""
 
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
+        global CALLS
+        CALLS += 1
         if _PROFILE is not None:
             import torch
             self.e0 = torch.cuda.Event(enable_timing=True)

@@ -12,13 +12,16 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct TrainLayout;
 // defined in mlp_train.hip: split-K wgrad + fixed-order reduce for any (Plan, TrainLayout)
+// n_beside: samples of ANOTHER net's weight gradient that runs on a second stream at the same time (train_step.hip: the coarse
+// net's backward beside the fine net's), 0 = this launch has the chip to itself - small calls then split their jobs for their
+// share of the CUs, n / (n + n_beside), so that both nets' workgroups are resident in one round
 int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
-                 float *flat_grad, hipStream_t s, int wide_nsplit = 0, bool accumulate = false);
+                 float *flat_grad, hipStream_t s, int wide_nsplit = 0, bool accumulate = false, int64_t n_beside = 0);
 // defined in mlp_train.hip / mlp_train_bf16.hip: dgrad + wgrad + reduce of one net on n samples (the bodies of snerf_mlp_bwd_f32 /
 // snerf_mlp_bwd_inputs_f32 and their split-precision twins); accumulate: flat_grad += instead of = (train_step.hip)
 int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n, float *dy,
                float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample, int spr, float *d_x,
-               float *d_dirs, snerf_stream_t stream, bool accumulate = false, bool beside_another_net = false);
+               float *d_dirs, snerf_stream_t stream, bool accumulate = false, bool beside_another_net = false, int64_t n_beside = 0);
 // (beside_another_net: the caller runs another net's backward on a second stream at the same time - train_step.hip)
 // defined in warp.hip: the body of snerf_warp_bwd_f32
 int launch_warp_bwd(const snerf_warp_desc *desc, const float *packed_t, const float *act, const float *d_warp, int64_t n, float *dy,

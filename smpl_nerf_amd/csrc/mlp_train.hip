@@ -18,6 +18,7 @@
 //                                order to the reference's [out, in] weight layout
 //
 // All MFMA work is v_mfma_f32_16x16x4_f32 (exact fp32), like the forward.
+#include <algorithm>
 #include <type_traits>
 
 #include "mlp_train_device.h"
@@ -828,7 +829,7 @@ int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, flo
 
 // split-K wgrad + reduce for any (Plan, TrainLayout)
 int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const float *dy, int64_t n, float *gpart,
-                 float *flat_grad, hipStream_t s, int wide_nsplit, bool accumulate) {
+                 float *flat_grad, hipStream_t s, int wide_nsplit, bool accumulate, int64_t n_beside) {
     // chunks: at most the wgrad_chunks(n) the partial buffer is sized for; with more wide workgroups than CUs, as many as
     // fill whole rounds of the chip (9 wide jobs x 128 chunks on 256 CUs = 4.5 rounds, the last one half empty: 113
     // chunks = 3.97 rounds of 13 % longer workgroups)
@@ -838,6 +839,11 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     {
         const int n_cu = device_cu_count("wgrad");
         if (n_cu < 1) return n_cu;
+        // this launch's share of the chip when another net's weight gradient runs beside it (r06).  Two small launches that each
+        // split their jobs over ALL CUs are two rounds of workgroups with half-length chunks and twice the partials: the 64-ray
+        // step's wide launches lasted 132 + 177 us side by side for 95 + 32 us of matrix work.  Split for the share instead and
+        // both nets' workgroups are resident at once, with equal chunk lengths.
+        const int cu_share = n_beside > 0 ? std::max(1, (int)((double)n_cu * (double)n / (double)(n + n_beside) + 0.5)) : n_cu;
 #ifndef WGD_WHOLE_ROUNDS
 #define WGD_WHOLE_ROUNDS 1
 #endif
@@ -848,7 +854,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             if ((int64_t)jobs_d * G_narrow > slots) G_narrow = min(G_narrow, max(1, (int)((int64_t)jobs_d * G_narrow / slots) * slots / jobs_d));
             // small calls (the README's 64-ray batches): 1024-sample chunks would fill a fifth of the slots, each wave walking 256
             // samples at the latency of its 4 k-steps in flight - shorter chunks (>= 64 samples), one round of the slots
-            else if (tuning().wgrad_small_chunks) G_narrow = max(G_narrow, min(min(wgrad_chunks(n), (int)((n + 63) / 64)), max(1, slots / jobs_d)));
+            else if (tuning().wgrad_small_chunks) G_narrow = max(G_narrow, min(min(wgrad_chunks(n), (int)((n + 63) / 64)), max(1, 3 * cu_share / jobs_d)));
         }
         const int jobs = wgrad_jobs(P);
         if (jobs > 0 && (int64_t)jobs * G > n_cu) {
@@ -859,7 +865,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             // small calls (the README's 64-ray batches: 4096 + 12 288 samples): 1024-sample chunks would put 9 x 4 workgroups
             // on 256 CUs - shorter chunks, one round of the chip (r04: 267 -> ~70 us per launch at 4096 samples; the reduce
             // reads 28 partials instead of 4)
-            G = max(G, min(wgrad_chunks(n), max(1, n_cu / jobs)));
+            G = max(G, min(wgrad_chunks(n), max(1, cu_share / jobs)));
         }
     }
     WgradArgs W{};
@@ -923,7 +929,7 @@ namespace snerf {
 // accumulate: flat_grad += instead of = (one ray chunk of a larger batch, train_step.hip)
 int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *act, const float *d_raw, int64_t n,
                float *dy, float *gpart, float *flat_grad, const float *x, const float *dirs, int dirs_per_sample,
-               int spr, float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate, bool beside_another_net) {
+               int spr, float *d_x, float *d_dirs, snerf_stream_t stream, bool accumulate, bool beside_another_net, int64_t n_beside) {
     Plan P;
     const char *why;
     if (!desc) return fail(SNERF_E_BADARG, "mlp_bwd: desc is null");
@@ -984,7 +990,7 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     const LatChoice lc = lat_choose_bwd(P, n, input_grad, beside_another_net);
     if (lc.mode == 1) {
         if (int lrc = launch_bwd_lat(P, A, s, 0)) return lrc;
-        return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);
+        return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate, n_beside);
     }
     const int64_t n_dgrad = lc.mode == 2 ? lc.n_main : n;   // samples of the throughput kernel below
     auto launch = [&](auto bw_c) -> int {
@@ -1037,7 +1043,7 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     int rc = check_launch("mlp_bwd(dgrad)");
     if (rc) return rc;
     if (lc.mode == 2 && (rc = launch_bwd_lat(P, A, s, lc.n_main))) return rc;
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, 0, accumulate, n_beside);
 }
 }  // namespace snerf
 

@@ -552,13 +552,16 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
         return snerf_mlp_fwd_train_bf16_f32(d, packed, precision, x, dirs, 0, add, n, spr, raw, act, stream);
     };
     auto bwd = [&](const snerf_mlp_desc *d, const void *packed_t, const float *act, const float *d_raw_, int64_t n, float *dy_,
-                   float *gpart_, float *grad, bool accumulate, snerf_stream_t st) {
+                   float *gpart_, float *grad, bool accumulate, snerf_stream_t st, int64_t n_beside) {
         if (precision == 0)
             return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw_, n, dy_, gpart_, grad, nullptr, nullptr, 0, 1,
-                              nullptr, nullptr, st, accumulate);
+                              nullptr, nullptr, st, accumulate, false, n_beside);
         return launch_bwd_bf16(d, packed_t, precision, act, d_raw_, n, dy_, gpart_, grad, nullptr, nullptr, 0, 1, nullptr, nullptr,
                                st, accumulate);
     };
+    // (the weight-gradient launches of a chunk small enough for the concurrent backward split their jobs for each net's share of the
+    // chip - by the size rule alone, with or without an auxiliary stream: the summation order, hence every bit of the gradients,
+    // does not depend on the streams the caller brings)
     for (int64_t r0 = 0; r0 < B; r0 += chunk) {
         const int64_t b = (B - r0 < chunk) ? B - r0 : chunk;
         const float *x = batch->ray_samples + r0 * Nc * 3, *d = batch->rays_d + r0 * 3, *z = batch->z_vals + r0 * Nc;
@@ -586,11 +589,11 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
             return fail(SNERF_E_LAUNCH, "nerf_train_grads: cannot fork onto the auxiliary stream");
         if (Nf > 0) {
             if ((rc = snerf_composite_bwd_f32(raw_f, z_fine, d, 0, nz_f, b, N, wb, d_rgb_f, d_raw, nullptr, stream))) return rc;
-            if ((rc = bwd(desc_fine, packed_t_fine, act_f, d_raw, b * N, dy, gpart, grad_fine, r0 > 0, stream))) return rc;
+            if ((rc = bwd(desc_fine, packed_t_fine, act_f, d_raw, b * N, dy, gpart, grad_fine, r0 > 0, stream, w.concurrent ? b * Nc : 0))) return rc;
             if (d_add && (rc = contract_additional(desc_fine, ig->params_fine, dy, b * N, N, d_add + r0 * add_dim, true, cscratch, stream))) return rc;
         }
         if ((rc = snerf_composite_bwd_f32(raw_c, z, d, 0, nz_c, b, Nc, wb, d_rgb_c, d_raw_c, nullptr, stream_c))) return rc;
-        if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, d_raw_c, b * Nc, dy_c, gpart_c, grad_coarse, r0 > 0, stream_c))) return rc;
+        if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, d_raw_c, b * Nc, dy_c, gpart_c, grad_coarse, r0 > 0, stream_c, w.concurrent ? b * N : 0))) return rc;
         // The collectives of the step are the same two on every rank, whatever its batch size, chunking and streams (RCCL matches
         // collectives by issue order and size; ADVICE r05: the concurrent form depends on the rank's own B): first the coarse net's
         // segment [cb0, cb1) - on the auxiliary stream while the fine net's backward still runs when the two run side by side, on
@@ -846,7 +849,7 @@ static int smpl_nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const v
                           bool accumulate, snerf_stream_t st) {
         if (precision == 0)
             return launch_bwd(d, reinterpret_cast<const float *>(packed_t), act, d_raw_, n, dy_, gpart_, grad, x, sd, 1, spr, d_x_, d_dirs_,
-                              st, accumulate, concurrent);
+                              st, accumulate, concurrent, b0.concurrent ? (spr == Nc ? n / Nc * N : n / N * Nc) : 0);
         return launch_bwd_bf16(d, packed_t, precision, act, d_raw_, n, dy_, gpart_, grad, x, sd, 1, spr, d_x_, d_dirs_, st, accumulate);
     };
     auto sum3 = [&](const float *a, const float *b, const float *c, int64_t n, float *out, snerf_stream_t st) {

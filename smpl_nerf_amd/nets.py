@@ -483,13 +483,25 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
     def _ordered_params(self):
         """Weights and biases in registration (= state_dict) order, which is the order the C-ABI's
         flat parameter vector uses (include/smplnerf.h: snerf_mlp_param_floats)."""
+        # (r06: every inference call asks for this list to validate its weight-stream cache - 70 nn.Module attribute look-ups per
+        # net were a third of the host time of a 64-ray render.  The list is kept and re-validated by identity against the
+        # layers' own parameter dicts, so a re-assigned `layer.weight = nn.Parameter(...)` is still seen.)
+        hit = self.__dict__.get("_op_cache")
+        if hit is not None:
+            for d, k, q in hit[0]:
+                if d.get(k) is not q:
+                    break
+            else:
+                return hit[1]
         mods = [self.positions_pose_input] + list(self.positional_net) + [
             self.additional_linear_layer, self.sigma_out_layer, self.directional_input] + list(
             self.directional_net) + [self.rgb_out_layer]
-        out = []
+        out, where = [], []
         for m in mods:
             out += [m.weight, m.bias]
-        return out
+            where += [(m._parameters, "weight", m.weight), (m._parameters, "bias", m.bias)]
+        self.__dict__["_op_cache"] = (where, out)
+        return list(out)
 
     def _skip_mask(self) -> int:
         mask = 0
@@ -499,8 +511,14 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         return mask
 
     def make_desc(self, pos_L, pos_id, dir_L, dir_id, add_dim, add_first=0) -> MlpDesc:
-        return MlpDesc(self.n_layers, self.width, pos_L, pos_id, dir_L, dir_id, add_dim, self._skip_mask(),
-                       1 if self.use_directional_input else 0, 1 if add_first else 0)
+        key = (self.n_layers, self.width, pos_L, pos_id, dir_L, dir_id, add_dim, self._skip_mask(),
+               1 if self.use_directional_input else 0, 1 if add_first else 0)
+        cache = self.__dict__.setdefault("_desc_cache", {})
+        d = cache.get(key)
+        if d is None:        # (descriptors are immutable by convention: one ctypes struct per shape, its key computed once)
+            d = cache[key] = MlpDesc(*key)
+            d._key = tuple(getattr(d, f[0]) for f in d._fields_)
+        return d
 
     def desc_for_encoders(self, position_encoder, direction_encoder, add_first=False) -> MlpDesc:
         """Descriptor of the fused (encode + MLP) path; checks that the encoders produce what this net
@@ -525,7 +543,8 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
 
     @staticmethod
     def _desc_key(desc):
-        return tuple(getattr(desc, f[0]) for f in desc._fields_)
+        key = getattr(desc, "_key", None)
+        return key if key is not None else tuple(getattr(desc, f[0]) for f in desc._fields_)
 
     def packed_weights(self, desc: MlpDesc, training: bool = False) -> torch.Tensor:
         """MFMA-ordered fp32 weight stream for `desc` (snerf_mlp_pack_f32), re-packed only when a parameter changed."""

@@ -19,6 +19,35 @@ from torch import nn
 from . import ops
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on_device(dev):
+    """torch.cuda.device(dev), or nothing when `dev` is already current (the usual case; the context manager costs ~10 us per call,
+    a fifth of the host time of a small render)."""
+    return _NULL if torch.cuda.current_device() == (dev.index or 0) else torch.cuda.device(dev)
+
+
+def _render_outputs(B, N, n_sample_tensors, dev):
+    """rgb [B,3], rgb_fine [B,3], n_sample_tensors x [B,N,3], densities [B,N] as views of ONE allocation (16-byte aligned each)."""
+    sizes = [B * 3, B * 3] + [B * N * 3] * n_sample_tensors + [B * N]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) & ~3
+    buf = torch.empty(off, device=dev, dtype=torch.float32)
+    shapes = [(B, 3), (B, 3)] + [(B, N, 3)] * n_sample_tensors + [(B, N)]
+    return [buf[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
 class PipelineArgs:
     """The fields of the reference's argparse namespace (config_parser.py) that the pipelines read.  Any object with these
     attributes works as `args` (the reference's own namespace included).
@@ -76,7 +105,31 @@ class NerfPipeline(nn.Module):
         std = getattr(self.args, "sigma_noise_std", 0.)
         return torch.normal(0, std, shape, device=device) if std > 0. else None
 
+    # keep_fine = True (checkers only: tools/ab/fuzz_*.py): forward() leaves the merged depths and the hierarchical sample points
+    # - which are not outputs of the reference's forward - in `last_fine`; off by default (a [B, N, 3] tensor pinned
+    # between calls, 38 MB for a 128 x 128 frame)
+    keep_fine = False
+    last_fine = None
+
+    def _single_call_ok(self, data) -> bool:
+        """Inference (autograd off) goes through the single C-ABI call of render_rays() - what inference.py:251-252's
+        `pipeline(data)` costs a host then is one call instead of five; same kernels, same results (tools/ab/fuzz_render.py holds
+        them bit for bit).  The five-call form stays for autograd, for a _lib.profile() (which brackets every launch with an
+        event pair: bench.py's roofline), for the strict sampler (a host round trip) and for the checkers' keep_fine."""
+        from . import _lib
+        if torch.is_grad_enabled() or _lib._PROFILE is not None or self.keep_fine or getattr(self.args, "strict_cumsum", 0):
+            return False
+        nets = [self.model_coarse, self.model_fine] + ([self.model_warp_field] if hasattr(self, "model_warp_field") else [])
+        if len({getattr(m, "precision", "fp32") for m in nets}) != 1:
+            return False
+        return all(torch.is_tensor(t) and t.is_cuda and (t.dtype == torch.float32) for t in data[:4])
+
     def forward(self, data):
+        if self._single_call_ok(data):
+            return self.render_rays(data)
+        return self._forward_calls(data)
+
+    def _forward_calls(self, data):
         ray_samples, ray_translation, ray_direction, z_vals, _ = data
         args = self.args
         B, Nc = z_vals.shape
@@ -93,7 +146,8 @@ class NerfPipeline(nn.Module):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]
-        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
+        if self.keep_fine:
+            self.last_fine = (z_fine, ray_samples_fine)
         N = z_fine.shape[1]
         raw_fine = self.model_fine.forward_fused(ray_samples_fine, ray_direction, N, self.position_encoder,
                                                  self.direction_encoder)
@@ -125,18 +179,18 @@ class NerfPipeline(nn.Module):
             descs.append(d)
             packed.append(m.packed_weights(d) if prec == 0 else m.packed_weights_bf16(d, prec))
         lib = _lib.load()
-        f32 = dict(device=dev, dtype=torch.float32)
         ws = torch.empty(int(lib.snerf_render_rays_workspace_bytes(B, Nc, Nf)), device=dev, dtype=torch.uint8)
-        rgb, rgb_fine = torch.empty((B, 3), **f32), torch.empty((B, 3), **f32)
-        samples_fine, dens = torch.empty((B, N, 3), **f32), torch.empty((B, N), **f32)
+        rgb, rgb_fine, samples_fine, dens = _render_outputs(B, N, 1, dev)
         u = ops.uniform_u(Nf, dev) if Nf else None
         nc, nf = self._noise((B, Nc), dev), (self._noise((B, N), dev) if Nf else None)
         x, o, d, z = (t.contiguous() for t in (ray_samples, ray_translation, ray_direction, z_vals))
-        with torch.cuda.device(dev), _lib.timed(f"render_rays[B={B}]"):
+        with _on_device(dev), _lib.timed("render_rays"):
             check(lib.snerf_render_rays_f32(descs[0], ptr(packed[0]), descs[1], ptr(packed[1]), prec, ptr(x), ptr(o),
                                             ptr(d), ptr(z), ptr(u), ptr(nc), ptr(nf), B, Nc, Nf,
                                             1 if args.white_background else 0, ptr(ws), ptr(rgb), ptr(rgb_fine),
                                             ptr(samples_fine), ptr(dens), current_stream()), "snerf_render_rays_f32")
+        if not Nf:
+            return rgb, rgb, ray_samples, dens      # (:43-44: the same tensor twice and the caller's own samples, quirk Q10)
         return rgb, rgb_fine, samples_fine, dens
 
 
@@ -169,7 +223,12 @@ class SmplNerfPipeline(NerfPipeline):
         raw = net.forward_fused(warped, sdirs, n_per_ray, self.position_encoder, self.direction_encoder)
         return warp, warped, sdirs, raw
 
-    def forward(self, data):
+    def _single_call_ok(self, data) -> bool:
+        # (the one-call entry covers the full coarse + fine march with the encoded pose)
+        return bool(self.args.human_pose_encoding and self.args.run_fine) and super()._single_call_ok(data) and \
+            torch.is_tensor(data[4]) and data[4].is_cuda and data[4].dtype == torch.float32
+
+    def _forward_calls(self, data):
         ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
         args = self.args
         B, Nc = z_vals.shape
@@ -189,7 +248,8 @@ class SmplNerfPipeline(NerfPipeline):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :68
-        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
+        if self.keep_fine:
+            self.last_fine = (z_fine, ray_samples_fine)
         N = z_fine.shape[1]
         warp_f, warped_f, _, raw_f = self._stage(self.model_fine, ray_samples_fine, ray_translation, pose_enc, N)
         rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
@@ -207,7 +267,7 @@ class SmplNerfPipeline(NerfPipeline):
         args = self.args
         if not args.human_pose_encoding or not args.run_fine:
             with torch.no_grad():
-                return self.forward(data)
+                return self._forward_calls(data)
         B, Nc = z_vals.shape
         Nf = int(args.number_fine_samples)
         N = Nc + Nf
@@ -229,15 +289,12 @@ class SmplNerfPipeline(NerfPipeline):
         wdesc = _lib.WarpDesc(mw.width, pe.number_frequencies, 1 if pe.include_identity else 0, mw.direcions_dim)
         wpacked = mw._packed(wdesc) if prec == 0 else mw._packed_bf16(wdesc)
         lib = _lib.load()
-        f32 = dict(device=dev, dtype=torch.float32)
         ws = torch.empty(int(lib.snerf_render_rays_smpl_workspace_bytes(B, Nc, Nf)), device=dev, dtype=torch.uint8)
-        rgb, rgb_fine = torch.empty((B, 3), **f32), torch.empty((B, 3), **f32)
-        warp_f, samples_f, warped_f = (torch.empty((B, N, 3), **f32) for _ in range(3))
-        dens = torch.empty((B, N), **f32)
+        rgb, rgb_fine, warp_f, samples_f, warped_f, dens = _render_outputs(B, N, 3, dev)
         u = ops.uniform_u(Nf, dev)
         nc, nf = self._noise((B, Nc), dev), self._noise((B, N), dev)
         x, o, d, z = (t.contiguous() for t in (ray_samples, ray_translation, ray_direction, z_vals))
-        with torch.cuda.device(dev), _lib.timed(f"render_rays_smpl[B={B}]"):
+        with _on_device(dev), _lib.timed("render_rays_smpl"):
             check(lib.snerf_render_rays_smpl_f32(descs[0], ptr(packed[0]), descs[1], ptr(packed[1]), wdesc, ptr(wpacked), prec,
                                                  ptr(x), ptr(o), ptr(d), ptr(z), ptr(pose_enc), ptr(u), ptr(nc), ptr(nf), B, Nc,
                                                  Nf, 1 if args.white_background else 0, ptr(ws), ptr(rgb), ptr(rgb_fine),
@@ -264,7 +321,14 @@ class AppendVerticesPipeline(NerfPipeline):
         self.smpl_estimator = smpl_estimator
         self.smpl_model = smpl_model
 
-    def forward(self, data):
+    def _single_call_ok(self, data) -> bool:
+        return False      # (estimator and body model are torch modules in front of the nets: no single-call entry)
+
+    def render_rays(self, data):
+        with torch.no_grad():
+            return self._forward_calls(data)
+
+    def _forward_calls(self, data):
         ray_samples, ray_translation, ray_direction, z_vals, images, _ = data
         args = self.args
         B, Nc = z_vals.shape
@@ -285,7 +349,8 @@ class AppendVerticesPipeline(NerfPipeline):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                         # :70
-        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
+        if self.keep_fine:
+            self.last_fine = (z_fine, ray_samples_fine)
         N = z_fine.shape[1]
         raw_f = self.model_fine.forward_rays(ray_inputs, ray_direction, N, B * N)
         rgb_fine, _, densities_fine = ops.composite(raw_f.view(B, N, 4), z_fine, ray_direction, wb,
@@ -307,7 +372,10 @@ class AppendSmplParamsPipeline(NerfPipeline):
     def _select(self, goal_pose):
         return goal_pose
 
-    def forward(self, data):
+    def _single_call_ok(self, data) -> bool:
+        return super()._single_call_ok(data) and torch.is_tensor(data[4]) and data[4].is_cuda and data[4].dtype == torch.float32
+
+    def _forward_calls(self, data):
         ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
         args = self.args
         B, Nc = z_vals.shape
@@ -324,7 +392,8 @@ class AppendSmplParamsPipeline(NerfPipeline):
         hs = ops.hierarchical_samples(ray_translation, ray_direction, z_vals, weights, args.number_fine_samples,
                                       strict=bool(getattr(args, "strict_cumsum", 0)))
         z_fine, ray_samples_fine = hs["z_fine"], hs["pts"]                                              # :60
-        self.last_fine = (z_fine, ray_samples_fine)      # (a reference for checkers: the merged depths are not an output)
+        if self.keep_fine:
+            self.last_fine = (z_fine, ray_samples_fine)
         N = z_fine.shape[1]
         raw_f = self.model_fine.forward_fused(ray_samples_fine, ray_direction, N, self.position_encoder,
                                               self.direction_encoder, additional=pose, add_first=True)  # :77-81
@@ -359,21 +428,21 @@ class AppendSmplParamsPipeline(NerfPipeline):
             descs.append(d)
             packed.append(m.packed_weights(d) if prec == 0 else m.packed_weights_bf16(d, prec))
         lib = _lib.load()
-        f32 = dict(device=dev, dtype=torch.float32)
         need = int(lib.snerf_render_rays_add_workspace_bytes(descs[0], descs[1], B, Nc, Nf))
         if need < 0:
             check(need, "snerf_render_rays_add_workspace_bytes")
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
-        rgb, rgb_fine = torch.empty((B, 3), **f32), torch.empty((B, 3), **f32)
-        samples_fine, dens = torch.empty((B, N, 3), **f32), torch.empty((B, N), **f32)
+        rgb, rgb_fine, samples_fine, dens = _render_outputs(B, N, 1, dev)
         u = ops.uniform_u(Nf, dev) if Nf else None
         nc, nf = self._noise((B, Nc), dev), (self._noise((B, N), dev) if Nf else None)
         x, o, d, z = (t.contiguous() for t in (ray_samples, ray_translation, ray_direction, z_vals))
-        with torch.cuda.device(dev), _lib.timed(f"render_rays_add[B={B}]"):
+        with _on_device(dev), _lib.timed("render_rays_add"):
             check(lib.snerf_render_rays_add_f32(descs[0], ptr(packed[0]), descs[1], ptr(packed[1]), prec, ptr(x), ptr(o), ptr(d),
                                                 ptr(z), ptr(pose), ptr(u), ptr(nc), ptr(nf), B, Nc, Nf,
                                                 1 if args.white_background else 0, ptr(ws), ptr(rgb), ptr(rgb_fine),
                                                 ptr(samples_fine), ptr(dens), current_stream()), "snerf_render_rays_add_f32")
+        if not Nf:
+            return rgb, rgb, ray_samples, dens      # (models/append_smpl_params_pipeline.py:56-57)
         return rgb, rgb_fine, samples_fine, dens
 
 

@@ -48,3 +48,15 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _no_leftover_checker_taps():
+    """oracle/torch_cpu_path.FINE_OVERRIDE makes the CPU restatement reuse somebody else's hierarchical samples; it is set through
+    the fine_override() context manager only, and no test may start or end with it set."""
+    import sys
+    mod = sys.modules.get("oracle.torch_cpu_path")
+    assert mod is None or mod.FINE_OVERRIDE is None, "a checker tap was left set before this test"
+    yield
+    mod = sys.modules.get("oracle.torch_cpu_path")
+    assert mod is None or mod.FINE_OVERRIDE is None, "this test left oracle.torch_cpu_path.FINE_OVERRIDE set"

@@ -228,8 +228,13 @@ def test_one_call_step_equals_the_autograd_step(dev, prec, cfg):
         runs.append((losses, [p.grad.clone() for p in tr.params], [p.detach().clone() for p in tr.params]))
         assert (tr._one_call_state() is not None) == (one_call is None)
     close(runs[0][0], runs[1][0], 2e-6, 1e-8)
+    # r06: the one-call step of a small batch splits its weight-gradient jobs for each net's share of the chip (the coarse net's
+    # backward runs beside the fine net's), the autograd form's launches each split for the whole chip: the same sums in another
+    # order.  A tensor whose gradient is a near-total cancellation (white background: the last layers of the coarse net, norm 1e-9
+    # against 1e-2 for the others) carries that round-off at full size - hence the term relative to the largest tensor.
+    top = max(float(gb.norm()) for gb in runs[1][1])
     for ga, gb in zip(runs[0][1], runs[1][1]):
-        assert float((ga - gb).norm()) <= 2e-5 * float(gb.norm()) + 1e-12
+        assert float((ga - gb).norm()) <= 2e-5 * float(gb.norm()) + 1e-7 * top + 1e-12
     for pa, pb in zip(runs[0][2], runs[1][2]):
         assert float((pa - pb).abs().max()) <= 2e-5
 

@@ -31,6 +31,75 @@ def render_ray_net(P, x, n_layers=8, positions_dim=60, directions_dim=24, additi
     return torch.cat([lin(o, "rgb_out_layer"), sigma], -1)
 
 
+RELU_LAYERS = lambda n_layers: ["positions_pose_input"] + [f"positional_net.{i}" for i in range(n_layers - 1)] + ["directional_net.0"]
+
+
+def layer_order(n_layers):
+    """nn.Linear names of models/render_ray_net.py in forward order."""
+    return (["positions_pose_input"] + [f"positional_net.{i}" for i in range(n_layers - 1)] +
+            ["additional_linear_layer", "sigma_out_layer", "directional_input", "directional_net.0", "rgb_out_layer"])
+
+
+def render_ray_net_preacts(P, x, n_layers=8, positions_dim=60, directions_dim=24, additional_input_dim=0, skips=(4,),
+                           use_directional_input=1):
+    """The pre-activations of every ReLU layer of render_ray_net() in the dtype of P / x (float64 for adjudication)."""
+    lin = lambda v, n: torch.nn.functional.linear(v, P[n + ".weight"], P[n + ".bias"])
+    pin = positions_dim + additional_input_dim
+    pp, dd = x[..., :pin], x[..., x.shape[-1] - directions_dim:]
+    pre = {"positions_pose_input": lin(pp, "positions_pose_input")}
+    o = torch.relu(pre["positions_pose_input"])
+    for i in range(n_layers - 1):
+        pre[f"positional_net.{i}"] = lin(torch.cat([o, pp], -1) if i in skips else o, f"positional_net.{i}")
+        o = torch.relu(pre[f"positional_net.{i}"])
+    o = lin(o, "additional_linear_layer")
+    o = lin(torch.cat([o, dd], -1) if use_directional_input else o, "directional_input")
+    pre["directional_net.0"] = lin(o, "directional_net.0")
+    return pre
+
+
+def check_grads_or_one_relu_kink(got, want, params64, x64, n_layers, skips, rtol=5e-4, atol_rel=5e-5, kink=1e-6, below=5e-2):
+    """Every parameter gradient `got[name]` against `want[name]` (numpy) at |err| <= rtol |g| + atol_rel max|g| - or ONE ReLU kink.
+
+    Two fp32 summation orders (MFMA k-blocks against the CPU's dot products) need not agree on the sign of a pre-activation that is
+    zero to round-off; the ReLU mask bit of that one (sample, feature) then differs and the gradients differ by that sample's
+    contribution: in ONE row of that layer's weight gradient (one element of its bias gradient), nowhere in the layers towards the
+    output, and by a bounded amount in every layer towards the input.  A miss passes only with exactly that
+    signature, the feature's smallest |pre-activation| recomputed in float64 below `kink`; anything else fails.  Returns None or a
+    description of the adjudicated kink."""
+    viol = {}
+    for k, g in want.items():
+        a = got[k]
+        bad = np.abs(a - g) > rtol * np.abs(g) + atol_rel * np.abs(g).max()
+        if bad.any():
+            viol[k] = bad
+    if not viol:
+        return None
+    order = layer_order(n_layers)
+    layers_bad = [l for l in order if l + ".weight" in viol or l + ".bias" in viol]
+    top = layers_bad[-1]
+    if "sigma_out_layer" in layers_bad:
+        # a sibling of the colour branch: it reads the trunk's output, which a kink leaves unchanged - unless the kink sits in the
+        # trunk, where the head's own gradient (d sigma x o) still does not change
+        raise AssertionError(f"gradient mismatch in sigma_out_layer (no ReLU kink explains it); layers off: {layers_bad}")
+    assert top in RELU_LAYERS(n_layers), f"gradient mismatch with its topmost layer {top} not a ReLU layer; layers off: {layers_bad}"
+    wbad = viol.get(top + ".weight")
+    rows = sorted(set(np.nonzero(wbad)[0].tolist())) if wbad is not None else []
+    brows = sorted(np.nonzero(viol[top + ".bias"])[0].tolist()) if top + ".bias" in viol else []
+    rows_all = sorted(set(rows) | set(brows))
+    assert len(rows_all) == 1, f"gradient mismatch in {len(rows_all)} rows of {top} (a single kink touches one): {rows_all[:8]}"
+    f = rows_all[0]
+    pre = render_ray_net_preacts(params64, x64, n_layers=n_layers, skips=skips)[top][:, f]
+    smallest = float(pre.abs().min())
+    assert smallest < kink, f"row {f} of {top} is off but its smallest |pre-activation| in float64 is {smallest:.3e} (not a kink)"
+    # towards the input: the one sample's contribution, bounded
+    for l in layers_bad[:-1]:
+        for suffix in (".weight", ".bias"):
+            k = l + suffix
+            err = np.linalg.norm(got[k] - want[k]) / max(np.linalg.norm(want[k]), 1e-30)
+            assert err <= below, f"{k}: relative error {err:.2e} below the kink of {top} row {f} exceeds {below}"
+    return f"ReLU kink: {top} row {f}, float64 pre-activation {float(pre[pre.abs().argmin()]):.3e} at sample {int(pre.abs().argmin())}"
+
+
 def raw2outputs(raw, z, dirs, wb, noise=None):
     dists = z[..., 1:] - z[..., :-1]
     dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1) * torch.norm(dirs, dim=-1)

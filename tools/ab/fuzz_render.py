@@ -99,23 +99,21 @@ for case in range(cases):
             cls = AppendToNerfPipeline if kind == "append_to_nerf" else AppendSmplParamsPipeline
             pipe = cls(nets[0], nets[1], args, pe, de, PositionalEncoder(10, 0))
             ref_fn = lambda: TP.append_pose_pipeline_forward(P[0], P[1], targs, tpe, tde, the, cpu, two_joints=kind == "append_to_nerf")
+        pipe.keep_fine = True           # (opt-in: forward() leaves its hierarchical samples in pipe.last_fine)
         with torch.no_grad():
             out = pipe(batch)
             ref_own = ref_fn()          # the CPU path on its own hierarchical samples
             # ... and on the HIP path's samples: the reference's sampler is discontinuous where a bin's mass sits at
             # its 1e-5 threshold (utils.py:224), so a last-bit difference of the coarse weights moves a ray's samples - with equal
             # samples the fine pass is held to the tolerance of the coarse one, no "rays off" allowance
-            TP.FINE_OVERRIDE = tuple(t.detach().cpu() for t in pipe.last_fine) if run_fine else None
-            try:
+            with TP.fine_override(tuple(t.detach().cpu() for t in pipe.last_fine) if run_fine else None):
                 ref = ref_fn()
-            finally:
-                TP.FINE_OVERRIDE = None
         # the single-call entries (snerf_render_rays_f32 / _smpl_f32 / _add_f32) against the five-launch forward: bit for bit
         one_call_ok = True
         mixed = kind == "smpl_nerf" and pipe.model_warp_field.precision != prec      # (the one-call entry wants one precision for all nets)
         if not (kind == "smpl_nerf" and Nf == 0) and not mixed:
             args.strict_cumsum = 0
-            with torch.no_grad():
+            with torch.no_grad():      # (keep_fine is on: pipe(batch) is the five-launch forward)
                 fwd, one = pipe(batch), pipe.render_rays(batch)
             one_call_ok = all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(fwd, one))
             args.strict_cumsum = 1
@@ -134,22 +132,20 @@ for case in range(cases):
         if not ok and os.environ.get("FUZZ_ADJUDICATE", "1") != "0":
             # the flagged case in float64 on the CPU, same samples: who is further from the exact value?
             try:
-                TP.FINE_OVERRIDE = tuple(t.detach().cpu().double() for t in pipe.last_fine) if run_fine else None
-                P64 = [{k: v.double() for k, v in p_.items()} for p_ in P]
-                cpu64 = [t.double() if t.is_floating_point() else t for t in cpu]
-                if kind == "nerf":
-                    r64 = TP.nerf_pipeline_forward(P64[0], P64[1], targs, tpe, tde, cpu64)
-                elif kind == "smpl_nerf":
-                    r64 = TP.smpl_nerf_pipeline_forward(P64[0], P64[1], {k: v.double() for k, v in Pw.items()}, targs, tpe, tde, the, cpu64)
-                else:
-                    r64 = TP.append_pose_pipeline_forward(P64[0], P64[1], targs, tpe, tde, the, cpu64, two_joints=kind == "append_to_nerf")
-                print(f"     fp64 adjudication (max abs error of the fine colours): HIP {float((out[1].cpu().double() - r64[1]).abs().max()):.2e}, "
-                      f"CPU fp32 restatement {float((ref[1].double() - r64[1]).abs().max()):.2e}; coarse: HIP {float((out[0].cpu().double() - r64[0]).abs().max()):.2e}, "
-                      f"CPU fp32 {float((ref[0].double() - r64[0]).abs().max()):.2e}", flush=True)
+                with TP.fine_override(tuple(t.detach().cpu().double() for t in pipe.last_fine) if run_fine else None):
+                    P64 = [{k: v.double() for k, v in p_.items()} for p_ in P]
+                    cpu64 = [t.double() if t.is_floating_point() else t for t in cpu]
+                    if kind == "nerf":
+                        r64 = TP.nerf_pipeline_forward(P64[0], P64[1], targs, tpe, tde, cpu64)
+                    elif kind == "smpl_nerf":
+                        r64 = TP.smpl_nerf_pipeline_forward(P64[0], P64[1], {k: v.double() for k, v in Pw.items()}, targs, tpe, tde, the, cpu64)
+                    else:
+                        r64 = TP.append_pose_pipeline_forward(P64[0], P64[1], targs, tpe, tde, the, cpu64, two_joints=kind == "append_to_nerf")
+                    print(f"     fp64 adjudication (max abs error of the fine colours): HIP {float((out[1].cpu().double() - r64[1]).abs().max()):.2e}, "
+                          f"CPU fp32 restatement {float((ref[1].double() - r64[1]).abs().max()):.2e}; coarse: HIP {float((out[0].cpu().double() - r64[0]).abs().max()):.2e}, "
+                          f"CPU fp32 {float((ref[0].double() - r64[0]).abs().max()):.2e}", flush=True)
             except Exception as e:      # noqa: BLE001
                 print(f"     fp64 adjudication failed: {type(e).__name__}: {str(e)[:200]}", flush=True)
-            finally:
-                TP.FINE_OVERRIDE = None
     except Exception as e:   # noqa: BLE001
         bad += 1
         print("EXC " + desc + f": {type(e).__name__}: {str(e)[:300]}", flush=True)

@@ -99,9 +99,11 @@ for case in range(cases):
             tr = DataParallelTrainer(pipe, nets, lr=1e-3, one_call=one_call)
             tr.rays_per_chunk = chunk
             if len(runs) == 0 and run_fine:      # the HIP path's hierarchical samples at the initial weights (for the CPU comparison below)
+                pipe.keep_fine = True      # (opt-in: forward() leaves its hierarchical samples in pipe.last_fine)
                 with torch.no_grad():
                     pipe(batch)
                 gpu_fine = tuple(t.detach().cpu() for t in pipe.last_fine)
+                pipe.keep_fine, pipe.last_fine = False, None
             loss = float(tr.step(batch))
             # (split-precision smpl_nerf with identity columns / more frequencies: the trainer keeps the autograd path by design)
             by_design = kind == "smpl_nerf" and prec != "fp32" and (idp or Lp > 10)
@@ -140,12 +142,11 @@ for case in range(cases):
             # on the HIP path's fine samples: the reference's sampler is discontinuous where a bin's mass sits at its 1e-5
             # threshold (utils.py:224: nearly opaque rays), so a last-bit difference of the coarse weights would move samples - with
             # equal samples the fine net's gradient is held as tightly as the coarse net's
-            TP.FINE_OVERRIDE = gpu_fine if run_fine else None
-            out = TP.nerf_pipeline_forward(P[0], P[1], TP.Args(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine),
-                                           TP.PositionalEncoder(Lp, idp), TP.PositionalEncoder(Ld, idd), cb,
-                                           net_kw=dict(n_layers=depth, positions_dim=3 * pe.output_dim, directions_dim=3 * de.output_dim,
-                                                       skips=tuple(skips), use_directional_input=use_dir))
-            TP.FINE_OVERRIDE = None
+            with TP.fine_override(gpu_fine if run_fine else None):
+                out = TP.nerf_pipeline_forward(P[0], P[1], TP.Args(white_background=wb, number_fine_samples=max(Nf, 1), run_fine=run_fine),
+                                               TP.PositionalEncoder(Lp, idp), TP.PositionalEncoder(Ld, idd), cb,
+                                               net_kw=dict(n_layers=depth, positions_dim=3 * pe.output_dim, directions_dim=3 * de.output_dim,
+                                                           skips=tuple(skips), use_directional_input=use_dir))
             lt = torch.nn.functional.mse_loss(out[0], cb[-1]) + torch.nn.functional.mse_loss(out[1], cb[-1])
             lt.backward()
             ref = [v.grad for p_ in P for v in p_.values()]
