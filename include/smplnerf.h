@@ -88,7 +88,7 @@ extern "C" {
                              auxiliary stream: small chunks run the coarse chain beside the fine chain); snerf_mlp_desc.width
                              up to 512
                              0.1.9: + snerf_nerf_train_step_dp_ig_f32; the data-parallel steps issue the same collectives on every
-                             rank whatever its batch size (B == 0 included); SNERF_RCCL_LIB */
+                             rank whatever its batch size (B == 0 included); SNERF_RCCL_LIB; snerf_linear_* / snerf_relu_bwd_f32 (any --netwidth) */
 
 #define SNERF_OK 0
 #define SNERF_E_BADARG (-1)   /* null pointer, negative size, unsupported shape */
@@ -643,6 +643,29 @@ SNERF_API int snerf_smpl_nerf_train_step_f32(const snerf_mlp_desc *desc_coarse, 
  * data-parallel caller runs behind snerf_adam_step_f32. */
 SNERF_API int snerf_warp_repack_f32(const snerf_warp_desc *desc_warp, const float *params, int64_t n_params, int64_t warp_param_offset,
                           float *packed_warp, float *packed_t_warp, snerf_stream_t stream);
+
+/* ---- a2 / a7 for ANY width: nn.Linear as stand-alone fp32 MFMA GEMMs (0.1.9) -----------------------------------------------
+ * config_parser.py:20,24,30 accept any --netwidth / --netwidth_fine / --netwidth_warp.  The fused kernels above cover
+ * RenderRayNet up to 512 features and WarpFieldNet up to 256; wider nets run one nn.Linear at a time with the activations in HBM,
+ * as models/render_ray_net.py:42-61 / models/warp_field_net.py:17-21 do, through these entries.  Weights are read in the
+ * reference's own layout: w is [m, k] = [out, in] row-major with leading dimension ldw (a slice of the flat parameter vector; a
+ * column block of a wider matrix - the two input blocks of a skip layer - is w + offset with the full matrix's ldw).  All matrices
+ * row-major fp32 with explicit leading dimensions (in floats); exact fp32 (v_mfma_f32_16x16x4_f32).
+ *   snerf_linear_fwd_f32         y[n, m]  (+)= x[n, k] w^T, then + bias[m] (nullable), then ReLU (relu != 0)
+ *   snerf_linear_bwd_input_f32   dx[n, k] (+)= dy[n, m] w
+ *   snerf_linear_bwd_weight_f32  dw[m, k] (+)= dy^T x and db[m] (+)= column sums of dy (db nullable); the sum over the samples is
+ *                                split into slices whose partials go through `scratch`
+ *                                (snerf_linear_bwd_weight_scratch_floats(n, m, k) floats) and are added in slice order
+ *   snerf_relu_bwd_f32           dy[i, j] = y[i, j] > 0 ? dy[i, j] : 0, in place
+ * (accumulate != 0: += instead of =). */
+SNERF_API int snerf_linear_fwd_f32(const float *x, int64_t n, int k, int64_t ldx, const float *w, int64_t ldw, int m, const float *bias,
+                         int accumulate, int relu, float *y, int64_t ldy, snerf_stream_t stream);
+SNERF_API int snerf_linear_bwd_input_f32(const float *dy, int64_t n, int m, int64_t lddy, const float *w, int64_t ldw, int k, int accumulate,
+                               float *dx, int64_t lddx, snerf_stream_t stream);
+SNERF_API int64_t snerf_linear_bwd_weight_scratch_floats(int64_t n, int m, int k);
+SNERF_API int snerf_linear_bwd_weight_f32(const float *dy, int64_t n, int m, int64_t lddy, const float *x, int64_t ldx, int k, int accumulate,
+                                float *dw, int64_t lddw, float *db, float *scratch, snerf_stream_t stream);
+SNERF_API int snerf_relu_bwd_f32(float *dy, const float *y, int64_t n, int m, int64_t lddy, int64_t ldy, snerf_stream_t stream);
 
 /* ---- 8(e): the data-parallel step as one call ---------------------------------------------------------------------------
  * Rays of independent images shard over the GPUs of a node, one process per GPU; the only exchange of the path is the average of

@@ -201,9 +201,10 @@ def nerf_pipeline_forward(Pc, Pf, args, position_encoder, direction_encoder, dat
     return rgb, rgb_fine, ray_samples_fine, densities
 
 
-def smpl_nerf_pipeline_forward(Pc, Pf, Pw, args, position_encoder, direction_encoder, human_pose_encoder, data):
+def smpl_nerf_pipeline_forward(Pc, Pf, Pw, args, position_encoder, direction_encoder, human_pose_encoder, data, net_kw=None):
     """models/smpl_nerf_pipeline.py:16-100 (human_pose_encoding = 1);
     data = [ray_samples, ray_translation, ray_direction, z_vals, goal_pose, rgb_truth]."""
+    net_kw = net_kw or {}
     ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
     goal_pose = torch.stack([goal_pose[:, 38], goal_pose[:, 41]], axis=-1)
     pose_enc = human_pose_encoder.encode(goal_pose)
@@ -219,7 +220,7 @@ def smpl_nerf_pipeline_forward(Pc, Pf, Pw, args, position_encoder, direction_enc
         sdn = sdirs / torch.norm(sdirs, dim=-1, keepdim=True)
         denc = direction_encoder.encode(sdn)
         inputs = torch.cat([enc_w.view(B * N, -1), denc.view(B * N, -1)], -1)
-        return warp, warped, sdirs, render_ray_net(P, inputs).view(B, N, 4)
+        return warp, warped, sdirs, render_ray_net(P, inputs, **net_kw).view(B, N, 4)
 
     warp, warped, sdirs, raw = stage(Pc, ray_samples)
     rgb, weights, densities = raw2outputs(raw, z_vals, sdirs, args)

@@ -149,6 +149,12 @@ SIGNATURES = {
     "snerf_nerf_train_step_ig_f32": (c_int, [POINTER(MlpDesc), _P, _P, POINTER(MlpDesc), _P, _P, c_int, POINTER(NerfBatch), c_int64,
                                              _P, _P, _P, _P, _P, _P, POINTER(AdamState), POINTER(AdamRange), c_int, POINTER(AdamNet), c_int,
                                              POINTER(InputGrads), _P, _P]),
+    # any --netwidth: nn.Linear as stand-alone GEMMs (csrc/linear.hip)
+    "snerf_linear_fwd_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, c_int, _P, c_int, c_int, _P, c_int64, _P]),
+    "snerf_linear_bwd_input_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, c_int, c_int, _P, c_int64, _P]),
+    "snerf_linear_bwd_weight_scratch_floats": (c_int64, [c_int64, c_int, c_int]),
+    "snerf_linear_bwd_weight_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, c_int, c_int, _P, c_int64, _P, _P, _P]),
+    "snerf_relu_bwd_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, c_int64, _P]),
     # 8(e): RCCL inside the boundary
     "snerf_comm_unique_id": (c_int, [_P]),
     "snerf_comm_init_rank": (c_int, [_P, c_int, c_int, POINTER(_P)]),

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libsmplnerf_hip.so")
-SOURCES = ["api.hip", "searchsorted.hip", "posenc.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_train.hip", "warp.hip", "raygen.hip", "mlp_bf16.hip", "render.hip", "mlp_train_bf16.hip", "warp_bf16.hip", "train_step.hip", "contract.hip", "mlp_lat.hip", "dp_comm.hip"]
+SOURCES = ["api.hip", "searchsorted.hip", "posenc.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_train.hip", "warp.hip", "raygen.hip", "mlp_bf16.hip", "render.hip", "mlp_train_bf16.hip", "warp_bf16.hip", "train_step.hip", "contract.hip", "mlp_lat.hip", "dp_comm.hip", "linear.hip"]
 HEADERS = ["exports.map", "snerf_common.h", "mlp_plan.h", "mlp_device.h", "mlp_bf16_device.h", "mlp_train_device.h", "mlp_lat_device.h", "warp_plan.h", os.path.join("..", "..", "include", "smplnerf.h")]
 # -fvisibility=hidden: the SNERF_API entry points of include/smplnerf.h are the library's only dynamic symbols
 # -ffp-contract=off: the HBM-bound ops reproduce the reference's eager (unfused) fp32 op order.

@@ -472,19 +472,27 @@ struct LatLaunch {
     int S, grid, passes;
     int64_t tile_off, tile_end;
 };
-static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2]) {
+// pair_s: the largest S' of which TWO workgroups fit a CU's LDS (0: none - the split of the cost model)
+static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2], int pair_s = 0) {
     int k = 0;
     int64_t done = 0;
     const int S = (int)std::min<int64_t>(s_max, (n16 + n_cu - 1) / n_cu);
     const int64_t per_round = (int64_t)S * n_cu;
     const int passes = (int)(n16 / per_round);
+    // r06: a ONE-pass launch with an even number of tiles per CU runs as TWO workgroups of S / 2 tiles per CU (16 waves: the kernels
+    // keep to 128 VGPRs and 2 x lat_lds(2) fits the LDS): each workgroup's MFMAs cover the other's layer boundaries (barrier,
+    // descriptor load, first operand read).  Measured (tools/ab/host_profile_render.py, train_loop.py): 128-ray render 0.408 ->
+    // 0.358 ms, 128 / 256-ray steps -2 %; with several passes per workgroup the doubled weight stream costs what the overlap gains
+    // (800-ray render 2.02 -> 2.07 ms) - those stay one workgroup per CU.  Same tiles, same arithmetic: bit-identical.
     if (passes > 0) {
-        out[k++] = LatLaunch{S, n_cu, passes, 0, per_round * passes};
+        if (passes == 1 && S % 2 == 0 && S / 2 <= pair_s) out[k++] = LatLaunch{S / 2, 2 * n_cu, 1, 0, per_round};
+        else out[k++] = LatLaunch{S, n_cu, passes, 0, per_round * passes};
         done = per_round * passes;
     }
     const int64_t r = n16 - done;
     if (r > 0) {
-        const int S2 = (int)std::min<int64_t>(s_max, (r + n_cu - 1) / n_cu);
+        int S2 = (int)std::min<int64_t>(s_max, (r + n_cu - 1) / n_cu);
+        if (S2 % 2 == 0 && S2 / 2 <= pair_s) S2 /= 2;
         out[k++] = LatLaunch{S2, (int)((r + S2 - 1) / S2), 1, done, n16};
     }
     return k;
@@ -588,7 +596,10 @@ int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t first
     make_train_layout(P, L);
     const int64_t t0 = first_sample / 16, n16 = (A.n + 15) / 16 - t0;
     LatLaunch Q[2];
-    const int nq = lat_split(n16, n_cu, s_max, Q);
+    int pair_s = 0;
+    for (int h = 1; h <= 2; ++h)
+        if (2 * lat_lds_fwd(h, P).total <= 160 * 1024) pair_s = h;
+    const int nq = lat_split(n16, n_cu, s_max, Q, pair_s);
     for (int i = 0; i < nq; ++i) {
         Q[i].tile_off += t0;
         Q[i].tile_end += t0;
@@ -663,7 +674,10 @@ int launch_bwd_lat(const Plan &P, const BwdArgs &A, hipStream_t s, int64_t first
     make_train_layout(P, L);
     const int64_t t0 = first_sample / 16, n16 = (A.n + 15) / 16 - t0;
     LatLaunch Q[2];
-    const int nq = lat_split(n16, n_cu, s_max, Q);
+    int pair_s = 0;
+    for (int h = 1; h <= 2; ++h)
+        if (2 * lat_lds(h, 0, 0, (P.n_hidden + 2) * 512).total <= 160 * 1024) pair_s = h;
+    const int nq = lat_split(n16, n_cu, s_max, Q, pair_s);
     for (int i = 0; i < nq; ++i) {
         Q[i].tile_off += t0;
         Q[i].tile_end += t0;

@@ -259,11 +259,16 @@ class _FusedMlpFn(torch.autograd.Function):
             # default: a quarter of what this process can get on THIS device - free at the driver plus what torch's caching
             # allocator holds without using (driver-free memory alone shrinks as the cache fills, so the same batch
             # could flip between the stored and the block-wise backward) - decided ONCE per net and device, not per forward
+            # ... but not forever: a call that wants to STORE its activations under the remembered budget looks at what
+            # is obtainable now, and a budget remembered from emptier times is replaced - so a second pipeline, larger batches or
+            # validation frames that arrived in between turn the call to the block-wise backward instead of an out-of-memory error
             cache = net.__dict__.setdefault("_activation_budget_cache", {})
             budget = cache.get(dev.index)
-            if budget is None:
+            need = 4 * (act_floats + dy_floats + gpart_floats)
+            if budget is None or (need <= budget and need > (1 << 28)):
                 free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                budget = cache[dev.index] = int(0.25 * free)
+                if budget is None or need > 0.5 * free:
+                    budget = cache[dev.index] = int(0.25 * free)
         budget = int(budget or 0)
         ctx.block = 0
         if budget > 0 and 4 * (act_floats + dy_floats + gpart_floats) > budget and n > group:
@@ -433,11 +438,12 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
     def __init__(self, n_layers=8, width=256, positions_dim=60, directions_dim=24, additional_input_dim=0,
                  skips=[4], use_directional_input=1):
         super(RenderRayNet, self).__init__()
-        if not 2 <= int(width) <= MAX_WIDTH or not 1 <= int(n_layers) <= 16:
-            # the reference's parser accepts any --netwidth / --netdepth (config_parser.py:19-20); every configuration it ships
-            # uses 256 / 8.  Fail here, by name, rather than at the first forward
-            raise ValueError(f"RenderRayNet: width {width} / n_layers {n_layers} not supported by the HIP kernels: "
-                             f"2 <= width <= {MAX_WIDTH} (the layer chain is register-resident), 1 <= n_layers <= 16")
+        if int(width) < 2 or int(n_layers) < 1:
+            raise ValueError(f"RenderRayNet: width {width} / n_layers {n_layers}: need width >= 2 and n_layers >= 1")
+        # the reference's parser accepts any --netwidth / --netdepth (config_parser.py:19-20); every configuration it ships uses
+        # 256 / 8.  The fused kernels keep the layer chain in registers up to 512 features and 16 layers; above that the net runs
+        # layer by layer (layered.py, csrc/linear.hip: one exact-fp32 MFMA GEMM per nn.Linear, activations in HBM) - r06
+        self._layered = int(width) > MAX_WIDTH or int(n_layers) > 16
         self.n_layers = n_layers
         self.width = width
         self.positions_dim = positions_dim
@@ -617,6 +623,12 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         (models/render_ray_net.py:42-61)."""
         if not x.is_cuda:
             raise RuntimeError("RenderRayNet.forward: input must be on the GPU (no CPU path)")
+        if self._layered:
+            from . import layered
+            xf = x.reshape(-1, x.shape[-1]).float()
+            pin = self.positions_dim + self.additional_input_dim
+            dd = xf[:, xf.shape[1] - self.direcions_dim:] if self.use_directional_input else None      # :43-44
+            return layered.render_ray_net(self, xf[:, :pin], dd).reshape(x.shape[:-1] + (4,))
         desc = self.desc_for_encoded()
         xf = x.reshape(-1, x.shape[-1]).contiguous().float()
         n = xf.shape[0]
@@ -639,7 +651,7 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
         [n/samples_per_ray, 3] (per ray) or [n, 3] (per sample), un-normalised; additional: optional
         [n/samples_per_ray, additional_input_dim] per-ray constants whose weight columns sit after
         (add_first=False) or before (add_first=True) the position-encoding columns.  Returns raw [n, 4]."""
-        desc = self.desc_for_encoders(position_encoder, direction_encoder, add_first)
+        desc = self.desc_for_encoders(position_encoder, direction_encoder, add_first) if not self._layered else None
         _need_f32_cuda("RenderRayNet.forward_fused", positions, directions, additional)
         x = positions.reshape(-1, 3).contiguous()
         n = x.shape[0]
@@ -655,6 +667,11 @@ class RenderRayNet(_PackedWeightsEpoch, nn.Module):
             if additional is None:
                 raise RuntimeError("forward_fused: this net needs `additional` inputs")
             add = additional.reshape(-1, self.additional_input_dim).contiguous()
+        if self._layered:
+            from . import layered
+            if 3 * position_encoder.output_dim != self.positions_dim or 3 * direction_encoder.output_dim != self.direcions_dim:
+                raise RuntimeError("RenderRayNet: encoder output sizes do not match positions_dim/directions_dim")
+            return layered.render_ray_net_fused(self, x, d, int(samples_per_ray), position_encoder, direction_encoder, add, add_first)
         if torch.is_grad_enabled() and (x.requires_grad or d.requires_grad or (add is not None and add.requires_grad) or
                                         any(p.requires_grad for p in self.parameters())):
             return _FusedMlpFn.apply(self, desc, x, d, per_sample, int(samples_per_ray), add, *self._ordered_params())
@@ -752,8 +769,10 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
 
     def __init__(self, n_layers=8, width=256, positions_dim=60, pose_dim=24):
         super(WarpFieldNet, self).__init__()
-        if not 1 <= int(width) <= MAX_WARP_WIDTH:
-            raise ValueError(f"WarpFieldNet: width {width} not supported by the HIP kernels (1 <= --netwidth_warp <= {MAX_WARP_WIDTH})")
+        if int(width) < 1:
+            raise ValueError(f"WarpFieldNet: width {width}: need width >= 1")
+        # (config_parser.py:30 --netwidth_warp is free: above the fused kernels' 256 features the net runs layer by layer, layered.py)
+        self._layered = int(width) > MAX_WARP_WIDTH
         self.positions_dim = positions_dim
         self.direcions_dim = pose_dim  # (sic) reference attribute name, :12
         self.width = width
@@ -811,6 +830,9 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
             raise RuntimeError(f"WarpFieldNet.forward: rows of {x.shape[-1]} floats, linear1 expects "
                                f"{self.linear1.weight.shape[1]}")
         rows = x.reshape(-1, x.shape[-1]).contiguous().float()
+        if self._layered:
+            from . import layered
+            return layered.warp_field_net(self, rows).reshape(x.shape[:-1] + (3,))
         desc = _lib.WarpDesc(self.width, 0, 0, rows.shape[1])
         n = rows.shape[0]
         if torch.is_grad_enabled() and (rows.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -838,6 +860,13 @@ class WarpFieldNet(_PackedWeightsEpoch, nn.Module):
         o = ray_translation.reshape(-1, 3).contiguous()
         if pe.shape[0] * samples_per_ray != n or o.shape[0] * samples_per_ray != n:
             raise RuntimeError("forward_fused: per-ray inputs do not match positions / samples_per_ray")
+        if self._layered:      # models/smpl_nerf_pipeline.py:38-56: rows = [PE(x) | pose], x' = x + warp, per-sample directions x' - o
+            from . import layered
+            xs = x.detach()
+            rows = torch.cat([position_encoder.encode(xs), pe.repeat_interleave(int(samples_per_ray), dim=0)], -1)
+            warp = layered.warp_field_net(self, rows)
+            warped = xs + warp
+            return warp, warped, warped - o.detach().repeat_interleave(int(samples_per_ray), dim=0)
         if torch.is_grad_enabled() and (pe.requires_grad or any(p.requires_grad for p in self.parameters())):
             return _WarpFn.apply(self, desc, x.detach(), pe, o.detach(), int(samples_per_ray), *self._params())
         warp, warped, sdirs = (torch.empty((n, 3), device=x.device, dtype=torch.float32) for _ in range(3))
@@ -901,6 +930,18 @@ class AppendVerticesNet(RenderRayNet):
         _need_f32_cuda("AppendVerticesNet.forward_rays", ray_inputs, directions)
         add = ray_inputs.reshape(-1, self.positions_dim).contiguous()
         d = directions.reshape(-1, 3).contiguous()
+        if self._layered:
+            from . import layered
+            from .ops import PositionalEncoder
+            L, ident = _encoder_shape(self.direcions_dim)
+            dn = d.detach() / torch.norm(d.detach(), dim=-1, keepdim=True)
+            dd = PositionalEncoder(L, bool(ident)).encode(dn).repeat_interleave(int(samples_per_ray), dim=0)
+            keep = self.additional_input_dim
+            try:
+                self.additional_input_dim = 0
+                return layered.render_ray_net(self, add.repeat_interleave(int(samples_per_ray), dim=0), dd)
+            finally:
+                self.additional_input_dim = keep
         dummy_x = torch.zeros((n, 3), device=add.device, dtype=torch.float32)   # no position encoder: never read for slots
         if torch.is_grad_enabled() and (add.requires_grad or any(p.requires_grad for p in self.parameters())):
             # `add` keeps its graph: the vertex floats come from smpl_model(smpl_estimator(images)), whose parameters

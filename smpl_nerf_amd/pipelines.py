@@ -120,8 +120,8 @@ class NerfPipeline(nn.Module):
         if torch.is_grad_enabled() or _lib._PROFILE is not None or self.keep_fine or getattr(self.args, "strict_cumsum", 0):
             return False
         nets = [self.model_coarse, self.model_fine] + ([self.model_warp_field] if hasattr(self, "model_warp_field") else [])
-        if len({getattr(m, "precision", "fp32") for m in nets}) != 1:
-            return False
+        if len({getattr(m, "precision", "fp32") for m in nets}) != 1 or any(getattr(m, "_layered", False) for m in nets):
+            return False      # (nets above the fused kernels' widths run layer by layer: layered.py)
         return all(torch.is_tensor(t) and t.is_cuda and (t.dtype == torch.float32) for t in data[:4])
 
     def forward(self, data):
@@ -161,6 +161,9 @@ class NerfPipeline(nn.Module):
         same outputs, one host call instead of five - the entry point a non-Python host binds.  No autograd."""
         from . import _lib
         from ._lib import check, ptr, current_stream
+        if any(getattr(m, "_layered", False) for m in self.children()):      # (widths above the fused kernels': layered.py)
+            with torch.no_grad():
+                return self._forward_calls(data)
         ray_samples, ray_translation, ray_direction, z_vals, _ = data
         args = self.args
         B, Nc = z_vals.shape
@@ -263,6 +266,9 @@ class SmplNerfPipeline(NerfPipeline):
         of eight) go through forward() under no_grad - the same kernels, the same results."""
         from . import _lib
         from ._lib import check, ptr, current_stream
+        if any(getattr(m, "_layered", False) for m in self.children()):      # (widths above the fused kernels': layered.py)
+            with torch.no_grad():
+                return self._forward_calls(data)
         ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
         args = self.args
         if not args.human_pose_encoding or not args.run_fine:
@@ -407,6 +413,9 @@ class AppendSmplParamsPipeline(NerfPipeline):
         rows as the nets' per-ray additional inputs, folded per ray inside the call in fp32.  Same outputs as forward()."""
         from . import _lib
         from ._lib import check, ptr, current_stream
+        if any(getattr(m, "_layered", False) for m in self.children()):      # (widths above the fused kernels': layered.py)
+            with torch.no_grad():
+                return self._forward_calls(data)
         ray_samples, ray_translation, ray_direction, z_vals, goal_pose, _ = data
         args = self.args
         B, Nc = z_vals.shape

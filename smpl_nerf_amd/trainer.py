@@ -380,6 +380,9 @@ class DataParallelTrainer:
         want = AppendVerticesNet if verts else RenderRayNet
         if type(mc) is not want or type(mf) is not want or mc is mf:
             return None
+        if getattr(mc, "_layered", False) or getattr(mf, "_layered", False) or \
+                (smpl and getattr(pipe.model_warp_field, "_layered", False)):
+            return None        # widths above the fused kernels': the layer-by-layer autograd path (layered.py)
         mine = [mc, mf]
         upstream = []      # trained modules in front of the nets (AppendVerticesSolver's second parameter group: the pose estimator,
         if verts:          # solver/append_vertices_solver.py, lrate_pose): they receive d loss / d vertices from the call (r05)

@@ -82,10 +82,14 @@ def test_mlp_descriptor_arithmetic(lib):
     assert lib.snerf_mlp_pack_f32(bad, None, None, None) == -1 and b"width must be in [2, 512]" in lib.snerf_last_error_string()
     from smpl_nerf_amd.nets import RenderRayNet, WarpFieldNet
     RenderRayNet(8, 320, 60, 24)                                 # config_parser.py:20 accepts it, and so do the kernels since r05
-    with pytest.raises(ValueError, match="width 640"):          # the limit is named up front
-        RenderRayNet(8, 640, 60, 24)
-    with pytest.raises(ValueError, match="netwidth_warp"):
-        WarpFieldNet(8, 512, 60, 40)
+    # r06: any width constructs - above the fused kernels' limits (the snerf_mlp_* entries above stay at 512: SNERF_E_BADARG) the net
+    # runs one nn.Linear at a time through snerf_linear_* (smpl_nerf_amd/layered.py)
+    assert RenderRayNet(8, 640, 60, 24)._layered and not RenderRayNet(8, 512, 60, 24)._layered
+    assert WarpFieldNet(8, 512, 60, 40)._layered and not WarpFieldNet(8, 256, 60, 40)._layered
+    assert RenderRayNet(20, 64, 60, 24)._layered                 # ... and any --netdepth (config_parser.py:19)
+    with pytest.raises(ValueError):
+        RenderRayNet(8, 1, 60, 24)
+    assert lib.snerf_linear_bwd_weight_scratch_floats(1000, 768, 828) == 4 * (768 * 828 + 768)
     assert lib.snerf_mlp_packed_bf16_bytes(w200, 3) < 0     # the split-precision entry points: width 256 only
     assert lib.snerf_mlp_pack_f32(d, None, None, None) == -1
 
