@@ -587,7 +587,7 @@ def main():
     ap.add_argument("--points", default="64,800,2048",
                     help="comma-separated ray counts of the extra operating points (render; training at 2048 when among them); "
                          "empty = skip")
-    ap.add_argument("--netwidth-points", default="512",
+    ap.add_argument("--netwidth-points", default="512,768",
                     help="comma-separated --netwidth values above 256 (config_parser.py:20) measured as extra points of the nerf "
                          "workload: one frame rendered, one training step, each with its fraction of the fp32 MFMA peak; empty = skip")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -800,7 +800,8 @@ def main():
                 dt = (time.perf_counter() - t0) / steps
             k = pp.summary()
         # the RenderRayNet launches' own time where the pipeline ran them as separate C-ABI calls; else the whole step
-        mlp_ms = sum(v[1] for n, v in k.items() if n.startswith("mlp_fwd")) / steps
+        # (above 512 features: the layer-by-layer path - its GEMM launches are the "linear_fwd" records, smpl_nerf_amd/layered.py)
+        mlp_ms = sum(v[1] for n, v in k.items() if n.startswith(("mlp_fwd", "linear_fwd"))) / steps
         tf = flop * rays * 256 / (mlp_ms * 1e-3) / 1e12 if mlp_ms else None
         tf_step = flop * rays * 256 / dt / 1e12
         n_train = min(4096, rays)
@@ -816,7 +817,9 @@ def main():
         torch.cuda.synchronize()
         dts = (time.perf_counter() - t0) / steps
         ttf = 3 * flop * n_train * 256 / dts / 1e12
-        return {"netwidth": width, "kernel_width": (width + 63) // 64 * 64, "flop_per_eval": flop, "rays_per_step": rays,
+        return {"netwidth": width, "kernel_width": (width + 63) // 64 * 64 if width <= 512 else None,
+                "path": "fused register-resident chain" if width <= 512 else "layer by layer (snerf_linear_*: one fp32 MFMA GEMM per nn.Linear)",
+                "flop_per_eval": flop, "rays_per_step": rays,
                 "render_ms_per_step": dt * 1e3, "render_ray_samples_per_s": rays * 256 / dt,
                 "render_mlp_kernels_ms_per_step": mlp_ms or None, "render_mlp_roofline_frac": tf / PEAK_F32_MFMA_TFLOPS if tf else None,
                 "render_roofline_frac_whole_step": tf_step / PEAK_F32_MFMA_TFLOPS,

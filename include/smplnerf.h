@@ -28,40 +28,10 @@
  *     (fork / join of the concurrent backward; snerf_shutdown() destroys them);
  *   - per HIP device ordinal (up to 64 devices): the CU count and, per kernel, whether its dynamic-LDS limit was
  *     raised (hipFuncSetAttribute is per device) - so one process may drive several GPUs through the library;
- *   - tuning knobs: the environment variables below are read ONCE, at the first call that consults them.  They choose
- *     between equivalent kernels / launch shapes for A/B measurements; results are identical under every setting - except
- *     the two fold knobs, which change the summation order of the folded columns - and a release build can ignore them.
- *     (unset = default)
- *       SNERF_FWD_PERSISTENT=0            fp32 render kernel: one workgroup per 128-sample tile instead of one per CU
- *       SNERF_FWD_WAVES=4                 fp32 kernels: two 4-wave workgroups per CU instead of one 8-wave workgroup
- *       SNERF_FWD_SMALL_TILES=0           fp32 forward: 128-sample tiles also for calls of <= 64 x CUs samples (default: 64-sample
- *                                         tiles there - half the latency of a small call)
- *       SNERF_BF16_PERSISTENT=0           split-precision forward / dgrad: one workgroup per tile
- *       SNERF_WARP_RESIDENT=0             warp net: slab-streaming kernel instead of the LDS-resident one
- *       SNERF_WARP_BWD_RING=1             warp backward: slab-ring dgrad instead of the ring-free one
- *       SNERF_MLP_FOLD=0                  fp32 inference of nets with additional inputs: their columns as k-blocks per sample even
- *                                         when the caller brings a fold workspace (snerf_mlp_fwd_ws_f32)
- *       SNERF_WARP_FOLD=0                 warp inference: the pose columns of linear1 as k-blocks per sample even with a workspace
- *       SNERF_WGRAD_BF16=0                split-precision steps: all weight-gradient GEMMs in fp32
- *       SNERF_WGRAD_F16=0                 f16x3 steps: three bf16 parts for the wide weight-gradient GEMMs
- *       SNERF_WGRAD_NARROW_F16=0          f16x3 steps: narrow weight-gradient jobs in fp32
- *       SNERF_WGRAD_F16_SPLIT_PER_WAVE=1  f16x3 wide weight-gradient GEMMs: every wave converts its own operands
- *       SNERF_WGRAD_FOLD=0                fp32 steps: every narrow weight-gradient pair as its own job (default: the sigma head
- *                                         and the direction-encoding columns ride with directional_input's wide job)
- *       SNERF_WGRAD_SMALL_CHUNKS=0        narrow weight-gradient jobs of small calls: 1024-sample chunks as for large calls (default:
- *                                         chunks of >= 64 samples filling one round of the workgroup slots; changes the summation
- *                                         order of those gradients like a different batch size does)
- *       SNERF_LAT=0                       small calls: the throughput kernels everywhere (default: the latency-class kernels of
- *                                         csrc/mlp_lat.hip where their cost model wins; bit-identical results).  SNERF_LAT_FWD=0 /
- *                                         SNERF_LAT_BWD=0 / SNERF_LAT_BWD_IG=0: the same for the forwards / the dgrads / the dgrads
- *                                         with input gradients only; SNERF_LAT_MAX_TILES_PER_CU=k: the latency kernels for every
- *                                         call of up to k 16-sample tiles per CU, whatever the model says
- *       SNERF_DEBUG_POISON_LDS=1          debugging aid, not a tuning knob: every checked launch is followed by a kernel on the
- *                                         NULL stream that fills the LDS of every CU with NaNs (a kernel that reads LDS it has not
- *                                         written then computes with NaNs instead of its predecessor's leftovers); slow
- *     (smpl_nerf_amd/ reads two more, on the Python side only: SNERF_PRECISION = default arithmetic of new nets;
- *     SNERF_TRAIN_ACT_GB = activation budget of a training forward call on the autograd path, default a quarter of the
- *     device memory free at the call; SNERF_TRAIN_CHUNK_RAYS = rays per chunk of the one-call training step, default 2048.)
+ *   - environment variables, read ONCE at the first call that consults them: SNERF_LAT, SNERF_MLP_FOLD, SNERF_WARP_FOLD,
+ *     SNERF_RCCL_LIB and the debugging aid SNERF_DEBUG_POISON_LDS.  INTEGRATION.md ("Environment variables") describes them and
+ *     the Python host's; a release build can ignore all of them (results are identical under every setting, up to the summation
+ *     order of the folded per-ray columns).
  */
 #ifndef SMPLNERF_H
 #define SMPLNERF_H

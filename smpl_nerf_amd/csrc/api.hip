@@ -75,22 +75,8 @@ const Tuning &tuning() {
             return e ? atoi(e) != 0 : dflt;
         };
         Tuning k;
-        k.fwd_persistent = flag("SNERF_FWD_PERSISTENT", true);
-        const char *w = getenv("SNERF_FWD_WAVES");
-        k.fwd_waves = (w && atoi(w) == 4) ? 4 : 8;
-        k.fwd_small_tiles = flag("SNERF_FWD_SMALL_TILES", true);
-        k.bf16_persistent = flag("SNERF_BF16_PERSISTENT", true);
-        k.warp_resident = flag("SNERF_WARP_RESIDENT", true);
-        k.warp_bwd_ring = flag("SNERF_WARP_BWD_RING", false);
         k.warp_fold = flag("SNERF_WARP_FOLD", true);
         k.mlp_fold = flag("SNERF_MLP_FOLD", true);
-        k.wgrad_bf16 = flag("SNERF_WGRAD_BF16", true);
-        k.wgrad_f16 = flag("SNERF_WGRAD_F16", true);
-        k.wgrad_narrow_f16 = flag("SNERF_WGRAD_NARROW_F16", true);
-        k.wgrad_f16_split_per_wave = flag("SNERF_WGRAD_F16_SPLIT_PER_WAVE", false);
-        const char *fo = getenv("SNERF_WGRAD_FOLD");
-        k.wgrad_fold = fo ? (atoi(fo) != 0 ? 1 : 0) : 1;
-        k.wgrad_small_chunks = flag("SNERF_WGRAD_SMALL_CHUNKS", true);
         return k;
     }();
     return t;

@@ -57,7 +57,7 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     constexpr int NT = NWAVES * 64;
     constexpr int T = WIDTH / 16;   // tiles of the trunk
     constexpr int TD = WIDTH / 32;  // tiles of the directional branch
-    extern __shared__ __attribute__((aligned(16))) float ring[];  // RING_BYTES (SNERF_LAUNCH_RING)
+    extern __shared__ __attribute__((aligned(16))) float ring[];  // RING4_BYTES (DMA pipe: SNERF_LAUNCH_RING4) or RING_BYTES (SNERF_LAUNCH_RING)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,14 +68,12 @@ __device__ __forceinline__ void mlp_fwd_body(const FwdArgs &A) {
     // Persistent workgroups: one per CU (the 99 KiB ring allows no more), each walking the sample tiles blockIdx.x,
     // blockIdx.x + gridDim.x, ...  The weight ring keeps rolling from one tile into the next (the stream wraps around),
     // so only the first tile of a workgroup pays the pipeline fill and no CU idles between two workgroups.
-    // (SNERF_TRAIN_PERSIST: the training forward of the 256 kernel as persistent workgroups on the DMA pipe - its staging registers are
-    // what the persistent loop did not fit beside; A/B knob, mlp_device.h)
-    using Pipe = std::conditional_t<((TRAIN ? SNERF_TRAIN_PERSIST : SNERF_INFER_DMA) && WIDTH == 256 && NWAVES == 8), SlabPipeDma<NT>, PipeFor<WIDTH, NT>>;
+    using Pipe = std::conditional_t<(!TRAIN && WIDTH == 256 && NWAVES == 8), SlabPipeDma<NT>, PipeFor<WIDTH, NT>>;
     Pipe pipe;
     // raw inputs of a tile (positions, direction), fetched while the previous tile's last layers run so that a tile
     // never starts by waiting on HBM (inference variant; the training variant sits at the register limit)
     // The training variant (at the register limit: the persistent loop would spill) runs one workgroup per tile.
-    constexpr bool PERSIST = !TRAIN || (SNERF_TRAIN_PERSIST && WIDTH == 256 && NWAVES == 8);
+    constexpr bool PERSIST = !TRAIN;
     constexpr bool PREFETCH = !ENCODED && PERSIST && !TRAIN;
     float raw_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto load_raw = [&](int64_t t) __attribute__((always_inline)) {
@@ -327,11 +325,7 @@ __global__ __launch_bounds__(256) void mlp_add_fold_kernel(Plan P, const float *
     out[e] = sum;
 }
 
-#if SNERF_WIDE_DMA
 #define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING4
-#else
-#define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING
-#endif
 template <int NW, bool ENCODED, bool TRAIN, bool FOLD = false>
 static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t n_limit = -1) {
     const int64_t tile = NW * 16;
@@ -341,13 +335,10 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
     if (B.n_tiles > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd: n too large");
     const int n_cu = device_cu_count("mlp_fwd");  // one persistent workgroup per CU
     if (n_cu < 1) return n_cu;
-    // SNERF_FWD_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
-    const bool persistent = tuning().fwd_persistent;
-    constexpr bool TRAIN_PERSIST = TRAIN && SNERF_TRAIN_PERSIST && NW == 8;   // (width 256 only: the others ignore total_slabs)
-    const int64_t grid = ((!TRAIN || (TRAIN_PERSIST && P.width == 256)) && persistent && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
+    const int64_t grid = (!TRAIN && B.n_tiles > n_cu) ? n_cu : B.n_tiles;
     if constexpr (FOLD) {
         if (P.width == 256) {
-            if constexpr (SNERF_INFER_DMA && NW == 8) SNERF_LAUNCH_RING4((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+            if constexpr (NW == 8) SNERF_LAUNCH_RING4((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
             else SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         }
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_fold_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, B);
@@ -363,7 +354,7 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
                 return fail(SNERF_E_BADARG, "mlp_fwd: widths above 256 run 4-wave workgroups");
             }
         } else if (P.width == 256) {
-            if constexpr (TRAIN_PERSIST || (!TRAIN && SNERF_INFER_DMA && NW == 8)) SNERF_LAUNCH_RING4((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
+            if constexpr (!TRAIN && NW == 8) SNERF_LAUNCH_RING4((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
             else SNERF_LAUNCH_RING((mlp_fwd_kernel<256, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
         }
         else if (P.width == 128) SNERF_LAUNCH_RING((mlp_fwd_kernel<128, NW, ENCODED, TRAIN>), dim3((unsigned)grid), dim3(NW * 64), s, B);
@@ -375,7 +366,7 @@ static int launch_fwd_nw(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t
 // slots (layers with an additional-input segment) and bytes of the per-ray fold table of a call, 0 when the fold does not apply
 // (a fold pays when a ray's vector is reused: with fewer than 8 samples per ray the table costs more than it saves)
 static int64_t fold_table_bytes(const Plan &P, int64_t n, int spr, int *slots_out = nullptr) {
-    if (!P.add_dim || P.width > 256 || !tuning().mlp_fold || tuning().fwd_waves == 4 || spr < 8 || n <= 0 || n % spr != 0) return 0;
+    if (!P.add_dim || P.width > 256 || !tuning().mlp_fold || spr < 8 || n <= 0 || n % spr != 0) return 0;
     int slots = 0;
     for (int l = 0; l < P.nlayers; ++l)
         for (int sg = 0; sg < P.layer[l].nseg; ++sg) slots += P.layer[l].seg[sg].type == SEG_ADD ? 1 : 0;
@@ -409,15 +400,13 @@ static int launch_fwd_folded(const Plan &P, const FwdArgs &A, hipStream_t s) {
 
 template <bool ENCODED, bool TRAIN>
 static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
-    // 8 waves (128 samples) per workgroup = one workgroup per CU, 2 waves per SIMD (85.7 % of the fp32 MFMA
-    // peak on the 128x128 frame); SNERF_FWD_WAVES=4 selects two independent 4-wave workgroups per CU instead
-    // (83.1 %; twice the L2->LDS weight traffic).  Tuning knob, read once.
+    // 8 waves (128 samples) per workgroup = one workgroup per CU, 2 waves per SIMD (two independent 4-wave workgroups per CU
+    // measured 83.1 % against 85.7 % of the fp32 MFMA peak on the 128 x 128 frame, at twice the L2 -> LDS weight traffic: r02)
     if (P.width > 256) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);   // (--netwidth above 256: mlp_plan.h make_plan)
-    if (!ENCODED && !TRAIN && tuning().fwd_waves != 4) {   // per-ray additional inputs + a workspace: the folded form (8-wave tiles)
+    if (!ENCODED && !TRAIN) {   // per-ray additional inputs + a workspace: the folded form (8-wave tiles)
         const int rc = launch_fwd_folded<FWD_WAVES>(P, A, s);
         if (rc != 1) return rc;
     }
-    if (tuning().fwd_waves == 4) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
     // Calls of a few 16-sample tiles per CU (the README's 64-ray batches, inference.py's 800 rays): the latency-class kernels
     // (mlp_lat.hip: a tile's output features split over the waves of a workgroup; bit-identical results)
     if constexpr (!ENCODED) {
@@ -433,7 +422,7 @@ static int launch_fwd(const Plan &P, const FwdArgs &A, hipStream_t s) {
     // 64 x CUs samples is one tile's latency, not throughput (same per-sample arithmetic: bit-identical results).
     const int n_cu = device_cu_count("mlp_fwd");
     if (n_cu < 1) return n_cu;
-    if (tuning().fwd_small_tiles && A.n <= (int64_t)64 * n_cu) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
+    if (A.n <= (int64_t)64 * n_cu) return launch_fwd_nw<4, ENCODED, TRAIN>(P, A, s);
     return launch_fwd_nw<FWD_WAVES, ENCODED, TRAIN>(P, A, s);
 }
 

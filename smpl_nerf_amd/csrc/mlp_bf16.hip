@@ -436,9 +436,7 @@ static int launch_bf16(const FwdArgs &A, hipStream_t s) {
         return rc;
     const int n_cu = device_cu_count("mlp_fwd_bf16");  // one persistent workgroup per CU
     if (n_cu < 1) return n_cu;
-    // SNERF_BF16_PERSISTENT=0: one workgroup per tile (every tile pays the pipeline fill) - kept for A/B measurements
-    const bool persistent = tuning().bf16_persistent;
-    const int64_t grid = (persistent && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
+    const int64_t grid = A.n_tiles > n_cu ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_fwd_bf16: n too large");
     hipLaunchKernelGGL((mlp_fwd_bf16_kernel<256, NW, NS, TRAIN, FMT>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_fwd_bf16");

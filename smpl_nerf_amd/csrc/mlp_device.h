@@ -1,6 +1,7 @@
-// Device-side building blocks shared by the forward (mlp.hip) and training (mlp_train.hip) kernels:
-// the slab pipe (L2 -> registers -> 3-slot LDS ring), the k-block MFMA step, the layer walker and the
-// in-register positional-encoding operands.  See mlp_plan.h for the operand algebra.
+// Device-side building blocks shared by the forward (mlp.hip) and training (mlp_train.hip) kernels: the two slab pipes - SlabPipeDma
+// (L2 -> LDS by global_load_lds into a 4-slot ring: the headline inference kernel of width 256 and every kernel of the widths above
+// 256) and SlabPipe (L2 -> registers -> 3-slot LDS ring: training forward and dgrad up to width 256) -, the k-block MFMA step, the
+// layer walker and the in-register positional-encoding operands.  See mlp_plan.h for the operand algebra.
 #pragma once
 #include <type_traits>
 #include "snerf_common.h"
@@ -145,13 +146,8 @@ __device__ __forceinline__ void store_mask(float *buf, int mask_row, int idx, in
     }
 }
 
-#ifdef SNERF_DMA_MIN_WIDTH
-#define SNERF_DMA_MIN_WIDTH_ SNERF_DMA_MIN_WIDTH
-#else
-#define SNERF_DMA_MIN_WIDTH_ 257
-#endif
 // The 3-slot ring (99 KiB) is dynamic LDS: a launch gets 64 KiB unless the limit is raised per kernel once.
-constexpr int RING_BYTES = (SNERF_DMA_MIN_WIDTH_ <= 256 ? 4 : 3) * SLAB_FLOATS * 4;
+constexpr int RING_BYTES = 3 * SLAB_FLOATS * 4;
 #define SNERF_LAUNCH_RING(kernel, grid, block, stream, ...)                                                            \
     do {                                                                                                               \
         static ::snerf::LdsRaised snerf_lds_raised_; /* per device (snerf_common.h) */                                 \
@@ -171,24 +167,10 @@ constexpr int RING4_BYTES = 4 * SLAB_FLOATS * 4;
             return snerf_rc_;                                                                                          \
         hipLaunchKernelGGL(kernel, grid, block, ::snerf::RING4_BYTES, stream, __VA_ARGS__);                            \
     } while (0)
-#ifndef SNERF_WIDE_DMA
-#define SNERF_WIDE_DMA 1   // widths above 256: slabs global -> LDS by DMA into a 4-slot ring (0: the register-staged 3-slot ring)
-#endif
-#ifndef SNERF_INFER_DMA
-#define SNERF_INFER_DMA 1   // the 8-wave inference kernel of width 256 on the DMA pipe (r05: 38.07 -> 37.70 ms per frame, three interleaved
-                          // pairs on one box; 0 = the register-staged 3-slot ring of rounds 1-4.  The training forward and the dgrad
-                          // measured no gain from it and keep the register-staged ring)
-#endif
-#ifndef SNERF_DGRAD_DMA
-#define SNERF_DGRAD_DMA 0    // (A/B knob, mlp_train.hip: the 8-wave dgrad of width 256 on the DMA pipe - 4096-ray step 31.04 / 31.11 ms
-                            // without / with, three interleaved pairs: kept off)
-#endif
-#ifndef SNERF_TRAIN_PERSIST
-#define SNERF_TRAIN_PERSIST 0   // (A/B knob, mlp.hip: persistent training forward of the 256 kernel on the DMA pipe)
-#endif
-#ifndef SNERF_DMA_MIN_WIDTH
-#define SNERF_DMA_MIN_WIDTH 257   // (A/B knob: 0 = every width on the DMA pipe; the launches then take the 4-slot ring's LDS)
-#endif
+// Which kernels take which pipe (r05 measurements, DESIGN_HISTORY.md; the A/B switches that selected them are gone - the patches
+// under tools/ab/ are the record): the widths above 256 (one wave per SIMD) and the 8-wave inference kernel of width 256 stream
+// their slabs global -> LDS by DMA into the 4-slot ring (SlabPipeDma, below); the training forward and the dgrad of the widths up
+// to 256 measured no gain from it and keep the register-staged 3-slot ring (SlabPipe).
 
 // Streams the slab sequence global -> registers -> LDS ring (3 slots).
 template <int NT>
@@ -330,7 +312,7 @@ struct SlabPipeDma {
 };
 // the pipe of a kernel of WIDTH features on NT threads
 template <int WIDTH, int NT>
-using PipeFor = std::conditional_t<(WIDTH >= SNERF_DMA_MIN_WIDTH && SNERF_WIDE_DMA), SlabPipeDma<NT>, SlabPipe<NT>>;
+using PipeFor = std::conditional_t<(WIDTH > 256), SlabPipeDma<NT>, SlabPipe<NT>>;
 
 // per-lane view of the sample this lane works for
 struct SampleCtx {
@@ -398,9 +380,6 @@ __device__ __forceinline__ f4 add_operand(const SampleCtx &c, int add_dim, int k
 struct NoMid {
     __device__ __forceinline__ void operator()() const {}
 };
-#ifndef SNERF_STAGE_MID
-#define SNERF_STAGE_MID 1   // 0: stage at the end of the slab (the form of rounds 1-4; A/B knob)
-#endif
 template <int T_OUT, class Mid = NoMid>
 __device__ __forceinline__ void kblock(const float *a_kb, const float *a_next, f4 b, f4 (&acc)[T_OUT], f4 &pa0, f4 &pa1,
                                        int lane, Mid mid = Mid{}) {
@@ -477,7 +456,7 @@ struct LayerRun {
     __device__ __forceinline__ void step(f4 b, f4 (&acc)[T_OUT]) {
         const float *cur = slab + kbl * (T_OUT * 256);
         const float *nxt = (kbl + 1 < KPS) ? cur + T_OUT * 256 : pipe.peek_next();
-        if constexpr (SNERF_STAGE_MID && T_OUT >= 8) {
+        if constexpr (T_OUT >= 8) {
             const bool last = kbl + 1 == KPS;     // the slab's last k-block carries the staging between its MFMAs
             kblock<T_OUT>(cur, nxt, b, acc, pipe.pa0, pipe.pa1, lane, [&]() __attribute__((always_inline)) {
                 if (last) pipe.stage();

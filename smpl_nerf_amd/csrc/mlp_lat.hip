@@ -453,19 +453,6 @@ bool lat_enabled() {
     static const bool on = [] { const char *e = getenv("SNERF_LAT"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
-// SNERF_LAT_MAX_TILES_PER_CU=k (experiments): the latency kernels for every call of up to k 16-sample tiles per CU, whatever the
-// cost model below says; unset: the model decides
-// SNERF_LAT_FWD=0 / SNERF_LAT_BWD=0 (A/B measurements): the throughput kernels for every forward / every dgrad
-static bool lat_dir_enabled(bool bwd) {
-    static const bool f = [] { const char *e = getenv("SNERF_LAT_FWD"); return e ? atoi(e) != 0 : true; }();
-    static const bool b = [] { const char *e = getenv("SNERF_LAT_BWD"); return e ? atoi(e) != 0 : true; }();
-    return bwd ? b : f;
-}
-static int lat_max_tiles_override() {
-    static const int v = [] { const char *e = getenv("SNERF_LAT_MAX_TILES_PER_CU"); return e ? atoi(e) : -1; }();
-    return v;
-}
-
 // Splits n16 tiles into a main launch (n_cu workgroups x passes x S tiles) and a remainder launch of one pass; returns the number of
 // launches (1 or 2).  The makespan is passes * S + S' tile units against the ideal n16 / n_cu: at most one unit above it.
 struct LatLaunch {
@@ -528,8 +515,6 @@ LatChoice lat_choose(int kind_i, int64_t n, int n_cu, int s_max) {
     const int64_t max_tiles = kind == LAT_DGRAD ? 4 : 64;
     static const double round64[3] = {178, 191, 170}, round128[3] = {295, 352, 314};
     const int64_t n16 = (n + 15) / 16, per_round = (int64_t)128 * n_cu;
-    const int ovr = lat_max_tiles_override();
-    if (ovr >= 0) return LatChoice{n16 <= (int64_t)ovr * n_cu ? 1 : 0, 0};
     const double t_thr = n <= (int64_t)64 * n_cu ? round64[kind] : (double)((n + per_round - 1) / per_round) * round128[kind];
     LatChoice best{0, 0};
     double t_best = t_thr;
@@ -573,7 +558,7 @@ static bool lat_covers(const Plan &P) { return lat_enabled() && P.width == 256 &
 
 template <bool TRAIN>
 LatChoice lat_choose_fwd(const Plan &P, int64_t n) {
-    if (!lat_covers(P) || !lat_dir_enabled(false)) return LatChoice{0, 0};
+    if (!lat_covers(P)) return LatChoice{0, 0};
     const int n_cu = device_cu_count("mlp_fwd_lat"), s_max = lat_s_max_fwd(P);
     if (n_cu < 1 || !s_max) return LatChoice{0, 0};
     TrainLayout L;
@@ -635,11 +620,10 @@ static int lat_s_max_bwd(const Plan &P) {
     return lat_lds(s_max, 0, 0, (P.n_hidden + 2) * 512).total > 160 * 1024 ? 0 : s_max;
 }
 // input gradients: the default-sized encoders (4 position / 2 direction k-blocks; the kernel's waves 0, 1 hold two tiles each), nets
-// that read directions, and d_x / d_dirs within the store range; SNERF_LAT_BWD_IG=0: the throughput kernel (A/B)
+// that read directions, and d_x / d_dirs within the store range
 static bool lat_ig_covers(const Plan &P, int64_t n) {
-    static const bool on = [] { const char *e = getenv("SNERF_LAT_BWD_IG"); return e ? atoi(e) != 0 : true; }();
     const PeTiles pt = bwd_pe_tiles(P);
-    return on && pt.pos == 4 && pt.dir == 2 && P.add_dim == 0 && n * 12 < (int64_t)LAT_STORE_RANGE;
+    return pt.pos == 4 && pt.dir == 2 && P.add_dim == 0 && n * 12 < (int64_t)LAT_STORE_RANGE;
 }
 // With input gradients inside a step whose two backward chains run side by side (smpl_nerf, small chunks): the throughput kernels of
 // the two nets pack - 64 rays are 64 + 192 workgroups of 64 samples, one round of the chip for both, 190 us - while each latency
@@ -647,10 +631,10 @@ static bool lat_ig_covers(const Plan &P, int64_t n) {
 // form is kept for nets that leave room for the other one (up to 3/4 tile per CU); alone on the chip (autograd path, no auxiliary
 // stream: 189 -> 74 us at 4096 samples, 189 -> 166 at 12 288) the rule of the plain dgrad holds.
 LatChoice lat_choose_bwd(const Plan &P, int64_t n, bool input_grad, bool beside_another_net) {
-    if (!lat_covers(P) || (input_grad && !lat_ig_covers(P, n)) || !lat_dir_enabled(true)) return LatChoice{0, 0};
+    if (!lat_covers(P) || (input_grad && !lat_ig_covers(P, n))) return LatChoice{0, 0};
     const int n_cu = device_cu_count("mlp_bwd_lat"), s_max = lat_s_max_bwd(P);
     if (n_cu < 1 || !s_max) return LatChoice{0, 0};
-    if (input_grad && beside_another_net && lat_max_tiles_override() < 0 && (n + 15) / 16 > (int64_t)n_cu * 3 / 4) return LatChoice{0, 0};
+    if (input_grad && beside_another_net && (n + 15) / 16 > (int64_t)n_cu * 3 / 4) return LatChoice{0, 0};
     BwdPlan B;
     make_bwd_plan(P, B, input_grad);
     TrainLayout L;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(BwdArgs A) {
         store_tile(A.dy, A.dy_sig, A.n, sample, g, g == 0 ? f4{dr[3], 0.f, 0.f, 0.f} : zero);
     }
 
-    using Pipe = std::conditional_t<(SNERF_DGRAD_DMA && WIDTH == 256 && NWAVES == 8), SlabPipeDma<NT>, PipeFor<WIDTH, NT>>;
+    using Pipe = PipeFor<WIDTH, NT>;
     Pipe pipe;
     pipe.prologue(A.packed_t, ring, tid);
 
@@ -585,9 +585,6 @@ __global__ __launch_bounds__(WL_THREADS) void mlp_wgrad_kernel(Plan P, TrainLayo
 // jobs (42 % matrix-pipe busy); 7168 quarter waves balance.  And the loop is free of per-value vector work (tile / sample
 // masks, 64-bit address arithmetic: 3.2 vector instructions per MFMA before, and fp32 MFMAs do not co-issue with the vector
 // ALU): full k-steps run unmasked from wave-uniform row bases + one running 32-bit lane offset; masks only in the tail.
-#ifndef WGD_EXP
-#define WGD_EXP 0
-#endif
 constexpr int WG_WAVES = 4, WG_THREADS = WG_WAVES * 64;
 
 // buffer resource over this wave's segment of one tile-row: wave-uniform base in SGPRs, so a load is `buffer_load_dword v,
@@ -648,13 +645,7 @@ __device__ __forceinline__ void wgrad_direct_wave(const float *const (&ya)[4], c
                 a0[t] = ra[p][t];
                 b0[t] = rb[p][t];
             }
-#if WGD_EXP != 1
             load_ab(std::integral_constant<int, 256 * p>{}, voff, ra[p], rb[p]);
-#endif
-#if WGD_EXP == 2
-#pragma unroll
-            for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(a0[t]), "v"(b0[t]));
-#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (FULL || i < n_ti) {
@@ -664,7 +655,6 @@ __device__ __forceinline__ void wgrad_direct_wave(const float *const (&ya)[4], c
                     bsum[i] += a0[i];   // (unconditional: the four adds cost less than a second loop variant)
                 }
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);   // one k-step at a time: hoisting all 32 loads of a group spills
         });
     }
@@ -835,7 +825,7 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     // chunks = 3.97 rounds of 13 % longer workgroups)
     int G_narrow = wgrad_chunks_1k(n);
     int G = G_narrow;
-    const int fold = wide_nsplit ? 0 : tuning().wgrad_fold;   // the split-precision wide kernels do not carry folded tiles
+    const int fold = wide_nsplit ? 0 : 1;   // the split-precision wide kernels do not carry folded tiles
     {
         const int n_cu = device_cu_count("wgrad");
         if (n_cu < 1) return n_cu;
@@ -844,17 +834,14 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
         // step's wide launches lasted 132 + 177 us side by side for 95 + 32 us of matrix work.  Split for the share instead and
         // both nets' workgroups are resident at once, with equal chunk lengths.
         const int cu_share = n_beside > 0 ? std::max(1, (int)((double)n_cu * (double)n / (double)(n + n_beside) + 0.5)) : n_cu;
-#ifndef WGD_WHOLE_ROUNDS
-#define WGD_WHOLE_ROUNDS 1
-#endif
         // narrow jobs: 4-wave workgroups, three per CU (mlp_wgrad_direct_kernel: waves_per_eu(3, 3), 52 KB of LDS) - the same
         // whole-rounds rule: 14 jobs x 128 chunks = 1792 workgroups are 2.33 rounds of 768 slots, 109 chunks are 1.99
-        if (const int jobs_d = WGD_WHOLE_ROUNDS ? wgrad_direct_jobs(P, fold) : 0) {
+        if (const int jobs_d = wgrad_direct_jobs(P, fold)) {
             const int slots = 3 * n_cu;
             if ((int64_t)jobs_d * G_narrow > slots) G_narrow = min(G_narrow, max(1, (int)((int64_t)jobs_d * G_narrow / slots) * slots / jobs_d));
             // small calls (the README's 64-ray batches): 1024-sample chunks would fill a fifth of the slots, each wave walking 256
             // samples at the latency of its 4 k-steps in flight - shorter chunks (>= 64 samples), one round of the slots
-            else if (tuning().wgrad_small_chunks) G_narrow = max(G_narrow, min(min(wgrad_chunks(n), (int)((n + 63) / 64)), max(1, 3 * cu_share / jobs_d)));
+            else G_narrow = max(G_narrow, min(min(wgrad_chunks(n), (int)((n + 63) / 64)), max(1, 3 * cu_share / jobs_d)));
         }
         const int jobs = wgrad_jobs(P);
         if (jobs > 0 && (int64_t)jobs * G > n_cu) {
@@ -892,9 +879,8 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
     if (const int jobs = wgrad_direct_jobs(P, W.fold)) {
         W.chunk = (((n + G_narrow - 1) / G_narrow) + 15) / 16 * 16;
         G_narrow = (int)((n + W.chunk - 1) / W.chunk);
-        // f16x3 step: the narrow jobs with two fp16 parts as well (SNERF_WGRAD_NARROW_F16=0: fp32 MFMA)
-        const bool narrow_f16 = tuning().wgrad_narrow_f16;
-        if (wide_nsplit == SNERF_SPLIT_F16X3 && narrow_f16) {
+        // f16x3 step: the narrow jobs with two fp16 parts as well
+        if (wide_nsplit == SNERF_SPLIT_F16X3) {
             if ((rc = launch_wgrad_direct_f16(P, L, W, jobs, G_narrow, s))) return rc;
         } else {
             // 4 k-steps of operands in flight per wave (measured r03: 2 / 3 / 4 / 6 -> 0.61 / 0.58 / 0.56 / 0.57 ms per launch)
@@ -983,7 +969,7 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
     // passes in two thirds of the time (r04: 290 -> 190 us at 4096 samples)
     const int n_cu = device_cu_count("mlp_bwd");
     if (n_cu < 1) return n_cu;
-    const bool small = P.width > 256 || (tuning().fwd_small_tiles && n <= (int64_t)64 * n_cu);
+    const bool small = P.width > 256 || n <= (int64_t)64 * n_cu;
     const bool wide_pe = input_grad && bwd_pe_tiles(P).pos == 8;
     // calls of a few 16-sample tiles per CU: the latency-class dgrad (mlp_lat.hip; bit-identical d Y); a call of a few rounds and a
     // fraction: whole rounds here, the fraction there
@@ -999,11 +985,7 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
         if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd: n too large");
         if (P.width > 256) {   // one wave per SIMD, like the forward
             if constexpr (BW == 4) {
-#if SNERF_WIDE_DMA
 #define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING4
-#else
-#define SNERF_LAUNCH_WIDE SNERF_LAUNCH_RING
-#endif
 #define SNERF_BWD_WIDE(W_)                                                                                                          \
     do {                                                                                                                            \
         if (wide_pe) SNERF_LAUNCH_WIDE((mlp_bwd_kernel<W_, 4, true, 8, 8>), dim3((unsigned)grid), dim3(256), s, A);                 \
@@ -1019,15 +1001,9 @@ int launch_bwd(const snerf_mlp_desc *desc, const float *packed_t, const float *a
                 return fail(SNERF_E_BADARG, "mlp_bwd: widths above 256 run 4-wave workgroups");
             }
         } else if (P.width == 256) {
-            if constexpr (SNERF_DGRAD_DMA && BW == 8) {
-                if (wide_pe) SNERF_LAUNCH_RING4((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-                else if (input_grad) SNERF_LAUNCH_RING4((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-                else SNERF_LAUNCH_RING4((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-            } else {
-                if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-                else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-                else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
-            }
+            if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);
+            else SNERF_LAUNCH_RING((mlp_bwd_kernel<256, BW, false>), dim3((unsigned)grid), dim3(BW * 64), s, A);
         } else if (P.width == 128) {
             if (wide_pe) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true, 8, 8>), dim3((unsigned)grid), dim3(BW * 64), s, A);
             else if (input_grad) SNERF_LAUNCH_RING((mlp_bwd_kernel<128, BW, true>), dim3((unsigned)grid), dim3(BW * 64), s, A);

@@ -890,16 +890,11 @@ __global__ __launch_bounds__(WC_THREADS) void mlp_wgrad_f16_kernel(Plan P, Train
 }
 
 int launch_wgrad_wide_bf16(const Plan &P, const TrainLayout &L, const WgradArgs &W, int jobs, int G, int nsplit, hipStream_t s) {
-    static LdsRaised r2, r3, r16, rc16;   // per device
+    static LdsRaised r2, r3, rc16;   // per device
     int rc;
     if (nsplit == SNERF_SPLIT_F16X3) {
-        // SNERF_WGRAD_F16_SPLIT_PER_WAVE=1: mlp_wgrad_bf16_kernel<2, FMT_F16> (every wave converts its own operands)
-        const bool per_wave = tuning().wgrad_f16_split_per_wave;
-        if (per_wave) rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_bf16_kernel<2, FMT_F16>), WB_LDS_BYTES, r16, "wgrad_bf16");
-        else rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_f16_kernel), WC_LDS_BYTES, rc16, "wgrad_f16");
-        if (rc) return rc;
-        if (per_wave) hipLaunchKernelGGL((mlp_wgrad_bf16_kernel<2, FMT_F16>), dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
-        else hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(jobs, G), dim3(WC_THREADS), WC_LDS_BYTES, s, P, L, W);
+        if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_f16_kernel), WC_LDS_BYTES, rc16, "wgrad_f16"))) return rc;
+        hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(jobs, G), dim3(WC_THREADS), WC_LDS_BYTES, s, P, L, W);
     } else if (nsplit == 3) {
         if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_wgrad_bf16_kernel<3>), WB_LDS_BYTES, r3, "wgrad_bf16"))) return rc;
         hipLaunchKernelGGL(mlp_wgrad_bf16_kernel<3>, dim3(jobs, G), dim3(WB_THREADS), WB_LDS_BYTES, s, P, L, W);
@@ -928,8 +923,7 @@ static int launch_dgrad_bf16(const BwdArgs &A, hipStream_t s) {
         return rc;
     const int n_cu = device_cu_count("mlp_bwd_bf16");  // one persistent workgroup per CU
     if (n_cu < 1) return n_cu;
-    const bool persistent = tuning().bf16_persistent;
-    const int64_t grid = (persistent && !INPUT_GRAD && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
+    const int64_t grid = (!INPUT_GRAD && A.n_tiles > n_cu) ? n_cu : A.n_tiles;
     if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "mlp_bwd_bf16: n too large");
     hipLaunchKernelGGL((mlp_bwd_bf16_kernel<256, NW, NS, INPUT_GRAD, FMT>), dim3((unsigned)grid), dim3(NW * 64), lds, s, A);
     return check_launch("mlp_bwd_bf16(dgrad)");
@@ -1000,10 +994,7 @@ int launch_bwd_bf16(const snerf_mlp_desc *desc, const void *packed_t, int nsplit
     if (rc) return rc;
     // wide jobs on the 16-bit matrix cores in the same format (f16x3: with per-layer scales - a per-sample scale cannot be
     // factored out of a contraction over samples), narrow jobs and the reduce in fp32
-    const bool bf16_wgrad = tuning().wgrad_bf16;
-    // SNERF_WGRAD_F16=0: three bf16 parts for the wide jobs of an f16x3 step (A/B knob)
-    const bool f16_wgrad = tuning().wgrad_f16;
-    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, bf16_wgrad ? ((f16 && !f16_wgrad) ? 3 : nsplit) : 0, accumulate);
+    return launch_wgrad(P, L, act, dy, n, gpart, flat_grad, s, nsplit, accumulate);
 }
 
 }  // namespace snerf

@@ -39,23 +39,12 @@ struct LdsRaised {
 // raises the limit once per (kernel, device); idempotent, a race only repeats the driver call.  Returns 0 or SNERF_E_LAUNCH.
 int raise_dynamic_lds(const void *kernel, int bytes, LdsRaised &state, const char *what);
 
-// Tuning knobs: environment variables read ONCE, at the first call that consults them (include/smplnerf.h lists them).
-// They select between equivalent kernels / launch shapes for A/B measurements and never change results.
+// Tuning knobs: environment variables read ONCE, at the first call that consults them (INTEGRATION.md lists every knob of the
+// library and of the Python host).  r06: the A/B switches of rounds 2-5 whose experiments are decided are gone (their patches
+// and scripts under tools/ab/ are the record); what is left switches the per-ray folds of inference off.
 struct Tuning {
-    bool fwd_persistent;            // SNERF_FWD_PERSISTENT            (default 1)
-    int fwd_waves;                  // SNERF_FWD_WAVES                 (8; 4 = two 4-wave workgroups per CU)
-    bool fwd_small_tiles;           // SNERF_FWD_SMALL_TILES=0         fp32 forward: no 64-sample tiles for calls of <= 64 x CUs samples
-    bool bf16_persistent;           // SNERF_BF16_PERSISTENT           (1)
-    bool warp_resident;             // SNERF_WARP_RESIDENT             (1)
-    bool warp_bwd_ring;             // SNERF_WARP_BWD_RING             (0)
-    bool warp_fold;                 // SNERF_WARP_FOLD=0               warp inference: pose k-blocks per sample instead of the per-ray fold
-    bool mlp_fold;                  // SNERF_MLP_FOLD=0                fp32 inference: per-ray additional inputs as k-blocks per sample
-    bool wgrad_bf16;                // SNERF_WGRAD_BF16                (1)
-    bool wgrad_f16;                 // SNERF_WGRAD_F16                 (1)
-    bool wgrad_narrow_f16;          // SNERF_WGRAD_NARROW_F16          (1)
-    bool wgrad_f16_split_per_wave;  // SNERF_WGRAD_F16_SPLIT_PER_WAVE  (0)
-    int wgrad_fold;                 // SNERF_WGRAD_FOLD                (1)
-    bool wgrad_small_chunks;        // SNERF_WGRAD_SMALL_CHUNKS=0      narrow wgrad jobs of small calls: 1024-sample chunks as for large ones
+    bool warp_fold;   // SNERF_WARP_FOLD=0   warp inference: pose k-blocks per sample instead of the per-ray fold
+    bool mlp_fold;    // SNERF_MLP_FOLD=0    fp32 inference: per-ray additional inputs as k-blocks per sample
 };
 const Tuning &tuning();
 

@@ -308,17 +308,11 @@ struct TrainWs {
 // auxiliary stream.  A pure size rule, so that the workspace size does not depend on the device.  Measured (tools/ab/
 // conc_ab.sh, ms per step without / with): 128 rays 1.49 / 1.33, 256: 2.42 / 2.29-2.35, 512: 4.00 / 3.96, 800: 6.60 / 6.45-6.48,
 // 1024: 7.80 / 7.83, 2048: 15.29 / 15.21 - above 1024 rays nothing is left to fill, and the second d Y buffer would cost memory.
-#ifndef SNERF_CONCURRENT_MAX_FINE_SAMPLES
-#define SNERF_CONCURRENT_MAX_FINE_SAMPLES (1024 * 256)
-#endif
-constexpr int64_t CONCURRENT_MAX_FINE_SAMPLES = SNERF_CONCURRENT_MAX_FINE_SAMPLES;
+constexpr int64_t CONCURRENT_MAX_FINE_SAMPLES = 1024 * 256;
 // the same rule for the smpl_nerf step (its coarse chain carries the warp net's backward as well).  Measured r05 with the rule
 // lifted (coarse chain beside the fine chain at every chunk size): 4096 rays 34.00 -> 33.72 ms per step, 2048 rays the same
 // fraction, for 1.8 GB more workspace - both chains are bound by the matrix pipe there, nothing is left to fill.
-#ifndef SNERF_SMPL_CONCURRENT_MAX_FINE_SAMPLES
-#define SNERF_SMPL_CONCURRENT_MAX_FINE_SAMPLES SNERF_CONCURRENT_MAX_FINE_SAMPLES
-#endif
-constexpr int64_t SMPL_CONCURRENT_MAX_FINE_SAMPLES = SNERF_SMPL_CONCURRENT_MAX_FINE_SAMPLES;
+constexpr int64_t SMPL_CONCURRENT_MAX_FINE_SAMPLES = CONCURRENT_MAX_FINE_SAMPLES;
 
 // fork / join events of the concurrent backward: one pair per host thread and device (include/smplnerf.h "State"), kept in a
 // registry so that snerf_shutdown() can destroy them

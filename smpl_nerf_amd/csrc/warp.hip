@@ -246,39 +246,9 @@ struct WarpBwdArgs {
     int h_row;
 };
 
-template <int WIDTH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void warp_bwd_kernel(WarpBwdArgs A) {
-    constexpr int NT = NWAVES * 64;
-    constexpr int T = WIDTH / 16;
-    extern __shared__ __attribute__((aligned(16))) float ring[];  // RING_BYTES (SNERF_LAUNCH_RING)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int64_t sample = ((int64_t)blockIdx.x * NWAVES + wave) * 16 + (lane & 15);
-    const bool valid = sample < A.n;
-    const int64_t sc = valid ? sample : A.n - 1;
-    const float *dp = A.d_warp + sc * 3;
-    const f4 dw = g == 0 ? f4{dp[0], dp[1], dp[2], 0.f} : f4{0.f, 0.f, 0.f, 0.f};
-    if (valid) store_tile(A.dy, T, A.n, sample, g, dw);
-    SlabPipe<NT> pipe;
-    pipe.prologue(A.packed_t, ring, tid);
-    f4 acc[T], dh[T];
-    LayerRun<T, NT> run(pipe, lane);
-    run.init(acc);
-    run.step(dw, acc);
-    run.finish();
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const f4 m = load_tile(A.act, A.h_row + t, A.n, sc, g);
-        dh[t][0] = m[0] > 0.f ? acc[t][0] : 0.f;
-        dh[t][1] = m[1] > 0.f ? acc[t][1] : 0.f;
-        dh[t][2] = m[2] > 0.f ? acc[t][2] : 0.f;
-        dh[t][3] = m[3] > 0.f ? acc[t][3] : 0.f;
-    }
-    if (valid) store_tiles(A.dy, 0, A.n, sample, g, dh);
-}
-
-// The same without the slab ring: the transposed head is ONE k-block of T tiles (T KiB), so a workgroup keeps it in a
-// small static LDS block and walks its sample tiles; the ring version above loaded three 33 KiB slabs per 64 samples and,
-// with its 99 KiB of LDS, ran one 4-wave workgroup per CU - for a kernel that only moves 2 KB per sample.
+// No slab ring: the transposed head is ONE k-block of T tiles (T KiB), so a workgroup keeps it in a small static LDS block and
+// walks its sample tiles (the slab-ring form of r02 loaded three 33 KiB slabs per 64 samples and, with its 99 KiB of LDS, ran one
+// 4-wave workgroup per CU - for a kernel that only moves 2 KB per sample).
 template <int WIDTH, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void warp_bwd_light_kernel(WarpBwdArgs A, int64_t n_tiles) {
     constexpr int NT = NWAVES * 64;
@@ -377,21 +347,12 @@ int snerf::launch_warp_bwd(const snerf_warp_desc *desc, const float *packed_t, c
     warp_train_layout(P, L);
     WarpBwdArgs A{packed_t, act, d_warp, dy, n, L.x[1]};
     hipStream_t s = (hipStream_t)stream;
-    const bool light = !tuning().warp_bwd_ring;
-    if (light) {   // ring-free kernel (SNERF_WARP_BWD_RING=1: the slab-ring version, for A/B runs)
+    {   // the ring-free dgrad (the slab-ring form of r02 lost its A/B in r03 and is gone)
         constexpr int LW = 8;
         const int64_t n_tiles = (n + LW * 16 - 1) / (LW * 16);
         const int64_t g = n_tiles < 2048 ? n_tiles : 2048;   // grid-stride over the sample tiles
         if (P.width == 256) hipLaunchKernelGGL((warp_bwd_light_kernel<256, LW>), dim3((unsigned)g), dim3(LW * 64), 0, s, A, n_tiles);
         else hipLaunchKernelGGL((warp_bwd_light_kernel<128, LW>), dim3((unsigned)g), dim3(LW * 64), 0, s, A, n_tiles);
-    } else {
-        constexpr int NW = 4;
-        const int64_t grid = (n + NW * 16 - 1) / (NW * 16);
-        if (grid > 0x7fffffffLL) return fail(SNERF_E_BADARG, "warp_bwd: n too large");
-        if (P.width == 256)
-            SNERF_LAUNCH_RING((warp_bwd_kernel<256, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
-        else
-            SNERF_LAUNCH_RING((warp_bwd_kernel<128, NW>), dim3((unsigned)grid), dim3(NW * 64), s, A);
     }
     int rc = check_launch("warp_bwd");
     if (rc) return rc;
@@ -433,7 +394,7 @@ static int launch_warp_fwd(const snerf_warp_desc *desc, const float *packed, con
 // bytes of the per-ray pose-fold table of an inference call, 0 when the fold does not apply (warp_ray_bias_kernel)
 static int64_t warp_fold_bytes(const Plan &P, int64_t n, int spr) {
     const int T = P.width / 16, nkb0 = P.pos_nkb + P.add_nkb;
-    if (!tuning().warp_resident || warp_resident_bytes(T, nkb0) > 160 * 1024) return 0;
+    if (warp_resident_bytes(T, nkb0) > 160 * 1024) return 0;
     if (!(P.add_dim > 0 && P.pos_nkb > 0 && tuning().warp_fold && spr >= 8 && n > 0 && n % spr == 0)) return 0;
     const int64_t floats = (n / spr) * P.width;
     if ((floats + 255) / 256 > 0x7fffffffLL) return 0;   // (more rays than a grid holds: the per-sample form)
@@ -500,8 +461,8 @@ static int snerf::launch_warp_fwd(const snerf_warp_desc *desc, const float *pack
     A.add_nkb = P.add_nkb;
     A.act = act;
     hipStream_t s = (hipStream_t)stream;
-    {   // the LDS-resident persistent kernel whenever the net fits the 160 KiB of a CU (SNERF_WARP_RESIDENT=0: streaming kernel)
-        const bool resident = tuning().warp_resident;
+    {   // the LDS-resident persistent kernel whenever the net fits the 160 KiB of a CU (else the slab-streaming kernel)
+        const bool resident = true;
         const int T = P.width / 16, nkb0 = P.pos_nkb + P.add_nkb;
         const int bytes = warp_resident_bytes(T, nkb0);
         if (resident && bytes <= 160 * 1024) {

@@ -505,8 +505,8 @@ np.savez({path!r}, **out)
 def test_latency_dgrad_with_input_gradients_is_bit_identical(dev, tmp_path):
     """The latency-class dgrad with input gradients (csrc/mlp_lat.hip: mlp_bwd_lat_kernel<S, true>; the nets of SmplNerfPipeline
     back-propagate into the warped samples and their per-sample view directions, models/smpl_nerf_pipeline.py:49-56): d loss / d
-    positions, d loss / d directions and the weight gradient of a process with SNERF_LAT_BWD_IG=0 (throughput kernel) equal those of
-    one with the latency kernel bit for bit - ragged sample counts, one to four sample tiles per pass, per-ray and per-sample
+    positions, d loss / d directions and the weight gradient of a process with SNERF_LAT=0 (throughput kernels) equal those of
+    one with the latency kernels bit for bit - ragged sample counts, one to four sample tiles per pass, per-ray and per-sample
     directions, other depths / skip masks (skip layers carry encoder columns of their own)."""
     import os
     import subprocess
@@ -517,7 +517,7 @@ def test_latency_dgrad_with_input_gradients_is_bit_identical(dev, tmp_path):
     res = {}
     for ig in ("0", "1"):
         path = str(tmp_path / f"ig{ig}.npz")
-        env = dict(os.environ, SNERF_LAT_BWD_IG=ig)
+        env = dict(os.environ, SNERF_LAT=ig)
         subprocess.run([sys.executable, "-c", _IG_SCRIPT.format(root=ROOT, shapes=shapes, rays=rays, path=path)], check=True, env=env)
         res[ig] = dict(np.load(path))
     assert set(res["0"]) == set(res["1"]) and len(res["0"]) == 3 * len(shapes) * len(rays)
