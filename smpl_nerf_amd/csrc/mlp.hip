@@ -29,22 +29,25 @@ namespace snerf {
 // ------------------------------------------------------------------------------------------------
 // weight packing: params_flat (state_dict order) -> slab stream
 // ------------------------------------------------------------------------------------------------
+// PACK_PARTS workgroups per slab, one element per thread (r06: with one workgroup per slab every thread walked 33 elements of
+// index arithmetic - 29 us for the warp net's 8 slabs, on the critical path of every smpl_nerf training step, whose warp
+// streams are re-packed behind Adam)
+constexpr int PACK_PARTS = (SLAB_FLOATS + 255) / 256;
 __global__ __launch_bounds__(256) void mlp_pack_kernel(Plan P, const float *__restrict__ params,
                                                        float *__restrict__ packed) {
-    const int slab = blockIdx.x;
+    const int slab = blockIdx.x / PACK_PARTS;
+    const int e = (blockIdx.x - slab * PACK_PARTS) * 256 + threadIdx.x;
+    if (e >= SLAB_FLOATS) return;
     float *dst = packed + (int64_t)slab * SLAB_FLOATS;
     if (slab >= P.total_slabs) {  // zero padding behind the stream
-        for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) dst[e] = 0.f;
+        dst[e] = 0.f;
         return;
     }
     int li = 0;
     while (li + 1 < P.nlayers && slab >= P.layer[li + 1].first_slab) ++li;
     const Layer &Ly = P.layer[li];
-    const int sl = slab - Ly.first_slab;
-    for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
-        const int64_t src = fwd_slab_src(Ly, sl, e);
-        dst[e] = src >= 0 ? params[src] : 0.f;
-    }
+    const int64_t src = fwd_slab_src(Ly, slab - Ly.first_slab, e);
+    dst[e] = src >= 0 ? params[src] : 0.f;
 }
 
 // TRAIN additionally stores every layer input (post-activation) for the backward kernels.
@@ -282,7 +285,7 @@ static int fill_args(const snerf_mlp_desc *desc, Plan &P, FwdArgs &A) {
 }
 
 int launch_pack(const Plan &P, const float *params_flat, float *packed, hipStream_t s, const char *what) {
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(P.total_slabs + SLAB_PAD), dim3(256), 0, s, P, params_flat, packed);
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((P.total_slabs + SLAB_PAD) * PACK_PARTS), dim3(256), 0, s, P, params_flat, packed);
     return check_launch(what);
 }
 

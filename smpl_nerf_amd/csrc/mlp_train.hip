@@ -37,22 +37,22 @@ __device__ __forceinline__ void static_for(F &&f) {
 // ------------------------------------------------------------------------------------------------
 // transposed weight stream
 // ------------------------------------------------------------------------------------------------
+constexpr int PACK_T_PARTS = (SLAB_FLOATS + 255) / 256;   // workgroups per slab, one element per thread (mlp.hip: mlp_pack_kernel)
 __global__ __launch_bounds__(256) void mlp_pack_t_kernel(Plan P, BwdPlan B, const float *__restrict__ params,
                                                          float *__restrict__ packed) {
-    const int slab = blockIdx.x;
+    const int slab = blockIdx.x / PACK_T_PARTS;
+    const int e = (blockIdx.x - slab * PACK_T_PARTS) * 256 + threadIdx.x;
+    if (e >= SLAB_FLOATS) return;
     float *dst = packed + (int64_t)slab * SLAB_FLOATS;
     if (slab >= B.total_slabs) {
-        for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) dst[e] = 0.f;
+        dst[e] = 0.f;
         return;
     }
     int bi = 0;
     while (bi + 1 < B.nl && slab >= B.layer[bi + 1].first_slab) ++bi;
     const BwdLayer &Bl = B.layer[bi];
-    const int sl = slab - Bl.first_slab;
-    for (int e = threadIdx.x; e < SLAB_FLOATS; e += 256) {
-        const int64_t src = bwd_slab_src(P, Bl, sl, e);
-        dst[e] = src >= 0 ? params[src] : 0.f;
-    }
+    const int64_t src = bwd_slab_src(P, Bl, slab - Bl.first_slab, e);
+    dst[e] = src >= 0 ? params[src] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -661,9 +661,10 @@ __device__ __forceinline__ void wgrad_direct_wave(const float *const (&ya)[4], c
 }
 
 // everything behind the job decode, one instantiation per FULL (the accumulators of the two variants never meet)
+// gp_off: floats from the start of this chunk's partial to the layer's block; lnkb / lt_out: the layer's k-blocks and output tiles
 template <int WG_PREFETCH, bool FULL>
-__device__ __forceinline__ void wgrad_direct_block(const Layer &Ly, const TrainLayout &L, const WgradArgs &A, float *s_acc,
-                                                   const float *const (&ya)[4], const float *const (&xb)[4], int l, int kb0,
+__device__ __forceinline__ void wgrad_direct_block(float *part_chunk, int gp_off, int lnkb, int lt_out, float *s_acc,
+                                                   const float *const (&ya)[4], const float *const (&xb)[4], int kb0,
                                                    int bi, int bj, int n_ti, int n_tj, int64_t wb, int64_t we, bool want_bias,
                                                    int wave, int lane) {
     f4 acc[4][4];
@@ -698,7 +699,7 @@ __device__ __forceinline__ void wgrad_direct_block(const Layer &Ly, const TrainL
         }
     }
     // ---- write the partial of this (block, chunk) ---------------------------------------------------
-    float *part = A.part + (int64_t)blockIdx.y * L.gp_floats + L.gp[l];
+    float *part = part_chunk + gp_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i >= n_ti) continue;
@@ -706,15 +707,102 @@ __device__ __forceinline__ void wgrad_direct_block(const Layer &Ly, const TrainL
         for (int j = 0; j < 4; ++j) {
             if (j >= n_tj) continue;
             const int ti = 4 * bi + i, tj = kb0 + 4 * bj + j;
-            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * Ly.nkb + tj) * 64 + lane) * 4) = acc[i][j];
+            *reinterpret_cast<f4 *>(part + ((int64_t)(ti * lnkb + tj) * 64 + lane) * 4) = acc[i][j];
         }
         if (want_bias) {
             float v = bsum[i];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (lane < 16) part[(int64_t)Ly.t_out * Ly.nkb * 256 + (4 * bi + i) * 16 + lane] = v;
+            if (lane < 16) part[(int64_t)lt_out * lnkb * 256 + (4 * bi + i) * 16 + lane] = v;
         }
     }
+}
+
+// The jobs of a launch as a table the HOST builds from the Plan (r06).  The kernel used to find its job by walking P.layer[l].seg[s]
+// with run-time indices: the compiler copies a by-value struct that is indexed dynamically into scratch (500 bytes per lane, 121
+// scratch instructions and 84 scalar-load waits in front of the first operand load - a fifth of a small launch).  Now a workgroup
+// reads ONE 32-byte descriptor through the kernarg segment pointer (scalar load with a run-time offset, like mlp_lat_device.h).
+struct NarrowJob {
+    int dy_row;     // first d Y tile-row of the block: L.dy[l] + 4 bi
+    int x_row;      // first X tile-row: seg_act_row(l, s) + 4 bj
+    int gp;         // L.gp[l]: the layer's block inside a chunk's partial
+    int nkb, t_out; // of the layer: the partial's tile grid, and where its bias sums start
+    int bi_bj_kb0;  // bi | bj << 8 | kb0 << 16
+    int nt_bias;    // n_ti | n_tj << 4 | want_bias << 8
+    int pad_;
+};
+static_assert(sizeof(NarrowJob) == 32, "NarrowJob is read as 8 dwords");
+constexpr int MAX_NARROW_JOBS = 108;
+struct NarrowTable {
+    int n, pad_[7];
+    NarrowJob j[MAX_NARROW_JOBS];
+};
+// host: the jobs of wgrad_direct_jobs(P, fold) in the order the f16 twin of this kernel walks them; false: too many for the table
+static bool make_narrow_table(const Plan &P, const TrainLayout &L, int fold, NarrowTable &T) {
+    T.n = 0;
+    for (int l = 0; l < P.nlayers; ++l) {
+        const Layer &Ly = P.layer[l];
+        int first_seg = 0;   // the bias sums ride with the first non-empty input segment of the layer
+        while (first_seg < Ly.nseg && Ly.seg[first_seg].nkb == 0) ++first_seg;
+        int kb0 = 0;
+        for (int sg = 0; sg < Ly.nseg; ++sg) {
+            if (wgrad_kind(P, l, sg, fold) == 2) {
+                const int nbi = (Ly.t_out + 3) / 4, nbj = (Ly.seg[sg].nkb + 3) / 4;
+                for (int bi = 0; bi < nbi; ++bi)
+                    for (int bj = 0; bj < nbj; ++bj) {
+                        if (T.n >= MAX_NARROW_JOBS || bi > 255 || bj > 255 || kb0 > 32767) return false;
+                        NarrowJob &J = T.j[T.n++];
+                        J.dy_row = L.dy[l] + 4 * bi;
+                        J.x_row = seg_act_row(P, L, l, sg) + 4 * bj;
+                        J.gp = L.gp[l];
+                        J.nkb = Ly.nkb;
+                        J.t_out = Ly.t_out;
+                        J.bi_bj_kb0 = bi | (bj << 8) | (kb0 << 16);
+                        const int n_ti = std::min(4, Ly.t_out - 4 * bi), n_tj = std::min(4, Ly.seg[sg].nkb - 4 * bj);
+                        J.nt_bias = n_ti | (n_tj << 4) | ((sg == first_seg && bj == 0) ? 256 : 0);
+                        J.pad_ = 0;
+                    }
+            }
+            kb0 += Ly.seg[sg].nkb;
+        }
+    }
+    return true;
+}
+typedef int nj_i8 __attribute__((ext_vector_type(8)));
+
+template <int WG_PREFETCH>
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_wgrad_direct_tab_kernel(NarrowTable tab_in_kernarg, WgradArgs A,
+                                                                                                                   int64_t gp_floats) {
+    __shared__ __attribute__((aligned(16))) float s_acc[(WG_WAVES - 1) * (16 * 256 + 4 * 64)];   // 3 x (16 tiles + 4 bias sums)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    typedef const __attribute__((address_space(4))) NarrowTable *TabPtr;
+    const TabPtr tab = (TabPtr)__builtin_amdgcn_kernarg_segment_ptr();   // = &tab_in_kernarg, read in place
+    const nj_i8 v = *reinterpret_cast<const __attribute__((address_space(4))) nj_i8 *>(&tab->j[blockIdx.x]);
+    const NarrowJob J = __builtin_bit_cast(NarrowJob, v);
+    const int bi = J.bi_bj_kb0 & 255, bj = (J.bi_bj_kb0 >> 8) & 255, kb0 = J.bi_bj_kb0 >> 16;
+    const int n_ti = J.nt_bias & 15, n_tj = (J.nt_bias >> 4) & 15;
+    const bool want_bias = (J.nt_bias & 256) != 0;
+    const int64_t n = A.n;
+    // this wave's quarter of the chunk (multiples of 4 samples)
+    const int64_t begin = (int64_t)blockIdx.y * A.chunk;
+    const int64_t end = min(n, begin + A.chunk);
+    const int64_t sub = begin < end ? ((end - begin + 4 * WG_WAVES - 1) / (4 * WG_WAVES)) * 4 : 0;
+    const int64_t wb = min(end, begin + wave * sub), we = min(end, wb + sub);
+    // wave-uniform row bases at sample wb (rows the block does not have alias row 0: never read)
+    const float *ya[4], *xb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ya[t] = A.dy + ((int64_t)(J.dy_row + (t < n_ti ? t : 0)) * n + wb) * 16;
+        xb[t] = A.act + ((int64_t)(J.x_row + (t < n_tj ? t : 0)) * n + wb) * 16;
+    }
+    float *part_chunk = A.part + (int64_t)blockIdx.y * gp_floats;
+    // Every block runs the unpredicated 4 x 4 loop: the tile-rows a block does not have alias its first row (valid addresses, cache
+    // hits), their products are computed and not stored.  (Until r06 such blocks - the one-tile heads, the last k-block column of the
+    // warp net's 7-k-block layer: 8 of its 12 jobs - ran a second instantiation with a branch around every load and every MFMA row:
+    // 137 branches and 32 scratch accesses per group of four k-steps.  The kernel is bound by operand latency, not by the matrix
+    // pipe: the wasted MFMAs are free, the branches were not.)
+    wgrad_direct_block<WG_PREFETCH, true>(part_chunk, J.gp, J.nkb, J.t_out, s_acc, ya, xb, kb0, bi, bj, n_ti, n_tj, wb, we, want_bias, wave, lane);
 }
 
 template <int WG_PREFETCH>
@@ -756,10 +844,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         ya[t] = A.dy + ((int64_t)(L.dy[l] + 4 * bi + (t < n_ti ? t : 0)) * n + wb) * 16;
         xb[t] = A.act + ((int64_t)(seg_act_row(P, L, l, s) + 4 * bj + (t < n_tj ? t : 0)) * n + wb) * 16;
     }
-    if (n_ti == 4 && n_tj == 4)
-        wgrad_direct_block<WG_PREFETCH, true>(Ly, L, A, s_acc, ya, xb, l, kb0, bi, bj, n_ti, n_tj, wb, we, want_bias, wave, lane);
-    else
-        wgrad_direct_block<WG_PREFETCH, false>(Ly, L, A, s_acc, ya, xb, l, kb0, bi, bj, n_ti, n_tj, wb, we, want_bias, wave, lane);
+    wgrad_direct_block<WG_PREFETCH, true>(A.part + (int64_t)blockIdx.y * L.gp_floats, L.gp[l], Ly.nkb, Ly.t_out, s_acc, ya, xb, kb0, bi, bj, n_ti, n_tj, wb, we, want_bias, wave, lane);
 }
 
 // sum over the G partials and scatter slot order -> state_dict order
@@ -813,7 +898,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(Plan P, TrainLayo
 }
 
 int launch_pack_t(const Plan &P, const BwdPlan &B, const float *params_flat, float *packed_t, hipStream_t s, const char *what) {
-    hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(B.total_slabs + SLAB_PAD), dim3(256), 0, s, P, B, params_flat, packed_t);
+    hipLaunchKernelGGL(mlp_pack_t_kernel, dim3((B.total_slabs + SLAB_PAD) * PACK_T_PARTS), dim3(256), 0, s, P, B, params_flat, packed_t);
     return check_launch(what);
 }
 
@@ -884,7 +969,11 @@ int launch_wgrad(const Plan &P, const TrainLayout &L, const float *act, const fl
             if ((rc = launch_wgrad_direct_f16(P, L, W, jobs, G_narrow, s))) return rc;
         } else {
             // 4 k-steps of operands in flight per wave (measured r03: 2 / 3 / 4 / 6 -> 0.61 / 0.58 / 0.56 / 0.57 ms per launch)
-            hipLaunchKernelGGL(mlp_wgrad_direct_kernel<4>, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, P, L, W);
+            NarrowTable T;
+            if (make_narrow_table(P, L, W.fold, T) && T.n == jobs)
+                hipLaunchKernelGGL(mlp_wgrad_direct_tab_kernel<4>, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, T, W, (int64_t)L.gp_floats);
+            else   // (more narrow jobs than the table holds - nets with a hundred additional-input k-blocks: the job found in the kernel)
+                hipLaunchKernelGGL(mlp_wgrad_direct_kernel<4>, dim3(jobs, G_narrow), dim3(WG_THREADS), 0, s, P, L, W);
             if ((rc = check_launch("wgrad_direct"))) return rc;
         }
     }

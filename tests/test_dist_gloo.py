@@ -114,6 +114,69 @@ def test_data_parallel_steps_equal_single_process_on_the_concatenated_batch():
         assert torch.allclose(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-6)
 
 
+def _ragged_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smpl_nerf_amd.trainer import DataParallelTrainer
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+        class Pipe(torch.nn.Module):
+            def forward(self, data):
+                y = torch.sigmoid(net(data[0]))
+                return y, y * 0.5
+
+        g = torch.Generator().manual_seed(1)
+        x, gt = torch.rand(53, 6, generator=g), torch.rand(53, 3, generator=g)
+        b, e = (0, 48) if rank == 0 else (48, 53)          # unequal shards: RayBatchLoader's short last batch
+        tr = DataParallelTrainer(Pipe(), [net], lr=1e-2, fused=False)
+        assert tr._comm is False                            # (gloo: the ranks agreed on the three-call form at construction)
+        for _ in range(3):
+            tr.step([x[b:e], gt[b:e]])
+        q.put((rank, [p.detach().numpy().copy() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_steps_with_ragged_batches_per_rank():
+    """RayBatchLoader allows unequal shards and a short last batch, so the ranks of a step may hold different ray
+    counts.  The collective schedule must not depend on them (the GPU suite checks the in-library RCCL form with a recording
+    communicator, tests/test_gpu_round6.py); here the torch.distributed form at world size 2 with 48 and 5 rays: no rank waits for
+    a collective the other never issues, the replicas stay equal, and the step equals Adam on the mean of the ranks' gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get() for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)                        # replicas in lock-step
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    g = torch.Generator().manual_seed(1)
+    x, gt = torch.rand(53, 6, generator=g), torch.rand(53, 3, generator=g)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    mse = torch.nn.MSELoss()
+    for _ in range(3):
+        grads = []
+        for b, e in ((0, 48), (48, 53)):
+            net.zero_grad()
+            y = torch.sigmoid(net(x[b:e]))
+            (mse(y, gt[b:e]) + mse(y * 0.5, gt[b:e])).backward()
+            grads.append([p.grad.clone() for p in net.parameters()])
+        for p, g0, g1 in zip(net.parameters(), *grads):
+            p.grad = (g0 + g1) / 2
+        opt.step()
+    for a, b in zip(got[0], net.parameters()):
+        assert torch.allclose(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-6)
+
+
 def _replica_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
