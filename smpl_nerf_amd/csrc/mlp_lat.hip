@@ -46,10 +46,9 @@ constexpr int LAT_SIG_OFF = 15 * 1024;
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// wg: this workgroup's index among those that share G (blockIdx.x, or its index inside its half of a mixed launch)
 template <int S, bool TRAIN>
-__global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_in_kernarg, FwdArgs A, LatGeom G, LatLds Lo) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const LatTabPtr tab = lat_table_ptr();   // = &tab_in_kernarg, read in place (mlp_lat_device.h)
+__device__ __forceinline__ void mlp_fwd_lat_body(const LatTabPtr tab, const FwdArgs &A, const LatGeom &G, const LatLds &Lo, const int wg, char *lds) {
     const int tid = threadIdx.x;
     LatWave W;
     W.start(tab, A.packed, tid, G.passes);
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_i
 
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < G.passes; ++pass) {
-        const int64_t tile0 = G.tile_off + ((int64_t)blockIdx.x * G.passes + pass) * S;
+        const int64_t tile0 = G.tile_off + ((int64_t)wg * G.passes + pass) * S;
         // sample of this lane in sample tile s (clamped for loads; `okay` gates every store)
         auto sample_of = [&](int s) { return (tile0 + s) * 16 + (lane & 15); };
         auto okay = [&](int s) { return tile0 + s < G.tile_end && sample_of(s) < A.n; };
@@ -172,6 +171,22 @@ __global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_i
         // (the next pass's phase 0 writes the encoder region only, and its barrier stands between this pass's rgb reads and the
         // first activation write of the next pass)
     }
+}
+
+template <int S, bool TRAIN>
+__global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_kernel(LatTable tab_in_kernarg, FwdArgs A, LatGeom G, LatLds Lo) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    mlp_fwd_lat_body<S, TRAIN>(lat_table_ptr() /* = &tab_in_kernarg, read in place (mlp_lat_device.h) */, A, G, Lo, (int)blockIdx.x, lds);
+}
+// r06: THREE tiles per CU in one pass as a workgroup of two tiles and a workgroup of one, side by side on the CU (2 x lat_lds(2) fits
+// the LDS, 16 waves): each covers the other's layer boundaries - what the paired launches of an even tile count get from two equal
+// workgroups (lat_split).  The first n_a workgroups (dispatched first: one per CU) take two tiles each from GA, the others one tile
+// from GB; both walk the same table, built for the LDS layout of S = 2.  README.md:23's 64-ray batch is this case: 768 fine tiles.
+template <bool TRAIN>
+__global__ __launch_bounds__(LAT_THREADS) void mlp_fwd_lat_mixed_kernel(LatTable tab_in_kernarg, FwdArgs A, LatGeom GA, LatGeom GB, LatLds Lo, int n_a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if ((int)blockIdx.x < n_a) mlp_fwd_lat_body<2, TRAIN>(lat_table_ptr(), A, GA, Lo, (int)blockIdx.x, lds);
+    else mlp_fwd_lat_body<1, TRAIN>(lat_table_ptr(), A, GB, Lo, (int)blockIdx.x - n_a, lds);
 }
 
 static void lat_layer_stream(LatLayer &o, int first_slab, int nkb, int t_out) {
@@ -458,9 +473,10 @@ bool lat_enabled() {
 struct LatLaunch {
     int S, grid, passes;
     int64_t tile_off, tile_end;
+    int mixed_a;   // > 0: S = 3 as a mixed launch - mixed_a workgroups of two tiles, grid - mixed_a of one (forward kernels)
 };
 // pair_s: the largest S' of which TWO workgroups fit a CU's LDS (0: none - the split of the cost model)
-static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2], int pair_s = 0) {
+static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2], int pair_s = 0, bool mixed_ok = false) {
     int k = 0;
     int64_t done = 0;
     const int S = (int)std::min<int64_t>(s_max, (n16 + n_cu - 1) / n_cu);
@@ -471,16 +487,26 @@ static int lat_split(int64_t n16, int n_cu, int s_max, LatLaunch (&out)[2], int 
     // descriptor load, first operand read).  Measured (tools/ab/host_profile_render.py, train_loop.py): 128-ray render 0.408 ->
     // 0.358 ms, 128 / 256-ray steps -2 %; with several passes per workgroup the doubled weight stream costs what the overlap gains
     // (800-ray render 2.02 -> 2.07 ms) - those stay one workgroup per CU.  Same tiles, same arithmetic: bit-identical.
+    // three tiles per CU in one pass: a two-tile and a one-tile workgroup per CU (mlp_fwd_lat_mixed_kernel)
+    auto mixed = [&](int64_t first, int64_t tiles) {
+        const int n_a = (int)std::min<int64_t>(n_cu, tiles / 2);
+        return LatLaunch{3, n_a + (int)(tiles - 2 * (int64_t)n_a), 1, first, first + tiles, n_a};
+    };
     if (passes > 0) {
-        if (passes == 1 && S % 2 == 0 && S / 2 <= pair_s) out[k++] = LatLaunch{S / 2, 2 * n_cu, 1, 0, per_round};
-        else out[k++] = LatLaunch{S, n_cu, passes, 0, per_round * passes};
+        if (passes == 1 && S % 2 == 0 && S / 2 <= pair_s) out[k++] = LatLaunch{S / 2, 2 * n_cu, 1, 0, per_round, 0};
+        else if (passes == 1 && S == 3 && mixed_ok && pair_s >= 2) out[k++] = mixed(0, per_round);
+        else out[k++] = LatLaunch{S, n_cu, passes, 0, per_round * passes, 0};
         done = per_round * passes;
     }
     const int64_t r = n16 - done;
     if (r > 0) {
         int S2 = (int)std::min<int64_t>(s_max, (r + n_cu - 1) / n_cu);
+        if (S2 == 3 && mixed_ok && pair_s >= 2) {
+            out[k++] = mixed(done, r);
+            return k;
+        }
         if (S2 % 2 == 0 && S2 / 2 <= pair_s) S2 /= 2;
-        out[k++] = LatLaunch{S2, (int)((r + S2 - 1) / S2), 1, done, n16};
+        out[k++] = LatLaunch{S2, (int)((r + S2 - 1) / S2), 1, done, n16, 0};
     }
     return k;
 }
@@ -584,11 +610,23 @@ int launch_fwd_lat(const Plan &P, const FwdArgs &A, hipStream_t s, int64_t first
     int pair_s = 0;
     for (int h = 1; h <= 2; ++h)
         if (2 * lat_lds_fwd(h, P).total <= 160 * 1024) pair_s = h;
-    const int nq = lat_split(n16, n_cu, s_max, Q, pair_s);
+    const int nq = lat_split(n16, n_cu, s_max, Q, pair_s, true);
     for (int i = 0; i < nq; ++i) {
         Q[i].tile_off += t0;
         Q[i].tile_end += t0;
         int rc;
+        if (Q[i].mixed_a > 0) {
+            const LatLds Lo = lat_lds_fwd(2, P);
+            LatTable T;
+            lat_table_fwd(P, L, Lo, T);
+            static LdsRaised raised;   // per device, per instantiation
+            if ((rc = raise_dynamic_lds(reinterpret_cast<const void *>(mlp_fwd_lat_mixed_kernel<TRAIN>), Lo.total, raised, "mlp_fwd_lat"))) return rc;
+            const int64_t split = Q[i].tile_off + 2 * (int64_t)Q[i].mixed_a;
+            const LatGeom GA{Q[i].tile_off, split, 1}, GB{split, Q[i].tile_end, 1};
+            hipLaunchKernelGGL((mlp_fwd_lat_mixed_kernel<TRAIN>), dim3((unsigned)Q[i].grid), dim3(LAT_THREADS), Lo.total, s, T, A, GA, GB, Lo, Q[i].mixed_a);
+            if ((rc = check_launch("mlp_fwd_lat"))) return rc;
+            continue;
+        }
         switch (Q[i].S) {
             case 1: rc = launch_fwd_lat_s<1, TRAIN>(P, L, A, Q[i], s); break;
             case 2: rc = launch_fwd_lat_s<2, TRAIN>(P, L, A, Q[i], s); break;
