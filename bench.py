@@ -544,8 +544,8 @@ def train_section(precision, workload, data, rays, steps, world, rank, dev, back
             "raygen_ms_per_step": (kern["raygen"][1] / steps if "raygen" in kern else None),
             "collective": (dict(collective_info(backend, sum(p.numel() for p in tr.params),
                                                 ("ncclAllReduce(ncclAvg, fp32) of the flat gradient buffer INSIDE the one C-ABI call of a "
-                                                 "step, on the compute stream between the backward and Adam (small chunks: the coarse "
-                                                 "net's bucket on the auxiliary stream beside the fine net's backward) - "
+                                                 "step, on the compute stream between the backward and Adam (two launches: the coarse "
+                                                 "net's segment, then the rest; the same on every rank whatever its batch size) - "
                                                  "snerf_nerf_train_step_dp_f32, RCCL bound by the library") if in_call else
                                                 "one all-reduce (sum, then / world) of the flat fp32 gradient buffer per step"),
                                 allreduce_ms_per_step=(sum(ar) / len(ar) if ar else None), allreduce_calls=len(ar),

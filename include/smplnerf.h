@@ -655,10 +655,9 @@ SNERF_API int snerf_comm_allreduce_avg_f32(snerf_comm_t comm, float *buf, int64_
 /* snerf_nerf_train_step_f32 / snerf_smpl_nerf_train_step_f32 with the gradient average between the backward and the optimiser:
  * ... -> backward -> ncclAllReduce(ncclAvg) of adam->grads[0 .. adam->n_params) - the trainer's flat gradient buffer, which holds
  * grad_coarse / grad_fine (/ grad_warp) as segments and is the same size on every rank -> Adam.  The collectives of a nerf step
- * are the same two on every rank whatever its batch size, chunking and streams (0.1.9): the coarse net's segment first - on
- * aux_stream beside the fine net's backward when the chunk is small enough for the concurrent backward
- * (snerf_nerf_train_grads_f32), on `stream` otherwise - then the rest of the buffer (one grouped launch) on `stream` behind the
- * join; the smpl_nerf steps issue one all-reduce of the whole buffer on `stream`.  batch->B == 0 is valid here (a rank whose
+ * are the same two on every rank whatever its batch size, chunking and streams (0.1.9): the coarse net's segment, then the rest
+ * of the buffer (one grouped launch), both on `stream` behind the join of the concurrent backward - one communicator never has
+ * collectives in flight on two streams; the smpl_nerf steps issue one all-reduce of the whole buffer on `stream`.  batch->B == 0 is valid here (a rank whose
  * shard ran out): zero gradient, zero loss, the same collectives, the optimiser step.  Nothing is synchronised; every rank must
  * make the same calls in the same order (RCCL's rule).  Graph-capturable.  SNERF_RCCL_LIB=<path> (read at the first call)
  * names the library to bind instead of librccl.so.1. */

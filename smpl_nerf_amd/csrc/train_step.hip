@@ -590,14 +590,14 @@ static int nerf_train_grads_impl(const snerf_mlp_desc *desc_coarse, const void *
         if ((rc = bwd(desc_coarse, packed_t_coarse, act_c, d_raw_c, b * Nc, dy_c, gpart_c, grad_coarse, r0 > 0, stream_c, w.concurrent ? b * N : 0))) return rc;
         // The collectives of the step are the same two on every rank, whatever its batch size, chunking and streams (RCCL matches
         // collectives by issue order and size; ADVICE r05: the concurrent form depends on the rank's own B): first the coarse net's
-        // segment [cb0, cb1) - on the auxiliary stream while the fine net's backward still runs when the two run side by side, on
-        // `stream` otherwise - then the rest of the flat buffer behind the join.
+        // segment [cb0, cb1), then the rest of the flat buffer - both on `stream`, behind the join.
         const bool last = r0 + b >= B;
-        if (comm && last &&
-            (rc = dp_allreduce_avg(comm, flat_g, cb0, cb1, 0, 0, concurrent ? (hipStream_t)aux_stream : s, "nerf_train_step_dp")))
-            return rc;
         if (concurrent && (hipEventRecord(ev_join, (hipStream_t)aux_stream) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess))
             return fail(SNERF_E_LAUNCH, "nerf_train_grads: cannot join the auxiliary stream");
+        // (r06, late: both on `stream`, behind the join.  r05 put the coarse bucket on the auxiliary stream beside the fine net's
+        // backward - two collectives of ONE communicator in flight on two streams.  That has never run on more than one rank, it buys
+        // the overlap of a 2.4 MB all-reduce, and it is the one pattern of the step RCCL does not promise to order for us: one stream.)
+        if (comm && last && (rc = dp_allreduce_avg(comm, flat_g, cb0, cb1, 0, 0, s, "nerf_train_step_dp"))) return rc;
         if (comm && last && (rc = dp_allreduce_avg(comm, flat_g, 0, flat_n, cb0, cb1, s, "nerf_train_step_dp"))) return rc;
         // the coarse net's share of d loss / d additional inputs: behind the join (the two backwards may have run side by side; the
         // coarse net's d Y buffer is its own then), added to the fine net's

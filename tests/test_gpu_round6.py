@@ -182,8 +182,8 @@ def test_data_parallel_steps_reduce_every_gradient_exactly_once():
     snerf_*_dp_f32 - an element averaged twice or never - would pass.  Here the library binds tests/native/fake_rccl.cpp instead
     (SNERF_RCCL_LIB): its ncclAllReduce records (buffer, count, stream) and halves the range - the average with a zero-gradient
     peer.  For nerf (concurrent / sequential / chunked / run_fine = 0), smpl_nerf and the pose-conditioned step with a trained
-    estimator (snerf_nerf_train_step_dp_ig_f32, configs[4]): the recorded ranges tile the flat gradient buffer exactly once, the
-    coarse bucket goes to the auxiliary stream exactly when the backward runs concurrently, and parameters and
+    estimator (snerf_nerf_train_step_dp_ig_f32, configs[4]): the recorded ranges tile the flat gradient buffer exactly once, every
+    collective is issued on the compute stream behind the join of the concurrent backward, and parameters and
     losses after two steps equal, bit for bit, the three-call step (gradients -> x 0.5 -> Adam) of a single process.  ADVICE r05:
     the collectives are the same list for 800 rays (concurrent form), 2048 rays (sequential form), 3 rays and for a rank with NO
     rays (B = 0), which still steps its optimiser on the zero gradient."""
@@ -199,13 +199,13 @@ def test_data_parallel_steps_reduce_every_gradient_exactly_once():
         assert o["losses_equal"] and o["params_equal"], (name, o)
         assert o["covered"] == [True, True], (name, o["sched"])
     # nerf: two launches - the coarse net's segment, then the rest of the buffer as one group
-    for name, concurrent in (("nerf64", True), ("nerf1400", False), ("nerf300c", True), ("nerf100cf", False)):
+    for name in ("nerf64", "nerf1400", "nerf300c", "nerf100cf"):      # (concurrent backward, sequential, chunked + concurrent, run_fine = 0)
         o = out[name]
         assert o["moved"]
         sched = o["sched"]
         off, cnt = o["seg_coarse"]
         assert sched[0][:2] == [off, cnt], (name, sched)
-        assert sched[0][2] == concurrent, f"{name}: the coarse bucket runs on the auxiliary stream iff the backward is concurrent"
+        assert not sched[0][2], f"{name}: every collective of the step runs on the compute stream (one communicator, one stream)"
         assert all(not s[2] for s in sched[1:]) and len({s[3] for s in sched[1:]}) == 1 and sched[1][3] != sched[0][3], (name, sched)
     # smpl_nerf: one all-reduce of the whole buffer on the compute stream, behind the join
     for name in ("smpl64", "smpl300c"):
