@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_lat
 mkdir -p $OUT
-export SNERF_LAT_MAX_TILES_PER_CU=200
+# (r06: the size model decides which calls take the latency kernels - 4096 and 16384 samples do)
 CMD="python $R/tools/ab/lat_timing.py ${1:-infer} ${2:-4096,16384,262144}"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d /tmp/p1 -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p2 -- $CMD > /dev/null 2>&1

@@ -76,3 +76,11 @@ timeout 400 bash $ROOT/tools/ab/pmc_lat.sh infer 4096,16384 2>/dev/null | grep -
 timeout 400 python $ROOT/tools/ab/width_timing.py 256,320,384,448,512 2>/dev/null | grep width > $OUT/width_timing.txt
 timeout 600 bash $ROOT/tools/ab/pmc_width.sh 256,320,512 524288 2>/dev/null | grep -v amdgpu.ids > $OUT/pmc_width.txt
 [ -x $ROOT/smpl_nerf_amd/csrc/build/mfma_issue ] && timeout 120 $ROOT/smpl_nerf_amd/csrc/build/mfma_issue > $OUT/mfma_issue.txt 2>/dev/null
+# (l) round 6: timelines of one small training step (kernel, queue, start, duration) from the kernel trace; host cost of a small
+#     render (single-call dispatch under no_grad); the layer-by-layer path of widths above the fused kernels
+( timeout 200 bash $ROOT/tools/ab/step_timeline.sh 64 nerf 30 ) 2>/dev/null | grep -v "amdgpu.ids\|simple_timer" > $OUT/step_timeline_64.txt
+( timeout 200 bash $ROOT/tools/ab/step_timeline.sh 64 smpl_nerf 30 ) 2>/dev/null | grep -v "amdgpu.ids\|simple_timer" > $OUT/step_timeline_64_smpl_nerf.txt
+( timeout 200 bash $ROOT/tools/ab/step_timeline.sh 800 nerf 10 ) 2>/dev/null | grep -v "amdgpu.ids\|simple_timer" > $OUT/step_timeline_800.txt
+( for n in 64 128 800; do timeout 120 python $ROOT/tools/ab/host_profile_render.py $n 200; done ) 2>/dev/null | grep "rays\|bit for" > $OUT/host_profile_render.txt
+( timeout 300 python $ROOT/tools/ab/layered_timing.py 768; timeout 300 python $ROOT/tools/ab/layered_timing.py 1024 524288 131072 ) 2>/dev/null | grep width > $OUT/layered_timing.txt
+( for r in 64 128 256 800 2048 4096; do timeout 200 python $ROOT/tools/ab/train_loop.py $r nerf 30; done; for r in 64 4096; do timeout 200 python $ROOT/tools/ab/train_loop.py $r smpl_nerf 30; done ) 2>/dev/null | grep rays > $OUT/train_loop.txt
