@@ -254,7 +254,10 @@ extern "C" int snerf_linear_bwd_weight_f32(const float *dy, int64_t n, int m, in
     const int slices = wgrad_slices(n, m, k, n_cu);
     const int64_t per = (((n + slices - 1) / slices) + LIN_BK - 1) / LIN_BK * LIN_BK;
     const int used = (int)((n + per - 1) / per);
-    const int64_t stride = (int64_t)m * k + m;     // a slice's partial: [m, k] then [m] bias sums
+    // scratch: [used][m, k] partials of the weight gradient, then [cs_used][m] partials of the bias gradient - the column sums take
+    // their own, finer split (they stream all of d Y through (m / 64) x slices workgroups: with the GEMM's 4 slices of a 768 x 768
+    // layer that was 48 workgroups on 256 CUs, 6 % of the layer-by-layer training step)
+    const int64_t stride = (int64_t)m * k;
     if (k > 0) {
         // dw[m, k] = sum_s dy[s, m] x[s, k]: A (row = output feature, red = sample) at dy[red lddy + row], B (col, red) at x[red ldx + col]
         LinArgs G{dy, x, scratch, nullptr, m, k, n, lddy, ldx, k, 1, 1, 0, 0, per, stride};
@@ -265,10 +268,15 @@ extern "C" int snerf_linear_bwd_weight_f32(const float *dy, int64_t n, int m, in
         if (int rc = check_launch("linear_bwd_weight(sum)")) return rc;
     }
     if (db) {
-        hipLaunchKernelGGL(linear_colsum_kernel, dim3((unsigned)((m + 63) / 64), (unsigned)used), dim3(256), 0, s, dy, n, (int64_t)m, lddy, per,
-                           scratch + (int64_t)m * k, stride);
+        const int64_t col_groups = (m + 63) / 64;
+        int64_t cs = std::max<int64_t>(1, std::min<int64_t>((4 * (int64_t)n_cu + col_groups - 1) / col_groups, std::min<int64_t>(256, (n + 255) / 256)));
+        const int64_t cs_per = (n + cs - 1) / cs;
+        const int cs_used = (int)((n + cs_per - 1) / cs_per);
+        float *bias_part = scratch + (int64_t)used * stride;
+        hipLaunchKernelGGL(linear_colsum_kernel, dim3((unsigned)col_groups, (unsigned)cs_used), dim3(256), 0, s, dy, n, (int64_t)m, lddy, cs_per,
+                           bias_part, (int64_t)m);
         if (int rc = check_launch("linear_bwd_weight(bias)")) return rc;
-        hipLaunchKernelGGL(linear_slice_sum_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, scratch + (int64_t)m * k, used, stride, (int64_t)1,
+        hipLaunchKernelGGL(linear_slice_sum_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, bias_part, cs_used, (int64_t)m, (int64_t)1,
                            (int64_t)m, (int64_t)m, db, (int64_t)m, accumulate ? 1 : 0);
         if (int rc = check_launch("linear_bwd_weight(bias sum)")) return rc;
     }
